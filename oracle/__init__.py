@@ -1,0 +1,18 @@
+"""CPU checkers for the renderScene / renderScene_B hot path -- TEST INFRASTRUCTURE ONLY.
+
+Nothing under ``oracle/`` may be imported, linked or executed by the product package
+(``deodr_amd``).  Only ``tests/``, ``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg of
+``bench.py`` use it, and only as the thing results are compared against (or timed beside).
+
+Two checkers share one Python interface (:class:`oracle.api.CpuRenderer`):
+
+``oracle.ref``   ``oracle/_ref/libdeodr_ref.so``: the *unmodified* reference header
+                 ``/root/reference/C++/DifferentiableRenderer.h`` compiled where it lies by
+                 ``oracle/Makefile`` (``make ref``) behind ``oracle/ref_shim.cpp``.  A second build,
+                 ``libdeodr_ref_texfix.so``, carries the one-token ``=`` -> ``+=`` fix of
+                 ``bilinear_sample_B`` (H.h:621-624) and defines parity for ``texture_b``.
+``oracle.port``  ``oracle/libdeodr_oracle.so``: our plain-C restatement ``oracle/deodr_oracle.c``
+                 (every function cites the reference lines it follows).  Pinned against
+                 ``oracle.ref`` and against ``tests/golden/*.npz`` (vectors produced by the reference's
+                 own Python/Cython build with ``tests/golden/make_golden.py``).
+"""
