@@ -180,12 +180,14 @@ def sphere_scene(size=1024, nu=100, n_rings=100, nb_colors=4, depth_channel=True
     )  # fmt: skip
 
 
-def soup_scene(n_tri=200, width=256, height=256, seed=2, clockwise=False, textured_ratio=0.0, flat=True, min_area=300.0, texture_size=64):
+def soup_scene(n_tri=200, width=256, height=256, seed=2, clockwise=False, textured_ratio=0.0, flat=True, min_area=None, texture_size=64):
     """BASELINE configs[0]: a triangle soup with constant depth per triangle and all 3 edges flagged."""
     rs = np.random.RandomState(seed)
     ij = np.zeros((n_tri, 3, 2))
+    if min_area is None:
+        min_area = 0.0045 * width * height  # ~300 px^2 at 256x256 (the reference example rejects slivers too)
     for t in range(n_tri):
-        while True:
+        for _attempt in range(10000):
             c = rs.rand(2) * [width, height]
             p = c + (rs.rand(3, 2) - 0.5) * 0.5 * [width, height]
             u, v = p[1] - p[0], p[2] - p[0]

@@ -9,8 +9,9 @@ Two checkers share one Python interface (:class:`oracle.api.CpuRenderer`):
 ``oracle.ref``   ``oracle/_ref/libdeodr_ref.so``: the *unmodified* reference header
                  ``/root/reference/C++/DifferentiableRenderer.h`` compiled where it lies by
                  ``oracle/Makefile`` (``make ref``) behind ``oracle/ref_shim.cpp``.  A second build,
-                 ``libdeodr_ref_texfix.so``, carries the one-token ``=`` -> ``+=`` fix of
-                 ``bilinear_sample_B`` (H.h:621-624) and defines parity for ``texture_b``.
+                 ``libdeodr_ref_fixed.so``, repairs two adjoint defects of the shipped header (D1 ``texture_b``
+                 overwrite H.h:621-624, D2 missing row fold in ``rasterize_edge_interpolated_error_B`` H.h:2595)
+                 and defines parity where the shipped reference is mathematically wrong.
 ``oracle.port``  ``oracle/libdeodr_oracle.so``: our plain-C restatement ``oracle/deodr_oracle.c``
                  (every function cites the reference lines it follows).  Pinned against
                  ``oracle.ref`` and against ``tests/golden/*.npz`` (vectors produced by the reference's

@@ -243,17 +243,22 @@ def build_ref():
 _cache = {}
 
 
-def port():
+def port(fixed=False):
+    """Our C restatement.  fixed=False reproduces the reference as shipped (defects D1, D2 included);
+    fixed=True repairs them.  The switch is a process-wide global of the library, set on every call here."""
     if "port" not in _cache:
         _cache["port"] = CpuRenderer(build_port(), "deodr_oracle")
+    _cache["port"].lib.deodr_oracle_set_reference_defects(0 if fixed else 1)
     return _cache["port"]
 
 
-def ref(texfix=False):
-    """The real reference (or None when oracle/_ref was never built and /root/reference is absent)."""
-    key = "ref_texfix" if texfix else "ref"
+def ref(fixed=False):
+    """The real reference (or None when oracle/_ref was never built and /root/reference is absent).
+
+    fixed=True: the build with the two adjoint defects repaired (oracle/Makefile D1, D2)."""
+    key = "ref_fixed" if fixed else "ref"
     if key not in _cache:
-        path = os.path.join(HERE, "_ref", "libdeodr_ref_texfix.so" if texfix else "libdeodr_ref.so")
+        path = os.path.join(HERE, "_ref", "libdeodr_ref_fixed.so" if fixed else "libdeodr_ref.so")
         if not os.path.exists(path) and os.path.isdir(REFERENCE):
             build_ref()
         _cache[key] = CpuRenderer(path, "deodr_ref") if os.path.exists(path) else None

@@ -1,0 +1,1195 @@
+/* oracle/deodr_oracle.c -- TEST INFRASTRUCTURE ONLY.  Never linked, imported or executed by the product
+ * (deodr_amd/); it is the checker the HIP path is compared against, and the "port" CPU baseline of bench.py.
+ *
+ * A plain-C99 restatement of the reference rasterizer's algorithm
+ *     /root/reference/C++/DifferentiableRenderer.h   (cited below as H.h:<lines>)
+ * for the path renderScene (H.h:2717-2901) / renderScene_B (H.h:2903-3135).  It is organised differently from
+ * the reference (one row-walker per primitive kind driven by callbacks, table-driven 3x3 adjoint, one edge
+ * routine for the four edge variants) but performs the same IEEE-754 double operations in the same order, so
+ * that it reproduces the reference bit for bit.  Build with -ffp-contract=off: the reference is built for
+ * baseline x86-64 (no FMA), i.e. every a*b+c is two roundings.
+ *
+ * PARITY PINNED (tests/test_oracle.py): bit-exact against
+ *   - tests/golden/soup30_cw{0,1}.npz : SHA-256 of image / z_buffer / err_buffer, every gradient array and the
+ *     50-iteration loss curves produced by the reference's own Python + Cython build (last values
+ *     1331.3578738815468 / 1457.8585914203582 / 1331.357873881545 / 1457.8585914203607 are the goldens of the
+ *     reference's tests/test_triangle_soup_fitting.py:29-108; image hash 4de52cc3... is the golden of
+ *     tests/test_render_mesh.py:76-79);
+ *   - oracle/_ref/libdeodr_ref.so (the unmodified header compiled by oracle/Makefile) on seeded random scenes
+ *     covering textured / untextured, both windings, strict_edge on/off, perspective_correct, both pixel-centre
+ *     conventions, background colour / image and antialiase_error.
+ *
+ * One deliberate switch: deodr_oracle_set_reference_defects(0) repairs two adjoint defects of the shipped header
+ *   D1  bilinear_sample_B overwrites texture_b (`=`) instead of accumulating (`+=`), H.h:621-624
+ *   D2  rasterize_edge_interpolated_error_B never folds the per-row A0y_B into xy1_to_A_B (every sibling calls
+ *       mul_matrixNx3_vect_B at the end of the row, e.g. H.h:1752; the call is missing before H.h:2595)
+ * 1 (default) is the reference as shipped, defects included -- that is what the goldens pin.
+ */
+#include <limits.h>
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+typedef struct
+{ /* same layout as RefSceneFlat in oracle/ref_shim.cpp; mirrors struct Scene, H.h:56-90 */
+	const unsigned int *faces, *faces_uv;
+	const double *depths, *uv, *ij, *shade, *colors;
+	const unsigned char *edgeflags, *textured, *shaded;
+	const double *texture, *background_image, *background_color;
+	double *uv_b, *ij_b, *shade_b, *colors_b, *texture_b;
+	int nb_triangles, nb_vertices, nb_uv, height, width, nb_colors, texture_height, texture_width;
+	int clockwise, backface_culling, strict_edge, perspective_correct, integer_pixel_centers;
+} OScene;
+
+static const char *g_error = "";
+static int g_reference_defects = 1;
+
+const char *deodr_oracle_last_error(void) { return g_error; }
+void deodr_oracle_set_reference_defects(int on) { g_reference_defects = on; }
+
+#define MAXC 64 /* channels; the reference heap-allocates per call, we bound it */
+
+/* ---------------------------------------------------------------------------------------------- 3x3 algebra */
+
+/* cofactor m = s*(S[a]*S[b] - S[c]*S[d]); the order of the rows is the order in which the reference
+ * back-propagates through them (H.h:172-231), which fixes the rounding of the accumulated adjoint. */
+static const struct { int m, s, a, b, c, d; } COF[9] = {
+	{0, 1, 4, 8, 7, 5}, {3, -1, 3, 8, 6, 5}, {6, 1, 3, 7, 6, 4}, {1, -1, 1, 8, 7, 2}, {4, 1, 0, 8, 6, 2},
+	{7, -1, 0, 7, 6, 1}, {2, 1, 1, 5, 4, 2}, {5, -1, 0, 5, 3, 2}, {8, 1, 0, 4, 3, 1}};
+
+static double cofactors(const double S[9], double Tp[9])
+{ /* H.h:100-112: transposed cofactor matrix and 1/det */
+	for (int n = 0; n < 9; n++)
+	{
+		double v = S[COF[n].a] * S[COF[n].b] - S[COF[n].c] * S[COF[n].d];
+		Tp[COF[n].m] = COF[n].s > 0 ? v : -v;
+	}
+	return 1 / (S[0] * Tp[0] + S[1] * Tp[3] + S[2] * Tp[6]);
+}
+
+static void inv3(const double S[9], double T[9])
+{ /* inv_matrix_3x3, H.h:92-117 */
+	double inv_det = cofactors(S, T);
+	for (int k = 0; k < 9; k++)
+		T[k] *= inv_det;
+}
+
+static void inv3_adjoint(const double S[9], double S_B[9], const double T_B[9])
+{ /* inv_matrix_3x3_B, H.h:124-232 (S_B is accumulated into) */
+	double Tp[9], Tp_B[9] = {0};
+	double inv_det = cofactors(S, Tp);
+	double inv_det_b = 0;
+	for (int k = 0; k < 9; k++)
+	{
+		inv_det_b += Tp[k] * T_B[k];
+		Tp_B[k] += inv_det * T_B[k];
+	}
+	double t_B = inv_det_b * (-inv_det * inv_det);
+	for (int k = 0; k < 3; k++)
+	{ /* det = S0*Tp0 + S1*Tp3 + S2*Tp6 */
+		S_B[k] += Tp[3 * k] * t_B;
+		Tp_B[3 * k] += S[k] * t_B;
+	}
+	for (int n = 0; n < 9; n++)
+	{
+		double g = Tp_B[COF[n].m], s = COF[n].s;
+		S_B[COF[n].a] += (s * S[COF[n].b]) * g;
+		S_B[COF[n].b] += (s * S[COF[n].a]) * g;
+		S_B[COF[n].c] += (-s * S[COF[n].d]) * g;
+		S_B[COF[n].d] += (-s * S[COF[n].c]) * g;
+	}
+}
+
+/* row value of a plane p = [px, py, p1] at scanline y: dot(p, [0, y, 1]) with the reference's summation order
+ * (mul_matrixNx3_vect / dot_prod with t = {0, y, 1}, H.h:253-261, 359-365, 929-934) */
+static double row0(const double p[3], double y) { return ((0.0 + p[0] * 0.0) + p[1] * y) + p[2] * 1.0; }
+
+/* planes[3*i+j] = sum_k attr[k][i] * w[k] * x2b[3k+j]  (H.h:762-788, 1567-1585); w == NULL means 1 */
+static void attr_planes(int n, int nv, const double *const attr[3], const double *w, const double *x2b, double *planes)
+{
+	for (int i = 0; i < n; i++)
+		for (int j = 0; j < 3; j++)
+		{
+			double s = 0;
+			for (int k = 0; k < nv; k++)
+				s += (w ? attr[k][i] * w[k] : attr[k][i]) * x2b[3 * k + j];
+			planes[3 * i + j] = s;
+		}
+}
+
+/* out[j] = sum_k v[k] * x2b[3k+j]  (mul_vect_matrix3x3 H.h:272-280, mul_matrix(1,2,3) H.h:296-309) */
+static void scalar_plane(int nv, const double *v, const double *x2b, double out[3])
+{
+	for (int j = 0; j < 3; j++)
+	{
+		double s = 0;
+		for (int k = 0; k < nv; k++)
+			s += v[k] * x2b[3 * k + j];
+		out[j] = s;
+	}
+}
+
+/* ------------------------------------------------------------------------------------- robust integer division */
+
+static short floor_div(double a, double b, int x_min, int x_max)
+{ /* H.h:440-479: min(x_max, max(x_min, floor(a/b))) that survives b ~ 0 */
+	short x;
+	if (fabs(b) * SHRT_MAX > fabs(a) + fabs(b))
+	{
+		x = (short)floor(a / b);
+		if (x < x_min)
+			x = (short)x_min;
+		if (x > x_max)
+			x = (short)x_max;
+	}
+	else
+	{
+		x = (short)x_min;
+		if (b > 0)
+			while (((x + 1) * b <= a) && (x < x_max))
+				x++;
+		else
+			while (((x + 1) * b >= a) && (x < x_max))
+				x++;
+	}
+	return x;
+}
+
+static short ceil_div(double a, double b, int x_min, int x_max)
+{ /* H.h:481-519 */
+	short x;
+	if (fabs(b) * SHRT_MAX > fabs(a) + fabs(b))
+	{
+		x = (short)ceil(a / b);
+		if (x < x_min)
+			x = (short)x_min;
+		if (x > x_max)
+			x = (short)x_max;
+	}
+	else
+	{
+		x = (short)x_min;
+		if (b > 0)
+			while (((x + 1) * b < a) && (x < x_max))
+				x++;
+		else
+			while (((x + 1) * b > a) && (x < x_max))
+				x++;
+	}
+	return x;
+}
+
+/* ------------------------------------------------------------------------------------------- texture sampling */
+
+typedef struct
+{
+	int idx[4]; /* texel offsets 00, 10, 01, 11 (already multiplied by the channel count) */
+	double e[2];
+	int out[2];
+} Tap;
+
+static void bilinear_tap(const int size[2], const double p[2], int nc, Tap *t)
+{ /* H.h:527-556: clamp-to-edge; size = {width, height}; p = (u along width, v along height) */
+	int fp[2];
+	for (int k = 0; k < 2; k++)
+	{
+		fp[k] = (int)floor(p[k]);
+		t->e[k] = p[k] - fp[k];
+		t->out[k] = 0;
+	}
+	for (int k = 0; k < 2; k++)
+	{
+		if (fp[k] < 0)
+		{
+			t->out[k] = 1;
+			fp[k] = 0;
+			t->e[k] = 0;
+		}
+		if (fp[k] > size[k] - 2)
+		{
+			t->out[k] = 1;
+			fp[k] = size[k] - 2;
+			t->e[k] = 1;
+		}
+	}
+	t->idx[0] = nc * (fp[0] + size[0] * fp[1]);
+	t->idx[1] = nc * (fp[0] + 1 + size[0] * fp[1]);
+	t->idx[2] = nc * (fp[0] + size[0] * (fp[1] + 1));
+	t->idx[3] = nc * (fp[0] + 1 + size[0] * (fp[1] + 1));
+}
+
+static void bilinear_sample(double *A, const double *I, const int size[2], const double p[2], int nc)
+{ /* H.h:522-560 */
+	Tap t;
+	bilinear_tap(size, p, nc, &t);
+	for (int k = 0; k < nc; k++)
+		A[k] = ((1 - t.e[0]) * I[t.idx[0] + k] + t.e[0] * I[t.idx[1] + k]) * (1 - t.e[1]) +
+			   ((1 - t.e[0]) * I[t.idx[2] + k] + t.e[0] * I[t.idx[3] + k]) * t.e[1];
+}
+
+static void bilinear_sample_adjoint(const double *A_B, const double *I, double *I_B, const int size[2], const double p[2], double p_B[2], int nc)
+{ /* H.h:563-631 */
+	Tap t;
+	double e_B[2] = {0, 0};
+	bilinear_tap(size, p, nc, &t);
+	const double *e = t.e;
+	for (int k = 0; k < nc; k++)
+	{
+		double t1 = ((1 - e[0]) * I[t.idx[0] + k] + e[0] * I[t.idx[1] + k]);
+		double t2 = ((1 - e[0]) * I[t.idx[2] + k] + e[0] * I[t.idx[3] + k]);
+		e_B[1] += -A_B[k] * t1;
+		e_B[1] += A_B[k] * t2;
+		double t1_B = A_B[k] * (1 - e[1]);
+		double t2_B = A_B[k] * e[1];
+		e_B[0] += t1_B * (I[t.idx[1] + k] - I[t.idx[0] + k]);
+		e_B[0] += t2_B * (I[t.idx[3] + k] - I[t.idx[2] + k]);
+		double w[4] = {(1 - e[0]) * (1 - e[1]) * A_B[k], e[0] * (1 - e[1]) * A_B[k], (1 - e[0]) * e[1] * A_B[k], e[0] * e[1] * A_B[k]};
+		for (int q = 0; q < 4; q++)
+		{
+			if (g_reference_defects)
+				I_B[t.idx[q] + k] = w[q]; /* defect D1, H.h:621-624 */
+			else
+				I_B[t.idx[q] + k] += w[q];
+		}
+	}
+	for (int k = 0; k < 2; k++)
+		if (!t.out[k])
+			p_B[k] += e_B[k];
+}
+
+/* ----------------------------------------------------------------------------------------- triangle stencil */
+
+typedef struct
+{
+	double b2x[9];	  /* bary_to_xy1 */
+	double x2b[9];	  /* xy1_to_bary */
+	double eq[3][3];  /* edge equations a x + b y + c */
+	int x_min, x_max; /* unclipped column bounds */
+	int y_begin[2], y_end[2], left[2], right[2]; /* upper / lower half */
+} TriStencil;
+
+static void edge_equation(double e[3], const double v1[2], const double v2[2], int clockwise)
+{ /* Edge_equ3, H.h:373-389 */
+	if (clockwise)
+	{
+		e[0] = (v1[1] - v2[1]);
+		e[1] = (v2[0] - v1[0]);
+	}
+	else
+	{
+		e[0] = (v2[1] - v1[1]);
+		e[1] = (v1[0] - v2[0]);
+	}
+	e[2] = -0.5 * (e[0] * (v1[0] + v2[0]) + e[1] * (v1[1] + v2[1]));
+}
+
+static double signed_area(const double ij[3][2], int clockwise)
+{ /* H.h:391-398 */
+	double ux = ij[1][0] - ij[0][0], uy = ij[1][1] - ij[0][1];
+	double vx = ij[2][0] - ij[0][0], vy = ij[2][1] - ij[0][1];
+	return 0.5 * (ux * vy - vx * uy) * (clockwise ? 1 : -1);
+}
+
+static void sort3(const double v[3], double sv[3], int order[3])
+{ /* H.h:400-426: three compare-exchanges (0,1) (0,2) (1,2) */
+	static const int net[3][2] = {{0, 1}, {0, 2}, {1, 2}};
+	for (int k = 0; k < 3; k++)
+	{
+		sv[k] = v[k];
+		order[k] = k;
+	}
+	for (int n = 0; n < 3; n++)
+	{
+		int a = net[n][0], b = net[n][1];
+		if (sv[a] > sv[b])
+		{
+			double tv = sv[a];
+			sv[a] = sv[b];
+			sv[b] = tv;
+			int ti = order[a];
+			order[a] = order[b];
+			order[b] = ti;
+		}
+	}
+}
+
+static void tri_stencil(const double V[3][2], int strict, TriStencil *s)
+{ /* get_triangle_stencil_equations, H.h:633-739 */
+	for (int v = 0; v < 3; v++)
+	{
+		s->b2x[v] = V[v][0];
+		s->b2x[3 + v] = V[v][1];
+		s->b2x[6 + v] = 1;
+	}
+	inv3(s->b2x, s->x2b);
+	int cw = signed_area(V, 1) > 0;
+	edge_equation(s->eq[0], V[0], V[1], cw);
+	edge_equation(s->eq[1], V[1], V[2], cw);
+	edge_equation(s->eq[2], V[2], V[0], cw);
+	double xs[3] = {V[0][0], V[1][0], V[2][0]}, ys[3] = {V[0][1], V[1][1], V[2][1]}, sx[3], sy[3];
+	int ox[3], oy[3];
+	sort3(xs, sx, ox);
+	sort3(ys, sy, oy);
+	s->x_min = strict ? (short)floor(sx[0]) : (short)ceil(sx[0]);
+	s->x_max = (short)floor(sx[2]);
+	s->y_begin[0] = strict ? (short)floor(sy[0]) + 1 : (short)ceil(sy[0]);
+	s->y_end[0] = (short)floor(sy[1]);
+	s->y_begin[1] = strict ? (short)floor(sy[1]) + 1 : (short)ceil(sy[1]);
+	s->y_end[1] = (short)floor(sy[2]);
+	int id = oy[0]; /* top vertex: the two edges leaving it bound the upper half (H.h:715-726) */
+	if (s->eq[id % 3][0] > 0)
+	{
+		s->right[0] = (id + 2) % 3;
+		s->left[0] = id % 3;
+	}
+	else
+	{
+		s->right[0] = id % 3;
+		s->left[0] = (id + 2) % 3;
+	}
+	id = oy[2]; /* bottom vertex (H.h:728-738) */
+	if (s->eq[id % 3][0] < 0)
+	{
+		s->right[1] = id % 3;
+		s->left[1] = (id + 2) % 3;
+	}
+	else
+	{
+		s->right[1] = (id + 2) % 3;
+		s->left[1] = id % 3;
+	}
+}
+
+static void tri_xrange(int width, const double *left, const double *right, short y, int strict, short x_min, short x_max, short *xb, short *xe)
+{ /* get_xrange, H.h:864-906: left edge exclusive (strict) and right edge inclusive */
+	if (x_min < 0)
+		x_min = 0;
+	if (x_max > width - 1)
+		x_max = (short)(width - 1);
+	*xb = x_min;
+	*xe = x_max;
+	double num = -(left[1] * y + left[2]);
+	short t = strict ? (short)(1 + floor_div(num, left[0], x_min - 1, x_max)) : ceil_div(num, left[0], x_min - 1, x_max);
+	if (t > *xb)
+		*xb = t;
+	num = -(right[1] * y + right[2]);
+	t = floor_div(num, right[0], x_min - 1, x_max);
+	if (t < *xe)
+		*xe = t;
+}
+
+typedef void (*row_fn)(void *ctx, short y, int x_begin, int x_end);
+
+static void tri_rows(const TriStencil *s, int width, int height, int strict, row_fn fn, void *ctx)
+{ /* the two render_part_* calls of every rasterize_triangle_* (e.g. H.h:789-792) */
+	for (int half = 0; half < 2; half++)
+	{
+		int yb = s->y_begin[half] < 0 ? 0 : s->y_begin[half];
+		int ye = s->y_end[half] > height - 1 ? height - 1 : s->y_end[half];
+		for (short y = (short)yb; y <= ye; y++)
+		{
+			short xb, xe;
+			tri_xrange(width, s->eq[s->left[half]], s->eq[s->right[half]], y, strict, (short)s->x_min, (short)s->x_max, &xb, &xe);
+			fn(ctx, y, xb, xe);
+		}
+	}
+}
+
+/* --------------------------------------------------------------------------------------------- edge stencil */
+
+static void edge_normal(const double V[2][2], int clockwise, double nt[2], double *inv_norm)
+{ /* H.h:1383-1393 */
+	if (clockwise)
+	{
+		nt[0] = V[0][1] - V[1][1];
+		nt[1] = V[1][0] - V[0][0];
+	}
+	else
+	{
+		nt[0] = V[1][1] - V[0][1];
+		nt[1] = V[0][0] - V[1][0];
+	}
+	*inv_norm = 1 / sqrt(nt[0] * nt[0] + nt[1] * nt[1]);
+}
+
+static void edge_frame(const double V[2][2], const double n[2], double e2x[9])
+{ /* edge_to_xy1, H.h:1397-1404 */
+	for (int v = 0; v < 2; v++)
+	{
+		e2x[v] = V[v][0];
+		e2x[3 + v] = V[v][1];
+		e2x[6 + v] = 1;
+	}
+	e2x[2] = n[0];
+	e2x[5] = n[1];
+	e2x[8] = 0;
+}
+
+static void edge_stencil(const double V[2][2], int height, double sigma, int clockwise, double x2b[6], double x2t[3], double ineq[12], int *y_begin, int *y_end)
+{ /* get_edge_stencil_equations, H.h:1366-1460 */
+	double nt[2], inv_norm, n[2], e2x[9], x2e[9];
+	edge_normal(V, clockwise, nt, &inv_norm);
+	n[0] = nt[0] * inv_norm;
+	n[1] = nt[1] * inv_norm;
+	edge_frame(V, n, e2x);
+	inv3(e2x, x2e);
+	for (int k = 0; k < 6; k++)
+		x2b[k] = x2e[k];
+	for (int k = 0; k < 3; k++)
+		x2t[k] = (1 / sigma) * x2e[6 + k];
+	for (int k = 0; k < 6; k++)
+		ineq[k] = x2b[k];
+	for (int j = 0; j < 3; j++)
+		ineq[6 + j] = x2t[j];
+	ineq[9] = -x2t[0];
+	ineq[10] = -x2t[1];
+	ineq[11] = (1 - x2t[2]);
+	*y_begin = height - 1;
+	for (int k = 0; k < 2; k++)
+		if (V[k][1] - sigma < *y_begin)
+			*y_begin = (int)floor(V[k][1] - sigma) + 1;
+	if (*y_begin < 0)
+		*y_begin = 0;
+	*y_end = 0;
+	for (int k = 0; k < 2; k++)
+		if (V[k][1] + sigma > *y_end)
+			*y_end = (int)floor(V[k][1] + sigma);
+	if (*y_end > height - 1)
+		*y_end = height - 1;
+}
+
+static void edge_stencil_adjoint(const double V[2][2], double V_B[2][2], double sigma, const double x2b_B[6], const double x2t_B[3], int clockwise)
+{ /* get_edge_stencil_equations_B, H.h:1462-1539 */
+	double nt[2], inv_norm, n[2], e2x[9], e2x_B[9] = {0}, x2e_B[9] = {0};
+	edge_normal(V, clockwise, nt, &inv_norm);
+	n[0] = nt[0] * inv_norm;
+	n[1] = nt[1] * inv_norm;
+	edge_frame(V, n, e2x);
+	for (int k = 0; k < 3; k++)
+		x2e_B[6 + k] += x2t_B[k] * (1 / sigma);
+	for (int k = 0; k < 6; k++)
+		x2e_B[k] += x2b_B[k];
+	inv3_adjoint(e2x, e2x_B, x2e_B);
+	for (int v = 0; v < 2; v++)
+		for (int d = 0; d < 2; d++)
+			V_B[v][d] += e2x_B[3 * d + v];
+	double n_B[2] = {0, 0}, nt_B[2] = {0, 0}, inv_norm_B = 0;
+	for (int d = 0; d < 2; d++)
+		n_B[d] += e2x_B[3 * d + 2];
+	for (int k = 0; k < 2; k++)
+	{
+		nt_B[k] += n_B[k] * inv_norm;
+		inv_norm_B += n_B[k] * nt[k];
+	}
+	double nor_B = -inv_norm_B * (inv_norm * inv_norm);
+	double nor_s_B = nor_B * 0.5 * inv_norm;
+	nt_B[0] += 2 * nt[0] * nor_s_B;
+	nt_B[1] += 2 * nt[1] * nor_s_B;
+	double sgn = clockwise ? 1.0 : -1.0; /* H.h:1525-1538 */
+	V_B[0][1] += sgn * nt_B[0];
+	V_B[1][1] += -sgn * nt_B[0];
+	V_B[1][0] += sgn * nt_B[1];
+	V_B[0][0] += -sgn * nt_B[1];
+}
+
+static void edge_xrange(const double ineq[12], int width, int y, int *xb, int *xe)
+{ /* get_edge_xrange_from_ineq, H.h:2620-2648 */
+	*xb = 0;
+	*xe = width - 1;
+	for (int k = 0; k < 4; k++)
+	{
+		double num = -(ineq[3 * k + 1] * y + ineq[3 * k + 2]);
+		if (ineq[3 * k] < 0)
+		{
+			short t = floor_div(num, ineq[3 * k], *xb - 1, *xe + 1);
+			if (t < *xe)
+				*xe = t;
+		}
+		else
+		{
+			short t = (short)(1 + floor_div(num, ineq[3 * k], *xb - 1, *xe + 1));
+			if (t > *xb)
+				*xb = t;
+		}
+	}
+}
+
+/* ------------------------------------------------------------------------------------------- triangle passes */
+
+typedef struct
+{
+	const OScene *sc;
+	double *image, *image_b, *z_buffer;
+	int nc, textured, backward;
+	double xZ[3];
+	double xA[3 * MAXC], xA_B[3 * MAXC]; /* colour planes and their adjoint */
+	double xUV[6], xUV_B[6], xL[3], xL_B[3];
+	int tex_size[2];
+} TriCtx;
+
+static void tri_row(void *vctx, short y, int x_begin, int x_end)
+{
+	TriCtx *c = (TriCtx *)vctx;
+	const OScene *sc = c->sc;
+	const int nc = c->nc, persp = sc->perspective_correct;
+	double A0y[MAXC], A0y_B[MAXC], A[MAXC], A_B[MAXC], UV0y[2], UV0y_B[2] = {0, 0}, L0y = 0, L0y_B = 0;
+	double Z0y = row0(c->xZ, y);
+	if (c->textured)
+	{
+		for (int i = 0; i < 2; i++)
+			UV0y[i] = row0(c->xUV + 3 * i, y);
+		L0y = row0(c->xL, y);
+	}
+	else
+		for (int k = 0; k < nc; k++)
+		{
+			A0y[k] = row0(c->xA + 3 * k, y);
+			A0y_B[k] = 0;
+		}
+	int indx = y * sc->width + x_begin;
+	for (short x = (short)x_begin; x <= x_end; x++, indx++)
+	{
+		double Z = Z0y + c->xZ[0] * x;
+		if (persp)
+			Z = 1 / Z;
+		if (!c->backward)
+		{ /* render_part_interpolated H.h:908-972, render_part_textured_gouraud H.h:1159-1258 */
+			if (!(Z < c->z_buffer[indx]))
+				continue;
+			c->z_buffer[indx] = Z;
+			if (c->textured)
+			{
+				double L = L0y + c->xL[0] * x, UV[2];
+				for (int k = 0; k < 2; k++)
+					UV[k] = UV0y[k] + c->xUV[3 * k] * x;
+				if (persp)
+				{
+					L = L * Z;
+					for (int k = 0; k < 2; k++)
+						UV[k] = UV[k] * Z;
+				}
+				bilinear_sample(A, sc->texture, c->tex_size, UV, nc);
+				for (int k = 0; k < nc; k++)
+					c->image[nc * indx + k] = A[k] * L;
+			}
+			else if (persp)
+				for (int k = 0; k < nc; k++)
+					c->image[nc * indx + k] = (A0y[k] + c->xA[3 * k] * x) * Z;
+			else
+				for (int k = 0; k < nc; k++)
+					c->image[nc * indx + k] = A0y[k] + c->xA[3 * k] * x;
+		}
+		else
+		{ /* render_part_interpolated_B H.h:974-1040, render_part_textured_gouraud_B H.h:1260-1364 */
+			if (!(Z == c->z_buffer[indx]))
+				continue;
+			double *g = c->image_b + nc * indx;
+			if (c->textured)
+			{
+				double L = L0y + c->xL[0] * x, L_B = 0, UV[2], UV_B[2] = {0, 0};
+				for (int k = 0; k < 2; k++)
+					UV[k] = UV0y[k] + c->xUV[3 * k] * x;
+				bilinear_sample(A, sc->texture, c->tex_size, UV, nc);
+				for (int k = 0; k < nc; k++)
+				{
+					A_B[k] = 0;
+					A_B[k] += g[k] * L;
+					L_B += g[k] * A[k];
+				}
+				bilinear_sample_adjoint(A_B, sc->texture, sc->texture_b, c->tex_size, UV, UV_B, nc);
+				for (int k = 0; k < 2; k++)
+				{
+					UV0y_B[k] += UV_B[k];
+					c->xUV_B[3 * k] += UV_B[k] * x;
+				}
+				L0y_B += L_B;
+				c->xL_B[0] += x * L_B;
+			}
+			else
+				for (int k = 0; k < nc; k++)
+				{
+					A0y_B[k] += g[k];
+					c->xA_B[3 * k] += g[k] * x;
+					g[k] = 0;
+				}
+		}
+	}
+	if (c->backward)
+	{
+		const double t[3] = {0, (double)y, 1};
+		if (c->textured)
+		{
+			for (int i = 0; i < 2; i++)
+				for (int k = 0; k < 3; k++)
+					c->xUV_B[k + 3 * i] += UV0y_B[i] * t[k];
+			for (int i = 0; i < 3; i++)
+				c->xL_B[i] += L0y_B * t[i];
+		}
+		else
+			for (int i = 0; i < nc; i++)
+				for (int j = 0; j < 3; j++)
+					c->xA_B[3 * i + j] += A0y_B[i] * t[j];
+	}
+}
+
+/* one triangle of pass 1 (rasterize_triangle_interpolated H.h:742-794, _textured_gouraud H.h:1043-1092) or of
+ * its adjoint (rasterize_triangle_interpolated_B H.h:797-862, _textured_gouraud_B H.h:1095-1157) */
+static void do_triangle(const OScene *sc, int k, double off, double *image, double *z_buffer, double *image_b, int backward)
+{
+	const unsigned int *face = sc->faces + 3 * k, *face_uv = sc->faces_uv + 3 * k;
+	const int nc = sc->nb_colors;
+	const int textured = sc->textured[k] && sc->shaded[k];
+	if (sc->textured[k] && !sc->shaded[k])
+		return; /* neither branch of H.h:2798/2813 applies */
+	double V[3][2], Zv[3], inv_Z[3];
+	for (int i = 0; i < 3; i++)
+	{
+		V[i][0] = sc->ij[face[i] * 2] - off;
+		V[i][1] = sc->ij[face[i] * 2 + 1] - off;
+		Zv[i] = sc->depths[face[i]];
+		inv_Z[i] = 1 / Zv[i];
+	}
+	TriStencil st;
+	tri_stencil(V, sc->strict_edge, &st);
+	TriCtx c;
+	memset(&c, 0, sizeof c);
+	c.sc = sc;
+	c.image = image;
+	c.image_b = image_b;
+	c.z_buffer = z_buffer;
+	c.nc = nc;
+	c.textured = textured;
+	c.backward = backward;
+	c.tex_size[0] = sc->texture_width;
+	c.tex_size[1] = sc->texture_height;
+	const int persp = sc->perspective_correct;
+	const double *w = persp ? inv_Z : NULL;
+	scalar_plane(3, persp ? inv_Z : Zv, st.x2b, c.xZ);
+	double shade[3], uvv[3][2];
+	const double *attr[3];
+	if (textured)
+	{
+		for (int i = 0; i < 3; i++)
+		{
+			shade[i] = sc->shade[face[i]];
+			uvv[i][0] = sc->uv[face_uv[i] * 2];
+			uvv[i][1] = sc->uv[face_uv[i] * 2 + 1];
+			attr[i] = uvv[i];
+		}
+		if (persp)
+		{
+			double sdz[3];
+			for (int i = 0; i < 3; i++)
+				sdz[i] = inv_Z[i] * shade[i];
+			scalar_plane(3, sdz, st.x2b, c.xL);
+		}
+		else
+			scalar_plane(3, shade, st.x2b, c.xL);
+		attr_planes(2, 3, attr, w, st.x2b, c.xUV);
+	}
+	else
+	{
+		for (int i = 0; i < 3; i++)
+			attr[i] = sc->colors + (size_t)face[i] * nc;
+		attr_planes(nc, 3, attr, w, st.x2b, c.xA);
+	}
+	tri_rows(&st, sc->width, sc->height, sc->strict_edge, tri_row, &c);
+	if (!backward)
+		return;
+	double x2b_B[9] = {0}, b2x_B[9] = {0};
+	if (textured)
+	{
+		for (int i = 0; i < 2; i++)
+			for (int j = 0; j < 3; j++)
+				for (int v = 0; v < 3; v++)
+				{
+					sc->uv_b[face_uv[v] * 2 + i] += c.xUV_B[3 * i + j] * st.x2b[v * 3 + j];
+					x2b_B[v * 3 + j] += c.xUV_B[3 * i + j] * uvv[v][i];
+				}
+		for (int i = 0; i < 3; i++) /* mul_vect_matrix3x3_B, H.h:282-294 */
+			for (int j = 0; j < 3; j++)
+			{
+				x2b_B[3 * j + i] += c.xL_B[i] * shade[j];
+				sc->shade_b[face[j]] += c.xL_B[i] * st.x2b[3 * j + i];
+			}
+	}
+	else
+		for (int i = 0; i < nc; i++)
+			for (int j = 0; j < 3; j++)
+				for (int v = 0; v < 3; v++)
+				{
+					sc->colors_b[(size_t)face[v] * nc + i] += c.xA_B[3 * i + j] * st.x2b[v * 3 + j];
+					x2b_B[v * 3 + j] += attr[v][i] * c.xA_B[3 * i + j];
+				}
+	inv3_adjoint(st.b2x, b2x_B, x2b_B);
+	for (int v = 0; v < 3; v++)
+		for (int d = 0; d < 2; d++)
+			sc->ij_b[face[v] * 2 + d] += b2x_B[3 * d + v];
+}
+
+/* ----------------------------------------------------------------------------------------------- edge passes */
+
+/* One silhouette edge, all eight reference variants:
+ *   forward   rasterize_edge_interpolated H.h:1542-1649        rasterize_edge_textured_gouraud H.h:1782-1907
+ *             rasterize_edge_interpolated_error H.h:2371-2478  rasterize_edge_textured_gouraud_error H.h:2067-2197
+ *   adjoint   ..._B H.h:1652-1779, 1910-2064, 2481-2618, 2200-2368
+ * `image` is the rendered image (blended in place) or, in error mode, the observation (read only). */
+static void do_edge(const OScene *sc, int k, int n, double off, double sigma, double *image, double *z_buffer, double *image_b,
+					int error_mode, double *err_buffer, double *err_buffer_b, int backward)
+{
+	static const int list_sub[3][2] = {{1, 0}, {2, 1}, {0, 2}}; /* H.h:2822 */
+	const unsigned int *face = sc->faces + 3 * k, *face_uv = sc->faces_uv + 3 * k;
+	const int *sub = list_sub[n];
+	const int nc = sc->nb_colors, width = sc->width, persp = sc->perspective_correct;
+	const int textured = sc->textured[k] && sc->shaded[k];
+	const int tex_size[2] = {sc->texture_width, sc->texture_height};
+	double V[2][2], Zv[2], inv_Z[2], shade[2], uvv[2][2];
+	const double *attr[3] = {0, 0, 0};
+	for (int i = 0; i < 2; i++)
+	{
+		V[i][0] = sc->ij[face[sub[i]] * 2] - off;
+		V[i][1] = sc->ij[face[sub[i]] * 2 + 1] - off;
+		Zv[i] = sc->depths[face[sub[i]]];
+		inv_Z[i] = 1 / Zv[i];
+	}
+	double x2b[6], x2t[3], ineq[12], xZ[3], xA[3 * MAXC], xUV[6], xL[3];
+	int y_begin, y_end;
+	edge_stencil(V, sc->height, sigma, sc->clockwise, x2b, x2t, ineq, &y_begin, &y_end);
+	const double T_inc = x2t[0];
+	const double *w = persp ? inv_Z : NULL;
+	scalar_plane(2, persp ? inv_Z : Zv, x2b, xZ);
+	if (textured)
+	{
+		for (int i = 0; i < 2; i++)
+		{
+			shade[i] = sc->shade[face[sub[i]]];
+			uvv[i][0] = sc->uv[face_uv[sub[i]] * 2];
+			uvv[i][1] = sc->uv[face_uv[sub[i]] * 2 + 1];
+			attr[i] = uvv[i];
+		}
+		if (persp)
+		{
+			double sdz[2] = {inv_Z[0] * shade[0], inv_Z[1] * shade[1]};
+			scalar_plane(2, sdz, x2b, xL);
+		}
+		else
+			scalar_plane(2, shade, x2b, xL);
+		attr_planes(2, 2, attr, w, x2b, xUV);
+	}
+	else
+	{
+		for (int i = 0; i < 2; i++)
+			attr[i] = sc->colors + (size_t)face[sub[i]] * nc;
+		attr_planes(nc, 2, attr, w, x2b, xA);
+	}
+	double xA_B[3 * MAXC] = {0}, xUV_B[6] = {0}, xL_B[3] = {0}, x2t_B[3] = {0}, T_inc_B = 0;
+
+	for (int y = y_begin; y <= y_end; y++)
+	{
+		double A0y[MAXC], A0y_B[MAXC], A[MAXC], A_B[MAXC], UV0y[2] = {0, 0}, UV0y_B[2] = {0, 0}, L0y = 0, L0y_B = 0, T0y_B = 0;
+		const double T0y = row0(x2t, y), Z0y = row0(xZ, y);
+		if (textured)
+		{
+			L0y = row0(xL, y);
+			for (int i = 0; i < 2; i++)
+				UV0y[i] = row0(xUV + 3 * i, y);
+		}
+		else
+			for (int kk = 0; kk < nc; kk++)
+			{
+				A0y[kk] = row0(xA + 3 * kk, y);
+				A0y_B[kk] = 0;
+			}
+		int x_begin, x_end;
+		edge_xrange(ineq, width, y, &x_begin, &x_end);
+		int indx = y * width + x_begin;
+		for (int x = x_begin; x <= x_end; x++, indx++)
+		{
+			double Z = Z0y + xZ[0] * x;
+			if (persp)
+				Z = 1 / Z;
+			if (!(Z < z_buffer[indx]))
+				continue;
+			const double T = T0y + T_inc * x;
+			double L = 0, UV[2] = {0, 0}, L_B = 0, T_B = 0;
+			double *px = image + nc * indx;
+			if (textured)
+			{
+				L = L0y + xL[0] * x;
+				for (int kk = 0; kk < 2; kk++)
+					UV[kk] = UV0y[kk] + xUV[3 * kk] * x;
+				if (persp)
+				{
+					L *= Z;
+					for (int kk = 0; kk < 2; kk++)
+						UV[kk] *= Z;
+				}
+				bilinear_sample(A, sc->texture, tex_size, UV, nc);
+			}
+			else
+				for (int kk = 0; kk < nc; kk++)
+				{
+					A[kk] = A0y[kk] + xA[3 * kk] * x;
+					if (persp)
+						A[kk] = A[kk] * Z;
+				}
+			if (error_mode)
+			{
+				double Err = 0;
+				for (int kk = 0; kk < nc; kk++)
+				{
+					double diff = (textured ? A[kk] * L : A[kk]) - px[kk];
+					Err += diff * diff;
+				}
+				if (!backward)
+				{
+					err_buffer[indx] *= T;
+					err_buffer[indx] += (1 - T) * Err;
+					continue;
+				}
+				double Err_B = 0;
+				T_B += -Err * err_buffer_b[indx];
+				Err_B += (1 - T) * err_buffer_b[indx];
+				err_buffer[indx] -= (1 - T) * Err;
+				err_buffer[indx] /= T;
+				T_B += err_buffer_b[indx] * err_buffer[indx];
+				err_buffer_b[indx] *= T;
+				for (int kk = 0; kk < nc; kk++)
+				{
+					double diff = (textured ? A[kk] * L : A[kk]) - px[kk];
+					double diff_B = 2 * diff * Err_B;
+					if (textured)
+					{
+						A_B[kk] = 0;
+						A_B[kk] += diff_B * L;
+						L_B += diff_B * A[kk];
+					}
+					else
+					{
+						A0y_B[kk] += diff_B;
+						xA_B[3 * kk] += x * diff_B;
+					}
+				}
+			}
+			else if (!backward)
+			{
+				for (int kk = 0; kk < nc; kk++)
+				{
+					px[kk] *= T;
+					px[kk] += textured ? (1 - T) * A[kk] * L : (1 - T) * A[kk];
+				}
+				continue;
+			}
+			else
+			{
+				double *g = image_b + nc * indx;
+				for (int kk = 0; kk < nc; kk++)
+				{
+					if (textured)
+					{
+						A_B[kk] = 0;
+						T_B += -g[kk] * A[kk] * L;
+						A_B[kk] += L * (1 - T) * g[kk];
+						L_B += g[kk] * (1 - T) * A[kk];
+						px[kk] = (px[kk] - (1 - T) * A[kk] * L) / T; /* undo the blend */
+						T_B += g[kk] * px[kk];
+						g[kk] *= T;
+					}
+					else
+					{
+						T_B += -g[kk] * A[kk];
+						double a_b = (1 - T) * g[kk];
+						px[kk] = (px[kk] - (1 - T) * A[kk]) / T;
+						T_B += g[kk] * px[kk];
+						g[kk] *= T;
+						A0y_B[kk] += a_b;
+						xA_B[3 * kk] += x * a_b;
+					}
+				}
+			}
+			/* only the adjoint reaches this point */
+			if (textured)
+			{
+				double UV_B[2] = {0, 0};
+				bilinear_sample_adjoint(A_B, sc->texture, sc->texture_b, tex_size, UV, UV_B, nc);
+				for (int kk = 0; kk < 2; kk++)
+				{
+					UV0y_B[kk] += UV_B[kk];
+					xUV_B[3 * kk] += UV_B[kk] * x;
+				}
+				L0y_B += L_B;
+				xL_B[0] += x * L_B;
+			}
+			T0y_B += T_B;
+			T_inc_B += x * T_B;
+		}
+		if (backward)
+		{
+			const double t[3] = {0, (double)y, 1};
+			if (!textured && !(error_mode && g_reference_defects)) /* defect D2: the fold is absent at H.h:2595 */
+				for (int i = 0; i < nc; i++)
+					for (int j = 0; j < 3; j++)
+						xA_B[3 * i + j] += A0y_B[i] * t[j];
+			for (int kk = 0; kk < 3; kk++)
+				x2t_B[kk] += T0y_B * t[kk];
+			if (textured)
+			{
+				for (int i = 0; i < 2; i++)
+					for (int kk = 0; kk < 3; kk++)
+						xUV_B[kk + 3 * i] += UV0y_B[i] * t[kk];
+				for (int i = 0; i < 3; i++)
+					xL_B[i] += L0y_B * t[i];
+			}
+		}
+	}
+	if (!backward)
+		return;
+	double x2b_B[6] = {0}, V_B[2][2];
+	for (int i = 0; i < 2; i++)
+		for (int d = 0; d < 2; d++)
+			V_B[i][d] = sc->ij_b[face[sub[i]] * 2 + d];
+	if (textured)
+	{
+		for (int i = 0; i < 2; i++)
+			for (int j = 0; j < 3; j++)
+				for (int v = 0; v < 2; v++)
+				{
+					sc->uv_b[face_uv[sub[v]] * 2 + i] += xUV_B[3 * i + j] * x2b[v * 3 + j];
+					x2b_B[v * 3 + j] += xUV_B[3 * i + j] * uvv[v][i];
+				}
+		for (int kk = 0; kk < 3; kk++) /* mul_matrix_B(1,2,3,...), H.h:311-333 */
+			for (int j = 0; j < 2; j++)
+			{
+				sc->shade_b[face[sub[j]]] += xL_B[kk] * x2b[j * 3 + kk];
+				x2b_B[j * 3 + kk] += xL_B[kk] * shade[j];
+			}
+	}
+	else
+		for (int i = 0; i < nc; i++)
+			for (int j = 0; j < 3; j++)
+				for (int v = 0; v < 2; v++)
+				{
+					sc->colors_b[(size_t)face[sub[v]] * nc + i] += xA_B[3 * i + j] * x2b[v * 3 + j];
+					x2b_B[v * 3 + j] += attr[v][i] * xA_B[3 * i + j];
+				}
+	x2t_B[0] += T_inc_B;
+	edge_stencil_adjoint(V, V_B, sigma, x2b_B, x2t_B, sc->clockwise);
+	for (int i = 0; i < 2; i++)
+		for (int d = 0; d < 2; d++)
+			sc->ij_b[face[sub[i]] * 2 + d] = V_B[i][d];
+}
+
+/* ---------------------------------------------------------------------------------------------------- drivers */
+
+typedef struct
+{
+	double value;
+	size_t index;
+} SortKey;
+
+typedef struct
+{
+	SortKey *order; /* triangles far -> near */
+	double *area;
+} Prologue;
+
+static int check_scene(const OScene *sc, int with_grads)
+{ /* checkSceneValid, H.h:2664-2715 (messages shortened) */
+	if (!sc->faces || !sc->faces_uv || !sc->depths || !sc->uv || !sc->ij || !sc->shade || !sc->colors || !sc->edgeflags ||
+		!sc->textured || !sc->shaded || !sc->texture)
+	{
+		g_error = "scene array == NULL";
+		return 1;
+	}
+	if (!sc->background_image && !sc->background_color)
+	{
+		g_error = "scene.background == NULL and scene.background_color == NULL";
+		return 1;
+	}
+	if (with_grads && (!sc->uv_b || !sc->ij_b || !sc->shade_b || !sc->colors_b || !sc->texture_b))
+	{
+		g_error = "scene gradient array == NULL";
+		return 1;
+	}
+	if (sc->nb_colors > MAXC)
+	{
+		g_error = "nb_colors > MAXC";
+		return 1;
+	}
+	for (int k = 0; k < sc->nb_triangles * 3; k++)
+	{
+		if (sc->faces[k] >= (unsigned int)sc->nb_vertices)
+		{
+			g_error = "scene.faces value greater than scene.nb_vertices";
+			return 1;
+		}
+		if (sc->faces_uv[k] >= (unsigned int)sc->nb_uv)
+		{
+			g_error = "scene.faces_uv value greater than scene.nb_uv";
+			return 1;
+		}
+	}
+	return 0;
+}
+
+/* The reference sorts with std::sort (H.h:2781, introsort: NOT stable).  Its order for equal keys is an
+ * implementation detail of libstdc++; we use a stable merge sort on (value desc), i.e. equal keys keep index
+ * order.  Scenes with exactly tied depth sums are outside the pinned domain. */
+static void merge_sort_desc(SortKey *a, SortKey *tmp, size_t n)
+{
+	if (n < 2)
+		return;
+	size_t h = n / 2;
+	merge_sort_desc(a, tmp, h);
+	merge_sort_desc(a + h, tmp, n - h);
+	size_t i = 0, j = h, o = 0;
+	while (i < h && j < n)
+		tmp[o++] = (a[j].value > a[i].value) ? a[j++] : a[i++];
+	while (i < h)
+		tmp[o++] = a[i++];
+	while (j < n)
+		tmp[o++] = a[j++];
+	memcpy(a, tmp, n * sizeof *a);
+}
+
+static int prologue(const OScene *sc, Prologue *p)
+{ /* H.h:2746-2781 == 2917-2957 */
+	const int T = sc->nb_triangles;
+	p->order = (SortKey *)malloc((size_t)(T + 1) * sizeof(SortKey) * 2);
+	p->area = (double *)malloc((size_t)(T + 1) * sizeof(double));
+	if (!p->order || !p->area)
+	{
+		g_error = "out of memory";
+		return 1;
+	}
+	for (int k = 0; k < T; k++)
+	{
+		const unsigned int *face = sc->faces + 3 * k;
+		double sum = 0;
+		int front = 1;
+		for (int i = 0; i < 3; i++)
+		{
+			if (sc->depths[face[i]] < 0)
+				front = 0;
+			sum += sc->depths[face[i]];
+		}
+		p->order[k].value = sum;
+		p->order[k].index = (size_t)k;
+		if (front)
+		{
+			double ij[3][2];
+			for (int i = 0; i < 3; i++)
+				for (int j = 0; j < 2; j++)
+					ij[i][j] = sc->ij[face[i] * 2 + j];
+			p->area[k] = signed_area(ij, sc->clockwise);
+		}
+		else
+			p->area[k] = 0;
+	}
+	merge_sort_desc(p->order, p->order + T, (size_t)T);
+	return 0;
+}
+
+static void prologue_free(Prologue *p)
+{
+	free(p->order);
+	free(p->area);
+}
+
+int deodr_oracle_render_scene(const OScene *sc, double *image, double *z_buffer, double sigma, int antialiase_error, double *obs, double *err_buffer)
+{ /* renderScene, H.h:2717-2901 */
+	if (check_scene(sc, 0))
+		return 1;
+	const int npix = sc->height * sc->width, nc = sc->nb_colors;
+	if (sc->background_image)
+		memcpy(image, sc->background_image, (size_t)npix * nc * sizeof(double));
+	else
+		for (int i = 0; i < npix; i++)
+			for (int k = 0; k < nc; k++)
+				image[i * nc + k] = sc->background_color[k];
+	for (int i = 0; i < npix; i++)
+		z_buffer[i] = INFINITY;
+	Prologue p;
+	if (prologue(sc, &p))
+		return 1;
+	const double off = (double)(sc->integer_pixel_centers ? 0.0f : 0.5f);
+	for (int k = 0; k < sc->nb_triangles; k++) /* pass 1, index order, strict Z < z_buffer */
+		if (p.area[k] > 0 || !sc->backface_culling)
+			do_triangle(sc, k, off, image, z_buffer, NULL, 0);
+	if (antialiase_error)
+		for (int i = 0; i < npix; i++)
+		{ /* H.h:2824-2837 */
+			double s = 0;
+			for (int k = 0; k < nc; k++)
+			{
+				double d = image[nc * i + k] - obs[nc * i + k];
+				s += d * d;
+			}
+			err_buffer[i] = s;
+		}
+	if (sigma > 0) /* pass 2: silhouette edges far -> near, H.h:2839-2900 */
+		for (int it = 0; it < sc->nb_triangles; it++)
+		{
+			int k = (int)p.order[it].index;
+			if (!(p.area[k] > 0))
+				continue;
+			for (int n = 0; n < 3; n++)
+				if (sc->edgeflags[n + k * 3])
+					do_edge(sc, k, n, off, sigma, antialiase_error ? obs : image, z_buffer, NULL, antialiase_error, err_buffer, NULL, 0);
+		}
+	prologue_free(&p);
+	return 0;
+}
+
+int deodr_oracle_render_scene_b(const OScene *sc, double *image, double *z_buffer, double *image_b, double sigma, int antialiase_error,
+								double *obs, double *err_buffer, double *err_buffer_b)
+{ /* renderScene_B, H.h:2903-3135 */
+	if (check_scene(sc, 1))
+		return 1;
+	if (!sc->backface_culling)
+	{
+		g_error = "You have to use backface_culling true if you ant to compute gradients";
+		return 1;
+	}
+	if (sc->perspective_correct)
+	{
+		g_error = "backward gradient propagation not supported yet with perspective_correct=True";
+		return 1;
+	}
+	Prologue p;
+	if (prologue(sc, &p))
+		return 1;
+	const int npix = sc->height * sc->width, nc = sc->nb_colors;
+	const double off = (double)(sc->integer_pixel_centers ? 0.0f : 0.5f);
+	if (sigma > 0) /* adjoint of pass 2: near -> far, edges 2..0 (H.h:2961-3052) */
+		for (int it = sc->nb_triangles - 1; it >= 0; it--)
+		{
+			int k = (int)p.order[it].index;
+			if (!(p.area[k] > 0))
+				continue;
+			for (int n = 2; n >= 0; n--)
+				if (sc->edgeflags[n + k * 3])
+					do_edge(sc, k, n, off, sigma, antialiase_error ? obs : image, z_buffer, image_b, antialiase_error, err_buffer, err_buffer_b, 1);
+		}
+	double *own_image_b = NULL;
+	if (antialiase_error)
+	{ /* H.h:3054-3060 */
+		own_image_b = (double *)malloc((size_t)npix * nc * sizeof(double));
+		if (!own_image_b)
+		{
+			g_error = "out of memory";
+			prologue_free(&p);
+			return 1;
+		}
+		for (int i = 0; i < npix; i++)
+			for (int k = 0; k < nc; k++)
+				own_image_b[nc * i + k] = -2 * (obs[nc * i + k] - image[nc * i + k]) * err_buffer_b[i];
+		image_b = own_image_b;
+	}
+	for (int k = sc->nb_triangles - 1; k >= 0; k--) /* adjoint of pass 1 (H.h:3062-3129) */
+		if (p.area[k] > 0)
+			do_triangle(sc, k, off, image, z_buffer, image_b, 1);
+	free(own_image_b);
+	prologue_free(&p);
+	return 0;
+}

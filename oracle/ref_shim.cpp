@@ -10,9 +10,9 @@
 //
 // Built twice by oracle/Makefile:
 //   libdeodr_ref.so          header as shipped
-//   libdeodr_ref_texfix.so   same, with -DDEODR_REF_HEADER pointing at a temp copy where the
-//                            four `=` of bilinear_sample_B (H.h:621-624) are `+=` (SURVEY §0:
-//                            the shipped texture_b is "last pixel wins").
+//   libdeodr_ref_fixed.so    same, with -DDEODR_REF_HEADER pointing at a temp copy with two adjoint
+//                            defects repaired (oracle/Makefile: D1 texture_b overwrite H.h:621-624,
+//                            D2 missing A0y_B fold in rasterize_edge_interpolated_error_B H.h:2595).
 // The header uses SHRT_MAX without including <climits>; the Cython build gets it through
 // Python.h -> <limits.h>.  Same macro, same value.
 #include <climits>
