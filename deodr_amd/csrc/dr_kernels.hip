@@ -1,0 +1,1138 @@
+// deodr_amd/csrc/dr_kernels.hip -- HIP kernels (gfx950 / CDNA4, wave64) and the C ABI of libdeodr_hip.so.
+//
+// Pipeline of one renderScene + renderScene_B (n_views views per launch, blockIdx.y = view):
+//
+//   setup_bin_kernel   1 thread / triangle   cull, depth-sum, stencil + attribute planes in double (dr_prims.h),
+//                                            silhouette-edge records, binning of triangles and edges into 8x8 tiles
+//   raster_fwd_kernel  1 wavefront / tile    lane = pixel.  Pass 1 (z-buffered triangles, winner = min (Z, index)),
+//                                            shading of the winner, pass 2 (ordered edge overdraw) fused in registers;
+//                                            ONE coalesced write of image / z / owner id per pixel
+//   raster_bwd_kernel  1 wavefront / tile    adjoint of pass 2 (reverse order, forward chain replayed from the un-antialiased
+//                                            colour instead of the reference's un-blend by division) then of pass 1;
+//                                            per (tile, primitive): wave reduction of the image moments sum g [x, y, 1],
+//                                            one atomicAdd per moment into the per-primitive accumulators
+//   finalize_kernel    1 thread / triangle   moments -> plane adjoints -> 3x3-inverse adjoint -> vertex gradients
+//
+// No MFMA anywhere: the path is gather / scatter + streaming writes, bound by HBM and by launch latency.
+// The workspace is self-cleaning (tile counters are zeroed by the wave that consumed them, the spill counters by the
+// last block of the forward raster, the moment accumulators by finalize) so a call never needs a memset node.
+#include <hip/hip_runtime.h>
+
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/deodr_hip.h"
+#include "dr_prims.h"
+
+using namespace dr;
+
+namespace
+{
+
+constexpr int TILE = 8;		// 8 x 8 pixels = one wavefront, lane = (y & 7) * 8 + (x & 7)
+constexpr int K_TRI = 32;	// inline triangle slots per tile; more spill to the pool
+constexpr int K_EDGE = 16;	// inline edge slots per tile
+constexpr int CH = 4;		// colour channels kept in registers at a time
+constexpr int MAX_SORTED = 64; // edges of a tile whose blending order is cached in LDS
+
+struct WsHeader // 64 bytes per view at the start of the view's workspace
+{
+	uint32_t tri_spill_count;  // (tile, triangle) pairs pushed to the pool by the current set-up
+	uint32_t tri_spill_saved;  // the same, frozen by the last raster block for the adjoint / status query
+	uint32_t edge_spill_count;
+	uint32_t edge_spill_saved;
+	uint32_t raster_done; // ticket counter of raster_fwd_kernel blocks
+	uint32_t needed_max;  // sticky: largest spill count ever seen (host compares with the capacity)
+	uint32_t pad[10];
+};
+static_assert(sizeof(WsHeader) == 64, "");
+
+struct Layout
+{
+	size_t hdr, tri_rec, tri_planes, tri_acc, edge_rec, edge_planes, edge_acc, tri_cnt, edge_cnt, edge_saved, tri_list, edge_list, tri_pool,
+		edge_pool, face_id, view_bytes;
+	uint32_t tri_pool_cap, edge_pool_cap;
+	int tiles_x, tiles_y, ntiles, P;
+};
+
+size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+Layout make_layout(int T, int H, int W, int C, size_t pool_pairs)
+{
+	Layout L;
+	L.P = planes_per_prim(C);
+	L.tiles_x = (W + TILE - 1) / TILE;
+	L.tiles_y = (H + TILE - 1) / TILE;
+	L.ntiles = L.tiles_x * L.tiles_y;
+	size_t pool = pool_pairs ? pool_pairs : (size_t)4 * T + (size_t)4 * L.ntiles + 4096;
+	if (pool > 0x7fffffffu)
+		pool = 0x7fffffffu;
+	L.tri_pool_cap = L.edge_pool_cap = (uint32_t)pool;
+	size_t o = 0;
+	auto take = [&](size_t bytes) {
+		size_t at = o;
+		o = align256(o + bytes);
+		return at;
+	};
+	L.hdr = take(sizeof(WsHeader));
+	L.tri_rec = take(sizeof(TriRec) * (size_t)T);
+	L.tri_planes = take(sizeof(double) * 3 * L.P * (size_t)T);
+	L.tri_acc = take(sizeof(double) * 3 * L.P * (size_t)T);
+	L.edge_rec = take(sizeof(EdgeRec) * 3 * (size_t)T);
+	L.edge_planes = take(sizeof(double) * 3 * L.P * 3 * (size_t)T);
+	L.edge_acc = take(sizeof(double) * (3 * L.P + 3) * 3 * (size_t)T);
+	L.tri_cnt = take(sizeof(uint32_t) * L.ntiles);
+	L.edge_cnt = take(sizeof(uint32_t) * L.ntiles);
+	L.edge_saved = take(sizeof(uint32_t) * L.ntiles);
+	L.tri_list = take(sizeof(uint32_t) * K_TRI * (size_t)L.ntiles);
+	L.edge_list = take(sizeof(uint32_t) * K_EDGE * (size_t)L.ntiles);
+	L.tri_pool = take(sizeof(uint2) * (size_t)L.tri_pool_cap);
+	L.edge_pool = take(sizeof(uint2) * (size_t)L.edge_pool_cap);
+	L.face_id = take(sizeof(int32_t) * (size_t)H * W);
+	L.view_bytes = o;
+	return L;
+}
+
+struct KParams
+{
+	// scene
+	const uint32_t *faces, *faces_uv;
+	const uint8_t *textured, *shaded, *edgeflags;
+	const void *depths, *ij, *shade, *colors, *uv;
+	const void *texture, *bg_image, *bg_color;
+	void *uv_b, *ij_b, *shade_b, *colors_b, *texture_b;
+	int T, V, Vuv, H, W, C, tex_h, tex_w;
+	int clockwise, culling, strict, persp, vtx_f64;
+	double offset, sigma;
+	// pixel buffers of this call
+	void *image, *zbuf, *err;
+	const void *image_b, *obs, *err_b, *image_in;
+	int aa_err;
+	// workspace
+	char *ws;
+	Layout L;
+};
+
+struct ViewPtrs
+{
+	WsHeader *hdr;
+	TriRec *tri_rec;
+	double *tri_planes, *tri_acc;
+	EdgeRec *edge_rec;
+	double *edge_planes, *edge_acc;
+	uint32_t *tri_cnt, *edge_cnt, *edge_saved, *tri_list, *edge_list;
+	uint2 *tri_pool, *edge_pool;
+	int32_t *face_id;
+};
+
+__device__ __forceinline__ ViewPtrs view_ptrs(const KParams &p, int view)
+{
+	char *b = p.ws + (size_t)view * p.L.view_bytes;
+	ViewPtrs v;
+	v.hdr = (WsHeader *)(b + p.L.hdr);
+	v.tri_rec = (TriRec *)(b + p.L.tri_rec);
+	v.tri_planes = (double *)(b + p.L.tri_planes);
+	v.tri_acc = (double *)(b + p.L.tri_acc);
+	v.edge_rec = (EdgeRec *)(b + p.L.edge_rec);
+	v.edge_planes = (double *)(b + p.L.edge_planes);
+	v.edge_acc = (double *)(b + p.L.edge_acc);
+	v.tri_cnt = (uint32_t *)(b + p.L.tri_cnt);
+	v.edge_cnt = (uint32_t *)(b + p.L.edge_cnt);
+	v.edge_saved = (uint32_t *)(b + p.L.edge_saved);
+	v.tri_list = (uint32_t *)(b + p.L.tri_list);
+	v.edge_list = (uint32_t *)(b + p.L.edge_list);
+	v.tri_pool = (uint2 *)(b + p.L.tri_pool);
+	v.edge_pool = (uint2 *)(b + p.L.edge_pool);
+	v.face_id = (int32_t *)(b + p.L.face_id);
+	return v;
+}
+
+__device__ __forceinline__ SceneView scene_view(const KParams &p, int view)
+{
+	const size_t es = p.vtx_f64 ? 8 : 4;
+	SceneView s;
+	s.faces = p.faces;
+	s.faces_uv = p.faces_uv;
+	s.textured = p.textured;
+	s.shaded = p.shaded;
+	s.edgeflags = p.edgeflags + (size_t)view * 3 * p.T;
+	s.depths = (const char *)p.depths + (size_t)view * p.V * es;
+	s.ij = (const char *)p.ij + (size_t)view * p.V * 2 * es;
+	s.shade = (const char *)p.shade + (size_t)view * p.V * es;
+	s.colors = (const char *)p.colors + (size_t)view * p.V * p.C * es;
+	s.uv = p.uv;
+	s.T = p.T;
+	s.V = p.V;
+	s.Vuv = p.Vuv;
+	s.H = p.H;
+	s.W = p.W;
+	s.C = p.C;
+	s.P = p.L.P;
+	s.tex_h = p.tex_h;
+	s.tex_w = p.tex_w;
+	s.clockwise = p.clockwise;
+	s.culling = p.culling;
+	s.strict = p.strict;
+	s.persp = p.persp;
+	s.vtx_f64 = p.vtx_f64;
+	s.offset = p.offset;
+	s.sigma = p.sigma;
+	return s;
+}
+
+// ------------------------------------------------------------------------------------------------ wave primitives
+
+__device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+	for (int o = 32; o > 0; o >>= 1)
+		v += __shfl_xor(v, o, 64);
+	return v;
+}
+
+__device__ __forceinline__ void atomic_add_f64(double *p, double v) { unsafeAtomicAdd(p, v); }
+
+struct DeviceAdd // accumulate a vertex gradient (the reference's `+=` into scene.*_b)
+{
+	__device__ __forceinline__ void operator()(void *arr, size_t i, bool f64, double v) const
+	{
+		if (v == 0)
+			return;
+		if (f64)
+			unsafeAtomicAdd((double *)arr + i, v);
+		else
+			unsafeAtomicAdd((float *)arr + i, (float)v);
+	}
+};
+
+// XCD-aware block order: the dispatcher sends block b to XCD b % 8; give every XCD one contiguous band of the
+// screen so that neighbouring tiles (which share triangle records) share an L2.  Bijective for any block count.
+__device__ __forceinline__ int xcd_band(int b, int n)
+{
+	int q = n >> 3, r = n & 7, xcd = b & 7, idx = b >> 3;
+	return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
+// ----------------------------------------------------------------------------------------------------- set-up + bin
+
+__device__ __forceinline__ void push_tile(uint32_t *cnt, uint32_t *list, int cap_inline, uint2 *pool, uint32_t pool_cap, uint32_t *spill,
+										  int tile, uint32_t prim)
+{
+	uint32_t slot = atomicAdd(&cnt[tile], 1u);
+	if (slot < (uint32_t)cap_inline)
+		list[(size_t)tile * cap_inline + slot] = prim;
+	else
+	{
+		uint32_t o = atomicAdd(spill, 1u);
+		if (o < pool_cap)
+			pool[o] = make_uint2((uint32_t)tile, prim);
+	}
+}
+
+__global__ __launch_bounds__(256) void setup_bin_kernel(KParams p)
+{
+	const int view = blockIdx.y;
+	const int k = blockIdx.x * blockDim.x + threadIdx.x;
+	if (k >= p.T)
+		return;
+	const SceneView s = scene_view(p, view);
+	const ViewPtrs w = view_ptrs(p, view);
+	TriRec rec;
+	EdgeRec erec[3];
+	setup_triangle(s, k, rec, w.tri_planes + (size_t)k * 3 * s.P, erec, w.edge_planes + (size_t)k * 9 * s.P);
+	w.tri_rec[k] = rec;
+	for (int n = 0; n < 3; n++)
+		w.edge_rec[3 * (size_t)k + n] = erec[n];
+	if (rec.kind != KIND_NONE)
+	{
+		int x0 = rec.x_min < 0 ? 0 : rec.x_min, x1 = rec.x_max > s.W - 1 ? s.W - 1 : rec.x_max;
+		int y0 = rec.y_begin[0] < 0 ? 0 : rec.y_begin[0], y1 = rec.y_end[1] > s.H - 1 ? s.H - 1 : rec.y_end[1];
+		if (x0 <= x1 && y0 <= y1)
+			for (int ty = y0 / TILE; ty <= y1 / TILE; ty++)
+				for (int tx = x0 / TILE; tx <= x1 / TILE; tx++)
+					push_tile(w.tri_cnt, w.tri_list, K_TRI, w.tri_pool, p.L.tri_pool_cap, &w.hdr->tri_spill_count, ty * p.L.tiles_x + tx, (uint32_t)k);
+	}
+	for (int n = 0; n < 3; n++)
+	{
+		const EdgeRec &e = erec[n];
+		if (e.kind == KIND_NONE || e.x_begin > e.x_end || e.y_begin > e.y_end)
+			continue;
+		for (int ty = e.y_begin / TILE; ty <= e.y_end / TILE; ty++)
+			for (int tx = e.x_begin / TILE; tx <= e.x_end / TILE; tx++)
+				push_tile(w.edge_cnt, w.edge_list, K_EDGE, w.edge_pool, p.L.edge_pool_cap, &w.hdr->edge_spill_count, ty * p.L.tiles_x + tx,
+						  (uint32_t)(3 * k + n));
+	}
+}
+
+// ------------------------------------------------------------------------------------------- tile-level edge ordering
+
+// Edges are blended far -> near: descending depth sum of the owning triangle, ties by slot (= 3 * triangle + n), which
+// is the order of the reference's loops (H.h:2841-2853) with a stable sort.  `next_edge` returns the first edge of the
+// tile strictly after (last_key, last_slot) in that order, scanning the inline list and, if the tile spilled, the pool.
+struct EdgeCursor
+{
+	double key;
+	uint32_t slot;
+};
+
+__device__ __forceinline__ bool edge_before(double ka, uint32_t sa, double kb, uint32_t sb) { return ka > kb || (ka == kb && sa < sb); }
+
+__device__ uint32_t next_edge(const ViewPtrs &w, int tile, int nedge, uint32_t spill_n, bool first, EdgeCursor last, bool reverse, int lane,
+							  EdgeCursor &found)
+{
+	// per-lane best candidate
+	double bk = 0;
+	uint32_t bs = 0xffffffffu;
+	auto consider = [&](uint32_t slot) {
+		double key = w.edge_rec[slot].key;
+		bool after = first || (reverse ? edge_before(key, slot, last.key, last.slot) : edge_before(last.key, last.slot, key, slot));
+		if (!after)
+			return;
+		bool better = bs == 0xffffffffu || (reverse ? edge_before(bk, bs, key, slot) : edge_before(key, slot, bk, bs));
+		if (better)
+		{
+			bk = key;
+			bs = slot;
+		}
+	};
+	int n_inline = nedge < K_EDGE ? nedge : K_EDGE;
+	if (lane < n_inline)
+		consider(w.edge_list[(size_t)tile * K_EDGE + lane]);
+	if (nedge > K_EDGE)
+		for (uint32_t i = lane; i < spill_n; i += 64)
+		{
+			uint2 pr = w.edge_pool[i];
+			if ((int)pr.x == tile)
+				consider(pr.y);
+		}
+#pragma unroll
+	for (int o = 32; o > 0; o >>= 1)
+	{
+		double ok = __shfl_xor(bk, o, 64);
+		uint32_t os = (uint32_t)__shfl_xor((int)bs, o, 64);
+		bool take = os != 0xffffffffu && (bs == 0xffffffffu || (reverse ? edge_before(bk, bs, ok, os) : edge_before(ok, os, bk, bs)));
+		if (take)
+		{
+			bk = ok;
+			bs = os;
+		}
+	}
+	found.key = bk;
+	found.slot = bs;
+	return bs;
+}
+
+// per-pixel evaluation of one edge: is the pixel in the sigma band in front of what pass 1 left there?
+__device__ __forceinline__ bool edge_touches(const EdgeRec &e, int x, int y, int W, bool persp, double zbest, bool inb)
+{
+	if (!inb || !edge_covers(e, x, y, W))
+		return false;
+	double Z = plane_at(e.xZ, (double)x, (double)y);
+	if (persp)
+		Z = 1 / Z;
+	return Z < zbest;
+}
+
+template <class PixT>
+__device__ __forceinline__ double edge_channel(const EdgeRec &e, const double *planes, const PixT *texture, const Tap &tap, double L, int c, double x,
+											   double y, bool persp, double Z)
+{
+	if (e.kind == KIND_TEXTURED)
+		return textured_channel(texture, tap, c) * L;
+	return interp_channel(planes, c, x, y, persp, Z);
+}
+
+template <class PixT>
+__device__ __forceinline__ double background_channel(const KParams &p, int view, size_t pix, int c)
+{
+	if (p.bg_image)
+		return (double)((const PixT *)p.bg_image)[((size_t)view * p.H * p.W + pix) * p.C + c];
+	return (double)((const PixT *)p.bg_color)[c];
+}
+
+// ------------------------------------------------------------------------------------------------- forward raster
+
+template <class PixT>
+__global__ __launch_bounds__(256) void raster_fwd_kernel(KParams p)
+{
+	__shared__ volatile uint32_t s_order[4][MAX_SORTED];
+	const int view = blockIdx.y;
+	const int wave = uniform(threadIdx.x >> 6), lane = threadIdx.x & 63;
+	const ViewPtrs w = view_ptrs(p, view);
+	const int strips_x = (p.L.tiles_x + 3) / 4;
+	const int b = xcd_band(blockIdx.x, gridDim.x);
+	const int ty = b / strips_x, tx = (b % strips_x) * 4 + wave;
+	const int W = p.W, H = p.H, C = p.C, P = p.L.P;
+	const bool persp = p.persp, strict = p.strict;
+	const PixT *texture = (const PixT *)p.texture;
+
+	if (tx < p.L.tiles_x)
+	{
+		const int tile = ty * p.L.tiles_x + tx;
+		const int px = tx * TILE + (lane & 7), py = ty * TILE + (lane >> 3);
+		const bool inb = px < W && py < H;
+		const size_t pix = (size_t)py * W + px;
+		const size_t vpix = (size_t)view * H * W + pix;
+		const int ntri = uniform((int)w.tri_cnt[tile]);
+		const int nedge = uniform((int)w.edge_cnt[tile]);
+		if (lane == 0)
+		{ // self-cleaning tile counters; the adjoint finds the edge count in edge_saved
+			w.tri_cnt[tile] = 0;
+			w.edge_cnt[tile] = 0;
+			w.edge_saved[tile] = (uint32_t)nedge;
+		}
+		// ---- pass 1: visibility.  winner = min (Z, triangle index): identical to the reference's index-order loop
+		//      with the strict test Z < z_buffer (H.h:961)
+		double zbest = INFINITY;
+		int kbest = -1;
+		auto try_triangle = [&](int k) {
+			const TriRec &r = w.tri_rec[k];
+			if (inb && tri_covers(r, px, py, W, H, strict))
+			{
+				double Z = plane_at(r.xZ, (double)px, (double)py);
+				if (persp)
+					Z = 1 / Z;
+				if (Z < zbest || (Z == zbest && k < kbest))
+				{
+					zbest = Z;
+					kbest = k;
+				}
+			}
+		};
+		const int n_inline = ntri < K_TRI ? ntri : K_TRI;
+		for (int i = 0; i < n_inline; i++)
+			try_triangle(uniform((int)w.tri_list[(size_t)tile * K_TRI + i]));
+		if (ntri > K_TRI)
+		{ // the tile spilled: pick its pairs out of the pool
+			uint32_t spill_n = w.hdr->tri_spill_count;
+			if (spill_n > p.L.tri_pool_cap)
+				spill_n = p.L.tri_pool_cap;
+			for (uint32_t i0 = 0; i0 < spill_n; i0 += 64)
+			{
+				uint2 pr = (i0 + lane < spill_n) ? w.tri_pool[i0 + lane] : make_uint2(0xffffffffu, 0u);
+				unsigned long long m = __ballot((int)pr.x == tile);
+				while (m)
+				{
+					int l = __ffsll((long long)m) - 1;
+					m &= m - 1;
+					try_triangle(__shfl((int)pr.y, l, 64));
+				}
+			}
+		}
+		// ---- edge order of the tile (shared by all channel chunks)
+		uint32_t edge_spill_n = 0;
+		if (nedge > K_EDGE)
+		{
+			edge_spill_n = w.hdr->edge_spill_count;
+			if (edge_spill_n > p.L.edge_pool_cap)
+				edge_spill_n = p.L.edge_pool_cap;
+		}
+		const bool cached = nedge <= MAX_SORTED;
+		if (nedge > 0 && cached)
+		{
+			EdgeCursor cur = {0, 0};
+			for (int r = 0; r < nedge; r++)
+			{
+				EdgeCursor f;
+				uint32_t slot = next_edge(w, tile, nedge, edge_spill_n, r == 0, cur, false, lane, f);
+				if (lane == 0)
+					s_order[wave][r] = slot;
+				cur = f;
+			}
+			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+			__builtin_amdgcn_wave_barrier();
+		}
+		// owner's kind and planes
+		int kind = KIND_NONE;
+		const double *planes = nullptr;
+		Tap tap;
+		double L = 0, UV[2];
+		if (kbest >= 0)
+		{
+			kind = w.tri_rec[kbest].kind;
+			planes = w.tri_planes + (size_t)kbest * 3 * P;
+			if (kind == KIND_TEXTURED)
+				textured_tap(planes, (double)px, (double)py, persp, zbest, p.tex_w, p.tex_h, C, tap, L, UV);
+		}
+		double err_acc = 0;
+		for (int c0 = 0; c0 < C; c0 += CH)
+		{
+			double col[CH];
+#pragma unroll
+			for (int j = 0; j < CH; j++)
+			{
+				const int c = c0 + j;
+				col[j] = 0;
+				if (c < C && inb)
+				{
+					if (kbest < 0)
+						col[j] = background_channel<PixT>(p, view, pix, c);
+					else if (kind == KIND_TEXTURED)
+						col[j] = textured_channel(texture, tap, c) * L;
+					else
+						col[j] = interp_channel(planes, c, (double)px, (double)py, persp, zbest);
+				}
+			}
+			if (p.aa_err)
+			{ // err_buffer initialisation, H.h:2824-2837 (the image itself stays un-antialiased in this mode)
+#pragma unroll
+				for (int j = 0; j < CH; j++)
+					if (c0 + j < C && inb)
+					{
+						double d = col[j] - (double)((const PixT *)p.obs)[vpix * C + c0 + j];
+						err_acc += d * d;
+					}
+			}
+			else if (nedge > 0)
+			{ // ---- pass 2: discontinuity-edge overdraw, far -> near (H.h:1629-1644, 1865-1904)
+				EdgeCursor cur = {0, 0};
+				for (int r = 0; r < nedge; r++)
+				{
+					uint32_t slot;
+					if (cached)
+						slot = s_order[wave][r];
+					else
+					{
+						EdgeCursor f;
+						slot = next_edge(w, tile, nedge, edge_spill_n, r == 0, cur, false, lane, f);
+						cur = f;
+					}
+					slot = (uint32_t)uniform((int)slot);
+					const EdgeRec &e = w.edge_rec[slot];
+					if (edge_touches(e, px, py, W, persp, zbest, inb))
+					{
+						const double *ep = w.edge_planes + (size_t)slot * 3 * P;
+						double Ze = plane_at(e.xZ, (double)px, (double)py);
+						if (persp)
+							Ze = 1 / Ze;
+						const double Tr = plane_at(e.x2t, (double)px, (double)py);
+						Tap etap;
+						double eL = 0, eUV[2];
+						if (e.kind == KIND_TEXTURED)
+							textured_tap(ep, (double)px, (double)py, persp, Ze, p.tex_w, p.tex_h, C, etap, eL, eUV);
+#pragma unroll
+						for (int j = 0; j < CH; j++)
+							if (c0 + j < C)
+							{
+								double A = edge_channel(e, ep, texture, etap, eL, c0 + j, (double)px, (double)py, persp, Ze);
+								col[j] *= Tr;
+								col[j] += (1 - Tr) * A;
+							}
+					}
+				}
+			}
+			if (p.image && inb)
+			{
+				PixT *out = (PixT *)p.image + vpix * C + c0;
+#pragma unroll
+				for (int j = 0; j < CH; j++)
+					if (c0 + j < C)
+						out[j] = (PixT)col[j];
+			}
+		}
+		if (p.aa_err)
+		{ // edges antialiase the squared residual instead of the image (H.h:2441-2472, 2154-2193)
+			double err = err_acc;
+			EdgeCursor cur = {0, 0};
+			for (int r = 0; r < nedge; r++)
+			{
+				uint32_t slot;
+				if (cached)
+					slot = s_order[wave][r];
+				else
+				{
+					EdgeCursor f;
+					slot = next_edge(w, tile, nedge, edge_spill_n, r == 0, cur, false, lane, f);
+					cur = f;
+				}
+				slot = (uint32_t)uniform((int)slot);
+				const EdgeRec &e = w.edge_rec[slot];
+				if (edge_touches(e, px, py, W, persp, zbest, inb))
+				{
+					const double *ep = w.edge_planes + (size_t)slot * 3 * P;
+					double Ze = plane_at(e.xZ, (double)px, (double)py);
+					if (persp)
+						Ze = 1 / Ze;
+					const double Tr = plane_at(e.x2t, (double)px, (double)py);
+					Tap etap;
+					double eL = 0, eUV[2];
+					if (e.kind == KIND_TEXTURED)
+						textured_tap(ep, (double)px, (double)py, persp, Ze, p.tex_w, p.tex_h, C, etap, eL, eUV);
+					double Err = 0;
+					for (int c = 0; c < C; c++)
+					{
+						double d = edge_channel(e, ep, texture, etap, eL, c, (double)px, (double)py, persp, Ze) - (double)((const PixT *)p.obs)[vpix * C + c];
+						Err += d * d;
+					}
+					err *= Tr;
+					err += (1 - Tr) * Err;
+				}
+			}
+			if (p.err && inb)
+				((PixT *)p.err)[vpix] = (PixT)err;
+		}
+		if (inb)
+		{
+			if (p.zbuf)
+				((PixT *)p.zbuf)[vpix] = (PixT)zbest;
+			w.face_id[pix] = kbest;
+		}
+	}
+	// ---- the last block of the view freezes and resets the spill counters (no memset node per call)
+	__syncthreads();
+	if (threadIdx.x == 0)
+	{
+		uint32_t t = atomicAdd(&w.hdr->raster_done, 1u);
+		if (t == gridDim.x - 1)
+		{
+			uint32_t a = w.hdr->tri_spill_count, bq = w.hdr->edge_spill_count;
+			w.hdr->tri_spill_saved = a;
+			w.hdr->edge_spill_saved = bq;
+			uint32_t m = a > bq ? a : bq;
+			if (m > w.hdr->needed_max)
+				w.hdr->needed_max = m;
+			w.hdr->tri_spill_count = 0;
+			w.hdr->edge_spill_count = 0;
+			w.hdr->raster_done = 0;
+		}
+	}
+}
+
+// ------------------------------------------------------------------------------------------------ backward raster
+
+// adds  sum over the wave of  v * [x, y, 1]  to acc[0..2]
+__device__ __forceinline__ void add_moments(double *acc, double v, double x, double y, int lane)
+{
+	double mx = wave_sum(v * x), my = wave_sum(v * y), m1 = wave_sum(v);
+	if (lane == 0)
+	{
+		if (mx != 0)
+			atomic_add_f64(acc + 0, mx);
+		if (my != 0)
+			atomic_add_f64(acc + 1, my);
+		if (m1 != 0)
+			atomic_add_f64(acc + 2, m1);
+	}
+}
+
+template <class PixT>
+__device__ __forceinline__ void texture_scatter(PixT *texture_b, const Tap &tap, int c, const double wgt[4])
+{
+#pragma unroll
+	for (int q = 0; q < 4; q++)
+		if (wgt[q] != 0)
+			unsafeAtomicAdd(texture_b + tap.idx[q] + c, (PixT)wgt[q]);
+}
+
+template <class PixT>
+__global__ __launch_bounds__(256) void raster_bwd_kernel(KParams p)
+{
+	__shared__ volatile uint32_t s_order[4][MAX_SORTED];
+	const int view = blockIdx.y;
+	const int wave = uniform(threadIdx.x >> 6), lane = threadIdx.x & 63;
+	const ViewPtrs w = view_ptrs(p, view);
+	const int strips_x = (p.L.tiles_x + 3) / 4;
+	const int b = xcd_band(blockIdx.x, gridDim.x);
+	const int ty = b / strips_x, tx = (b % strips_x) * 4 + wave;
+	const int W = p.W, H = p.H, C = p.C, P = p.L.P;
+	const PixT *texture = (const PixT *)p.texture;
+	PixT *texture_b = (PixT *)p.texture_b;
+	if (tx >= p.L.tiles_x)
+		return;
+	const int tile = ty * p.L.tiles_x + tx;
+	const int px = tx * TILE + (lane & 7), py = ty * TILE + (lane >> 3);
+	const bool inb = px < W && py < H;
+	const size_t pix = (size_t)py * W + px;
+	const size_t vpix = (size_t)view * H * W + pix;
+	const double x = px, y = py;
+	const int nedge = uniform((int)w.edge_saved[tile]);
+	const int owner = inb ? w.face_id[pix] : -1;
+	if (__ballot(owner >= 0) == 0 && nedge == 0)
+		return;
+
+	// what pass 1 left at this pixel
+	int kind = KIND_NONE;
+	const double *planes = nullptr;
+	double zown = INFINITY;
+	Tap tap;
+	double L = 0, UV[2] = {0, 0};
+	if (owner >= 0)
+	{
+		const TriRec &r = w.tri_rec[owner];
+		kind = r.kind;
+		planes = w.tri_planes + (size_t)owner * 3 * P;
+		zown = plane_at(r.xZ, x, y);
+		if (kind == KIND_TEXTURED)
+			textured_tap(planes, x, y, false, zown, p.tex_w, p.tex_h, C, tap, L, UV);
+	}
+	auto base_channel = [&](int c) -> double { // un-antialiased colour of the pixel
+		if (owner < 0)
+			return inb ? background_channel<PixT>(p, view, pix, c) : 0.0;
+		if (kind == KIND_TEXTURED)
+			return textured_channel(texture, tap, c) * L;
+		return interp_channel(planes, c, x, y, false, zown);
+	};
+
+	// edge order + which edges touch this pixel
+	uint32_t edge_spill_n = 0;
+	if (nedge > K_EDGE)
+	{
+		edge_spill_n = w.hdr->edge_spill_saved;
+		if (edge_spill_n > p.L.edge_pool_cap)
+			edge_spill_n = p.L.edge_pool_cap;
+	}
+	const bool cached = nedge <= MAX_SORTED;
+	unsigned long long touched = 0;
+	if (nedge > 0 && cached)
+	{
+		EdgeCursor cur = {0, 0};
+		for (int r = 0; r < nedge; r++)
+		{
+			EdgeCursor f;
+			uint32_t slot = next_edge(w, tile, nedge, edge_spill_n, r == 0, cur, false, lane, f);
+			if (lane == 0)
+				s_order[wave][r] = slot;
+			cur = f;
+			if (edge_touches(w.edge_rec[slot], px, py, W, false, zown, inb))
+				touched |= 1ull << r;
+		}
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+		__builtin_amdgcn_wave_barrier();
+	}
+	// r-th edge of the tile in blending order (cached in LDS, or searched when the tile has more than MAX_SORTED edges)
+	auto edge_at = [&](int r) -> uint32_t {
+		if (cached)
+			return (uint32_t)uniform((int)s_order[wave][r]);
+		EdgeCursor cur = {0, 0}, f;
+		uint32_t slot = 0;
+		for (int i = 0; i <= r; i++)
+		{
+			slot = next_edge(w, tile, nedge, edge_spill_n, i == 0, cur, false, lane, f);
+			cur = f;
+		}
+		return (uint32_t)uniform((int)slot);
+	};
+	auto is_touched = [&](int r, uint32_t slot) -> bool {
+		if (cached)
+			return (touched >> r) & 1ull;
+		return edge_touches(w.edge_rec[slot], px, py, W, false, zown, inb);
+	};
+
+	// per-pixel scalar adjoints that sum over channels (textured owner): accumulated across the channel chunks
+	double own_L_B = 0, own_e_B[2] = {0, 0};
+
+	if (!p.aa_err)
+	{
+		for (int c0 = 0; c0 < C; c0 += CH)
+		{
+			double g[CH], base[CH];
+#pragma unroll
+			for (int j = 0; j < CH; j++)
+			{
+				g[j] = (c0 + j < C && inb) ? (double)((const PixT *)p.image_b)[vpix * C + c0 + j] : 0.0;
+				base[j] = 0;
+			}
+			if (nedge > 0)
+			{
+#pragma unroll
+				for (int j = 0; j < CH; j++)
+					if (c0 + j < C)
+						base[j] = base_channel(c0 + j);
+				// adjoint of pass 2: near -> far (H.h:2961-3052); the colour before edge r is obtained by replaying
+				// edges 0..r-1 on the un-antialiased colour (exact; the reference divides by T, H.h:1738)
+				for (int r = nedge - 1; r >= 0; r--)
+				{
+					const uint32_t slot = edge_at(r);
+					const bool hit = is_touched(r, slot);
+					if (__ballot(hit) == 0)
+						continue;
+					const EdgeRec &e = w.edge_rec[slot];
+					const double *ep = w.edge_planes + (size_t)slot * 3 * P;
+					double *eacc = w.edge_acc + (size_t)slot * (3 * P + 3);
+					double prev[CH];
+#pragma unroll
+					for (int j = 0; j < CH; j++)
+						prev[j] = base[j];
+					for (int q = 0; q < r; q++)
+					{
+						const uint32_t sq = edge_at(q);
+						if (!is_touched(q, sq))
+							continue;
+						const EdgeRec &eq = w.edge_rec[sq];
+						const double *qp = w.edge_planes + (size_t)sq * 3 * P;
+						const double Tq = plane_at(eq.x2t, x, y);
+						Tap qtap;
+						double qL = 0, qUV[2];
+						if (eq.kind == KIND_TEXTURED)
+							textured_tap(qp, x, y, false, 0.0, p.tex_w, p.tex_h, C, qtap, qL, qUV);
+#pragma unroll
+						for (int j = 0; j < CH; j++)
+							if (c0 + j < C)
+							{
+								prev[j] *= Tq;
+								prev[j] += (1 - Tq) * edge_channel(eq, qp, texture, qtap, qL, c0 + j, x, y, false, 0.0);
+							}
+					}
+					const double Tr = plane_at(e.x2t, x, y);
+					Tap etap;
+					double eL = 0, eUV[2] = {0, 0};
+					if (e.kind == KIND_TEXTURED && hit)
+						textured_tap(ep, x, y, false, 0.0, p.tex_w, p.tex_h, C, etap, eL, eUV);
+					double T_B = 0, L_B = 0, e_B[2] = {0, 0};
+#pragma unroll
+					for (int j = 0; j < CH; j++)
+					{
+						const int c = c0 + j;
+						if (c >= C)
+							continue;
+						double A_B = 0;
+						if (hit)
+						{
+							if (e.kind == KIND_TEXTURED)
+							{ // H.h:2006-2021
+								const double i00 = ldp(texture, etap.idx[0] + c), i10 = ldp(texture, etap.idx[1] + c);
+								const double i01 = ldp(texture, etap.idx[2] + c), i11 = ldp(texture, etap.idx[3] + c);
+								const double A = bilinear_mix(etap, i00, i10, i01, i11);
+								T_B += g[j] * (prev[j] - A * eL);
+								const double a_b = eL * (1 - Tr) * g[j];
+								L_B += g[j] * (1 - Tr) * A;
+								double wgt[4];
+								bilinear_mix_adjoint(etap, a_b, i00, i10, i01, i11, wgt, e_B);
+								if (texture_b)
+									texture_scatter(texture_b, etap, c, wgt);
+							}
+							else
+							{ // H.h:1726-1746
+								const double A = interp_channel(ep, c, x, y, false, 0.0);
+								T_B += g[j] * (prev[j] - A);
+								A_B = (1 - Tr) * g[j];
+							}
+							g[j] *= Tr;
+						}
+						if (e.kind != KIND_TEXTURED)
+							add_moments(eacc + 3 * c, A_B, x, y, lane);
+					}
+					if (e.kind == KIND_TEXTURED)
+					{
+						add_moments(eacc + 0, (hit && !etap.out[0]) ? e_B[0] : 0.0, x, y, lane);
+						add_moments(eacc + 3, (hit && !etap.out[1]) ? e_B[1] : 0.0, x, y, lane);
+						add_moments(eacc + 6, L_B, x, y, lane);
+					}
+					add_moments(eacc + 3 * P, T_B, x, y, lane);
+				}
+			}
+			// adjoint of pass 1: what is left of g belongs to the triangle that owns the pixel (H.h:1024-1037, 1320-1353)
+			if (kind == KIND_TEXTURED)
+			{
+#pragma unroll
+				for (int j = 0; j < CH; j++)
+				{
+					const int c = c0 + j;
+					if (c >= C)
+						continue;
+					const double i00 = ldp(texture, tap.idx[0] + c), i10 = ldp(texture, tap.idx[1] + c);
+					const double i01 = ldp(texture, tap.idx[2] + c), i11 = ldp(texture, tap.idx[3] + c);
+					const double A = bilinear_mix(tap, i00, i10, i01, i11);
+					own_L_B += g[j] * A;
+					double wgt[4];
+					bilinear_mix_adjoint(tap, g[j] * L, i00, i10, i01, i11, wgt, own_e_B);
+					if (texture_b)
+						texture_scatter(texture_b, tap, c, wgt);
+				}
+			}
+			// segmented wave reduction over the distinct interpolated owners of the tile
+			unsigned long long rem = __ballot(owner >= 0 && kind == KIND_INTERP);
+			while (rem)
+			{
+				const int l = __ffsll((long long)rem) - 1;
+				const int cur = __shfl(owner, l, 64);
+				const bool mine = owner == cur;
+				rem &= ~__ballot(mine);
+				double *acc = w.tri_acc + (size_t)cur * 3 * P;
+#pragma unroll
+				for (int j = 0; j < CH; j++)
+					if (c0 + j < C)
+						add_moments(acc + 3 * (c0 + j), mine ? g[j] : 0.0, x, y, lane);
+			}
+		}
+	}
+	// textured owners: the channel sums are complete, reduce the UV and shade plane adjoints
+	unsigned long long rem = __ballot(owner >= 0 && kind == KIND_TEXTURED);
+	while (rem)
+	{
+		const int l = __ffsll((long long)rem) - 1;
+		const int cur = __shfl(owner, l, 64);
+		const bool mine = owner == cur && kind == KIND_TEXTURED;
+		rem &= ~__ballot(owner == cur);
+		double *acc = w.tri_acc + (size_t)cur * 3 * P;
+		add_moments(acc + 0, (mine && !tap.out[0]) ? own_e_B[0] : 0.0, x, y, lane);
+		add_moments(acc + 3, (mine && !tap.out[1]) ? own_e_B[1] : 0.0, x, y, lane);
+		add_moments(acc + 6, mine ? own_L_B : 0.0, x, y, lane);
+	}
+}
+
+// ------------------------------------------------------------------------------------------------------- finalize
+
+__global__ __launch_bounds__(256) void finalize_kernel(KParams p)
+{
+	const int view = blockIdx.y;
+	const int k = blockIdx.x * blockDim.x + threadIdx.x;
+	if (k >= p.T)
+		return;
+	const SceneView s = scene_view(p, view);
+	const ViewPtrs w = view_ptrs(p, view);
+	const size_t es = p.vtx_f64 ? 8 : 4;
+	GradView g;
+	g.ij_b = (char *)p.ij_b + (size_t)view * p.V * 2 * es;
+	g.colors_b = (char *)p.colors_b + (size_t)view * p.V * p.C * es;
+	g.shade_b = (char *)p.shade_b + (size_t)view * p.V * es;
+	g.uv_b = p.uv_b;
+	const int P = s.P;
+	const TriRec rec = w.tri_rec[k];
+	if (rec.front && rec.kind != KIND_NONE)
+	{
+		double *acc = w.tri_acc + (size_t)k * 3 * P;
+		finalize_triangle(s, g, k, rec, acc, DeviceAdd());
+		for (int i = 0; i < 3 * P; i++)
+			acc[i] = 0; // self-cleaning accumulators
+	}
+	for (int n = 0; n < 3; n++)
+	{
+		const EdgeRec e = w.edge_rec[3 * (size_t)k + n];
+		if (e.kind == KIND_NONE)
+			continue;
+		double *acc = w.edge_acc + (3 * (size_t)k + n) * (3 * P + 3);
+		finalize_edge(s, g, k, n, e, acc, DeviceAdd());
+		for (int i = 0; i < 3 * P + 3; i++)
+			acc[i] = 0;
+	}
+}
+
+// ------------------------------------------------------------------------------------------------------ host side
+
+thread_local char g_error[256] = "";
+
+int fail(const char *msg)
+{
+	snprintf(g_error, sizeof g_error, "%s", msg);
+	return 1;
+}
+
+int check_hip(hipError_t e, const char *what)
+{
+	if (e == hipSuccess)
+		return 0;
+	snprintf(g_error, sizeof g_error, "%s: %s", what, hipGetErrorString(e));
+	return 1;
+}
+
+int fill_params(const DeodrHipScene *sc, double sigma, void *workspace, size_t workspace_bytes, KParams &p, bool backward)
+{
+	if (!sc)
+		return fail("scene == NULL");
+	// the checks of checkSceneValid (H.h:2664-2715) that do not need to read device memory
+	if (!sc->faces || !sc->faces_uv || !sc->depths || !sc->uv || !sc->ij || !sc->shade || !sc->colors || !sc->edgeflags || !sc->textured ||
+		!sc->shaded)
+		return fail("scene array == NULL");
+	if ((sc->background_image == nullptr) == (sc->background_color == nullptr))
+		return fail("exactly one of scene.background_image / scene.background_color must be given");
+	if (sc->nb_triangles < 0 || sc->nb_vertices <= 0 || sc->nb_uv <= 0 || sc->height <= 0 || sc->width <= 0 || sc->n_views <= 0)
+		return fail("invalid scene dimensions");
+	if (sc->nb_colors <= 0 || sc->nb_colors > DEODR_HIP_MAX_COLORS)
+		return fail("nb_colors out of range");
+	if (sc->height > 32767 || sc->width > 32767)
+		return fail("image larger than 32767 pixels (pixel coordinates are 16-bit, as in the reference)");
+	if ((sc->vertex_dtype != DEODR_HIP_F32 && sc->vertex_dtype != DEODR_HIP_F64) || (sc->pixel_dtype != DEODR_HIP_F32 && sc->pixel_dtype != DEODR_HIP_F64))
+		return fail("unknown dtype tag");
+	if (sc->texture && (sc->texture_height < 2 || sc->texture_width < 2))
+		return fail("texture must be at least 2 x 2");
+	if (backward)
+	{
+		if (!sc->backface_culling)
+			return fail("You have to use backface_culling true if you ant to compute gradients"); // H.h:2924
+		if (sc->perspective_correct)
+			return fail("backward gradient propagation not supported yet with perspective_correct=True"); // H.h:810
+		if (!sc->uv_b || !sc->ij_b || !sc->shade_b || !sc->colors_b)
+			return fail("scene gradient array == NULL");
+	}
+	if (!workspace)
+		return fail("workspace == NULL");
+	memset(&p, 0, sizeof p);
+	p.L = make_layout(sc->nb_triangles, sc->height, sc->width, sc->nb_colors, 0);
+	const size_t need = p.L.view_bytes * (size_t)sc->n_views;
+	if (workspace_bytes < need)
+		return fail("workspace too small (see deodr_hip_workspace_bytes)");
+	if (workspace_bytes > need)
+	{ // a larger workspace means a larger spill pool was requested: recover pool_pairs from the size
+		size_t per_view = workspace_bytes / (size_t)sc->n_views;
+		size_t lo = p.L.tri_pool_cap, hi = 0x7fffffffu;
+		while (lo < hi)
+		{
+			size_t mid = lo + (hi - lo + 1) / 2;
+			if (make_layout(sc->nb_triangles, sc->height, sc->width, sc->nb_colors, mid).view_bytes <= per_view)
+				lo = mid;
+			else
+				hi = mid - 1;
+		}
+		p.L = make_layout(sc->nb_triangles, sc->height, sc->width, sc->nb_colors, lo);
+	}
+	p.faces = sc->faces;
+	p.faces_uv = sc->faces_uv;
+	p.textured = sc->textured;
+	p.shaded = sc->shaded;
+	p.edgeflags = sc->edgeflags;
+	p.depths = sc->depths;
+	p.ij = sc->ij;
+	p.shade = sc->shade;
+	p.colors = sc->colors;
+	p.uv = sc->uv;
+	p.texture = sc->texture;
+	p.bg_image = sc->background_image;
+	p.bg_color = sc->background_color;
+	p.uv_b = sc->uv_b;
+	p.ij_b = sc->ij_b;
+	p.shade_b = sc->shade_b;
+	p.colors_b = sc->colors_b;
+	p.texture_b = sc->texture_b;
+	p.T = sc->nb_triangles;
+	p.V = sc->nb_vertices;
+	p.Vuv = sc->nb_uv;
+	p.H = sc->height;
+	p.W = sc->width;
+	p.C = sc->nb_colors;
+	p.tex_h = sc->texture_height;
+	p.tex_w = sc->texture_width;
+	p.clockwise = sc->clockwise != 0;
+	p.culling = sc->backface_culling != 0;
+	p.strict = sc->strict_edge != 0;
+	p.persp = sc->perspective_correct != 0;
+	p.vtx_f64 = sc->vertex_dtype == DEODR_HIP_F64;
+	p.offset = sc->integer_pixel_centers ? 0.0 : 0.5;
+	p.sigma = sigma;
+	p.ws = (char *)workspace;
+	return 0;
+}
+
+int launch_forward(const DeodrHipScene *sc, KParams &p, hipStream_t stream)
+{
+	const int n_views = sc->n_views;
+	if (p.T > 0)
+	{
+		dim3 grid((p.T + 255) / 256, n_views);
+		hipLaunchKernelGGL(setup_bin_kernel, grid, dim3(256), 0, stream, p);
+	}
+	const int strips_x = (p.L.tiles_x + 3) / 4;
+	dim3 grid(strips_x * p.L.tiles_y, n_views);
+	if (sc->pixel_dtype == DEODR_HIP_F64)
+		hipLaunchKernelGGL(raster_fwd_kernel<double>, grid, dim3(256), 0, stream, p);
+	else
+		hipLaunchKernelGGL(raster_fwd_kernel<float>, grid, dim3(256), 0, stream, p);
+	return check_hip(hipGetLastError(), "forward launch");
+}
+
+} // namespace
+
+extern "C" {
+
+int deodr_hip_abi_version(void) { return DEODR_HIP_ABI_VERSION; }
+
+const char *deodr_hip_last_error(void) { return g_error; }
+
+size_t deodr_hip_workspace_bytes(int nb_triangles, int height, int width, int nb_colors, int n_views, size_t pool_pairs)
+{
+	if (nb_triangles < 0 || height <= 0 || width <= 0 || nb_colors <= 0 || n_views <= 0)
+		return 0;
+	return make_layout(nb_triangles, height, width, nb_colors, pool_pairs).view_bytes * (size_t)n_views;
+}
+
+int deodr_hip_render_scene(const DeodrHipScene *sc, void *image, void *z_buffer, double sigma, int antialiase_error, const void *obs,
+						   void *err_buffer, void *workspace, size_t workspace_bytes, void *stream)
+{
+	KParams p;
+	if (fill_params(sc, sigma, workspace, workspace_bytes, p, false))
+		return 1;
+	if (antialiase_error && (!obs || !err_buffer))
+		return fail("antialiase_error needs obs and err_buffer");
+	p.image = image;
+	p.zbuf = z_buffer;
+	p.aa_err = antialiase_error != 0;
+	p.obs = obs;
+	p.err = err_buffer;
+	return launch_forward(sc, p, (hipStream_t)stream);
+}
+
+int deodr_hip_render_scene_b(const DeodrHipScene *sc, const void *image, const void *z_buffer, const void *image_b, double sigma,
+							 int antialiase_error, const void *obs, const void *err_buffer, const void *err_buffer_b, void *workspace,
+							 size_t workspace_bytes, int have_forward_state, void *stream)
+{
+	(void)z_buffer;
+	(void)err_buffer;
+	KParams p;
+	if (fill_params(sc, sigma, workspace, workspace_bytes, p, true))
+		return 1;
+	if (antialiase_error)
+	{
+		if (!obs || !err_buffer_b || !image)
+			return fail("antialiase_error needs image, obs and err_buffer_b");
+		return fail("antialiase_error adjoint: not implemented yet");
+	}
+	else if (!image_b)
+		return fail("image_b == NULL");
+	hipStream_t st = (hipStream_t)stream;
+	if (!have_forward_state)
+	{ // stateless use: rebuild records, tile lists and the owner buffer (no image / z written)
+		KParams f = p;
+		f.image = nullptr;
+		f.zbuf = nullptr;
+		f.aa_err = 0;
+		if (launch_forward(sc, f, st))
+			return 1;
+	}
+	p.image_b = image_b;
+	p.image_in = image;
+	p.obs = obs;
+	p.err_b = err_buffer_b;
+	p.aa_err = antialiase_error != 0;
+	const int strips_x = (p.L.tiles_x + 3) / 4;
+	dim3 grid(strips_x * p.L.tiles_y, sc->n_views);
+	if (sc->pixel_dtype == DEODR_HIP_F64)
+		hipLaunchKernelGGL(raster_bwd_kernel<double>, grid, dim3(256), 0, st, p);
+	else
+		hipLaunchKernelGGL(raster_bwd_kernel<float>, grid, dim3(256), 0, st, p);
+	if (p.T > 0)
+	{
+		dim3 g2((p.T + 255) / 256, sc->n_views);
+		hipLaunchKernelGGL(finalize_kernel, g2, dim3(256), 0, st, p);
+	}
+	return check_hip(hipGetLastError(), "backward launch");
+}
+
+int deodr_hip_workspace_status(const DeodrHipScene *sc, void *workspace, size_t workspace_bytes, void *stream, int *overflowed,
+							   unsigned long long *needed_pairs)
+{
+	KParams p;
+	if (fill_params(sc, 1.0, workspace, workspace_bytes, p, false))
+		return 1;
+	if (check_hip(hipStreamSynchronize((hipStream_t)stream), "status sync"))
+		return 1;
+	unsigned long long worst = 0;
+	for (int v = 0; v < sc->n_views; v++)
+	{
+		WsHeader h;
+		if (check_hip(hipMemcpy(&h, (char *)workspace + (size_t)v * p.L.view_bytes + p.L.hdr, sizeof h, hipMemcpyDeviceToHost), "status copy"))
+			return 1;
+		if (h.needed_max > worst)
+			worst = h.needed_max;
+	}
+	if (needed_pairs)
+		*needed_pairs = worst;
+	if (overflowed)
+		*overflowed = worst > p.L.tri_pool_cap;
+	return 0;
+}
+
+} // extern "C"

@@ -1,0 +1,305 @@
+// deodr_amd/csrc/dr_prims.h -- per-primitive set-up (forward) and finalize (adjoint) of the rasterizer.
+//
+// One call handles ONE triangle (and the up to three silhouette-edge slots it owns) of ONE view: it is the body of
+// one thread of `setup_bin_kernel` / `finalize_kernel` in dr_kernels.hip.  Like dr_math.h the code is
+// `__host__ __device__` so that tests/sim/tile_sim.cpp can run the identical arithmetic sequentially on the CPU.
+//
+// Layout of the per-primitive plane arrays (P = max(nb_colors, 3) planes of 3 doubles each):
+//   KIND_INTERP    plane c          = colour channel c                              (H.h:779-785, 1579-1585)
+//   KIND_TEXTURED  plane 0, 1       = texture coordinates u, v ; plane 2 = shade L  (H.h:1079-1087, 1825-1834)
+// and of the adjoint accumulators filled by the backward raster kernel: the same P planes, each holding the three
+// image moments  sum g [x, y, 1]  of the plane's adjoint; edges carry one more plane (index P) for the transparency T.
+#pragma once
+#include "dr_math.h"
+
+namespace dr
+{
+
+struct SceneView // one view of the scene: plain device (or host, in the simulator) pointers
+{
+	const uint32_t *faces, *faces_uv;
+	const uint8_t *textured, *shaded, *edgeflags;
+	const void *depths, *ij, *shade, *colors, *uv; // vertex dtype
+	int T, V, Vuv, H, W, C, P;
+	int tex_h, tex_w;
+	bool clockwise, culling, strict, persp;
+	bool vtx_f64;
+	double offset; // 0 (integer pixel centres) or 0.5, H.h:2783
+	double sigma;
+};
+
+DR_HD double ldv(const void *p, size_t i, bool f64) { return f64 ? ((const double *)p)[i] : (double)((const float *)p)[i]; }
+
+static const int LIST_SUB[3][2] = {{1, 0}, {2, 1}, {0, 2}}; // H.h:2822: edge n joins vertices LIST_SUB[n]
+
+DR_HD int planes_per_prim(int nb_colors) { return nb_colors < 3 ? 3 : nb_colors; }
+
+// Per-triangle prologue of renderScene / renderScene_B (H.h:2751-2779): depth sum (the far->near sort key of its
+// edges) and signed area (0 when a vertex is behind the camera).
+DR_HD void tri_cull(const SceneView &s, int k, double &sum_depth, double &area)
+{
+	const uint32_t *face = s.faces + 3 * (size_t)k;
+	sum_depth = 0;
+	bool front = true;
+	double V[3][2];
+	for (int i = 0; i < 3; i++)
+	{
+		double d = ldv(s.depths, face[i], s.vtx_f64);
+		if (d < 0)
+			front = false;
+		sum_depth += d;
+		V[i][0] = ldv(s.ij, 2 * (size_t)face[i], s.vtx_f64);
+		V[i][1] = ldv(s.ij, 2 * (size_t)face[i] + 1, s.vtx_f64);
+	}
+	area = front ? signed_area(V, s.clockwise) : 0.0;
+}
+
+// attribute planes of a primitive with nv vertices; vid / uvid are the vertex indices of its corners
+DR_HD void attr_planes(const SceneView &s, int kind, int nv, const uint32_t vid[3], const uint32_t uvid[3], const double Zv[3],
+					   const double *x2b, double *planes)
+{
+	double w[3] = {1, 1, 1};
+	if (s.persp)
+		for (int i = 0; i < nv; i++)
+			w[i] = 1 / Zv[i];
+	if (kind == KIND_TEXTURED)
+	{
+		for (int c = 0; c < 2; c++)
+		{
+			double a[3];
+			for (int i = 0; i < nv; i++)
+			{
+				a[i] = ldv(s.uv, 2 * (size_t)uvid[i] + c, s.vtx_f64);
+				if (s.persp)
+					a[i] = a[i] * w[i];
+			}
+			for (int j = 0; j < 3; j++)
+				planes[3 * c + j] = plane_coef(nv, a, x2b, j);
+		}
+		double a[3];
+		for (int i = 0; i < nv; i++)
+		{
+			a[i] = ldv(s.shade, vid[i], s.vtx_f64);
+			if (s.persp)
+				a[i] = w[i] * a[i];
+		}
+		for (int j = 0; j < 3; j++)
+			planes[6 + j] = plane_coef(nv, a, x2b, j);
+	}
+	else
+		for (int c = 0; c < s.C; c++)
+		{
+			double a[3];
+			for (int i = 0; i < nv; i++)
+			{
+				a[i] = ldv(s.colors, (size_t)vid[i] * s.C + c, s.vtx_f64);
+				if (s.persp)
+					a[i] = a[i] * w[i];
+			}
+			for (int j = 0; j < 3; j++)
+				planes[3 * c + j] = plane_coef(nv, a, x2b, j);
+		}
+}
+
+// Set up triangle k: its record, its attribute planes and its (up to) three silhouette-edge records.
+// Returns through `rec` / `erec[3]`; planes are written straight to the arrays.  Pass-1 kind follows H.h:2785-2819,
+// edge eligibility H.h:2847-2853, edge kind H.h:2868-2895.
+DR_HD void setup_triangle(const SceneView &s, int k, TriRec &rec, double *tri_planes /*[3P]*/, EdgeRec erec[3],
+						  double *edge_planes /*[3][3P]*/)
+{
+	const uint32_t *face = s.faces + 3 * (size_t)k, *face_uv = s.faces_uv + 3 * (size_t)k;
+	double sum_depth, area;
+	tri_cull(s, k, sum_depth, area);
+	const bool tex = s.textured[k] != 0, both = tex && s.shaded[k] != 0;
+	double V[3][2], Zv[3];
+	for (int i = 0; i < 3; i++)
+	{
+		V[i][0] = ldv(s.ij, 2 * (size_t)face[i], s.vtx_f64) - s.offset;
+		V[i][1] = ldv(s.ij, 2 * (size_t)face[i] + 1, s.vtx_f64) - s.offset;
+		Zv[i] = ldv(s.depths, face[i], s.vtx_f64);
+	}
+	double x2b[9];
+	tri_stencil(V, s.strict, rec, x2b);
+	rec.front = area > 0;
+	rec.kind = KIND_NONE;
+	if (area > 0 || !s.culling)
+		rec.kind = both ? KIND_TEXTURED : (tex ? KIND_NONE : KIND_INTERP);
+	{
+		double zz[3];
+		for (int i = 0; i < 3; i++)
+			zz[i] = s.persp ? 1 / Zv[i] : Zv[i];
+		for (int j = 0; j < 3; j++)
+			rec.xZ[j] = plane_coef(3, zz, x2b, j);
+	}
+	if (rec.kind != KIND_NONE)
+		attr_planes(s, rec.kind, 3, face, face_uv, Zv, x2b, tri_planes);
+	for (int n = 0; n < 3; n++)
+	{
+		EdgeRec &e = erec[n];
+		e.kind = KIND_NONE;
+		if (!(s.sigma > 0) || !(area > 0) || !s.edgeflags[3 * (size_t)k + n])
+			continue;
+		const int *sub = LIST_SUB[n];
+		double EV[2][2] = {{V[sub[0]][0], V[sub[0]][1]}, {V[sub[1]][0], V[sub[1]][1]}};
+		double EZ[3] = {Zv[sub[0]], Zv[sub[1]], 0};
+		uint32_t vid[3] = {face[sub[0]], face[sub[1]], 0}, uvid[3] = {face_uv[sub[0]], face_uv[sub[1]], 0};
+		edge_stencil(EV, s.H, s.W, s.sigma, s.clockwise, e);
+		e.kind = both ? KIND_TEXTURED : KIND_INTERP; // textured && !shaded edges are drawn interpolated (H.h:2884)
+		e.key = sum_depth;
+		double zz[2] = {s.persp ? 1 / EZ[0] : EZ[0], s.persp ? 1 / EZ[1] : EZ[1]};
+		for (int j = 0; j < 3; j++)
+			e.xZ[j] = plane_coef(2, zz, e.x2b, j);
+		attr_planes(s, e.kind, 2, vid, uvid, EZ, e.x2b, edge_planes + (size_t)n * 3 * s.P);
+	}
+}
+
+// ------------------------------------------------------------------------------------------------------- finalize
+
+struct GradView // adjoint arrays of one view (vertex dtype), accumulated into
+{
+	void *ij_b, *colors_b, *shade_b, *uv_b;
+};
+
+// `Add` is a functor  add(void* array, size_t index, bool f64, double value)  (atomicAdd on the device)
+template <class Add>
+DR_HD void finalize_triangle(const SceneView &s, const GradView &g, int k, const TriRec &rec, const double *acc /*[3P]*/, Add add)
+{
+	if (!rec.front || rec.kind == KIND_NONE)
+		return; // the adjoint only visits front-facing triangles (H.h:3063) of a drawable kind
+	const uint32_t *face = s.faces + 3 * (size_t)k, *face_uv = s.faces_uv + 3 * (size_t)k;
+	double V[3][2];
+	for (int i = 0; i < 3; i++)
+	{
+		V[i][0] = ldv(s.ij, 2 * (size_t)face[i], s.vtx_f64) - s.offset;
+		V[i][1] = ldv(s.ij, 2 * (size_t)face[i] + 1, s.vtx_f64) - s.offset;
+	}
+	double b2x[9], x2b[9], x2b_B[9], b2x_B[9];
+	bary_frame(V, b2x);
+	inv3(b2x, x2b);
+	for (int i = 0; i < 9; i++)
+		x2b_B[i] = b2x_B[i] = 0;
+	if (rec.kind == KIND_TEXTURED)
+	{ // H.h:1138-1148
+		for (int c = 0; c < 2; c++)
+		{
+			double a[3], a_B[3] = {0, 0, 0};
+			for (int i = 0; i < 3; i++)
+				a[i] = ldv(s.uv, 2 * (size_t)face_uv[i] + c, s.vtx_f64);
+			plane_adjoint(3, acc + 3 * c, a, a_B, x2b, x2b_B);
+			for (int i = 0; i < 3; i++)
+				add(g.uv_b, 2 * (size_t)face_uv[i] + c, s.vtx_f64, a_B[i]);
+		}
+		double a[3], a_B[3] = {0, 0, 0};
+		for (int i = 0; i < 3; i++)
+			a[i] = ldv(s.shade, face[i], s.vtx_f64);
+		plane_adjoint(3, acc + 6, a, a_B, x2b, x2b_B);
+		for (int i = 0; i < 3; i++)
+			add(g.shade_b, face[i], s.vtx_f64, a_B[i]);
+	}
+	else
+		for (int c = 0; c < s.C; c++)
+		{ // H.h:841-851
+			double a[3], a_B[3] = {0, 0, 0};
+			for (int i = 0; i < 3; i++)
+				a[i] = ldv(s.colors, (size_t)face[i] * s.C + c, s.vtx_f64);
+			plane_adjoint(3, acc + 3 * c, a, a_B, x2b, x2b_B);
+			for (int i = 0; i < 3; i++)
+				add(g.colors_b, (size_t)face[i] * s.C + c, s.vtx_f64, a_B[i]);
+		}
+	inv3_adjoint(b2x, b2x_B, x2b_B); // H.h:854-858
+	for (int v = 0; v < 3; v++)
+		for (int d = 0; d < 2; d++)
+			add(g.ij_b, 2 * (size_t)face[v] + d, s.vtx_f64, b2x_B[3 * d + v]);
+}
+
+template <class Add>
+DR_HD void finalize_edge(const SceneView &s, const GradView &g, int k, int n, const EdgeRec &e, const double *acc /*[3P+3]*/, Add add)
+{
+	if (e.kind == KIND_NONE)
+		return;
+	const uint32_t *face = s.faces + 3 * (size_t)k, *face_uv = s.faces_uv + 3 * (size_t)k;
+	const int *sub = LIST_SUB[n];
+	const uint32_t vid[2] = {face[sub[0]], face[sub[1]]}, uvid[2] = {face_uv[sub[0]], face_uv[sub[1]]};
+	double V[2][2];
+	for (int i = 0; i < 2; i++)
+	{
+		V[i][0] = ldv(s.ij, 2 * (size_t)vid[i], s.vtx_f64) - s.offset;
+		V[i][1] = ldv(s.ij, 2 * (size_t)vid[i] + 1, s.vtx_f64) - s.offset;
+	}
+	double x2b_B[6] = {0, 0, 0, 0, 0, 0};
+	if (e.kind == KIND_TEXTURED)
+	{ // H.h:2045-2056
+		for (int c = 0; c < 2; c++)
+		{
+			double a[3], a_B[3] = {0, 0, 0};
+			for (int i = 0; i < 2; i++)
+				a[i] = ldv(s.uv, 2 * (size_t)uvid[i] + c, s.vtx_f64);
+			plane_adjoint(2, acc + 3 * c, a, a_B, e.x2b, x2b_B);
+			for (int i = 0; i < 2; i++)
+				add(g.uv_b, 2 * (size_t)uvid[i] + c, s.vtx_f64, a_B[i]);
+		}
+		double a[3], a_B[3] = {0, 0, 0};
+		for (int i = 0; i < 2; i++)
+			a[i] = ldv(s.shade, vid[i], s.vtx_f64);
+		plane_adjoint(2, acc + 6, a, a_B, e.x2b, x2b_B);
+		for (int i = 0; i < 2; i++)
+			add(g.shade_b, vid[i], s.vtx_f64, a_B[i]);
+	}
+	else
+		for (int c = 0; c < s.C; c++)
+		{ // H.h:1758-1767
+			double a[3], a_B[3] = {0, 0, 0};
+			for (int i = 0; i < 2; i++)
+				a[i] = ldv(s.colors, (size_t)vid[i] * s.C + c, s.vtx_f64);
+			plane_adjoint(2, acc + 3 * c, a, a_B, e.x2b, x2b_B);
+			for (int i = 0; i < 2; i++)
+				add(g.colors_b, (size_t)vid[i] * s.C + c, s.vtx_f64, a_B[i]);
+		}
+	// transparency plane: moments [x, y, 1] -> xy1_to_transp_B (H.h:1754-1755, 1771)
+	const double *x2t_B = acc + 3 * (size_t)s.P;
+	double V_B[2][2] = {{0, 0}, {0, 0}};
+	edge_stencil_adjoint(V, V_B, s.sigma, x2b_B, x2t_B, s.clockwise);
+	for (int i = 0; i < 2; i++)
+		for (int d = 0; d < 2; d++)
+			add(g.ij_b, 2 * (size_t)vid[i] + d, s.vtx_f64, V_B[i][d]);
+}
+
+// ------------------------------------------------------------------------------------------------- per-pixel helpers
+
+// texel fetch as double from a pixel-typed texture
+template <class PixT>
+DR_HD double ldp(const PixT *p, size_t i)
+{
+	return (double)p[i];
+}
+
+// colour channel c of the fragment of a drawn triangle at pixel (x, y); Z is the fragment depth (only used when
+// perspective_correct).  For KIND_TEXTURED the caller prepares the tap once per pixel with `textured_tap`.
+DR_HD double interp_channel(const double *planes, int c, double x, double y, bool persp, double Z)
+{
+	double a = plane_at(planes + 3 * c, x, y);
+	return persp ? a * Z : a;
+}
+
+DR_HD void textured_tap(const double *planes, double x, double y, bool persp, double Z, int tex_w, int tex_h, int nc, Tap &tap, double &L,
+						double UV[2])
+{
+	L = plane_at(planes + 6, x, y);
+	UV[0] = plane_at(planes, x, y);
+	UV[1] = plane_at(planes + 3, x, y);
+	if (persp)
+	{
+		L = L * Z;
+		UV[0] = UV[0] * Z;
+		UV[1] = UV[1] * Z;
+	}
+	bilinear_tap(tex_w, tex_h, UV[0], UV[1], nc, tap);
+}
+
+template <class PixT>
+DR_HD double textured_channel(const PixT *texture, const Tap &tap, int c)
+{
+	return bilinear_mix(tap, ldp(texture, tap.idx[0] + c), ldp(texture, tap.idx[1] + c), ldp(texture, tap.idx[2] + c), ldp(texture, tap.idx[3] + c));
+}
+
+} // namespace dr

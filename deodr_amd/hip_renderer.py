@@ -1,0 +1,322 @@
+"""Host side of the HIP rasterizer: ctypes binding of ``libdeodr_hip.so`` (C ABI in ``include/deodr_hip.h``).
+
+Two levels, both without any CPU fallback (a missing library or a missing GPU raises):
+
+* :class:`DeviceScene` + :class:`HipRasterizer` -- the device-resident path: PyTorch-ROCm tensors in, PyTorch-ROCm tensors
+  out, nothing crosses PCIe, calls are asynchronous on the current torch stream, ``n_views`` views per launch.
+* :func:`renderSceneCpp` / :func:`renderSceneBCpp` -- drop-in replacements of the reference's Cython entry points
+  (deodr/differentiable_renderer_cython.pyx:50-57 and :206-215): duck-typed ``scene`` with NumPy (or CPU torch) arrays,
+  caller-owned float64 output buffers written in place, ``scene.*_b`` rebound to ``old + new`` (pyx:406-410).  They copy to
+  the GPU, run the same kernels with float64 storage and copy back; the call is complete on return.
+
+torch is used for device memory and streams only.
+"""
+
+import ctypes as C
+import os
+
+import numpy as np
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libdeodr_hip.so")
+ABI_VERSION = 1
+
+
+class _SceneC(C.Structure):
+    _fields_ = (
+        [(n, C.c_void_p) for n in ("faces", "faces_uv", "textured", "shaded", "depths", "ij", "shade", "colors", "edgeflags", "uv")]
+        + [(n, C.c_void_p) for n in ("texture", "background_image", "background_color")]
+        + [(n, C.c_void_p) for n in ("uv_b", "ij_b", "shade_b", "colors_b", "texture_b")]
+        + [(n, C.c_int) for n in ("nb_triangles", "nb_vertices", "nb_uv", "height", "width", "nb_colors", "texture_height", "texture_width")]
+        + [(n, C.c_int) for n in ("clockwise", "backface_culling", "strict_edge", "perspective_correct", "integer_pixel_centers")]
+        + [(n, C.c_int) for n in ("n_views", "vertex_dtype", "pixel_dtype")]
+    )
+
+
+_lib = None
+
+
+def lib():
+    """The HIP library; raises (never falls back) when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950). deodr_amd has no CPU fallback."
+            )
+        L = C.CDLL(LIB_PATH)
+        L.deodr_hip_abi_version.restype = C.c_int
+        if L.deodr_hip_abi_version() != ABI_VERSION:
+            raise ImportError("libdeodr_hip.so ABI version mismatch; rebuild it")
+        L.deodr_hip_last_error.restype = C.c_char_p
+        L.deodr_hip_workspace_bytes.restype = C.c_size_t
+        L.deodr_hip_workspace_bytes.argtypes = [C.c_int] * 5 + [C.c_size_t]
+        L.deodr_hip_render_scene.restype = C.c_int
+        L.deodr_hip_render_scene.argtypes = [C.POINTER(_SceneC), C.c_void_p, C.c_void_p, C.c_double, C.c_int, C.c_void_p, C.c_void_p,
+                                             C.c_void_p, C.c_size_t, C.c_void_p]  # fmt: skip
+        L.deodr_hip_render_scene_b.restype = C.c_int
+        L.deodr_hip_render_scene_b.argtypes = [C.POINTER(_SceneC), C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_int, C.c_void_p,
+                                               C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]  # fmt: skip
+        L.deodr_hip_workspace_status.restype = C.c_int
+        L.deodr_hip_workspace_status.argtypes = [C.POINTER(_SceneC), C.c_void_p, C.c_size_t, C.c_void_p, C.POINTER(C.c_int),
+                                                 C.POINTER(C.c_ulonglong)]  # fmt: skip
+        _lib = L
+    return _lib
+
+
+def _check(rc):
+    if rc:
+        raise RuntimeError("deodr_hip: " + lib().deodr_hip_last_error().decode())
+
+
+def _ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class DeviceScene:
+    """The arrays of ``struct Scene`` (reference H.h:56-90) as contiguous ROCm tensors, for ``n_views`` views of one mesh.
+
+    Shapes: faces / faces_uv ``[T,3] int32|uint32``; textured / shaded ``[T] uint8|bool``; uv ``[Vuv,2]``;
+    per view (leading dim ``n_views``, optional for one view): ij ``[n,V,2]``, depths ``[n,V]``, colors ``[n,V,C]``,
+    shade ``[n,V]``, edgeflags ``[n,T,3]``; texture ``[Ht,Wt,C]`` or None; background_color ``[C]`` or
+    background_image ``[n,H,W,C]``.  Vertex arrays share one float dtype, pixel arrays another."""
+
+    def __init__(self, faces, faces_uv, textured, shaded, uv, ij, depths, colors, shade, edgeflags, height, width, texture=None,
+                 background_color=None, background_image=None, clockwise=False, backface_culling=True, strict_edge=True,
+                 perspective_correct=False, integer_pixel_centers=True, vertex_dtype=torch.float64, pixel_dtype=torch.float32,
+                 device="cuda"):  # fmt: skip
+        dev = torch.device(device)
+        if dev.type != "cuda":
+            raise RuntimeError("deodr_amd needs a ROCm device; there is no CPU path")
+        self.device, self.vertex_dtype, self.pixel_dtype = dev, vertex_dtype, pixel_dtype
+        as_t = lambda a, dt: torch.as_tensor(np.asarray(a) if not torch.is_tensor(a) else a).to(device=dev, dtype=dt).contiguous()
+        self.faces = as_t(np.asarray(faces).astype(np.int64) if not torch.is_tensor(faces) else faces, torch.int32)
+        self.faces_uv = as_t(np.asarray(faces_uv).astype(np.int64) if not torch.is_tensor(faces_uv) else faces_uv, torch.int32)
+        self.textured = as_t(textured, torch.uint8)
+        self.shaded = as_t(shaded, torch.uint8)
+        self.uv = as_t(uv, vertex_dtype).reshape(-1, 2)
+        self.height, self.width = int(height), int(width)
+        self.flags = dict(clockwise=bool(clockwise), backface_culling=bool(backface_culling), strict_edge=bool(strict_edge),
+                          perspective_correct=bool(perspective_correct), integer_pixel_centers=bool(integer_pixel_centers))  # fmt: skip
+        self.texture = None
+        if texture is not None and np.size(texture) > 0:
+            self.texture = as_t(texture, pixel_dtype)
+        self.background_color = None if background_color is None else as_t(background_color, pixel_dtype).reshape(-1)
+        self.background_image = None if background_image is None else as_t(background_image, pixel_dtype)
+        self.set_views(ij, depths, colors, shade, edgeflags)
+        if self.background_image is not None:
+            self.background_image = self.background_image.reshape(self.n_views, self.height, self.width, self.nb_colors).contiguous()
+
+    def set_views(self, ij=None, depths=None, colors=None, shade=None, edgeflags=None):
+        """Replace per-view arrays (tensors are used as they are when already contiguous on the device)."""
+        dev, vd = self.device, self.vertex_dtype
+        conv = lambda a, dt: (a if torch.is_tensor(a) else torch.as_tensor(np.asarray(a))).to(device=dev, dtype=dt).contiguous()
+        if depths is not None:
+            d = conv(depths, vd)
+            self.depths = d.reshape(1, -1) if d.dim() == 1 else d
+        n, V = self.depths.shape
+        self.n_views = n
+        if ij is not None:
+            self.ij = conv(ij, vd).reshape(n, V, 2)
+        if colors is not None:
+            self.colors = conv(colors, vd).reshape(n, V, -1)
+        if shade is not None:
+            self.shade = conv(shade, vd).reshape(n, V)
+        if edgeflags is not None:
+            self.edgeflags = conv(edgeflags, torch.uint8).reshape(n, -1, 3)
+        self.nb_colors = int(self.colors.shape[2])
+
+    @property
+    def nb_triangles(self):
+        return int(self.faces.shape[0])
+
+    def zero_grads(self):
+        vd, pd, dev = self.vertex_dtype, self.pixel_dtype, self.device
+        g = dict(
+            ij_b=torch.zeros_like(self.ij), colors_b=torch.zeros_like(self.colors), shade_b=torch.zeros_like(self.shade),
+            uv_b=torch.zeros_like(self.uv), texture_b=None if self.texture is None else torch.zeros_like(self.texture),
+        )  # fmt: skip
+        return g
+
+    def c_struct(self, grads=None):
+        s = _SceneC()
+        for name in ("faces", "faces_uv", "textured", "shaded", "depths", "ij", "shade", "colors", "edgeflags", "uv", "texture",
+                     "background_image", "background_color"):  # fmt: skip
+            setattr(s, name, _ptr(getattr(self, name)))
+        if grads is not None:
+            for name in ("uv_b", "ij_b", "shade_b", "colors_b", "texture_b"):
+                setattr(s, name, _ptr(grads[name]))
+        s.nb_triangles, s.nb_vertices, s.nb_uv = self.nb_triangles, int(self.depths.shape[1]), int(self.uv.shape[0])
+        s.height, s.width, s.nb_colors = self.height, self.width, self.nb_colors
+        if self.texture is not None:
+            s.texture_height, s.texture_width = int(self.texture.shape[0]), int(self.texture.shape[1])
+        for k, v in self.flags.items():
+            setattr(s, k, int(v))
+        s.n_views = self.n_views
+        s.vertex_dtype = 1 if self.vertex_dtype == torch.float64 else 0
+        s.pixel_dtype = 1 if self.pixel_dtype == torch.float64 else 0
+        return s
+
+
+class HipRasterizer:
+    """Owns the device workspace of one scene shape and runs renderScene / renderScene_B on it.
+
+    The workspace keeps the forward state (per-primitive records, tile lists, per-pixel owner ids) between
+    :meth:`render` and :meth:`render_backward`, like ``Scene2D.store_backward`` does in the reference (dr.py:618-627)."""
+
+    def __init__(self, nb_triangles, height, width, nb_colors, n_views=1, device="cuda", pool_pairs=0):
+        self.dims = (int(nb_triangles), int(height), int(width), int(nb_colors), int(n_views))
+        self.device = torch.device(device)
+        self._alloc(pool_pairs)
+        self._checked = False
+
+    def _alloc(self, pool_pairs):
+        self.pool_pairs = int(pool_pairs)
+        nbytes = lib().deodr_hip_workspace_bytes(*self.dims, self.pool_pairs)
+        if nbytes == 0:
+            raise ValueError("invalid scene dimensions")
+        self.workspace = torch.zeros(nbytes, dtype=torch.uint8, device=self.device)  # must start zero-filled
+        self.nbytes = nbytes
+
+    @classmethod
+    def for_scene(cls, ds, pool_pairs=0):
+        return cls(ds.nb_triangles, ds.height, ds.width, ds.nb_colors, ds.n_views, ds.device, pool_pairs)
+
+    def render(self, ds, sigma=1.0, antialiase_error=False, obs=None, out=None, check_overflow=None):
+        """-> (image [n,H,W,C], z_buffer [n,H,W][, err_buffer [n,H,W]]) as pixel-dtype device tensors.
+
+        ``check_overflow`` (default: only on the first call) synchronises once to make sure no tile list spilled past the
+        pool; if one did the workspace is regrown and the render repeated."""
+        n, H, W, Cc = ds.n_views, ds.height, ds.width, ds.nb_colors
+        assert (ds.nb_triangles, H, W, Cc, n) == self.dims, "scene shape differs from the workspace shape"
+        pd = ds.pixel_dtype
+        if out is None:
+            image = torch.empty((n, H, W, Cc), dtype=pd, device=ds.device)
+            z = torch.empty((n, H, W), dtype=pd, device=ds.device)
+        else:
+            image, z = out
+        err = obs_t = None
+        if antialiase_error:
+            obs_t = obs.to(device=ds.device, dtype=pd).reshape(n, H, W, Cc).contiguous()
+            err = torch.empty((n, H, W), dtype=pd, device=ds.device)
+        sc = ds.c_struct()
+        while True:
+            _check(lib().deodr_hip_render_scene(C.byref(sc), _ptr(image), _ptr(z), float(sigma), int(antialiase_error), _ptr(obs_t),
+                                                _ptr(err), _ptr(self.workspace), self.nbytes, _stream()))  # fmt: skip
+            if check_overflow is False or (check_overflow is None and self._checked):
+                break
+            over, need = C.c_int(0), C.c_ulonglong(0)
+            _check(lib().deodr_hip_workspace_status(C.byref(sc), _ptr(self.workspace), self.nbytes, _stream(), C.byref(over), C.byref(need)))
+            self._checked = True
+            if not over.value:
+                break
+            self._alloc(max(2 * int(need.value), 1024))  # regrow (zero-filled) and render again
+        self._last = (ds, float(sigma), bool(antialiase_error), obs_t, image, err)
+        return (image, z, err) if antialiase_error else (image, z)
+
+    def render_backward(self, ds, image_b=None, err_buffer_b=None, grads=None, have_forward_state=True):
+        """Adjoint of the last :meth:`render` of ``ds``; returns the dict of gradient tensors (accumulated into ``grads``
+        when given, fresh zeros otherwise).  Nothing passed in is mutated."""
+        last_ds, sigma, aa, obs_t, image, _ = self._last
+        n, H, W, Cc = ds.n_views, ds.height, ds.width, ds.nb_colors
+        pd = ds.pixel_dtype
+        if grads is None:
+            grads = ds.zero_grads()
+        sc = ds.c_struct(grads)
+        ib = eb = None
+        if aa:
+            eb = err_buffer_b.to(device=ds.device, dtype=pd).reshape(n, H, W).contiguous()
+        else:
+            ib = image_b.to(device=ds.device, dtype=pd).reshape(n, H, W, Cc).contiguous()
+        _check(lib().deodr_hip_render_scene_b(C.byref(sc), _ptr(image), None, _ptr(ib), sigma, int(aa), _ptr(obs_t), None, _ptr(eb),
+                                              _ptr(self.workspace), self.nbytes, int(have_forward_state and last_ds is ds), _stream()))  # fmt: skip
+        return grads
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# drop-in NumPy entry points (reference pyx:50-57, 206-215)
+
+
+def _np(a, dtype=None):
+    if torch.is_tensor(a):
+        a = a.detach().cpu().numpy()
+    return np.ascontiguousarray(a, dtype=dtype)
+
+
+_ctx_cache = {}
+
+
+def _device_scene(scene, nb_colors):
+    tex = _np(scene.texture, np.float64)
+    bgi = getattr(scene, "background_image", None)
+    bgc = getattr(scene, "background_color", None)
+    return DeviceScene(
+        faces=_np(scene.faces), faces_uv=_np(scene.faces_uv), textured=_np(scene.textured, np.uint8), shaded=_np(scene.shaded, np.uint8),
+        uv=_np(scene.uv, np.float64), ij=_np(scene.ij, np.float64)[None], depths=_np(scene.depths, np.float64)[None],
+        colors=_np(scene.colors, np.float64).reshape(1, -1, nb_colors), shade=_np(scene.shade, np.float64)[None],
+        edgeflags=_np(scene.edgeflags, np.uint8)[None], height=scene.height, width=scene.width,
+        texture=tex if tex.size else None, background_color=None if bgc is None else _np(bgc, np.float64),
+        background_image=None if bgi is None else _np(bgi, np.float64)[None], clockwise=scene.clockwise,
+        backface_culling=scene.backface_culling, strict_edge=scene.strict_edge, perspective_correct=scene.perspective_correct,
+        integer_pixel_centers=scene.integer_pixel_centers, vertex_dtype=torch.float64, pixel_dtype=torch.float64,
+    )  # fmt: skip
+
+
+def _rasterizer_for(ds):
+    key = (ds.nb_triangles, ds.height, ds.width, ds.nb_colors)
+    if key not in _ctx_cache:
+        if len(_ctx_cache) > 8:
+            _ctx_cache.clear()
+        _ctx_cache[key] = HipRasterizer.for_scene(ds)
+    return _ctx_cache[key]
+
+
+def renderSceneCpp(scene, sigma, image, z_buffer, antialiase_error=False, obs=None, err_buffer=None, check_valid=True):
+    """Same contract as the reference's Cython ``renderSceneCpp``: fills ``image`` / ``z_buffer`` (/ ``err_buffer``) in place."""
+    if check_valid:
+        from .differentiable_renderer import check_scene
+
+        check_scene(scene, image, z_buffer, False, None, antialiase_error, obs, err_buffer)
+    ds = _device_scene(scene, image.shape[2])
+    r = _rasterizer_for(ds)
+    out = r.render(ds, sigma, bool(antialiase_error), None if obs is None else torch.as_tensor(_np(obs, np.float64)), check_overflow=True)
+    image[...] = out[0][0].cpu().numpy()
+    z_buffer[...] = out[1][0].cpu().numpy()
+    if antialiase_error:
+        err_buffer[...] = out[2][0].cpu().numpy()
+
+
+def renderSceneBCpp(scene, sigma, image, z_buffer, image_b=None, antialiase_error=False, obs=None, err_buffer=None, err_buffer_b=None,
+                    check_valid=True):  # fmt: skip
+    """Same contract as the reference's Cython ``renderSceneBCpp``: ``scene.{uv,ij,shade,colors,texture}_b`` are rebound to
+    ``old + new`` (pyx:406-410).  Stateless like the reference: the forward state is recomputed on the device.  The
+    reference's in-place side effects on ``image`` / ``image_b`` / ``err_buffer`` are NOT reproduced."""
+    if check_valid:
+        from .differentiable_renderer import check_scene
+
+        check_scene(scene, image, z_buffer, True, image_b, antialiase_error, obs, err_buffer)
+    if scene.perspective_correct:
+        raise RuntimeError("backward gradient propagation not supported yet with perspective_correct=True")
+    nb_colors = image.shape[2]
+    ds = _device_scene(scene, nb_colors)
+    r = _rasterizer_for(ds)
+    dev = ds.device
+    img_t = torch.as_tensor(_np(image, np.float64)).to(dev)[None]
+    obs_t = None if obs is None else torch.as_tensor(_np(obs, np.float64)).to(dev)[None].contiguous()
+    r._last = (ds, float(sigma), bool(antialiase_error), obs_t, img_t, None)
+    if antialiase_error:
+        g = r.render_backward(ds, err_buffer_b=torch.as_tensor(_np(err_buffer_b, np.float64)), have_forward_state=False)
+    else:
+        g = r.render_backward(ds, image_b=torch.as_tensor(_np(image_b, np.float64)), have_forward_state=False)
+    for name in ("uv_b", "ij_b", "shade_b", "colors_b", "texture_b"):
+        new = g[name]
+        old = getattr(scene, name, None)
+        if new is None or old is None or np.size(old) == 0:
+            continue
+        setattr(scene, name, _np(old, np.float64) + new.cpu().numpy().reshape(np.shape(old)))

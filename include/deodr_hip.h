@@ -1,0 +1,117 @@
+/* include/deodr_hip.h -- C ABI of libdeodr_hip.so, the MI355X (gfx950) implementation of DEODR's rasterizer hot path.
+ *
+ * Drop-in boundary.  The two compute entry points replace, argument for argument, the two
+ * functions the reference's FFI shim binds:
+ *
+ *   deodr_hip_render_scene     <->  void renderScene  (Scene, double* image, double* z_buffer, double sigma,
+ *                                                      bool antialiaseError, double* obs, double* err_buffer)
+ *                                   /root/reference/C++/DifferentiableRenderer.h:2717, bound at
+ *                                   deodr/differentiable_renderer_cython.pyx:44 and called at pyx:202
+ *   deodr_hip_render_scene_b   <->  void renderScene_B(Scene, double* image, double* z_buffer, double* image_b,
+ *                                                      double sigma, bool antialiaseError, double* obs,
+ *                                                      double* err_buffer, double* err_buffer_b)
+ *                                   DifferentiableRenderer.h:2903, bound at pyx:45 and called at pyx:405
+ *   DeodrHipScene              <->  struct Scene, DifferentiableRenderer.h:56-90 (same fields, same meaning; pointers are
+ *                                   DEVICE pointers, `bool` flags are int, plus dtype tags and a view count)
+ *
+ * Differences from the reference interface, all forced by the device:
+ *   - every array pointer is a device pointer (HBM); nothing is copied to or from the host by this library;
+ *   - the caller passes a `stream` (hipStream_t as void*) and a device workspace (size from deodr_hip_workspace_bytes);
+ *     calls are asynchronous on that stream and never allocate;
+ *   - errors are returned (0 = ok), never thrown (the reference's `throw "literal"` terminates the process through the
+ *     Cython shim); deodr_hip_last_error() gives the message;
+ *   - the adjoint never mutates `image` / `image_b` / `err_buffer` / `err_buffer_b` (the reference un-antialiases
+ *     `image` in place and scales `image_b`, H.h:1738-1742); gradients are ACCUMULATED into the *_b arrays exactly as
+ *     the reference does (H.h:2982, 3048, 3073, 3128);
+ *   - `n_views` independent views of the same mesh (same faces / uv / texture, per-view ij / depths / colors / shade /
+ *     edgeflags) are rasterized by one call: the natural batch axis of the path (deodr/mesh_fitter.py:536-546).
+ *
+ * Floating-point layout: "vertex" arrays (depths, uv, ij, shade, colors and their adjoints) share `vertex_dtype`;
+ * "pixel" arrays (image, z_buffer, image_b, obs, err_buffer(_b), texture(_b), background_*) share `pixel_dtype`.
+ * All arithmetic is done in double precision whatever the storage type.
+ */
+#ifndef DEODR_HIP_H
+#define DEODR_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DEODR_HIP_F32 0
+#define DEODR_HIP_F64 1
+
+#define DEODR_HIP_MAX_COLORS 64
+
+typedef struct DeodrHipScene
+{
+	/* topology, shared by all views */
+	const uint32_t *faces;	  /* [T,3] */
+	const uint32_t *faces_uv; /* [T,3] */
+	const uint8_t *textured;  /* [T] */
+	const uint8_t *shaded;	  /* [T] */
+	/* per-view vertex attributes, dense [n_views, ...], dtype = vertex_dtype */
+	const void *depths;		  /* [n_views, V] */
+	const void *ij;			  /* [n_views, V, 2]  ij[:,0] = x (column), ij[:,1] = y (row) */
+	const void *shade;		  /* [n_views, V] */
+	const void *colors;		  /* [n_views, V, C] */
+	const uint8_t *edgeflags; /* [n_views, T, 3] */
+	const void *uv;			  /* [Vuv, 2] shared */
+	/* pixel-typed inputs */
+	const void *texture;		  /* [Ht, Wt, C] or NULL when no triangle is textured */
+	const void *background_image; /* [n_views, H, W, C] or NULL */
+	const void *background_color; /* [C] (device) or NULL; exactly one of the two backgrounds is given */
+	/* adjoints (only read by deodr_hip_render_scene_b; accumulated into) */
+	void *uv_b;		 /* [Vuv, 2]          vertex_dtype, summed over views */
+	void *ij_b;		 /* [n_views, V, 2]   vertex_dtype */
+	void *shade_b;	 /* [n_views, V]      vertex_dtype */
+	void *colors_b;	 /* [n_views, V, C]   vertex_dtype */
+	void *texture_b; /* [Ht, Wt, C]       pixel_dtype, summed over views; may be NULL when texture is NULL */
+	int nb_triangles, nb_vertices, nb_uv;
+	int height, width, nb_colors;
+	int texture_height, texture_width;
+	int clockwise, backface_culling, strict_edge, perspective_correct, integer_pixel_centers;
+	int n_views;
+	int vertex_dtype; /* DEODR_HIP_F32 / DEODR_HIP_F64 */
+	int pixel_dtype;  /* DEODR_HIP_F32 / DEODR_HIP_F64 */
+} DeodrHipScene;
+
+/* Size in bytes of the device workspace for a scene of these dimensions.  `pool_pairs` bounds the number of
+ * (tile, primitive) pairs that spill out of the fixed per-tile lists (0 = default heuristic).  The workspace carries
+ * the forward state (per-primitive records, tile lists, the per-pixel owner buffer) that the adjoint reuses; it must be
+ * zero-filled once after allocation (hipMemset) and then belongs to one scene stream of calls. */
+size_t deodr_hip_workspace_bytes(int nb_triangles, int height, int width, int nb_colors, int n_views, size_t pool_pairs);
+
+/* renderScene.  image [n_views,H,W,C], z_buffer [n_views,H,W]; with antialiase_error: obs [n_views,H,W,C] (read) and
+ * err_buffer [n_views,H,W] (written).  image / z_buffer may be NULL to compute only the forward state. */
+int deodr_hip_render_scene(const DeodrHipScene *scene, void *image, void *z_buffer, double sigma, int antialiase_error,
+						   const void *obs, void *err_buffer, void *workspace, size_t workspace_bytes, void *stream);
+
+/* renderScene_B.  Requires backface_culling and !perspective_correct like the reference (H.h:2922, 810).
+ * have_forward_state != 0: the workspace still holds the state of the matching deodr_hip_render_scene call (same scene
+ * arrays, same sigma) and is reused; 0: the forward state is recomputed first (stateless use, as the reference). */
+int deodr_hip_render_scene_b(const DeodrHipScene *scene, const void *image, const void *z_buffer, const void *image_b,
+							 double sigma, int antialiase_error, const void *obs, const void *err_buffer,
+							 const void *err_buffer_b, void *workspace, size_t workspace_bytes, int have_forward_state,
+							 void *stream);
+
+/* Synchronises `stream` and reports whether any forward since the workspace was zero-filled overflowed the spill pool
+ * (then that result was incomplete and the call must be repeated with a workspace sized for a larger `pool_pairs`):
+ * *needed_pairs receives the largest number of spilled pairs seen in any view.  Costs a device synchronisation: call it
+ * once after the first render of a scene (or after a batch of renders), not per frame. */
+int deodr_hip_workspace_status(const DeodrHipScene *scene, void *workspace, size_t workspace_bytes, void *stream, int *overflowed,
+							   unsigned long long *needed_pairs);
+
+/* Message of the last error returned on this host thread. */
+const char *deodr_hip_last_error(void);
+
+/* ABI version of this header; bumped on any incompatible change. */
+int deodr_hip_abi_version(void);
+#define DEODR_HIP_ABI_VERSION 1
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DEODR_HIP_H */

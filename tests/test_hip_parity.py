@@ -1,0 +1,214 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU checkers on identical Scene2D inputs.
+
+Tolerances are the north star's: forward image / depth within 1e-5, gradients within 1e-4 (relative to the largest
+entry of the reference gradient) with float32 pixel buffers; with float64 pixel buffers the same kernels must agree to
+round-off (1e-9), which shows that the algorithm, not the tolerance, carries the parity.
+
+`texture_b` (defect D1) and the antialiase_error `colors_b` (defect D2) are compared with the REPAIRED reference
+(oracle.ref(fixed=True) / oracle.port(fixed=True)), everything else with the reference as shipped.
+"""
+
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, golden_soup
+from deodr_amd import scenes
+from test_oracle import FLAG_CASES, random_scene
+
+pytestmark = pytest.mark.gpu
+
+F32, F64 = torch.float32, torch.float64
+TOL = {F32: (1e-5, 1e-4), F64: (1e-9, 1e-8)}
+
+
+def checker(api, fixed=False):
+    return api.ref(fixed=fixed) or api.port(fixed=fixed)
+
+
+def compare_forward(api, s, sigma, dt, aa=False, obs=None):
+    from hip_util import hip_render, image_report
+
+    ref = checker(api)
+    out_ref = ref.render(s, sigma, aa, obs)
+    ds, r, out = hip_render(s, sigma, dt, aa, obs)
+    tol_img = TOL[dt][0]
+    err, flipped = image_report(out[0][0], out_ref[0], out[1][0], out_ref[1], tol_img)
+    assert flipped == 0, f"{flipped} pixels changed owner"
+    assert err < tol_img, err
+    zr = out_ref[1]
+    fin = np.isfinite(zr)
+    assert np.array_equal(np.isfinite(out[1][0]), fin)
+    assert np.abs(out[1][0][fin] - zr[fin]).max() < tol_img * max(1.0, np.abs(zr[fin]).max()) if fin.any() else True
+    if aa:
+        assert np.abs(out[2][0] - out_ref[2]).max() < 10 * tol_img * max(1.0, out_ref[2].max())
+    return ds, r, out, out_ref
+
+
+@pytest.mark.parametrize("dt", [F32, F64])
+@pytest.mark.parametrize("case", range(len(FLAG_CASES)))
+@pytest.mark.parametrize("sigma", [0.0, 1.0, 2.5])
+def test_forward_parity_flag_space(oracle_api, case, sigma, dt):
+    s = random_scene(100 + case, **FLAG_CASES[case])
+    if case in (0, 2):
+        s.ij = np.round(s.ij)  # integer vertices exercise every tie of the fill rule
+    obs = np.random.RandomState(5).rand(s.height, s.width, 3)
+    compare_forward(oracle_api, s, sigma, dt)
+    compare_forward(oracle_api, s, sigma, dt, True, obs)
+
+
+def compare_backward(api, s, sigma, dt, seed=7):
+    from hip_util import hip_grads, rel_err
+
+    ds, r, out, out_ref = compare_forward(api, s, sigma, dt)
+    rs = np.random.RandomState(seed)
+    image_b = rs.randn(*out_ref[0].shape)
+    g = hip_grads(ds, r, image_b=image_b)
+    g_ref = checker(api).grads(s, sigma, out_ref[0], out_ref[1], image_b)
+    g_fix = checker(api, fixed=True).grads(s, sigma, out_ref[0], out_ref[1], image_b)
+    tol = TOL[dt][1]
+    for k in ("ij_b", "colors_b", "uv_b", "shade_b"):
+        assert rel_err(g[k][0] if k not in ("uv_b",) else g[k], g_ref[k]) < tol, k
+    if g["texture_b"] is not None and np.size(s.texture):
+        assert rel_err(g["texture_b"], g_fix["texture_b"]) < tol, "texture_b (vs repaired reference, defect D1)"
+    return g, g_ref
+
+
+@pytest.mark.parametrize("dt", [F32, F64])
+@pytest.mark.parametrize("case", [0, 1, 3])
+@pytest.mark.parametrize("sigma", [0.0, 1.0, 2.5])
+def test_backward_parity_flag_space(oracle_api, case, sigma, dt):
+    s = random_scene(200 + case, **FLAG_CASES[case])
+    s.backface_culling = True
+    compare_backward(oracle_api, s, sigma, dt)
+
+
+@pytest.mark.parametrize("clockwise", [0, 1])
+def test_reference_golden_soup(oracle_api, clockwise):
+    """The scene of the reference's own triangle-soup tests (tests/golden/soup30_cw*.npz): image, z and every gradient."""
+    from hip_util import hip_grads, hip_render, rel_err
+
+    gt, d = golden_soup(clockwise, "gt_")
+    target = checker(oracle_api).render(gt, 1)[0]
+    init, _ = golden_soup(clockwise, "init_")
+    ds, r, out = hip_render(init, 1.0, F32)
+    image_ref = checker(oracle_api).render(init, 1)[0]
+    assert np.abs(out[0][0] - image_ref).max() < 1e-5
+    g = hip_grads(ds, r, image_b=2 * (image_ref - target))
+    for k in ("ij_b", "colors_b", "uv_b", "shade_b"):
+        got = g[k] if k == "uv_b" else g[k][0]
+        assert rel_err(got, d["aa0_" + k]) < 1e-4, k  # the arrays the reference's own build produced
+
+
+def test_config1_soup_256(oracle_api):
+    """BASELINE configs[0]: 256x256, 200 flat-colour soup triangles."""
+    s = scenes.soup_scene(n_tri=200, width=256, height=256, seed=2)
+    rs = np.random.RandomState(2)
+    s.ij = s.ij + rs.randn(*s.ij.shape)
+    compare_backward(oracle_api, s, 1.0, F32)
+
+
+def test_config2_hand_textured(oracle_api):
+    """BASELINE configs[1]: 1024x1024 hand mesh, Gouraud + 256x256 texture: uv_b / shade_b / texture_b included."""
+    s = scenes.hand_scene(os.path.join(GOLDEN, "hand_mesh.npz"), size=1024, textured=True)
+    compare_backward(oracle_api, s, 1.0, F32)
+
+
+def test_config3_sphere_20k(oracle_api):
+    """BASELINE configs[2], the roofline config: 1024x1024, 20 000 triangles, RGB + depth channel."""
+    s = scenes.sphere_scene()
+    assert s.faces.shape[0] == 20000 and s.colors.shape[1] == 4
+    compare_backward(oracle_api, s, 1.0, F32)
+
+
+def test_batched_views_equal_single_views(oracle_api):
+    """configs[3] shape: several poses of one mesh in one launch give exactly the per-view results."""
+    from hip_util import hip_grads, hip_render
+
+    path = os.path.join(GOLDEN, "hand_mesh.npz")
+    views = [scenes.hand_scene(path, size=256, angle=a, textured=False) for a in np.linspace(-0.5, 0.5, 4)]
+    ds, r, out = hip_render(views, 1.0, F32)
+    rs = np.random.RandomState(0)
+    image_b = rs.randn(4, 256, 256, 3)
+    g = hip_grads(ds, r, image_b=image_b)
+    for i, v in enumerate(views):
+        ds1, r1, out1 = hip_render(v, 1.0, F32)
+        assert np.array_equal(out1[0][0], out[0][i]) and np.array_equal(out1[1][0], out[1][i])
+        g1 = hip_grads(ds1, r1, image_b=image_b[i])
+        assert np.allclose(g1["ij_b"][0], g["ij_b"][i], rtol=1e-9, atol=1e-9)
+        assert np.allclose(g1["colors_b"][0], g["colors_b"][i], rtol=1e-9, atol=1e-9)
+
+
+def test_spill_pool_regrows(oracle_api):
+    """Many large overlapping triangles overflow the fixed per-tile lists and a deliberately tiny spill pool."""
+    from hip_util import hip_render
+
+    s = scenes.soup_scene(n_tri=300, width=64, height=64, seed=9, min_area=600.0)
+    ref = checker(oracle_api).render(s, 1.0)
+    ds, r, out = hip_render(s, 1.0, F64, pool_pairs=16)
+    assert r.pool_pairs > 16  # regrown
+    assert np.abs(out[0][0] - ref[0]).max() < 1e-9
+
+
+def test_known_answers_pixel_and_texel_centres():
+    """The reference's tests/test_pixel_center_coordinates.py and tests/test_texture_coordinates.py, restated."""
+    from deodr_amd.differentiable_renderer import Scene2D
+
+    height, width, eps = 4, 3, 0.001
+    corners = [(0, 0), (width - 1, 0), (0, height - 1), (width - 1, height - 1)]
+    for integer_pixel_centers in (False, True):
+        off = 0.0 if integer_pixel_centers else 0.5
+        for cx, cy in corners:
+            ij = np.array([[-eps, -eps], [-eps, eps], [eps, -eps]]) + np.array([cx + off, cy + off])
+            sc = Scene2D(
+                ij=ij, faces=np.array([[0, 2, 1]], dtype=np.uint32), faces_uv=np.array([[0, 2, 1]], dtype=np.uint32),
+                uv=np.zeros((3, 2)), texture=np.ones((2, 2, 1)), height=height, width=width, nb_colors=1, background_image=None,
+                background_color=np.array([0.0]), depths=np.array([1.0, 1, 1]), textured=np.array([0], dtype=bool),
+                shade=np.array([1.0, 1, 1]), colors=np.array([[1.0], [1], [1]]), shaded=np.array([0], dtype=bool),
+                edgeflags=np.zeros((1, 3), dtype=bool), strict_edge=False, perspective_correct=True, clockwise=True,
+                integer_pixel_centers=integer_pixel_centers,
+            )  # fmt: skip
+            image, _ = sc.render(sigma=0)
+            expected = np.zeros((height, width, 1))
+            expected[cy, cx, 0] = 1
+            assert np.allclose(expected, image)
+    texture = np.array([[[1, 0, 0], [0, 1, 0]], [[0, 0, 1], [1, 1, 1]]], dtype=np.float64)
+    for clockwise in (False, True):
+        f = np.array([[0, 2, 1]] if clockwise else [[0, 1, 2]], dtype=np.uint32)
+        sc = Scene2D(
+            ij=np.array([[1.0, 1], [1, 15], [15, 1]]), faces=f, faces_uv=f.copy(), uv=np.array([[0.0, 0], [1, 0], [0, 1]]),
+            texture=texture, height=40, width=60, nb_colors=3, background_image=None, background_color=np.zeros(3),
+            depths=np.ones(3), textured=np.array([1], dtype=bool), shade=np.ones(3), colors=np.eye(3),
+            shaded=np.array([1], dtype=bool), edgeflags=np.zeros((1, 3), dtype=bool), strict_edge=False, perspective_correct=True,
+            clockwise=clockwise,
+        )  # fmt: skip
+        image, _ = sc.render(sigma=0)
+        assert np.allclose(image[0, :, :], 0) and np.allclose(image[:, 0, :], 0)
+        assert np.allclose(image[1, 1, :], [1, 0, 0]) and np.allclose(image[15, 1, :], [0, 1, 0]) and np.allclose(image[1, 15, :], [0, 0, 1])
+
+
+def test_dropin_scene2d_matches_reference(oracle_api):
+    """Scene2D.render_compare_and_backward through the NumPy drop-in entry points (stateless adjoint)."""
+    from hip_util import rel_err
+
+    gt, d = golden_soup(0, "gt_")
+    target = checker(oracle_api).render(gt, 1)[0]
+    s, _ = golden_soup(0, "init_")
+    image, z, err_buffer, err = s.render_compare_and_backward(obs=target, sigma=1)
+    assert abs(err - float(d["aa0_loss"])) < 1e-8 * float(d["aa0_loss"])
+    for k in ("ij_b", "colors_b", "uv_b", "shade_b"):
+        assert rel_err(getattr(s, k), d["aa0_" + k]) < 1e-9, k
+
+
+def test_errors_are_returned(oracle_api):
+    from hip_util import device_scene
+    from deodr_amd.hip_renderer import HipRasterizer
+
+    s = random_scene(1, backface_culling=False)
+    ds = device_scene(s)
+    r = HipRasterizer.for_scene(ds)
+    r.render(ds, 1.0)
+    with pytest.raises(RuntimeError, match="backface_culling"):
+        r.render_backward(ds, image_b=torch.zeros(1, s.height, s.width, 3))
