@@ -23,6 +23,9 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <utility>
+#include <vector>
+
 #include "../../include/deodr_hip.h"
 #include "dr_prims.h"
 
@@ -432,6 +435,7 @@ __global__ __launch_bounds__(256) void raster_fwd_kernel(KParams p)
 				edge_spill_n = p.L.edge_pool_cap;
 		}
 		const bool cached = nedge <= MAX_SORTED;
+		int n_sorted = nedge; // edges actually retrievable (fewer than nedge only when the spill pool overflowed)
 		if (nedge > 0 && cached)
 		{
 			EdgeCursor cur = {0, 0};
@@ -439,6 +443,11 @@ __global__ __launch_bounds__(256) void raster_fwd_kernel(KParams p)
 			{
 				EdgeCursor f;
 				uint32_t slot = next_edge(w, tile, nedge, edge_spill_n, r == 0, cur, false, lane, f);
+				if (slot == 0xffffffffu)
+				{
+					n_sorted = r;
+					break;
+				}
 				if (lane == 0)
 					s_order[wave][r] = slot;
 				cur = f;
@@ -490,7 +499,7 @@ __global__ __launch_bounds__(256) void raster_fwd_kernel(KParams p)
 			else if (nedge > 0)
 			{ // ---- pass 2: discontinuity-edge overdraw, far -> near (H.h:1629-1644, 1865-1904)
 				EdgeCursor cur = {0, 0};
-				for (int r = 0; r < nedge; r++)
+				for (int r = 0; r < n_sorted; r++)
 				{
 					uint32_t slot;
 					if (cached)
@@ -502,6 +511,8 @@ __global__ __launch_bounds__(256) void raster_fwd_kernel(KParams p)
 						cur = f;
 					}
 					slot = (uint32_t)uniform((int)slot);
+					if (slot == 0xffffffffu)
+						break;
 					const EdgeRec &e = w.edge_rec[slot];
 					if (edge_touches(e, px, py, W, persp, zbest, inb))
 					{
@@ -538,7 +549,7 @@ __global__ __launch_bounds__(256) void raster_fwd_kernel(KParams p)
 		{ // edges antialiase the squared residual instead of the image (H.h:2441-2472, 2154-2193)
 			double err = err_acc;
 			EdgeCursor cur = {0, 0};
-			for (int r = 0; r < nedge; r++)
+			for (int r = 0; r < n_sorted; r++)
 			{
 				uint32_t slot;
 				if (cached)
@@ -550,6 +561,8 @@ __global__ __launch_bounds__(256) void raster_fwd_kernel(KParams p)
 					cur = f;
 				}
 				slot = (uint32_t)uniform((int)slot);
+				if (slot == 0xffffffffu)
+					break;
 				const EdgeRec &e = w.edge_rec[slot];
 				if (edge_touches(e, px, py, W, persp, zbest, inb))
 				{
@@ -687,6 +700,7 @@ __global__ __launch_bounds__(256) void raster_bwd_kernel(KParams p)
 	}
 	const bool cached = nedge <= MAX_SORTED;
 	unsigned long long touched = 0;
+	int n_sorted = nedge;
 	if (nedge > 0 && cached)
 	{
 		EdgeCursor cur = {0, 0};
@@ -694,6 +708,11 @@ __global__ __launch_bounds__(256) void raster_bwd_kernel(KParams p)
 		{
 			EdgeCursor f;
 			uint32_t slot = next_edge(w, tile, nedge, edge_spill_n, r == 0, cur, false, lane, f);
+			if (slot == 0xffffffffu)
+			{
+				n_sorted = r;
+				break;
+			}
 			if (lane == 0)
 				s_order[wave][r] = slot;
 			cur = f;
@@ -719,13 +738,110 @@ __global__ __launch_bounds__(256) void raster_bwd_kernel(KParams p)
 	auto is_touched = [&](int r, uint32_t slot) -> bool {
 		if (cached)
 			return (touched >> r) & 1ull;
-		return edge_touches(w.edge_rec[slot], px, py, W, false, zown, inb);
+		return slot != 0xffffffffu && edge_touches(w.edge_rec[slot], px, py, W, false, zown, inb);
 	};
 
 	// per-pixel scalar adjoints that sum over channels (textured owner): accumulated across the channel chunks
 	double own_L_B = 0, own_e_B[2] = {0, 0};
 
-	if (!p.aa_err)
+	// ---- antialiase_error mode: the edges blended the squared residual err_buffer, not the image (H.h:2200-2368, 2481-2618)
+	double eb = 0; // running adjoint of err_buffer at this pixel
+	if (p.aa_err)
+	{
+		const PixT *obs = (const PixT *)p.obs + vpix * C;
+		eb = inb ? (double)((const PixT *)p.err_b)[vpix] : 0.0;
+		if (nedge > 0)
+		{
+			double err0 = 0; // residual before any edge: sum_c (image - obs)^2 with the un-antialiased image (H.h:2824-2837)
+			if (inb)
+				for (int c = 0; c < C; c++)
+				{
+					double d = base_channel(c) - (double)obs[c];
+					err0 += d * d;
+				}
+			// squared distance between the colour an edge would paint here and the observation
+			auto edge_err = [&](const EdgeRec &e, const double *ep, const Tap &etap, double eL) -> double {
+				double Err = 0;
+				for (int c = 0; c < C; c++)
+				{
+					double d = edge_channel(e, ep, texture, etap, eL, c, x, y, false, 0.0) - (double)obs[c];
+					Err += d * d;
+				}
+				return Err;
+			};
+			for (int r = n_sorted - 1; r >= 0; r--)
+			{
+				const uint32_t slot = edge_at(r);
+				if (slot == 0xffffffffu)
+					continue;
+				const bool hit = is_touched(r, slot);
+				if (__ballot(hit) == 0)
+					continue;
+				const EdgeRec &e = w.edge_rec[slot];
+				const double *ep = w.edge_planes + (size_t)slot * 3 * P;
+				double *eacc = w.edge_acc + (size_t)slot * (3 * P + 3);
+				double prev = err0; // err_buffer before this edge: replay of the earlier edges
+				for (int q = 0; q < r; q++)
+				{
+					const uint32_t sq = edge_at(q);
+					if (sq == 0xffffffffu || !is_touched(q, sq))
+						continue;
+					const EdgeRec &eq = w.edge_rec[sq];
+					const double *qp = w.edge_planes + (size_t)sq * 3 * P;
+					const double Tq = plane_at(eq.x2t, x, y);
+					Tap qtap;
+					double qL = 0, qUV[2];
+					if (eq.kind == KIND_TEXTURED)
+						textured_tap(qp, x, y, false, 0.0, p.tex_w, p.tex_h, C, qtap, qL, qUV);
+					prev *= Tq;
+					prev += (1 - Tq) * edge_err(eq, qp, qtap, qL);
+				}
+				const double Tr = plane_at(e.x2t, x, y);
+				Tap etap;
+				double eL = 0, eUV[2] = {0, 0};
+				if (e.kind == KIND_TEXTURED && hit)
+					textured_tap(ep, x, y, false, 0.0, p.tex_w, p.tex_h, C, etap, eL, eUV);
+				double T_B = 0, L_B = 0, e_B[2] = {0, 0}, Err_B = 0;
+				if (hit)
+				{
+					const double Err = edge_err(e, ep, etap, eL);
+					T_B = eb * (prev - Err);
+					Err_B = (1 - Tr) * eb;
+					eb *= Tr;
+				}
+				for (int c = 0; c < C; c++)
+				{
+					double A_B = 0;
+					if (hit)
+					{
+						if (e.kind == KIND_TEXTURED)
+						{ // H.h:2315-2326
+							const double i00 = ldp(texture, etap.idx[0] + c), i10 = ldp(texture, etap.idx[1] + c);
+							const double i01 = ldp(texture, etap.idx[2] + c), i11 = ldp(texture, etap.idx[3] + c);
+							const double A = bilinear_mix(etap, i00, i10, i01, i11);
+							const double diff_B = 2 * (A * eL - (double)obs[c]) * Err_B;
+							L_B += diff_B * A;
+							double wgt[4];
+							bilinear_mix_adjoint(etap, diff_B * eL, i00, i10, i01, i11, wgt, e_B);
+							if (texture_b)
+								texture_scatter(texture_b, etap, c, wgt);
+						}
+						else // H.h:2579-2588, with the row fold the reference forgot (defect D2) restored
+							A_B = 2 * (interp_channel(ep, c, x, y, false, 0.0) - (double)obs[c]) * Err_B;
+					}
+					if (e.kind != KIND_TEXTURED)
+						add_moments(eacc + 3 * c, A_B, x, y, lane);
+				}
+				if (e.kind == KIND_TEXTURED)
+				{
+					add_moments(eacc + 0, (hit && !etap.out[0]) ? e_B[0] : 0.0, x, y, lane);
+					add_moments(eacc + 3, (hit && !etap.out[1]) ? e_B[1] : 0.0, x, y, lane);
+					add_moments(eacc + 6, L_B, x, y, lane);
+				}
+				add_moments(eacc + 3 * P, T_B, x, y, lane);
+			}
+		}
+	}
 	{
 		for (int c0 = 0; c0 < C; c0 += CH)
 		{
@@ -733,10 +849,17 @@ __global__ __launch_bounds__(256) void raster_bwd_kernel(KParams p)
 #pragma unroll
 			for (int j = 0; j < CH; j++)
 			{
-				g[j] = (c0 + j < C && inb) ? (double)((const PixT *)p.image_b)[vpix * C + c0 + j] : 0.0;
+				g[j] = 0;
 				base[j] = 0;
+				if (c0 + j < C && inb)
+				{
+					if (p.aa_err) // image_b = -2 (obs - image) err_buffer_b, H.h:3054-3060
+						g[j] = -2 * ((double)((const PixT *)p.obs)[vpix * C + c0 + j] - base_channel(c0 + j)) * eb;
+					else
+						g[j] = (double)((const PixT *)p.image_b)[vpix * C + c0 + j];
+				}
 			}
-			if (nedge > 0)
+			if (nedge > 0 && !p.aa_err)
 			{
 #pragma unroll
 				for (int j = 0; j < CH; j++)
@@ -744,9 +867,11 @@ __global__ __launch_bounds__(256) void raster_bwd_kernel(KParams p)
 						base[j] = base_channel(c0 + j);
 				// adjoint of pass 2: near -> far (H.h:2961-3052); the colour before edge r is obtained by replaying
 				// edges 0..r-1 on the un-antialiased colour (exact; the reference divides by T, H.h:1738)
-				for (int r = nedge - 1; r >= 0; r--)
+				for (int r = n_sorted - 1; r >= 0; r--)
 				{
 					const uint32_t slot = edge_at(r);
+					if (slot == 0xffffffffu)
+						continue; // only when the spill pool overflowed (the host then repeats the call)
 					const bool hit = is_touched(r, slot);
 					if (__ballot(hit) == 0)
 						continue;
@@ -760,7 +885,7 @@ __global__ __launch_bounds__(256) void raster_bwd_kernel(KParams p)
 					for (int q = 0; q < r; q++)
 					{
 						const uint32_t sq = edge_at(q);
-						if (!is_touched(q, sq))
+						if (sq == 0xffffffffu || !is_touched(q, sq))
 							continue;
 						const EdgeRec &eq = w.edge_rec[sq];
 						const double *qp = w.edge_planes + (size_t)sq * 3 * P;
@@ -962,14 +1087,11 @@ int fill_params(const DeodrHipScene *sc, double sigma, void *workspace, size_t w
 	if (!workspace)
 		return fail("workspace == NULL");
 	memset(&p, 0, sizeof p);
-	p.L = make_layout(sc->nb_triangles, sc->height, sc->width, sc->nb_colors, 0);
-	const size_t need = p.L.view_bytes * (size_t)sc->n_views;
-	if (workspace_bytes < need)
-		return fail("workspace too small (see deodr_hip_workspace_bytes)");
-	if (workspace_bytes > need)
-	{ // a larger workspace means a larger spill pool was requested: recover pool_pairs from the size
-		size_t per_view = workspace_bytes / (size_t)sc->n_views;
-		size_t lo = p.L.tri_pool_cap, hi = 0x7fffffffu;
+	{ // the spill-pool capacity is implied by the workspace size: the largest pool_pairs whose layout fits
+		const size_t per_view = workspace_bytes / (size_t)sc->n_views;
+		if (make_layout(sc->nb_triangles, sc->height, sc->width, sc->nb_colors, 1).view_bytes > per_view)
+			return fail("workspace too small (see deodr_hip_workspace_bytes)");
+		size_t lo = 1, hi = 0x7fffffffu;
 		while (lo < hi)
 		{
 			size_t mid = lo + (hi - lo + 1) / 2;
@@ -1017,20 +1139,74 @@ int fill_params(const DeodrHipScene *sc, double sigma, void *workspace, size_t w
 	return 0;
 }
 
+// ---- optional per-kernel timing (bench.py's roofline leg): hipEvents recorded on the launch stream around each kernel
+enum KernelId
+{
+	KID_SETUP = 0,
+	KID_RASTER_FWD = 1,
+	KID_RASTER_BWD = 2,
+	KID_FINALIZE = 3,
+	KID_COUNT = 4
+};
+struct ProfEvent
+{
+	hipEvent_t start, stop;
+	int kid;
+};
+bool g_profile = false;
+std::vector<ProfEvent> g_prof_events;
+std::vector<std::pair<hipEvent_t, hipEvent_t>> g_prof_free;
+
+struct ScopedKernelTimer
+{
+	hipStream_t stream;
+	ProfEvent ev;
+	bool on;
+	ScopedKernelTimer(int kid, hipStream_t st) : stream(st), on(g_profile)
+	{
+		if (!on)
+			return;
+		if (g_prof_free.empty())
+		{
+			(void)hipEventCreate(&ev.start);
+			(void)hipEventCreate(&ev.stop);
+		}
+		else
+		{
+			ev.start = g_prof_free.back().first;
+			ev.stop = g_prof_free.back().second;
+			g_prof_free.pop_back();
+		}
+		ev.kid = kid;
+		(void)hipEventRecord(ev.start, stream);
+	}
+	~ScopedKernelTimer()
+	{
+		if (!on)
+			return;
+		(void)hipEventRecord(ev.stop, stream);
+		g_prof_events.push_back(ev);
+	}
+};
+
 int launch_forward(const DeodrHipScene *sc, KParams &p, hipStream_t stream)
 {
 	const int n_views = sc->n_views;
 	if (p.T > 0)
 	{
 		dim3 grid((p.T + 255) / 256, n_views);
+		ScopedKernelTimer t(KID_SETUP, stream);
 		hipLaunchKernelGGL(setup_bin_kernel, grid, dim3(256), 0, stream, p);
 	}
 	const int strips_x = (p.L.tiles_x + 3) / 4;
 	dim3 grid(strips_x * p.L.tiles_y, n_views);
-	if (sc->pixel_dtype == DEODR_HIP_F64)
-		hipLaunchKernelGGL(raster_fwd_kernel<double>, grid, dim3(256), 0, stream, p);
-	else
-		hipLaunchKernelGGL(raster_fwd_kernel<float>, grid, dim3(256), 0, stream, p);
+	{
+		ScopedKernelTimer t(KID_RASTER_FWD, stream);
+		if (sc->pixel_dtype == DEODR_HIP_F64)
+			hipLaunchKernelGGL(raster_fwd_kernel<double>, grid, dim3(256), 0, stream, p);
+		else
+			hipLaunchKernelGGL(raster_fwd_kernel<float>, grid, dim3(256), 0, stream, p);
+	}
 	return check_hip(hipGetLastError(), "forward launch");
 }
 
@@ -1039,6 +1215,34 @@ int launch_forward(const DeodrHipScene *sc, KParams &p, hipStream_t stream)
 extern "C" {
 
 int deodr_hip_abi_version(void) { return DEODR_HIP_ABI_VERSION; }
+
+int deodr_hip_profile_enable(int on)
+{
+	g_profile = on != 0;
+	return 0;
+}
+
+int deodr_hip_profile_read(double ms_sum[4], unsigned long long launches[4])
+{
+	for (int i = 0; i < KID_COUNT; i++)
+	{
+		ms_sum[i] = 0;
+		launches[i] = 0;
+	}
+	for (ProfEvent &e : g_prof_events)
+	{
+		if (check_hip(hipEventSynchronize(e.stop), "profile sync"))
+			return 1;
+		float ms = 0;
+		if (check_hip(hipEventElapsedTime(&ms, e.start, e.stop), "profile elapsed"))
+			return 1;
+		ms_sum[e.kid] += ms;
+		launches[e.kid] += 1;
+		g_prof_free.push_back({e.start, e.stop});
+	}
+	g_prof_events.clear();
+	return 0;
+}
 
 const char *deodr_hip_last_error(void) { return g_error; }
 
@@ -1076,9 +1280,8 @@ int deodr_hip_render_scene_b(const DeodrHipScene *sc, const void *image, const v
 		return 1;
 	if (antialiase_error)
 	{
-		if (!obs || !err_buffer_b || !image)
-			return fail("antialiase_error needs image, obs and err_buffer_b");
-		return fail("antialiase_error adjoint: not implemented yet");
+		if (!obs || !err_buffer_b)
+			return fail("antialiase_error needs obs and err_buffer_b");
 	}
 	else if (!image_b)
 		return fail("image_b == NULL");
@@ -1099,13 +1302,17 @@ int deodr_hip_render_scene_b(const DeodrHipScene *sc, const void *image, const v
 	p.aa_err = antialiase_error != 0;
 	const int strips_x = (p.L.tiles_x + 3) / 4;
 	dim3 grid(strips_x * p.L.tiles_y, sc->n_views);
-	if (sc->pixel_dtype == DEODR_HIP_F64)
-		hipLaunchKernelGGL(raster_bwd_kernel<double>, grid, dim3(256), 0, st, p);
-	else
-		hipLaunchKernelGGL(raster_bwd_kernel<float>, grid, dim3(256), 0, st, p);
+	{
+		ScopedKernelTimer t(KID_RASTER_BWD, st);
+		if (sc->pixel_dtype == DEODR_HIP_F64)
+			hipLaunchKernelGGL(raster_bwd_kernel<double>, grid, dim3(256), 0, st, p);
+		else
+			hipLaunchKernelGGL(raster_bwd_kernel<float>, grid, dim3(256), 0, st, p);
+	}
 	if (p.T > 0)
 	{
 		dim3 g2((p.T + 255) / 256, sc->n_views);
+		ScopedKernelTimer t(KID_FINALIZE, st);
 		hipLaunchKernelGGL(finalize_kernel, g2, dim3(256), 0, st, p);
 	}
 	return check_hip(hipGetLastError(), "backward launch");

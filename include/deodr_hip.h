@@ -104,6 +104,13 @@ int deodr_hip_render_scene_b(const DeodrHipScene *scene, const void *image, cons
 int deodr_hip_workspace_status(const DeodrHipScene *scene, void *workspace, size_t workspace_bytes, void *stream, int *overflowed,
 							   unsigned long long *needed_pairs);
 
+/* Measurement hooks (bench.py): while enabled, every kernel launch of this library is bracketed by hipEvents recorded on
+ * the launch stream.  deodr_hip_profile_read waits for them and returns, per kernel
+ *   [0] setup_bin_kernel  [1] raster_fwd_kernel  [2] raster_bwd_kernel  [3] finalize_kernel
+ * the summed elapsed milliseconds and the number of launches since the previous read.  Not thread-safe. */
+int deodr_hip_profile_enable(int on);
+int deodr_hip_profile_read(double ms_sum[4], unsigned long long launches[4]);
+
 /* Message of the last error returned on this host thread. */
 const char *deodr_hip_last_error(void);
 

@@ -85,6 +85,34 @@ def test_backward_parity_flag_space(oracle_api, case, sigma, dt):
     compare_backward(oracle_api, s, sigma, dt)
 
 
+@pytest.mark.parametrize("dt", [F32, F64])
+@pytest.mark.parametrize("case", [0, 1, 3])
+@pytest.mark.parametrize("sigma", [0.0, 1.0, 2.5])
+def test_backward_parity_antialiase_error(oracle_api, case, sigma, dt):
+    """renderScene_B with antialiaseError: every gradient against the REPAIRED reference (defects D1 + D2); uv_b / shade_b
+    (untouched by the defects) also against the reference as shipped."""
+    from hip_util import hip_grads, hip_render, rel_err
+
+    s = random_scene(300 + case, **FLAG_CASES[case])
+    s.backface_culling = True
+    rs = np.random.RandomState(11)
+    obs = rs.rand(s.height, s.width, 3)
+    err_b = rs.rand(s.height, s.width)
+    ds, r, out = hip_render(s, sigma, dt, True, obs)
+    stock, fixed = checker(oracle_api), checker(oracle_api, fixed=True)
+    image, z, err = stock.render(s, sigma, True, obs)
+    assert np.abs(out[2][0] - err).max() < 10 * TOL[dt][0] * max(1.0, err.max())
+    g = hip_grads(ds, r, err_buffer_b=err_b)
+    g_fix = fixed.grads(s, sigma, image, z, None, True, obs, err, err_b)
+    g_stock = stock.grads(s, sigma, image, z, None, True, obs, err, err_b)
+    tol = TOL[dt][1]
+    for k in ("ij_b", "colors_b", "shade_b"):
+        assert rel_err(g[k][0], g_fix[k]) < tol, k
+    assert rel_err(g["uv_b"], g_fix["uv_b"]) < tol
+    assert rel_err(g["texture_b"], g_fix["texture_b"]) < tol
+    assert rel_err(g["uv_b"], g_stock["uv_b"]) < tol and rel_err(g["shade_b"][0], g_stock["shade_b"]) < tol
+
+
 @pytest.mark.parametrize("clockwise", [0, 1])
 def test_reference_golden_soup(oracle_api, clockwise):
     """The scene of the reference's own triangle-soup tests (tests/golden/soup30_cw*.npz): image, z and every gradient."""
