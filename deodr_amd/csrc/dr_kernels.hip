@@ -21,6 +21,7 @@
 #include <math.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <utility>
@@ -36,26 +37,28 @@ namespace
 
 constexpr int TILE = 8;		// 8 x 8 pixels = one wavefront, lane = (y & 7) * 8 + (x & 7)
 constexpr int K_TRI = 32;	// inline triangle slots per tile; more spill to the pool
-constexpr int K_EDGE = 16;	// inline edge slots per tile
+constexpr int K_EDGE = 32;	// inline edge slots per tile (== TB: one staged batch)
 constexpr int CH = 4;		// colour channels kept in registers at a time
 constexpr int MAX_SORTED = 64; // edges of a tile whose blending order is cached in LDS
 
 struct WsHeader // 64 bytes per view at the start of the view's workspace
 {
-	uint32_t tri_spill_count;  // (tile, triangle) pairs pushed to the pool by the current set-up
-	uint32_t tri_spill_saved;  // the same, frozen by the last raster block for the adjoint / status query
-	uint32_t edge_spill_count;
-	uint32_t edge_spill_saved;
-	uint32_t raster_done; // ticket counter of raster_fwd_kernel blocks
-	uint32_t needed_max;  // sticky: largest spill count ever seen (host compares with the capacity)
-	uint32_t pad[10];
+	// Spill counters are double-buffered by the parity of `epoch` (one forward = one epoch): the set-up kernel of a forward
+	// counts into [cur] and clears [1 - cur] for the next forward, so no memset node and no last-block ticket is needed.
+	uint32_t tri_spill[2];	// (tile, triangle) pairs pushed to the pool
+	uint32_t edge_spill[2]; // (tile, edge) pairs pushed to the pool
+	uint32_t epoch;			// number of forwards run on this workspace (advanced by one thread of the forward raster)
+	uint32_t cur;			// parity used by the forward whose state the workspace holds (written by its set-up kernel)
+	uint32_t needed_max;	// sticky: largest spill count ever seen (the host compares it with the pool capacity)
+	uint32_t heavy_count[2]; // tiles the fast adjoint kernel deferred to raster_bwd_heavy_kernel (parity of the adjoint's forward)
+	uint32_t pad[7];
 };
 static_assert(sizeof(WsHeader) == 64, "");
 
 struct Layout
 {
 	size_t hdr, tri_rec, tri_planes, tri_acc, edge_rec, edge_planes, edge_acc, tri_cnt, edge_cnt, edge_saved, tri_list, edge_list, tri_pool,
-		edge_pool, face_id, view_bytes;
+		edge_pool, face_id, heavy_list, view_bytes;
 	uint32_t tri_pool_cap, edge_pool_cap;
 	int tiles_x, tiles_y, ntiles, P;
 };
@@ -94,6 +97,7 @@ Layout make_layout(int T, int H, int W, int C, size_t pool_pairs)
 	L.tri_pool = take(sizeof(uint2) * (size_t)L.tri_pool_cap);
 	L.edge_pool = take(sizeof(uint2) * (size_t)L.edge_pool_cap);
 	L.face_id = take(sizeof(int32_t) * (size_t)H * W);
+	L.heavy_list = take(sizeof(uint32_t) * L.ntiles);
 	L.view_bytes = o;
 	return L;
 }
@@ -113,6 +117,7 @@ struct KParams
 	void *image, *zbuf, *err;
 	const void *image_b, *obs, *err_b, *image_in;
 	int aa_err;
+	int debug; // ablation switches for profiling (DEODR_HIP_DEBUG), 0 in production
 	// workspace
 	char *ws;
 	Layout L;
@@ -128,6 +133,7 @@ struct ViewPtrs
 	uint32_t *tri_cnt, *edge_cnt, *edge_saved, *tri_list, *edge_list;
 	uint2 *tri_pool, *edge_pool;
 	int32_t *face_id;
+	uint32_t *heavy_list;
 };
 
 __device__ __forceinline__ ViewPtrs view_ptrs(const KParams &p, int view)
@@ -149,6 +155,7 @@ __device__ __forceinline__ ViewPtrs view_ptrs(const KParams &p, int view)
 	v.tri_pool = (uint2 *)(b + p.L.tri_pool);
 	v.edge_pool = (uint2 *)(b + p.L.edge_pool);
 	v.face_id = (int32_t *)(b + p.L.face_id);
+	v.heavy_list = (uint32_t *)(b + p.L.heavy_list);
 	return v;
 }
 
@@ -244,6 +251,14 @@ __global__ __launch_bounds__(256) void setup_bin_kernel(KParams p)
 		return;
 	const SceneView s = scene_view(p, view);
 	const ViewPtrs w = view_ptrs(p, view);
+	const uint32_t cur = w.hdr->epoch & 1u; // stable during this kernel: only the forward raster advances the epoch
+	if (k == 0)
+	{
+		w.hdr->cur = cur;
+		w.hdr->tri_spill[1 - cur] = 0;
+		w.hdr->edge_spill[1 - cur] = 0;
+		w.hdr->heavy_count[1 - cur] = 0;
+	}
 	TriRec rec;
 	EdgeRec erec[3];
 	setup_triangle(s, k, rec, w.tri_planes + (size_t)k * 3 * s.P, erec, w.edge_planes + (size_t)k * 9 * s.P);
@@ -257,7 +272,7 @@ __global__ __launch_bounds__(256) void setup_bin_kernel(KParams p)
 		if (x0 <= x1 && y0 <= y1)
 			for (int ty = y0 / TILE; ty <= y1 / TILE; ty++)
 				for (int tx = x0 / TILE; tx <= x1 / TILE; tx++)
-					push_tile(w.tri_cnt, w.tri_list, K_TRI, w.tri_pool, p.L.tri_pool_cap, &w.hdr->tri_spill_count, ty * p.L.tiles_x + tx, (uint32_t)k);
+					push_tile(w.tri_cnt, w.tri_list, K_TRI, w.tri_pool, p.L.tri_pool_cap, &w.hdr->tri_spill[cur], ty * p.L.tiles_x + tx, (uint32_t)k);
 	}
 	for (int n = 0; n < 3; n++)
 	{
@@ -266,7 +281,7 @@ __global__ __launch_bounds__(256) void setup_bin_kernel(KParams p)
 			continue;
 		for (int ty = e.y_begin / TILE; ty <= e.y_end / TILE; ty++)
 			for (int tx = e.x_begin / TILE; tx <= e.x_end / TILE; tx++)
-				push_tile(w.edge_cnt, w.edge_list, K_EDGE, w.edge_pool, p.L.edge_pool_cap, &w.hdr->edge_spill_count, ty * p.L.tiles_x + tx,
+				push_tile(w.edge_cnt, w.edge_list, K_EDGE, w.edge_pool, p.L.edge_pool_cap, &w.hdr->edge_spill[cur], ty * p.L.tiles_x + tx,
 						  (uint32_t)(3 * k + n));
 	}
 }
@@ -411,7 +426,7 @@ __global__ __launch_bounds__(256) void raster_fwd_kernel(KParams p)
 			try_triangle(uniform((int)w.tri_list[(size_t)tile * K_TRI + i]));
 		if (ntri > K_TRI)
 		{ // the tile spilled: pick its pairs out of the pool
-			uint32_t spill_n = w.hdr->tri_spill_count;
+			uint32_t spill_n = w.hdr->tri_spill[w.hdr->cur];
 			if (spill_n > p.L.tri_pool_cap)
 				spill_n = p.L.tri_pool_cap;
 			for (uint32_t i0 = 0; i0 < spill_n; i0 += 64)
@@ -430,7 +445,7 @@ __global__ __launch_bounds__(256) void raster_fwd_kernel(KParams p)
 		uint32_t edge_spill_n = 0;
 		if (nedge > K_EDGE)
 		{
-			edge_spill_n = w.hdr->edge_spill_count;
+			edge_spill_n = w.hdr->edge_spill[w.hdr->cur];
 			if (edge_spill_n > p.L.edge_pool_cap)
 				edge_spill_n = p.L.edge_pool_cap;
 		}
@@ -595,23 +610,425 @@ __global__ __launch_bounds__(256) void raster_fwd_kernel(KParams p)
 			w.face_id[pix] = kbest;
 		}
 	}
-	// ---- the last block of the view freezes and resets the spill counters (no memset node per call)
-	__syncthreads();
-	if (threadIdx.x == 0)
+	if (blockIdx.x == 0 && threadIdx.x == 0)
+	{ // one thread per view closes the epoch; nobody else reads `epoch` or `needed_max` during this kernel
+		const uint32_t cur = w.hdr->cur;
+		const uint32_t a = w.hdr->tri_spill[cur], bq = w.hdr->edge_spill[cur];
+		const uint32_t m = a > bq ? a : bq;
+		if (m > w.hdr->needed_max)
+			w.hdr->needed_max = m;
+		w.hdr->epoch = w.hdr->epoch + 1;
+	}
+}
+
+// ---------------------------------------------------------------------------------- forward raster, LDS-staged fast path
+//
+// Same arithmetic as raster_fwd_kernel, restructured for latency: the tile's primitives are fetched with ONE batched
+// load (ids -> 128-byte records + planes, 16 B per lane) into LDS instead of one dependent global round trip per
+// primitive; the reference's scanline spans (two double divisions each, H.h:864-906) are computed once per
+// (primitive, row) by lane = primitive_slot * 8 + row -- not once per pixel -- and exchanged as 8-bit column masks;
+// the depth test and shading then read plane coefficients as LDS broadcasts.  Handles nb_colors <= 4 without
+// antialiase_error; everything else runs on raster_fwd_kernel.
+
+constexpr int TB = 32; // triangles (or edges) staged per batch
+
+struct alignas(16) WaveLds
+{
+	TriRec rec[TB];			   // EdgeRec has the same size and is staged in the same place
+	double planes[TB * 12];	   // 3 * P doubles per primitive, P <= 4
+	uint32_t ids[TB];
+	uint8_t cover[TILE][TB];   // [row][primitive] -> bit x set when the primitive covers column x of the row
+	uint32_t order[TB];
+};
+
+struct PixState
+{
+	double zbest;
+	int kbest;
+	int kind;
+	double v[CH]; // colours of the current winner (KIND_INTERP) or u, v, shade awaiting the texture fetch (KIND_TEXTURED)
+};
+
+__device__ __forceinline__ void lds_sync()
+{ // the 64 lanes of a wave exchange data through LDS: order the compiler, the hardware executes DS ops in order
+	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+	__builtin_amdgcn_wave_barrier();
+	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__device__ __forceinline__ uint32_t column_mask(int xb, int xe, int x0)
+{
+	int lo = (xb > x0 ? xb : x0) - x0, hi = (xe < x0 + TILE - 1 ? xe : x0 + TILE - 1) - x0;
+	if (lo > hi)
+		return 0;
+	return ((1u << (hi + 1)) - 1u) & ~((1u << lo) - 1u);
+}
+
+// bit j of the result = bit `lx` of byte j of the 32-byte row `bytes` (coverage of my column by primitive j)
+__device__ __forceinline__ uint32_t gather_column_bits(const uint8_t *row_bytes, int lx)
+{
+	const uint4 a = ((const uint4 *)row_bytes)[0], b = ((const uint4 *)row_bytes)[1];
+	const uint32_t wd[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+	uint32_t m = 0;
+#pragma unroll
+	for (int i = 0; i < 8; i++)
 	{
-		uint32_t t = atomicAdd(&w.hdr->raster_done, 1u);
-		if (t == gridDim.x - 1)
+		uint32_t t = (wd[i] >> lx) & 0x01010101u;
+		m |= (((t * 0x01020408u) >> 24) & 0xfu) << (4 * i);
+	}
+	return m;
+}
+
+// stage `nb` primitives whose ids are in S.ids: records (128 B each, 8 lanes x 16 B) and planes (3P doubles each)
+template <class Rec>
+__device__ __forceinline__ void stage_batch(WaveLds &S, const Rec *recs, const double *planes, int P, int nb, int lane)
+{
+	const int piece = lane & 7;
+#pragma unroll
+	for (int q = 0; q < TB / 8; q++)
+	{
+		const int j = q * 8 + (lane >> 3);
+		if (j < nb)
+			((uint4 *)&S.rec[j])[piece] = ((const uint4 *)(recs + S.ids[j]))[piece];
+	}
+	const int np = 3 * P;
+	for (int i = lane; i < nb * np; i += 64)
+	{
+		const int j = i / np, c = i - j * np;
+		S.planes[j * 12 + c] = planes[(size_t)S.ids[j] * np + c];
+	}
+}
+
+__device__ __forceinline__ void tri_batch(const KParams &p, WaveLds &S, int nb, int lane, int x0, int y0, bool inb, PixState &st)
+{
+	const int W = p.W, H = p.H, C = p.C;
+	const bool persp = p.persp, strict = p.strict;
+	// spans: lane = slot * 8 + row
+#pragma unroll
+	for (int q = 0; q < TB / 8; q++)
+	{
+		const int j = q * 8 + (lane >> 3), r = lane & 7;
+		uint32_t m = 0;
+		if (j < nb)
 		{
-			uint32_t a = w.hdr->tri_spill_count, bq = w.hdr->edge_spill_count;
-			w.hdr->tri_spill_saved = a;
-			w.hdr->edge_spill_saved = bq;
-			uint32_t m = a > bq ? a : bq;
-			if (m > w.hdr->needed_max)
-				w.hdr->needed_max = m;
-			w.hdr->tri_spill_count = 0;
-			w.hdr->edge_spill_count = 0;
-			w.hdr->raster_done = 0;
+			const TriRec &rec = S.rec[j];
+			if (rec.kind != KIND_NONE)
+			{
+				const int yy = y0 + r;
+#pragma unroll
+				for (int half = 0; half < 2; half++)
+				{
+					int xb, xe;
+					tri_half_span(rec, half, yy, W, H, strict, xb, xe);
+					m |= column_mask(xb, xe, x0);
+				}
+			}
 		}
+		if (j < TB)
+			S.cover[r][j] = (uint8_t)m;
+	}
+	lds_sync();
+	const int lx = lane & 7, row = lane >> 3;
+	uint32_t mine = gather_column_bits(&S.cover[row][0], lx);
+	if (!inb)
+		mine = 0;
+	const double x = x0 + lx, y = y0 + row;
+	for (int j = 0; j < nb; j++)
+	{
+		const bool c = (mine >> j) & 1u;
+		if (__ballot(c) == 0)
+			continue;
+		const TriRec &rec = S.rec[j];
+		double Z = plane_at(rec.xZ, x, y);
+		if (persp)
+			Z = 1 / Z;
+		const int k = (int)S.ids[j];
+		if (c && (Z < st.zbest || (Z == st.zbest && k < st.kbest)))
+		{
+			st.zbest = Z;
+			st.kbest = k;
+			st.kind = rec.kind;
+			const double *pl = &S.planes[j * 12];
+			if (rec.kind == KIND_TEXTURED)
+			{
+				st.v[0] = plane_at(pl, x, y);
+				st.v[1] = plane_at(pl + 3, x, y);
+				st.v[2] = plane_at(pl + 6, x, y);
+				if (persp)
+				{
+					st.v[2] = st.v[2] * Z;
+					st.v[0] = st.v[0] * Z;
+					st.v[1] = st.v[1] * Z;
+				}
+			}
+			else
+			{
+#pragma unroll
+				for (int cc = 0; cc < CH; cc++)
+					if (cc < C)
+						st.v[cc] = interp_channel(pl, cc, x, y, persp, Z);
+			}
+		}
+	}
+	lds_sync(); // the next batch overwrites the staging area
+}
+
+template <class PixT>
+__global__ __launch_bounds__(256) void raster_fwd_fast_kernel(KParams p)
+{
+	__shared__ WaveLds s_lds[4];
+	const int view = blockIdx.y;
+	const int wave = uniform(threadIdx.x >> 6), lane = threadIdx.x & 63;
+	const ViewPtrs w = view_ptrs(p, view);
+	const int strips_x = (p.L.tiles_x + 3) / 4;
+	const int b = xcd_band(blockIdx.x, gridDim.x);
+	const int ty = b / strips_x, tx = (b % strips_x) * 4 + wave;
+	const int W = p.W, H = p.H, C = p.C, P = p.L.P;
+	const bool persp = p.persp;
+	const PixT *texture = (const PixT *)p.texture;
+	WaveLds &S = s_lds[wave];
+
+	if (tx < p.L.tiles_x)
+	{
+		const int tile = ty * p.L.tiles_x + tx;
+		const int x0 = tx * TILE, y0 = ty * TILE;
+		const int px = x0 + (lane & 7), py = y0 + (lane >> 3);
+		const bool inb = px < W && py < H;
+		const size_t pix = (size_t)py * W + px;
+		const size_t vpix = (size_t)view * H * W + pix;
+		const double x = px, y = py;
+		int ntri = uniform((int)w.tri_cnt[tile]);
+		int nedge = uniform((int)w.edge_cnt[tile]);
+		if (p.debug & 1)
+			ntri = 0;
+		if (p.debug & 2)
+			nedge = 0;
+		if (lane == 0 && (ntri | nedge))
+		{
+			w.tri_cnt[tile] = 0;
+			w.edge_cnt[tile] = 0;
+		}
+		if (lane == 0)
+			w.edge_saved[tile] = (uint32_t)nedge;
+		PixState st;
+		st.zbest = INFINITY;
+		st.kbest = -1;
+		st.kind = KIND_NONE;
+#pragma unroll
+		for (int cc = 0; cc < CH; cc++)
+			st.v[cc] = 0;
+		// ---- pass 1
+		if (ntri > 0)
+		{
+			const int n_inline = ntri < K_TRI ? ntri : K_TRI;
+			if (lane < n_inline)
+				S.ids[lane] = w.tri_list[(size_t)tile * K_TRI + lane];
+			lds_sync();
+			stage_batch(S, w.tri_rec, w.tri_planes, P, n_inline, lane);
+			lds_sync();
+			tri_batch(p, S, n_inline, lane, x0, y0, inb, st);
+			if (ntri > K_TRI)
+			{ // spilled pairs of this tile: compact them out of the pool, TB at a time
+				uint32_t spill_n = w.hdr->tri_spill[w.hdr->cur];
+				if (spill_n > p.L.tri_pool_cap)
+					spill_n = p.L.tri_pool_cap;
+				int fill = 0;
+				for (uint32_t i0 = 0; i0 < spill_n; i0 += 64)
+				{
+					const uint2 pr = (i0 + lane < spill_n) ? w.tri_pool[i0 + lane] : make_uint2(0xffffffffu, 0u);
+					unsigned long long m = __ballot((int)pr.x == tile);
+					while (m)
+					{
+						const int room = TB - fill;
+						const int cnt = __popcll(m);
+						// lanes whose pair matches take consecutive slots; at most `room` of them this round
+						const int rank = __popcll(m & ((1ull << lane) - 1ull));
+						const bool sel = ((m >> lane) & 1ull) && rank < room;
+						if (sel)
+							S.ids[fill + rank] = pr.y;
+						const unsigned long long taken = __ballot(sel);
+						m &= ~taken;
+						fill += cnt < room ? cnt : room;
+						if (fill == TB)
+						{
+							lds_sync();
+							stage_batch(S, w.tri_rec, w.tri_planes, P, TB, lane);
+							lds_sync();
+							tri_batch(p, S, TB, lane, x0, y0, inb, st);
+							fill = 0;
+						}
+					}
+				}
+				if (fill > 0)
+				{
+					lds_sync();
+					stage_batch(S, w.tri_rec, w.tri_planes, P, fill, lane);
+					lds_sync();
+					tri_batch(p, S, fill, lane, x0, y0, inb, st);
+				}
+			}
+		}
+		// ---- resolve the winner's colour
+		double col[CH];
+#pragma unroll
+		for (int cc = 0; cc < CH; cc++)
+			col[cc] = st.v[cc];
+		if (st.kbest < 0)
+		{
+#pragma unroll
+			for (int cc = 0; cc < CH; cc++)
+				col[cc] = (cc < C && inb) ? background_channel<PixT>(p, view, pix, cc) : 0.0;
+		}
+		else if (st.kind == KIND_TEXTURED)
+		{
+			Tap tap;
+			bilinear_tap(p.tex_w, p.tex_h, st.v[0], st.v[1], C, tap);
+			const double L = st.v[2];
+#pragma unroll
+			for (int cc = 0; cc < CH; cc++)
+				col[cc] = cc < C ? textured_channel(texture, tap, cc) * L : 0.0;
+		}
+		// ---- pass 2
+		if (nedge > 0 && nedge <= K_EDGE)
+		{
+			EdgeRec *erec = (EdgeRec *)S.rec;
+			if (lane < nedge)
+				S.ids[lane] = w.edge_list[(size_t)tile * K_EDGE + lane];
+			lds_sync();
+			stage_batch(S, w.edge_rec, w.edge_planes, P, nedge, lane);
+			lds_sync();
+			// blending order: rank of each edge among the tile's edges (far -> near, ties by slot)
+			if (lane < nedge)
+			{
+				const double key = erec[lane].key;
+				const uint32_t slot = S.ids[lane];
+				int rank = 0;
+				for (int j = 0; j < nedge; j++)
+					rank += edge_before(erec[j].key, S.ids[j], key, slot) ? 1 : 0;
+				S.order[rank] = (uint32_t)lane;
+			}
+			// band spans: lane = slot * 8 + row
+#pragma unroll
+			for (int q = 0; q < K_EDGE / 8; q++)
+			{
+				const int j = q * 8 + (lane >> 3), r = lane & 7;
+				uint32_t m = 0;
+				if (j < nedge)
+				{
+					const EdgeRec &e = erec[j];
+					const int yy = y0 + r;
+					if (yy >= e.y_begin && yy <= e.y_end)
+					{
+						int xb, xe;
+						edge_row_span(e, yy, W, xb, xe);
+						m = column_mask(xb, xe, x0);
+					}
+				}
+				S.cover[r][j] = (uint8_t)m;
+			}
+			lds_sync();
+			const int lx = lane & 7, row = lane >> 3;
+			const uint32_t ecov = inb ? gather_column_bits(&S.cover[row][0], lx) : 0u;
+			for (int r = 0; r < nedge; r++)
+			{
+				const int j = (int)S.order[r];
+				const bool c = (ecov >> j) & 1u;
+				if (__ballot(c) == 0)
+					continue;
+				const EdgeRec &e = erec[j];
+				double Ze = plane_at(e.xZ, x, y);
+				if (persp)
+					Ze = 1 / Ze;
+				if (c && Ze < st.zbest)
+				{
+					const double *ep = &S.planes[j * 12];
+					const double Tr = plane_at(e.x2t, x, y);
+					Tap etap;
+					double eL = 0, eUV[2];
+					if (e.kind == KIND_TEXTURED)
+						textured_tap(ep, x, y, persp, Ze, p.tex_w, p.tex_h, C, etap, eL, eUV);
+#pragma unroll
+					for (int cc = 0; cc < CH; cc++)
+						if (cc < C)
+						{
+							const double A = edge_channel(e, ep, texture, etap, eL, cc, x, y, persp, Ze);
+							col[cc] *= Tr;
+							col[cc] += (1 - Tr) * A;
+						}
+				}
+			}
+		}
+		else if (nedge > K_EDGE)
+		{ // rare: more silhouette edges than the inline list holds -> ordered search through list + pool
+			uint32_t edge_spill_n = w.hdr->edge_spill[w.hdr->cur];
+			if (edge_spill_n > p.L.edge_pool_cap)
+				edge_spill_n = p.L.edge_pool_cap;
+			EdgeCursor cur = {0, 0};
+			for (int r = 0; r < nedge; r++)
+			{
+				EdgeCursor f;
+				const uint32_t slot = next_edge(w, tile, nedge, edge_spill_n, r == 0, cur, false, lane, f);
+				cur = f;
+				if (slot == 0xffffffffu)
+					break;
+				const EdgeRec &e = w.edge_rec[slot];
+				if (edge_touches(e, px, py, W, persp, st.zbest, inb))
+				{
+					const double *ep = w.edge_planes + (size_t)slot * 3 * P;
+					double Ze = plane_at(e.xZ, x, y);
+					if (persp)
+						Ze = 1 / Ze;
+					const double Tr = plane_at(e.x2t, x, y);
+					Tap etap;
+					double eL = 0, eUV[2];
+					if (e.kind == KIND_TEXTURED)
+						textured_tap(ep, x, y, persp, Ze, p.tex_w, p.tex_h, C, etap, eL, eUV);
+#pragma unroll
+					for (int cc = 0; cc < CH; cc++)
+						if (cc < C)
+						{
+							const double A = edge_channel(e, ep, texture, etap, eL, cc, x, y, persp, Ze);
+							col[cc] *= Tr;
+							col[cc] += (1 - Tr) * A;
+						}
+				}
+			}
+		}
+		// ---- one write per pixel
+		if (inb && !(p.debug & 4))
+		{
+			if (p.image)
+			{
+				PixT *out = (PixT *)p.image + vpix * C;
+				if (C == 4)
+				{
+					struct alignas(4 * sizeof(PixT)) V4
+					{
+						PixT a, b, c, d;
+					};
+					*(V4 *)out = V4{(PixT)col[0], (PixT)col[1], (PixT)col[2], (PixT)col[3]};
+				}
+				else
+				{
+#pragma unroll
+					for (int cc = 0; cc < CH; cc++)
+						if (cc < C)
+							out[cc] = (PixT)col[cc];
+				}
+			}
+			if (p.zbuf)
+				((PixT *)p.zbuf)[vpix] = (PixT)st.zbest;
+			w.face_id[pix] = st.kbest;
+		}
+	}
+	if (blockIdx.x == 0 && threadIdx.x == 0)
+	{ // one thread per view closes the epoch; nobody else reads `epoch` or `needed_max` during this kernel
+		const uint32_t cur = w.hdr->cur;
+		const uint32_t a = w.hdr->tri_spill[cur], bq = w.hdr->edge_spill[cur];
+		const uint32_t m = a > bq ? a : bq;
+		if (m > w.hdr->needed_max)
+			w.hdr->needed_max = m;
+		w.hdr->epoch = w.hdr->epoch + 1;
 	}
 }
 
@@ -641,29 +1058,26 @@ __device__ __forceinline__ void texture_scatter(PixT *texture_b, const Tap &tap,
 			unsafeAtomicAdd(texture_b + tap.idx[q] + c, (PixT)wgt[q]);
 }
 
+// adjoint of one tile, any channel count / edge count / mode; `order` is a per-wave LDS array of MAX_SORTED entries
 template <class PixT>
-__global__ __launch_bounds__(256) void raster_bwd_kernel(KParams p)
+__device__ __noinline__ void bwd_tile_generic(const KParams &p, int view, int tx, int ty, int lane, volatile uint32_t *order)
 {
-	__shared__ volatile uint32_t s_order[4][MAX_SORTED];
-	const int view = blockIdx.y;
-	const int wave = uniform(threadIdx.x >> 6), lane = threadIdx.x & 63;
 	const ViewPtrs w = view_ptrs(p, view);
-	const int strips_x = (p.L.tiles_x + 3) / 4;
-	const int b = xcd_band(blockIdx.x, gridDim.x);
-	const int ty = b / strips_x, tx = (b % strips_x) * 4 + wave;
 	const int W = p.W, H = p.H, C = p.C, P = p.L.P;
 	const PixT *texture = (const PixT *)p.texture;
 	PixT *texture_b = (PixT *)p.texture_b;
-	if (tx >= p.L.tiles_x)
-		return;
 	const int tile = ty * p.L.tiles_x + tx;
 	const int px = tx * TILE + (lane & 7), py = ty * TILE + (lane >> 3);
 	const bool inb = px < W && py < H;
 	const size_t pix = (size_t)py * W + px;
 	const size_t vpix = (size_t)view * H * W + pix;
 	const double x = px, y = py;
-	const int nedge = uniform((int)w.edge_saved[tile]);
-	const int owner = inb ? w.face_id[pix] : -1;
+	int nedge = uniform((int)w.edge_saved[tile]);
+	if (p.debug & 32)
+		nedge = 0;
+	int owner = inb ? w.face_id[pix] : -1;
+	if (p.debug & 16)
+		owner = -1;
 	if (__ballot(owner >= 0) == 0 && nedge == 0)
 		return;
 
@@ -694,7 +1108,7 @@ __global__ __launch_bounds__(256) void raster_bwd_kernel(KParams p)
 	uint32_t edge_spill_n = 0;
 	if (nedge > K_EDGE)
 	{
-		edge_spill_n = w.hdr->edge_spill_saved;
+		edge_spill_n = w.hdr->edge_spill[w.hdr->cur];
 		if (edge_spill_n > p.L.edge_pool_cap)
 			edge_spill_n = p.L.edge_pool_cap;
 	}
@@ -714,7 +1128,7 @@ __global__ __launch_bounds__(256) void raster_bwd_kernel(KParams p)
 				break;
 			}
 			if (lane == 0)
-				s_order[wave][r] = slot;
+				order[r] = slot;
 			cur = f;
 			if (edge_touches(w.edge_rec[slot], px, py, W, false, zown, inb))
 				touched |= 1ull << r;
@@ -725,7 +1139,7 @@ __global__ __launch_bounds__(256) void raster_bwd_kernel(KParams p)
 	// r-th edge of the tile in blending order (cached in LDS, or searched when the tile has more than MAX_SORTED edges)
 	auto edge_at = [&](int r) -> uint32_t {
 		if (cached)
-			return (uint32_t)uniform((int)s_order[wave][r]);
+			return (uint32_t)uniform((int)order[r]);
 		EdgeCursor cur = {0, 0}, f;
 		uint32_t slot = 0;
 		for (int i = 0; i <= r; i++)
@@ -1000,6 +1414,421 @@ __global__ __launch_bounds__(256) void raster_bwd_kernel(KParams p)
 	}
 }
 
+template <class PixT>
+__global__ __launch_bounds__(256) void raster_bwd_kernel(KParams p)
+{
+	__shared__ volatile uint32_t s_order[4][MAX_SORTED];
+	const int wave = uniform(threadIdx.x >> 6), lane = threadIdx.x & 63;
+	const int strips_x = (p.L.tiles_x + 3) / 4;
+	const int b = xcd_band(blockIdx.x, gridDim.x);
+	const int ty = b / strips_x, tx = (b % strips_x) * 4 + wave;
+	if (tx < p.L.tiles_x)
+		bwd_tile_generic<PixT>(p, blockIdx.y, tx, ty, lane, s_order[wave]);
+}
+
+// ---------------------------------------------------------------------------------- backward raster, LDS-staged fast path
+//
+// nb_colors <= 4, no antialiase_error, at most K_EDGE edges in the tile (other tiles call bwd_tile_generic).
+// Differences from the generic tile: edges are staged / ranked / span-tested exactly as in raster_fwd_fast_kernel, and the
+// segmented reductions "sum over the pixels of a primitive" are done with LDS atomics (ds_add_f64, one slot per distinct
+// primitive of the tile) followed by ONE global atomic per (primitive, moment), issued by 64 lanes in parallel -- instead
+// of a 64-lane butterfly per moment and primitive.
+
+constexpr int NLOC = 16; // distinct owners accumulated per pass
+constexpr int NMOM = 12; // moments per owner slot: 3 per channel (or 9 for a textured owner)
+
+struct alignas(16) BwdLds
+{
+	EdgeRec rec[TB];
+	double planes[TB * 12];
+	uint32_t ids[TB];
+	uint8_t cover[TILE][TB];
+	uint32_t order[TB];
+	uint32_t own[NLOC];
+	double tab[NLOC * NMOM];
+	double etab[16];
+};
+
+__device__ __forceinline__ void lds_add(double *slot, double v)
+{
+	if (v != 0)
+		unsafeAtomicAdd(slot, v);
+}
+
+template <class PixT>
+__global__ __launch_bounds__(256) void raster_bwd_fast_kernel(KParams p)
+{
+	__shared__ BwdLds s_lds[4];
+	const int view = blockIdx.y;
+	const int wave = uniform(threadIdx.x >> 6), lane = threadIdx.x & 63;
+	const ViewPtrs w = view_ptrs(p, view);
+	const int strips_x = (p.L.tiles_x + 3) / 4;
+	const int b = xcd_band(blockIdx.x, gridDim.x);
+	const int ty = b / strips_x, tx = (b % strips_x) * 4 + wave;
+	const int W = p.W, H = p.H, C = p.C, P = p.L.P;
+	const PixT *texture = (const PixT *)p.texture;
+	PixT *texture_b = (PixT *)p.texture_b;
+	BwdLds &S = s_lds[wave];
+	if (tx >= p.L.tiles_x)
+		return;
+	const int tile = ty * p.L.tiles_x + tx;
+	const int x0 = tx * TILE, y0 = ty * TILE;
+	const int px = x0 + (lane & 7), py = y0 + (lane >> 3);
+	const bool inb = px < W && py < H;
+	const size_t pix = (size_t)py * W + px;
+	const size_t vpix = (size_t)view * H * W + pix;
+	const double x = px, y = py;
+	int nedge = uniform((int)w.edge_saved[tile]);
+	if (p.debug & 32)
+		nedge = 0;
+	if (nedge > K_EDGE)
+	{ // rare: more edges than one staged batch -> queued for raster_bwd_heavy_kernel
+		if (lane == 0)
+			w.heavy_list[atomicAdd(&w.hdr->heavy_count[w.hdr->cur], 1u)] = (uint32_t)tile;
+		return;
+	}
+	int owner = inb ? w.face_id[pix] : -1;
+	if (p.debug & 16)
+		owner = -1;
+	if (__ballot(owner >= 0) == 0 && nedge == 0)
+		return;
+
+	double g[CH];
+	{
+		const PixT *gin = (const PixT *)p.image_b + vpix * C;
+#pragma unroll
+		for (int cc = 0; cc < CH; cc++)
+			g[cc] = (cc < C && inb) ? (double)gin[cc] : 0.0;
+	}
+	// what pass 1 left at this pixel
+	int kind = KIND_NONE;
+	const double *planes = nullptr;
+	double zown = INFINITY;
+	Tap tap;
+	double L = 0, UV[2] = {0, 0};
+	if (owner >= 0)
+	{
+		kind = w.tri_rec[owner].kind;
+		planes = w.tri_planes + (size_t)owner * 3 * P;
+		if (kind == KIND_TEXTURED)
+			textured_tap(planes, x, y, false, 0.0, p.tex_w, p.tex_h, C, tap, L, UV);
+	}
+
+	// ---- adjoint of pass 2 (near -> far)
+	if (nedge > 0)
+	{
+		if (lane < nedge)
+			S.ids[lane] = w.edge_list[(size_t)tile * K_EDGE + lane];
+		lds_sync();
+		stage_batch(*(WaveLds *)&S, w.edge_rec, w.edge_planes, P, nedge, lane);
+		lds_sync();
+		if (lane < nedge)
+		{
+			const double key = S.rec[lane].key;
+			const uint32_t slot = S.ids[lane];
+			int rank = 0;
+			for (int j = 0; j < nedge; j++)
+				rank += edge_before(S.rec[j].key, S.ids[j], key, slot) ? 1 : 0;
+			S.order[rank] = (uint32_t)lane;
+		}
+#pragma unroll
+		for (int q = 0; q < K_EDGE / 8; q++)
+		{
+			const int j = q * 8 + (lane >> 3), r = lane & 7;
+			uint32_t m = 0;
+			if (j < nedge)
+			{
+				const EdgeRec &e = S.rec[j];
+				const int yy = y0 + r;
+				if (yy >= e.y_begin && yy <= e.y_end)
+				{
+					int xb, xe;
+					edge_row_span(e, yy, W, xb, xe);
+					m = column_mask(xb, xe, x0);
+				}
+			}
+			S.cover[r][j] = (uint8_t)m;
+		}
+		lds_sync();
+		const uint32_t ecov = inb ? gather_column_bits(&S.cover[lane >> 3][0], lane & 7) : 0u;
+		// depth and un-antialiased colour of the pixel (only pixels inside some band need them)
+		double base[CH] = {0, 0, 0, 0};
+		if (ecov)
+		{
+			if (owner >= 0)
+			{
+				zown = plane_at(w.tri_rec[owner].xZ, x, y);
+#pragma unroll
+				for (int cc = 0; cc < CH; cc++)
+					if (cc < C)
+						base[cc] = kind == KIND_TEXTURED ? textured_channel(texture, tap, cc) * L : interp_channel(planes, cc, x, y, false, 0.0);
+			}
+			else
+			{
+#pragma unroll
+				for (int cc = 0; cc < CH; cc++)
+					if (cc < C)
+						base[cc] = background_channel<PixT>(p, view, pix, cc);
+			}
+		}
+		// bit r of tmask: the r-th edge in blending order is drawn over this pixel
+		uint32_t tmask = 0;
+		for (int r = 0; r < nedge; r++)
+		{
+			const int j = (int)S.order[r];
+			if ((ecov >> j) & 1u)
+				if (plane_at(S.rec[j].xZ, x, y) < zown)
+					tmask |= 1u << r;
+		}
+		// antialiased colour of the pixel: one forward sweep over the edges that touch it
+		double cur[CH];
+#pragma unroll
+		for (int cc = 0; cc < CH; cc++)
+			cur[cc] = base[cc];
+		for (int q = 0; q < nedge; q++)
+		{
+			const bool hq = (tmask >> q) & 1u;
+			if (__ballot(hq) == 0)
+				continue;
+			const int jq = (int)S.order[q];
+			const EdgeRec &eq = S.rec[jq];
+			const double *qp = &S.planes[jq * 12];
+			if (hq)
+			{
+				const double Tq = plane_at(eq.x2t, x, y);
+				Tap qtap;
+				double qL = 0, qUV[2];
+				if (eq.kind == KIND_TEXTURED)
+					textured_tap(qp, x, y, false, 0.0, p.tex_w, p.tex_h, C, qtap, qL, qUV);
+#pragma unroll
+				for (int cc = 0; cc < CH; cc++)
+					if (cc < C)
+					{
+						cur[cc] *= Tq;
+						cur[cc] += (1 - Tq) * edge_channel(eq, qp, texture, qtap, qL, cc, x, y, false, 0.0);
+					}
+			}
+		}
+		for (int r = nedge - 1; r >= 0; r--)
+		{
+			const bool hit = (tmask >> r) & 1u;
+			if (__ballot(hit) == 0)
+				continue;
+			const int j = (int)S.order[r];
+			const EdgeRec &e = S.rec[j];
+			const double *ep = &S.planes[j * 12];
+			if (lane < 16)
+				S.etab[lane] = 0;
+			// colour before this edge: un-blend like the reference (H.h:1738) when T is safely away from 0, otherwise
+			// replay the earlier edges from the un-antialiased colour (the reference yields inf / NaN there)
+			double prev[CH];
+			const double Tr_here = hit ? plane_at(e.x2t, x, y) : 1.0;
+			const bool need_replay = hit && !(Tr_here > 1e-6);
+#pragma unroll
+			for (int cc = 0; cc < CH; cc++)
+				prev[cc] = base[cc];
+			if (hit && !need_replay)
+			{
+				Tap utap;
+				double uL = 0, uUV[2];
+				if (e.kind == KIND_TEXTURED)
+					textured_tap(ep, x, y, false, 0.0, p.tex_w, p.tex_h, C, utap, uL, uUV);
+#pragma unroll
+				for (int cc = 0; cc < CH; cc++)
+					if (cc < C)
+					{
+						prev[cc] = (cur[cc] - (1 - Tr_here) * edge_channel(e, ep, texture, utap, uL, cc, x, y, false, 0.0)) / Tr_here;
+						cur[cc] = prev[cc];
+					}
+			}
+			if (__ballot(need_replay))
+			for (int q = 0; q < r; q++)
+			{
+				if (!need_replay || !((tmask >> q) & 1u))
+					continue;
+				const int jq = (int)S.order[q];
+				const EdgeRec &eq = S.rec[jq];
+				const double *qp = &S.planes[jq * 12];
+				const double Tq = plane_at(eq.x2t, x, y);
+				Tap qtap;
+				double qL = 0, qUV[2];
+				if (eq.kind == KIND_TEXTURED)
+					textured_tap(qp, x, y, false, 0.0, p.tex_w, p.tex_h, C, qtap, qL, qUV);
+#pragma unroll
+				for (int cc = 0; cc < CH; cc++)
+					if (cc < C)
+					{
+						prev[cc] *= Tq;
+						prev[cc] += (1 - Tq) * edge_channel(eq, qp, texture, qtap, qL, cc, x, y, false, 0.0);
+					}
+			}
+			if (need_replay)
+			{
+#pragma unroll
+				for (int cc = 0; cc < CH; cc++)
+					cur[cc] = prev[cc];
+			}
+			lds_sync();
+			if (hit)
+			{
+				const double Tr = plane_at(e.x2t, x, y);
+				double T_B = 0;
+				if (e.kind == KIND_TEXTURED)
+				{ // H.h:2006-2021
+					Tap etap;
+					double eL, eUV[2], L_B = 0, e_B[2] = {0, 0};
+					textured_tap(ep, x, y, false, 0.0, p.tex_w, p.tex_h, C, etap, eL, eUV);
+#pragma unroll
+					for (int cc = 0; cc < CH; cc++)
+						if (cc < C)
+						{
+							const double i00 = ldp(texture, etap.idx[0] + cc), i10 = ldp(texture, etap.idx[1] + cc);
+							const double i01 = ldp(texture, etap.idx[2] + cc), i11 = ldp(texture, etap.idx[3] + cc);
+							const double A = bilinear_mix(etap, i00, i10, i01, i11);
+							T_B += g[cc] * (prev[cc] - A * eL);
+							L_B += g[cc] * (1 - Tr) * A;
+							double wgt[4];
+							bilinear_mix_adjoint(etap, eL * (1 - Tr) * g[cc], i00, i10, i01, i11, wgt, e_B);
+							if (texture_b)
+								texture_scatter(texture_b, etap, cc, wgt);
+							g[cc] *= Tr;
+						}
+					const double ub = etap.out[0] ? 0.0 : e_B[0], vb = etap.out[1] ? 0.0 : e_B[1];
+					lds_add(&S.etab[0], ub * x);
+					lds_add(&S.etab[1], ub * y);
+					lds_add(&S.etab[2], ub);
+					lds_add(&S.etab[3], vb * x);
+					lds_add(&S.etab[4], vb * y);
+					lds_add(&S.etab[5], vb);
+					lds_add(&S.etab[6], L_B * x);
+					lds_add(&S.etab[7], L_B * y);
+					lds_add(&S.etab[8], L_B);
+				}
+				else
+				{ // H.h:1726-1746
+#pragma unroll
+					for (int cc = 0; cc < CH; cc++)
+						if (cc < C)
+						{
+							const double A = interp_channel(ep, cc, x, y, false, 0.0);
+							T_B += g[cc] * (prev[cc] - A);
+							const double A_B = (1 - Tr) * g[cc];
+							g[cc] *= Tr;
+							lds_add(&S.etab[3 * cc + 0], A_B * x);
+							lds_add(&S.etab[3 * cc + 1], A_B * y);
+							lds_add(&S.etab[3 * cc + 2], A_B);
+						}
+				}
+				lds_add(&S.etab[12], T_B * x);
+				lds_add(&S.etab[13], T_B * y);
+				lds_add(&S.etab[14], T_B);
+			}
+			lds_sync();
+			if (lane < 15)
+			{ // planes 0..3 hold 3 moments each, then the transparency plane at index 3P of the global accumulator
+				const double v = S.etab[lane];
+				const int plane = lane / 3, m = lane - 3 * plane;
+				if (v != 0 && (plane < P || plane == 4))
+				{
+					double *eacc = w.edge_acc + (size_t)S.ids[j] * (3 * P + 3);
+					atomic_add_f64(eacc + (plane == 4 ? 3 * P : 3 * plane) + m, v);
+				}
+			}
+			lds_sync();
+		}
+	}
+
+	// ---- adjoint of pass 1: g now belongs to the triangle that owns the pixel
+	double mom[NMOM];
+#pragma unroll
+	for (int i = 0; i < NMOM; i++)
+		mom[i] = 0;
+	if (kind == KIND_TEXTURED)
+	{ // H.h:1320-1353
+		double L_B = 0, e_B[2] = {0, 0};
+#pragma unroll
+		for (int cc = 0; cc < CH; cc++)
+			if (cc < C)
+			{
+				const double i00 = ldp(texture, tap.idx[0] + cc), i10 = ldp(texture, tap.idx[1] + cc);
+				const double i01 = ldp(texture, tap.idx[2] + cc), i11 = ldp(texture, tap.idx[3] + cc);
+				L_B += g[cc] * bilinear_mix(tap, i00, i10, i01, i11);
+				double wgt[4];
+				bilinear_mix_adjoint(tap, g[cc] * L, i00, i10, i01, i11, wgt, e_B);
+				if (texture_b)
+					texture_scatter(texture_b, tap, cc, wgt);
+			}
+		const double ub = tap.out[0] ? 0.0 : e_B[0], vb = tap.out[1] ? 0.0 : e_B[1];
+		mom[0] = ub * x, mom[1] = ub * y, mom[2] = ub;
+		mom[3] = vb * x, mom[4] = vb * y, mom[5] = vb;
+		mom[6] = L_B * x, mom[7] = L_B * y, mom[8] = L_B;
+	}
+	else if (kind == KIND_INTERP)
+	{ // H.h:1024-1037
+#pragma unroll
+		for (int cc = 0; cc < CH; cc++)
+			if (cc < C)
+			{
+				mom[3 * cc + 0] = g[cc] * x;
+				mom[3 * cc + 1] = g[cc] * y;
+				mom[3 * cc + 2] = g[cc];
+			}
+	}
+	const int nm = 3 * P; // moments per owner in the global accumulator (P = max(C, 3) planes)
+	unsigned long long rem = __ballot(owner >= 0 && kind != KIND_NONE);
+	while (rem)
+	{ // up to NLOC distinct owners per pass: slot ids, zeroed table, LDS atomics, parallel flush
+		int slot = -1, nloc = 0;
+		while (rem && nloc < NLOC)
+		{
+			const int l = __ffsll((long long)rem) - 1;
+			const int cur = __shfl(owner, l, 64);
+			const bool mine = owner == cur;
+			if (mine)
+				slot = nloc;
+			if (lane == 0)
+				S.own[nloc] = (uint32_t)cur;
+			nloc++;
+			rem &= ~__ballot(mine);
+		}
+		for (int i = lane; i < nloc * NMOM; i += 64)
+			S.tab[i] = 0;
+		lds_sync();
+		if (slot >= 0 && !(p.debug & 64))
+		{
+#pragma unroll
+			for (int i = 0; i < NMOM; i++)
+				if (i < nm)
+					lds_add(&S.tab[slot * NMOM + i], mom[i]);
+		}
+		lds_sync();
+		for (int i = lane; i < nloc * NMOM; i += 64)
+		{
+			const int sl = i / NMOM, m = i - sl * NMOM;
+			const double v = S.tab[i];
+			if (m < nm && v != 0 && !(p.debug & 128))
+				atomic_add_f64(w.tri_acc + (size_t)S.own[sl] * nm + m, v);
+		}
+		lds_sync();
+	}
+}
+
+template <class PixT>
+__global__ __launch_bounds__(256) void raster_bwd_heavy_kernel(KParams p)
+{ // the few tiles raster_bwd_fast_kernel deferred (more than K_EDGE silhouette edges); normally the queue is empty
+	__shared__ volatile uint32_t s_order[4][MAX_SORTED];
+	const int view = blockIdx.y;
+	const int wave = uniform(threadIdx.x >> 6), lane = threadIdx.x & 63;
+	const ViewPtrs w = view_ptrs(p, view);
+	const uint32_t cur = w.hdr->cur;
+	const uint32_t n = w.hdr->heavy_count[cur];
+	for (uint32_t i = blockIdx.x * 4 + wave; i < n; i += gridDim.x * 4)
+	{
+		const int tile = (int)w.heavy_list[i];
+		bwd_tile_generic<PixT>(p, view, tile % p.L.tiles_x, tile / p.L.tiles_x, lane, s_order[wave]);
+	}
+}
+
 // ------------------------------------------------------------------------------------------------------- finalize
 
 __global__ __launch_bounds__(256) void finalize_kernel(KParams p)
@@ -1017,6 +1846,8 @@ __global__ __launch_bounds__(256) void finalize_kernel(KParams p)
 	g.shade_b = (char *)p.shade_b + (size_t)view * p.V * es;
 	g.uv_b = p.uv_b;
 	const int P = s.P;
+	if (k == 0)
+		w.hdr->heavy_count[w.hdr->cur] = 0; // the deferred-tile queue of this adjoint has been drained
 	const TriRec rec = w.tri_rec[k];
 	if (rec.front && rec.kind != KIND_NONE)
 	{
@@ -1136,6 +1967,10 @@ int fill_params(const DeodrHipScene *sc, double sigma, void *workspace, size_t w
 	p.offset = sc->integer_pixel_centers ? 0.0 : 0.5;
 	p.sigma = sigma;
 	p.ws = (char *)workspace;
+	{
+		static const int dbg = getenv("DEODR_HIP_DEBUG") ? atoi(getenv("DEODR_HIP_DEBUG")) : 0;
+		p.debug = dbg;
+	}
 	return 0;
 }
 
@@ -1154,6 +1989,7 @@ struct ProfEvent
 	int kid;
 };
 bool g_profile = false;
+bool g_force_generic = false; // DEODR_HIP_FORCE_GENERIC=1: run the un-staged kernels (tests cover both)
 std::vector<ProfEvent> g_prof_events;
 std::vector<std::pair<hipEvent_t, hipEvent_t>> g_prof_free;
 
@@ -1202,10 +2038,21 @@ int launch_forward(const DeodrHipScene *sc, KParams &p, hipStream_t stream)
 	dim3 grid(strips_x * p.L.tiles_y, n_views);
 	{
 		ScopedKernelTimer t(KID_RASTER_FWD, stream);
+		const bool fast = !p.aa_err && p.C <= CH && !g_force_generic;
 		if (sc->pixel_dtype == DEODR_HIP_F64)
-			hipLaunchKernelGGL(raster_fwd_kernel<double>, grid, dim3(256), 0, stream, p);
+		{
+			if (fast)
+				hipLaunchKernelGGL(raster_fwd_fast_kernel<double>, grid, dim3(256), 0, stream, p);
+			else
+				hipLaunchKernelGGL(raster_fwd_kernel<double>, grid, dim3(256), 0, stream, p);
+		}
 		else
-			hipLaunchKernelGGL(raster_fwd_kernel<float>, grid, dim3(256), 0, stream, p);
+		{
+			if (fast)
+				hipLaunchKernelGGL(raster_fwd_fast_kernel<float>, grid, dim3(256), 0, stream, p);
+			else
+				hipLaunchKernelGGL(raster_fwd_kernel<float>, grid, dim3(256), 0, stream, p);
+		}
 	}
 	return check_hip(hipGetLastError(), "forward launch");
 }
@@ -1215,6 +2062,12 @@ int launch_forward(const DeodrHipScene *sc, KParams &p, hipStream_t stream)
 extern "C" {
 
 int deodr_hip_abi_version(void) { return DEODR_HIP_ABI_VERSION; }
+
+int deodr_hip_force_generic(int on)
+{
+	g_force_generic = on != 0;
+	return 0;
+}
 
 int deodr_hip_profile_enable(int on)
 {
@@ -1304,10 +2157,29 @@ int deodr_hip_render_scene_b(const DeodrHipScene *sc, const void *image, const v
 	dim3 grid(strips_x * p.L.tiles_y, sc->n_views);
 	{
 		ScopedKernelTimer t(KID_RASTER_BWD, st);
+		const bool fast = !p.aa_err && p.C <= CH && !g_force_generic;
 		if (sc->pixel_dtype == DEODR_HIP_F64)
-			hipLaunchKernelGGL(raster_bwd_kernel<double>, grid, dim3(256), 0, st, p);
+		{
+			if (fast)
+				hipLaunchKernelGGL(raster_bwd_fast_kernel<double>, grid, dim3(256), 0, st, p);
+			else
+				hipLaunchKernelGGL(raster_bwd_kernel<double>, grid, dim3(256), 0, st, p);
+		}
 		else
-			hipLaunchKernelGGL(raster_bwd_kernel<float>, grid, dim3(256), 0, st, p);
+		{
+			if (fast)
+				hipLaunchKernelGGL(raster_bwd_fast_kernel<float>, grid, dim3(256), 0, st, p);
+			else
+				hipLaunchKernelGGL(raster_bwd_kernel<float>, grid, dim3(256), 0, st, p);
+		}
+		if (fast)
+		{ // a few blocks per view drain the deferred-tile queue (usually empty); finalize_kernel resets it
+			dim3 gh(16, sc->n_views);
+			if (sc->pixel_dtype == DEODR_HIP_F64)
+				hipLaunchKernelGGL(raster_bwd_heavy_kernel<double>, gh, dim3(256), 0, st, p);
+			else
+				hipLaunchKernelGGL(raster_bwd_heavy_kernel<float>, gh, dim3(256), 0, st, p);
+		}
 	}
 	if (p.T > 0)
 	{

@@ -62,6 +62,8 @@ def lib():
         L.deodr_hip_workspace_status.restype = C.c_int
         L.deodr_hip_workspace_status.argtypes = [C.POINTER(_SceneC), C.c_void_p, C.c_size_t, C.c_void_p, C.POINTER(C.c_int),
                                                  C.POINTER(C.c_ulonglong)]  # fmt: skip
+        if os.environ.get("DEODR_HIP_FORCE_GENERIC") == "1":  # test hook: exercise the un-staged kernels too
+            L.deodr_hip_force_generic(1)
         _lib = L
     return _lib
 

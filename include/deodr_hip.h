@@ -111,6 +111,10 @@ int deodr_hip_workspace_status(const DeodrHipScene *scene, void *workspace, size
 int deodr_hip_profile_enable(int on);
 int deodr_hip_profile_read(double ms_sum[4], unsigned long long launches[4]);
 
+/* Test hook: non-zero makes every call use the generic (un-staged) kernels that otherwise only serve nb_colors > 4 and
+ * antialiase_error, so that the parity suite can exercise both code paths on the same scenes. */
+int deodr_hip_force_generic(int on);
+
 /* Message of the last error returned on this host thread. */
 const char *deodr_hip_last_error(void);
 
