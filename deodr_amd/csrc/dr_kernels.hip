@@ -196,15 +196,36 @@ __device__ __forceinline__ SceneView scene_view(const KParams &p, int view)
 
 __device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
-__device__ __forceinline__ double wave_sum(double v)
-{
-#pragma unroll
-	for (int o = 32; o > 0; o >>= 1)
-		v += __shfl_xor(v, o, 64);
-	return v;
-}
-
 __device__ __forceinline__ void atomic_add_f64(double *p, double v) { unsafeAtomicAdd(p, v); }
+
+// Cross-lane moves on the VALU (DPP), no LDS round trip.  CTRL: 0x110 + n = row_shr:n (lane i <- lane i - n inside its
+// 16-lane row), 0x100 + n = row_shl:n (lane i <- lane i + n); lanes without a source read 0.
+template <int CTRL>
+__device__ __forceinline__ int dpp_i(int v)
+{
+	return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true);
+}
+template <int CTRL>
+__device__ __forceinline__ double dpp_d(double v)
+{
+	return __hiloint2double(dpp_i<CTRL>(__double2hiint(v)), dpp_i<CTRL>(__double2loint(v)));
+}
+// sum over the 64 lanes, returned to every lane (4 DPP steps inside each 16-lane row, then 4 readlanes)
+__device__ __forceinline__ double wave_sum_dpp(double v)
+{
+	v += dpp_d<0x111>(v);
+	v += dpp_d<0x112>(v);
+	v += dpp_d<0x114>(v);
+	v += dpp_d<0x118>(v);
+	const int hi = __double2hiint(v), lo = __double2loint(v);
+	double r = __hiloint2double(__builtin_amdgcn_readlane(hi, 15), __builtin_amdgcn_readlane(lo, 15));
+	r += __hiloint2double(__builtin_amdgcn_readlane(hi, 31), __builtin_amdgcn_readlane(lo, 31));
+	r += __hiloint2double(__builtin_amdgcn_readlane(hi, 47), __builtin_amdgcn_readlane(lo, 47));
+	r += __hiloint2double(__builtin_amdgcn_readlane(hi, 63), __builtin_amdgcn_readlane(lo, 63));
+	return r;
+}
+// NOTE: must be called with all 64 lanes enabled (a DPP move reads 0 from a disabled lane)
+__device__ __forceinline__ double wave_sum(double v) { return wave_sum_dpp(v); }
 
 struct DeviceAdd // accumulate a vertex gradient (the reference's `+=` into scene.*_b)
 {
@@ -1279,8 +1300,32 @@ __device__ __noinline__ void bwd_tile_generic(const KParams &p, int view, int tx
 				for (int j = 0; j < CH; j++)
 					if (c0 + j < C)
 						base[j] = base_channel(c0 + j);
-				// adjoint of pass 2: near -> far (H.h:2961-3052); the colour before edge r is obtained by replaying
-				// edges 0..r-1 on the un-antialiased colour (exact; the reference divides by T, H.h:1738)
+				// antialiased colour of the pixel: one forward sweep over the edges that touch it
+				double aa[CH];
+#pragma unroll
+				for (int j = 0; j < CH; j++)
+					aa[j] = base[j];
+				for (int q = 0; q < n_sorted; q++)
+				{
+					const uint32_t sq = edge_at(q);
+					if (sq == 0xffffffffu || !is_touched(q, sq))
+						continue;
+					const EdgeRec &eq = w.edge_rec[sq];
+					const double *qp = w.edge_planes + (size_t)sq * 3 * P;
+					const double Tq = plane_at(eq.x2t, x, y);
+					Tap qtap;
+					double qL = 0, qUV[2];
+					if (eq.kind == KIND_TEXTURED)
+						textured_tap(qp, x, y, false, 0.0, p.tex_w, p.tex_h, C, qtap, qL, qUV);
+#pragma unroll
+					for (int j = 0; j < CH; j++)
+						if (c0 + j < C)
+						{
+							aa[j] *= Tq;
+							aa[j] += (1 - Tq) * edge_channel(eq, qp, texture, qtap, qL, c0 + j, x, y, false, 0.0);
+						}
+				}
+				// adjoint of pass 2: near -> far (H.h:2961-3052)
 				for (int r = n_sorted - 1; r >= 0; r--)
 				{
 					const uint32_t slot = edge_at(r);
@@ -1296,10 +1341,29 @@ __device__ __noinline__ void bwd_tile_generic(const KParams &p, int view, int tx
 #pragma unroll
 					for (int j = 0; j < CH; j++)
 						prev[j] = base[j];
+					// colour before this edge: un-blend the running antialiased colour like the reference (H.h:1738) when T
+					// is safely away from 0, otherwise replay the earlier edges from the un-antialiased colour
+					const double Tr_here = hit ? plane_at(e.x2t, x, y) : 1.0;
+					const bool need_replay = hit && !(Tr_here > 1e-6);
+					if (hit && !need_replay)
+					{
+						Tap utap;
+						double uL = 0, uUV[2];
+						if (e.kind == KIND_TEXTURED)
+							textured_tap(ep, x, y, false, 0.0, p.tex_w, p.tex_h, C, utap, uL, uUV);
+#pragma unroll
+						for (int j = 0; j < CH; j++)
+							if (c0 + j < C)
+							{
+								prev[j] = (aa[j] - (1 - Tr_here) * edge_channel(e, ep, texture, utap, uL, c0 + j, x, y, false, 0.0)) / Tr_here;
+								aa[j] = prev[j];
+							}
+					}
+					if (__ballot(need_replay))
 					for (int q = 0; q < r; q++)
 					{
 						const uint32_t sq = edge_at(q);
-						if (sq == 0xffffffffu || !is_touched(q, sq))
+						if (!need_replay || sq == 0xffffffffu || !is_touched(q, sq))
 							continue;
 						const EdgeRec &eq = w.edge_rec[sq];
 						const double *qp = w.edge_planes + (size_t)sq * 3 * P;
@@ -1315,6 +1379,12 @@ __device__ __noinline__ void bwd_tile_generic(const KParams &p, int view, int tx
 								prev[j] *= Tq;
 								prev[j] += (1 - Tq) * edge_channel(eq, qp, texture, qtap, qL, c0 + j, x, y, false, 0.0);
 							}
+					}
+					if (need_replay)
+					{
+#pragma unroll
+						for (int j = 0; j < CH; j++)
+							aa[j] = prev[j];
 					}
 					const double Tr = plane_at(e.x2t, x, y);
 					Tap etap;
@@ -1434,7 +1504,6 @@ __global__ __launch_bounds__(256) void raster_bwd_kernel(KParams p)
 // primitive of the tile) followed by ONE global atomic per (primitive, moment), issued by 64 lanes in parallel -- instead
 // of a 64-lane butterfly per moment and primitive.
 
-constexpr int NLOC = 16; // distinct owners accumulated per pass
 constexpr int NMOM = 12; // moments per owner slot: 3 per channel (or 9 for a textured owner)
 
 struct alignas(16) BwdLds
@@ -1444,9 +1513,6 @@ struct alignas(16) BwdLds
 	uint32_t ids[TB];
 	uint8_t cover[TILE][TB];
 	uint32_t order[TB];
-	uint32_t own[NLOC];
-	double tab[NLOC * NMOM];
-	double etab[16];
 };
 
 __device__ __forceinline__ void lds_add(double *slot, double v)
@@ -1617,8 +1683,6 @@ __global__ __launch_bounds__(256) void raster_bwd_fast_kernel(KParams p)
 			const int j = (int)S.order[r];
 			const EdgeRec &e = S.rec[j];
 			const double *ep = &S.planes[j * 12];
-			if (lane < 16)
-				S.etab[lane] = 0;
 			// colour before this edge: un-blend like the reference (H.h:1738) when T is safely away from 0, otherwise
 			// replay the earlier edges from the un-antialiased colour (the reference yields inf / NaN there)
 			double prev[CH];
@@ -1668,7 +1732,8 @@ __global__ __launch_bounds__(256) void raster_bwd_fast_kernel(KParams p)
 				for (int cc = 0; cc < CH; cc++)
 					cur[cc] = prev[cc];
 			}
-			lds_sync();
+			// per-pixel plane adjoints of this edge (0 where it does not touch the pixel) ...
+			double pb[5] = {0, 0, 0, 0, 0}; // planes 0..3 (colours, or u, v, shade) and the transparency plane
 			if (hit)
 			{
 				const double Tr = plane_at(e.x2t, x, y);
@@ -1693,16 +1758,9 @@ __global__ __launch_bounds__(256) void raster_bwd_fast_kernel(KParams p)
 								texture_scatter(texture_b, etap, cc, wgt);
 							g[cc] *= Tr;
 						}
-					const double ub = etap.out[0] ? 0.0 : e_B[0], vb = etap.out[1] ? 0.0 : e_B[1];
-					lds_add(&S.etab[0], ub * x);
-					lds_add(&S.etab[1], ub * y);
-					lds_add(&S.etab[2], ub);
-					lds_add(&S.etab[3], vb * x);
-					lds_add(&S.etab[4], vb * y);
-					lds_add(&S.etab[5], vb);
-					lds_add(&S.etab[6], L_B * x);
-					lds_add(&S.etab[7], L_B * y);
-					lds_add(&S.etab[8], L_B);
+					pb[0] = etap.out[0] ? 0.0 : e_B[0];
+					pb[1] = etap.out[1] ? 0.0 : e_B[1];
+					pb[2] = L_B;
 				}
 				else
 				{ // H.h:1726-1746
@@ -1712,29 +1770,28 @@ __global__ __launch_bounds__(256) void raster_bwd_fast_kernel(KParams p)
 						{
 							const double A = interp_channel(ep, cc, x, y, false, 0.0);
 							T_B += g[cc] * (prev[cc] - A);
-							const double A_B = (1 - Tr) * g[cc];
+							pb[cc] = (1 - Tr) * g[cc];
 							g[cc] *= Tr;
-							lds_add(&S.etab[3 * cc + 0], A_B * x);
-							lds_add(&S.etab[3 * cc + 1], A_B * y);
-							lds_add(&S.etab[3 * cc + 2], A_B);
 						}
 				}
-				lds_add(&S.etab[12], T_B * x);
-				lds_add(&S.etab[13], T_B * y);
-				lds_add(&S.etab[14], T_B);
+				pb[4] = T_B;
 			}
-			lds_sync();
-			if (lane < 15)
-			{ // planes 0..3 hold 3 moments each, then the transparency plane at index 3P of the global accumulator
-				const double v = S.etab[lane];
-				const int plane = lane / 3, m = lane - 3 * plane;
-				if (v != 0 && (plane < P || plane == 4))
-				{
-					double *eacc = w.edge_acc + (size_t)S.ids[j] * (3 * P + 3);
-					atomic_add_f64(eacc + (plane == 4 ? 3 * P : 3 * plane) + m, v);
-				}
+			// ... reduced over the tile on the VALU (DPP), one global atomic per moment
+			double *eacc = w.edge_acc + (size_t)S.ids[j] * (3 * P + 3);
+			double esum = 0; // lane 3 * pl + m keeps moment m of plane pl: 15 lanes then issue ONE atomic instruction
+#pragma unroll
+			for (int pl = 0; pl < 5; pl++)
+			{
+				if (pl < 4 && pl >= P)
+					continue;
+				const double mx = wave_sum_dpp(pb[pl] * x), my = wave_sum_dpp(pb[pl] * y), m1 = wave_sum_dpp(pb[pl]);
+				esum = lane == 3 * pl ? mx : (lane == 3 * pl + 1 ? my : (lane == 3 * pl + 2 ? m1 : esum));
 			}
-			lds_sync();
+			if (lane < 15 && esum != 0)
+			{
+				const int pl = lane / 3, m = lane - 3 * pl;
+				atomic_add_f64(eacc + (pl == 4 ? 3 * P : 3 * pl) + m, esum);
+			}
 		}
 	}
 
@@ -1774,43 +1831,55 @@ __global__ __launch_bounds__(256) void raster_bwd_fast_kernel(KParams p)
 				mom[3 * cc + 2] = g[cc];
 			}
 	}
+	// Segmented reduction over the pixels of each owner.  Inside a pixel row a triangle's pixels are runs of consecutive
+	// lanes, so: head-flag segmented inclusive scan over the 8 lanes of every row (3 DPP steps on the VALU, no LDS),
+	// then the last lane of each run adds the run total to the owner's accumulator (one global atomic per moment and run).
 	const int nm = 3 * P; // moments per owner in the global accumulator (P = max(C, 3) planes)
-	unsigned long long rem = __ballot(owner >= 0 && kind != KIND_NONE);
-	while (rem)
-	{ // up to NLOC distinct owners per pass: slot ids, zeroed table, LDS atomics, parallel flush
-		int slot = -1, nloc = 0;
-		while (rem && nloc < NLOC)
-		{
-			const int l = __ffsll((long long)rem) - 1;
-			const int cur = __shfl(owner, l, 64);
-			const bool mine = owner == cur;
-			if (mine)
-				slot = nloc;
-			if (lane == 0)
-				S.own[nloc] = (uint32_t)cur;
-			nloc++;
-			rem &= ~__ballot(mine);
-		}
-		for (int i = lane; i < nloc * NMOM; i += 64)
-			S.tab[i] = 0;
-		lds_sync();
-		if (slot >= 0 && !(p.debug & 64))
-		{
-#pragma unroll
-			for (int i = 0; i < NMOM; i++)
-				if (i < nm)
-					lds_add(&S.tab[slot * NMOM + i], mom[i]);
-		}
-		lds_sync();
-		for (int i = lane; i < nloc * NMOM; i += 64)
-		{
-			const int sl = i / NMOM, m = i - sl * NMOM;
-			const double v = S.tab[i];
-			if (m < nm && v != 0 && !(p.debug & 128))
-				atomic_add_f64(w.tri_acc + (size_t)S.own[sl] * nm + m, v);
-		}
-		lds_sync();
+	const int lx = lane & 7;
+	const int oid = (owner >= 0 && kind != KIND_NONE) ? owner : -1;
+	const int left_oid = dpp_i<0x111>(oid); // evaluated by ALL lanes: a DPP move under a divergent branch reads 0 from disabled lanes
+	const bool head = (lx == 0) | (left_oid != oid);
+	int f = head ? 1 : 0;
+#define DR_SEG_STEP(CTRL)                                                                                                    \
+	{                                                                                                                        \
+		const int tf = dpp_i<CTRL>(f);                                                                                       \
+		double t[NMOM];                                                                                                      \
+		_Pragma("unroll") for (int i = 0; i < NMOM; i++) t[i] = dpp_d<CTRL>(mom[i]);                                         \
+		/* branch-free on purpose: a DPP move must run with every lane enabled (a disabled source lane reads as 0) */       \
+		_Pragma("unroll") for (int i = 0; i < NMOM; i++) mom[i] += f ? 0.0 : t[i];                                           \
+		f = f ? f : tf;                                                                                                      \
 	}
+	DR_SEG_STEP(0x111)
+	DR_SEG_STEP(0x112)
+	DR_SEG_STEP(0x114)
+#undef DR_SEG_STEP
+	const int right_head = dpp_i<0x101>(head ? 1 : 0);
+	const bool tail = (lx == 7) | (right_head != 0);
+	// Run totals go through LDS so that the global atomics are issued moment-major by 64 lanes at once: the cost of an atomic
+	// instruction is per distinct cache line it touches, and the 3P moments of one owner are contiguous.
+	const bool emit = tail && oid >= 0;
+	const unsigned long long emask = __ballot(emit);
+	const int nrun = __popcll(emask);
+	const int my_run = __popcll(emask & ((1ull << lane) - 1ull));
+	double *tab = (double *)&S.rec[0];	  // staging area of the edge phase, free by now: 64 runs x 12 moments = 6 KB
+	uint32_t *own = (uint32_t *)&S.cover[0][0]; // 64 owner ids
+	lds_sync();
+	if (emit)
+	{
+		own[my_run] = (uint32_t)oid;
+#pragma unroll
+		for (int i = 0; i < NMOM; i++)
+			tab[my_run * NMOM + i] = mom[i];
+	}
+	lds_sync();
+	if (!(p.debug & 128))
+		for (int idx = lane; idx < nrun * NMOM; idx += 64)
+		{
+			const int r = idx / NMOM, m = idx - r * NMOM;
+			const double v = tab[idx];
+			if (m < nm && v != 0)
+				atomic_add_f64(w.tri_acc + (size_t)own[r] * nm + m, v);
+		}
 }
 
 template <class PixT>
