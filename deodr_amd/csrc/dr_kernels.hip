@@ -264,6 +264,23 @@ __device__ __forceinline__ void push_tile(uint32_t *cnt, uint32_t *list, int cap
 	}
 }
 
+// Conservative rejection for binning: a primitive covers a pixel only where every one of its half-plane functions
+// E = a x + b y + c is >= 0 (or > 0); if some E is clearly negative on all four corner pixels of the tile, no pixel of the
+// tile can be covered.  The slack keeps the test safe against the rounding of the exact span arithmetic used later.
+__device__ __forceinline__ bool tile_outside_halfplanes(const double *eq, int n, int tx, int ty)
+{
+	const double xa = tx * TILE, xb = tx * TILE + (TILE - 1), ya = ty * TILE, yb = ty * TILE + (TILE - 1);
+	for (int k = 0; k < n; k++)
+	{
+		const double a = eq[3 * k], b = eq[3 * k + 1], c = eq[3 * k + 2];
+		const double emax = a * (a > 0 ? xb : xa) + b * (b > 0 ? yb : ya) + c;
+		const double scale = fabs(a) * xb + fabs(b) * yb + fabs(c);
+		if (emax < -1e-9 * scale - 1e-12)
+			return true;
+	}
+	return false;
+}
+
 __global__ __launch_bounds__(256) void setup_bin_kernel(KParams p)
 {
 	const int view = blockIdx.y;
@@ -293,6 +310,7 @@ __global__ __launch_bounds__(256) void setup_bin_kernel(KParams p)
 		if (x0 <= x1 && y0 <= y1)
 			for (int ty = y0 / TILE; ty <= y1 / TILE; ty++)
 				for (int tx = x0 / TILE; tx <= x1 / TILE; tx++)
+					if (!tile_outside_halfplanes(&rec.eq[0][0], 3, tx, ty))
 					push_tile(w.tri_cnt, w.tri_list, K_TRI, w.tri_pool, p.L.tri_pool_cap, &w.hdr->tri_spill[cur], ty * p.L.tiles_x + tx, (uint32_t)k);
 	}
 	for (int n = 0; n < 3; n++)
@@ -300,8 +318,11 @@ __global__ __launch_bounds__(256) void setup_bin_kernel(KParams p)
 		const EdgeRec &e = erec[n];
 		if (e.kind == KIND_NONE || e.x_begin > e.x_end || e.y_begin > e.y_end)
 			continue;
+		const double band[12] = {e.x2b[0], e.x2b[1], e.x2b[2], e.x2b[3], e.x2b[4], e.x2b[5], e.x2t[0], e.x2t[1], e.x2t[2],
+								 -e.x2t[0], -e.x2t[1], 1 - e.x2t[2]}; // the four half-planes of the band, H.h:1418-1435
 		for (int ty = e.y_begin / TILE; ty <= e.y_end / TILE; ty++)
 			for (int tx = e.x_begin / TILE; tx <= e.x_end / TILE; tx++)
+				if (!tile_outside_halfplanes(band, 4, tx, ty))
 				push_tile(w.edge_cnt, w.edge_list, K_EDGE, w.edge_pool, p.L.edge_pool_cap, &w.hdr->edge_spill[cur], ty * p.L.tiles_x + tx,
 						  (uint32_t)(3 * k + n));
 	}
@@ -320,7 +341,7 @@ struct EdgeCursor
 
 __device__ __forceinline__ bool edge_before(double ka, uint32_t sa, double kb, uint32_t sb) { return ka > kb || (ka == kb && sa < sb); }
 
-__device__ uint32_t next_edge(const ViewPtrs &w, int tile, int nedge, uint32_t spill_n, bool first, EdgeCursor last, bool reverse, int lane,
+__device__ __forceinline__ uint32_t next_edge(const ViewPtrs &w, int tile, int nedge, uint32_t spill_n, bool first, EdgeCursor last, bool reverse, int lane,
 							  EdgeCursor &found)
 {
 	// per-lane best candidate
@@ -662,6 +683,7 @@ struct alignas(16) WaveLds
 	uint32_t order[TB];
 };
 
+
 struct PixState
 {
 	double zbest;
@@ -794,10 +816,100 @@ __device__ __forceinline__ void tri_batch(const KParams &p, WaveLds &S, int nb, 
 	lds_sync(); // the next batch overwrites the staging area
 }
 
+constexpr int EMAX = 128; // silhouette edges of one tile the staged kernels can order; more -> generic / deferred path
+
+struct EdgeSort
+{
+	double keys[EMAX];
+	uint32_t ids[EMAX];
+	uint32_t sorted[EMAX];
+};
+
+// All edges of the tile (inline list + its pairs in the spill pool), ordered far -> near (ties by slot) into es.sorted.
+// Returns their number, or -1 when there are more than EMAX (or the pool overflowed and some are missing).
+__device__ __forceinline__ int gather_sorted_edges(EdgeSort &es, const ViewPtrs &w, const KParams &p, int tile, int nedge, int lane)
+{
+	const int n_inline = nedge < K_EDGE ? nedge : K_EDGE;
+	if (lane < n_inline)
+		es.ids[lane] = w.edge_list[(size_t)tile * K_EDGE + lane];
+	int fill = n_inline;
+	if (nedge > K_EDGE)
+	{
+		if (nedge > EMAX)
+			return -1;
+		uint32_t spill_n = w.hdr->edge_spill[w.hdr->cur];
+		if (spill_n > p.L.edge_pool_cap)
+			spill_n = p.L.edge_pool_cap;
+		for (uint32_t i0 = 0; i0 < spill_n; i0 += 64)
+		{
+			const uint2 pr = (i0 + lane < spill_n) ? w.edge_pool[i0 + lane] : make_uint2(0xffffffffu, 0u);
+			const unsigned long long m = __ballot((int)pr.x == tile);
+			const int cnt = __popcll(m);
+			if (fill + cnt > EMAX)
+				return -1;
+			if ((m >> lane) & 1ull)
+				es.ids[fill + __popcll(m & ((1ull << lane) - 1ull))] = pr.y;
+			fill += cnt;
+		}
+		if (fill != nedge)
+			return -1; // pairs lost to a pool overflow: the host repeats the call with a larger pool
+	}
+	lds_sync();
+	for (int i = lane; i < fill; i += 64)
+		es.keys[i] = w.edge_rec[es.ids[i]].key;
+	lds_sync();
+	for (int i = lane; i < fill; i += 64)
+	{
+		const double key = es.keys[i];
+		const uint32_t slot = es.ids[i];
+		int rank = 0;
+		for (int j = 0; j < fill; j++)
+			rank += edge_before(es.keys[j], es.ids[j], key, slot) ? 1 : 0;
+		es.sorted[rank] = slot;
+	}
+	lds_sync();
+	return fill;
+}
+
+// stage edges sorted[first .. first + nb) and turn their scanline spans into column masks; returns, per pixel, the
+// 32-bit mask of the batch's edges whose band covers it
+__device__ __forceinline__ uint32_t stage_edge_batch(WaveLds &S, const EdgeSort &es, const ViewPtrs &w, int P, int first, int nb, int lane, int x0,
+													 int y0, int W, bool inb)
+{
+	lds_sync();
+	if (lane < nb)
+		S.ids[lane] = es.sorted[first + lane];
+	lds_sync();
+	stage_batch(S, w.edge_rec, w.edge_planes, P, nb, lane);
+	lds_sync();
+	const EdgeRec *erec = (const EdgeRec *)S.rec;
+#pragma unroll
+	for (int q = 0; q < TB / 8; q++)
+	{
+		const int j = q * 8 + (lane >> 3), r = lane & 7;
+		uint32_t m = 0;
+		if (j < nb)
+		{
+			const EdgeRec &e = erec[j];
+			const int yy = y0 + r;
+			if (yy >= e.y_begin && yy <= e.y_end)
+			{
+				int xb, xe;
+				edge_row_span(e, yy, W, xb, xe);
+				m = column_mask(xb, xe, x0);
+			}
+		}
+		S.cover[r][j] = (uint8_t)m;
+	}
+	lds_sync();
+	return inb ? gather_column_bits(&S.cover[lane >> 3][0], lane & 7) : 0u;
+}
+
 template <class PixT>
 __global__ __launch_bounds__(256) void raster_fwd_fast_kernel(KParams p)
 {
 	__shared__ WaveLds s_lds[4];
+	__shared__ EdgeSort s_es[4];
 	const int view = blockIdx.y;
 	const int wave = uniform(threadIdx.x >> 6), lane = threadIdx.x & 63;
 	const ViewPtrs w = view_ptrs(p, view);
@@ -909,78 +1021,48 @@ __global__ __launch_bounds__(256) void raster_fwd_fast_kernel(KParams p)
 			for (int cc = 0; cc < CH; cc++)
 				col[cc] = cc < C ? textured_channel(texture, tap, cc) * L : 0.0;
 		}
-		// ---- pass 2
-		if (nedge > 0 && nedge <= K_EDGE)
+		// ---- pass 2: edges far -> near, TB at a time (H.h:2839-2900)
+		int n_edges = 0;
+		if (nedge > 0)
+			n_edges = gather_sorted_edges(s_es[wave], w, p, tile, nedge, lane);
+		if (n_edges > 0)
 		{
-			EdgeRec *erec = (EdgeRec *)S.rec;
-			if (lane < nedge)
-				S.ids[lane] = w.edge_list[(size_t)tile * K_EDGE + lane];
-			lds_sync();
-			stage_batch(S, w.edge_rec, w.edge_planes, P, nedge, lane);
-			lds_sync();
-			// blending order: rank of each edge among the tile's edges (far -> near, ties by slot)
-			if (lane < nedge)
+			const EdgeRec *erec = (const EdgeRec *)S.rec;
+			for (int first = 0; first < n_edges; first += TB)
 			{
-				const double key = erec[lane].key;
-				const uint32_t slot = S.ids[lane];
-				int rank = 0;
-				for (int j = 0; j < nedge; j++)
-					rank += edge_before(erec[j].key, S.ids[j], key, slot) ? 1 : 0;
-				S.order[rank] = (uint32_t)lane;
-			}
-			// band spans: lane = slot * 8 + row
-#pragma unroll
-			for (int q = 0; q < K_EDGE / 8; q++)
-			{
-				const int j = q * 8 + (lane >> 3), r = lane & 7;
-				uint32_t m = 0;
-				if (j < nedge)
+				const int nb = n_edges - first < TB ? n_edges - first : TB;
+				const uint32_t ecov = stage_edge_batch(S, s_es[wave], w, P, first, nb, lane, x0, y0, W, inb);
+				for (int j = 0; j < nb; j++)
 				{
+					const bool c = (ecov >> j) & 1u;
+					if (__ballot(c) == 0)
+						continue;
 					const EdgeRec &e = erec[j];
-					const int yy = y0 + r;
-					if (yy >= e.y_begin && yy <= e.y_end)
+					double Ze = plane_at(e.xZ, x, y);
+					if (persp)
+						Ze = 1 / Ze;
+					if (c && Ze < st.zbest)
 					{
-						int xb, xe;
-						edge_row_span(e, yy, W, xb, xe);
-						m = column_mask(xb, xe, x0);
-					}
-				}
-				S.cover[r][j] = (uint8_t)m;
-			}
-			lds_sync();
-			const int lx = lane & 7, row = lane >> 3;
-			const uint32_t ecov = inb ? gather_column_bits(&S.cover[row][0], lx) : 0u;
-			for (int r = 0; r < nedge; r++)
-			{
-				const int j = (int)S.order[r];
-				const bool c = (ecov >> j) & 1u;
-				if (__ballot(c) == 0)
-					continue;
-				const EdgeRec &e = erec[j];
-				double Ze = plane_at(e.xZ, x, y);
-				if (persp)
-					Ze = 1 / Ze;
-				if (c && Ze < st.zbest)
-				{
-					const double *ep = &S.planes[j * 12];
-					const double Tr = plane_at(e.x2t, x, y);
-					Tap etap;
-					double eL = 0, eUV[2];
-					if (e.kind == KIND_TEXTURED)
-						textured_tap(ep, x, y, persp, Ze, p.tex_w, p.tex_h, C, etap, eL, eUV);
+						const double *ep = &S.planes[j * 12];
+						const double Tr = plane_at(e.x2t, x, y);
+						Tap etap;
+						double eL = 0, eUV[2];
+						if (e.kind == KIND_TEXTURED)
+							textured_tap(ep, x, y, persp, Ze, p.tex_w, p.tex_h, C, etap, eL, eUV);
 #pragma unroll
-					for (int cc = 0; cc < CH; cc++)
-						if (cc < C)
-						{
-							const double A = edge_channel(e, ep, texture, etap, eL, cc, x, y, persp, Ze);
-							col[cc] *= Tr;
-							col[cc] += (1 - Tr) * A;
-						}
+						for (int cc = 0; cc < CH; cc++)
+							if (cc < C)
+							{
+								const double A = edge_channel(e, ep, texture, etap, eL, cc, x, y, persp, Ze);
+								col[cc] *= Tr;
+								col[cc] += (1 - Tr) * A;
+							}
+					}
 				}
 			}
 		}
-		else if (nedge > K_EDGE)
-		{ // rare: more silhouette edges than the inline list holds -> ordered search through list + pool
+		else if (n_edges < 0)
+		{ // more than EMAX edges in one tile: ordered search through list + pool, records straight from memory
 			uint32_t edge_spill_n = w.hdr->edge_spill[w.hdr->cur];
 			if (edge_spill_n > p.L.edge_pool_cap)
 				edge_spill_n = p.L.edge_pool_cap;
@@ -1522,9 +1604,10 @@ __device__ __forceinline__ void lds_add(double *slot, double v)
 }
 
 template <class PixT>
-__global__ __launch_bounds__(256) void raster_bwd_fast_kernel(KParams p)
+__global__ __launch_bounds__(256, 3) void raster_bwd_fast_kernel(KParams p)
 {
 	__shared__ BwdLds s_lds[4];
+	__shared__ EdgeSort s_es[4];
 	const int view = blockIdx.y;
 	const int wave = uniform(threadIdx.x >> 6), lane = threadIdx.x & 63;
 	const ViewPtrs w = view_ptrs(p, view);
@@ -1547,8 +1630,11 @@ __global__ __launch_bounds__(256) void raster_bwd_fast_kernel(KParams p)
 	int nedge = uniform((int)w.edge_saved[tile]);
 	if (p.debug & 32)
 		nedge = 0;
-	if (nedge > K_EDGE)
-	{ // rare: more edges than one staged batch -> queued for raster_bwd_heavy_kernel
+	int n_edges = 0;
+	if (nedge > 0)
+		n_edges = gather_sorted_edges(s_es[wave], w, p, tile, nedge, lane);
+	if (n_edges < 0)
+	{ // more than EMAX edges in one tile (or pool overflow) -> queued for raster_bwd_heavy_kernel
 		if (lane == 0)
 			w.heavy_list[atomicAdd(&w.hdr->heavy_count[w.hdr->cur], 1u)] = (uint32_t)tile;
 		return;
@@ -1580,217 +1666,208 @@ __global__ __launch_bounds__(256) void raster_bwd_fast_kernel(KParams p)
 			textured_tap(planes, x, y, false, 0.0, p.tex_w, p.tex_h, C, tap, L, UV);
 	}
 
-	// ---- adjoint of pass 2 (near -> far)
-	if (nedge > 0)
+	// ---- adjoint of pass 2 (near -> far), TB staged edges at a time
+	if (n_edges > 0)
 	{
-		if (lane < nedge)
-			S.ids[lane] = w.edge_list[(size_t)tile * K_EDGE + lane];
-		lds_sync();
-		stage_batch(*(WaveLds *)&S, w.edge_rec, w.edge_planes, P, nedge, lane);
-		lds_sync();
-		if (lane < nedge)
-		{
-			const double key = S.rec[lane].key;
-			const uint32_t slot = S.ids[lane];
-			int rank = 0;
-			for (int j = 0; j < nedge; j++)
-				rank += edge_before(S.rec[j].key, S.ids[j], key, slot) ? 1 : 0;
-			S.order[rank] = (uint32_t)lane;
-		}
-#pragma unroll
-		for (int q = 0; q < K_EDGE / 8; q++)
-		{
-			const int j = q * 8 + (lane >> 3), r = lane & 7;
-			uint32_t m = 0;
-			if (j < nedge)
-			{
-				const EdgeRec &e = S.rec[j];
-				const int yy = y0 + r;
-				if (yy >= e.y_begin && yy <= e.y_end)
-				{
-					int xb, xe;
-					edge_row_span(e, yy, W, xb, xe);
-					m = column_mask(xb, xe, x0);
-				}
-			}
-			S.cover[r][j] = (uint8_t)m;
-		}
-		lds_sync();
-		const uint32_t ecov = inb ? gather_column_bits(&S.cover[lane >> 3][0], lane & 7) : 0u;
-		// depth and un-antialiased colour of the pixel (only pixels inside some band need them)
+		EdgeSort &es = s_es[wave];
+		// depth and un-antialiased colour of the pixel
 		double base[CH] = {0, 0, 0, 0};
-		if (ecov)
+		if (owner >= 0)
 		{
-			if (owner >= 0)
-			{
-				zown = plane_at(w.tri_rec[owner].xZ, x, y);
+			zown = plane_at(w.tri_rec[owner].xZ, x, y);
 #pragma unroll
-				for (int cc = 0; cc < CH; cc++)
-					if (cc < C)
-						base[cc] = kind == KIND_TEXTURED ? textured_channel(texture, tap, cc) * L : interp_channel(planes, cc, x, y, false, 0.0);
-			}
-			else
-			{
-#pragma unroll
-				for (int cc = 0; cc < CH; cc++)
-					if (cc < C)
-						base[cc] = background_channel<PixT>(p, view, pix, cc);
-			}
+			for (int cc = 0; cc < CH; cc++)
+				if (cc < C)
+					base[cc] = kind == KIND_TEXTURED ? textured_channel(texture, tap, cc) * L : interp_channel(planes, cc, x, y, false, 0.0);
 		}
-		// bit r of tmask: the r-th edge in blending order is drawn over this pixel
-		uint32_t tmask = 0;
-		for (int r = 0; r < nedge; r++)
+		else if (inb)
 		{
-			const int j = (int)S.order[r];
-			if ((ecov >> j) & 1u)
-				if (plane_at(S.rec[j].xZ, x, y) < zown)
-					tmask |= 1u << r;
+#pragma unroll
+			for (int cc = 0; cc < CH; cc++)
+				if (cc < C)
+					base[cc] = background_channel<PixT>(p, view, pix, cc);
 		}
-		// antialiased colour of the pixel: one forward sweep over the edges that touch it
+		// pass A, far -> near: which edges are drawn over this pixel (bit j of tm[b] = edge 32 b + j in blending order)
+		// and the antialiased colour they leave
+		uint32_t tm[EMAX / TB] = {0, 0, 0, 0};
 		double cur[CH];
 #pragma unroll
 		for (int cc = 0; cc < CH; cc++)
 			cur[cc] = base[cc];
-		for (int q = 0; q < nedge; q++)
+		const int nbatch = (n_edges + TB - 1) / TB;
+		for (int b = 0; b < nbatch; b++)
 		{
-			const bool hq = (tmask >> q) & 1u;
-			if (__ballot(hq) == 0)
-				continue;
-			const int jq = (int)S.order[q];
-			const EdgeRec &eq = S.rec[jq];
-			const double *qp = &S.planes[jq * 12];
-			if (hq)
+			const int first = b * TB, nb = n_edges - first < TB ? n_edges - first : TB;
+			const uint32_t ecov = stage_edge_batch(*(WaveLds *)&S, es, w, P, first, nb, lane, x0, y0, W, inb);
+			uint32_t tmb = 0;
+			for (int j = 0; j < nb; j++)
 			{
-				const double Tq = plane_at(eq.x2t, x, y);
-				Tap qtap;
-				double qL = 0, qUV[2];
-				if (eq.kind == KIND_TEXTURED)
-					textured_tap(qp, x, y, false, 0.0, p.tex_w, p.tex_h, C, qtap, qL, qUV);
+				const bool c = (ecov >> j) & 1u;
+				if (__ballot(c) == 0)
+					continue;
+				const EdgeRec &eq = S.rec[j];
+				if (c && plane_at(eq.xZ, x, y) < zown)
+				{
+					tmb |= 1u << j;
+					const double *qp = &S.planes[j * 12];
+					const double Tq = plane_at(eq.x2t, x, y);
+					Tap qtap;
+					double qL = 0, qUV[2];
+					if (eq.kind == KIND_TEXTURED)
+						textured_tap(qp, x, y, false, 0.0, p.tex_w, p.tex_h, C, qtap, qL, qUV);
 #pragma unroll
-				for (int cc = 0; cc < CH; cc++)
-					if (cc < C)
-					{
-						cur[cc] *= Tq;
-						cur[cc] += (1 - Tq) * edge_channel(eq, qp, texture, qtap, qL, cc, x, y, false, 0.0);
-					}
+					for (int cc = 0; cc < CH; cc++)
+						if (cc < C)
+						{
+							cur[cc] *= Tq;
+							cur[cc] += (1 - Tq) * edge_channel(eq, qp, texture, qtap, qL, cc, x, y, false, 0.0);
+						}
+				}
 			}
+#pragma unroll
+			for (int bb = 0; bb < EMAX / TB; bb++)
+				tm[bb] = bb == b ? tmb : tm[bb];
 		}
-		for (int r = nedge - 1; r >= 0; r--)
+		// pass B, near -> far (H.h:2961-3052)
+		for (int b = nbatch - 1; b >= 0; b--)
 		{
-			const bool hit = (tmask >> r) & 1u;
-			if (__ballot(hit) == 0)
-				continue;
-			const int j = (int)S.order[r];
-			const EdgeRec &e = S.rec[j];
-			const double *ep = &S.planes[j * 12];
-			// colour before this edge: un-blend like the reference (H.h:1738) when T is safely away from 0, otherwise
-			// replay the earlier edges from the un-antialiased colour (the reference yields inf / NaN there)
-			double prev[CH];
-			const double Tr_here = hit ? plane_at(e.x2t, x, y) : 1.0;
-			const bool need_replay = hit && !(Tr_here > 1e-6);
-#pragma unroll
-			for (int cc = 0; cc < CH; cc++)
-				prev[cc] = base[cc];
-			if (hit && !need_replay)
+			const int first = b * TB, nb = n_edges - first < TB ? n_edges - first : TB;
+			if (nbatch > 1) // with a single batch the records staged by pass A are still in LDS
 			{
-				Tap utap;
-				double uL = 0, uUV[2];
-				if (e.kind == KIND_TEXTURED)
-					textured_tap(ep, x, y, false, 0.0, p.tex_w, p.tex_h, C, utap, uL, uUV);
-#pragma unroll
-				for (int cc = 0; cc < CH; cc++)
-					if (cc < C)
-					{
-						prev[cc] = (cur[cc] - (1 - Tr_here) * edge_channel(e, ep, texture, utap, uL, cc, x, y, false, 0.0)) / Tr_here;
-						cur[cc] = prev[cc];
-					}
+				lds_sync();
+				if (lane < nb)
+					S.ids[lane] = es.sorted[first + lane];
+				lds_sync();
+				stage_batch(*(WaveLds *)&S, w.edge_rec, w.edge_planes, P, nb, lane);
+				lds_sync();
 			}
-			if (__ballot(need_replay))
-			for (int q = 0; q < r; q++)
+			uint32_t tmb = 0;
+#pragma unroll
+			for (int bb = 0; bb < EMAX / TB; bb++)
+				tmb = bb == b ? tm[bb] : tmb;
+			for (int r = nb - 1; r >= 0; r--)
 			{
-				if (!need_replay || !((tmask >> q) & 1u))
+				const bool hit = (tmb >> r) & 1u;
+				if (__ballot(hit) == 0)
 					continue;
-				const int jq = (int)S.order[q];
-				const EdgeRec &eq = S.rec[jq];
-				const double *qp = &S.planes[jq * 12];
-				const double Tq = plane_at(eq.x2t, x, y);
-				Tap qtap;
-				double qL = 0, qUV[2];
-				if (eq.kind == KIND_TEXTURED)
-					textured_tap(qp, x, y, false, 0.0, p.tex_w, p.tex_h, C, qtap, qL, qUV);
+				const EdgeRec &e = S.rec[r];
+				const double *ep = &S.planes[r * 12];
+				// colour before this edge: un-blend like the reference (H.h:1738) when T is safely away from 0, otherwise
+				// replay every earlier edge from the un-antialiased colour (the reference yields inf / NaN there)
+				double prev[CH];
+				const double Tr_here = hit ? plane_at(e.x2t, x, y) : 1.0;
+				const bool need_replay = hit && !(Tr_here > 1e-6);
 #pragma unroll
 				for (int cc = 0; cc < CH; cc++)
-					if (cc < C)
-					{
-						prev[cc] *= Tq;
-						prev[cc] += (1 - Tq) * edge_channel(eq, qp, texture, qtap, qL, cc, x, y, false, 0.0);
-					}
-			}
-			if (need_replay)
-			{
-#pragma unroll
-				for (int cc = 0; cc < CH; cc++)
-					cur[cc] = prev[cc];
-			}
-			// per-pixel plane adjoints of this edge (0 where it does not touch the pixel) ...
-			double pb[5] = {0, 0, 0, 0, 0}; // planes 0..3 (colours, or u, v, shade) and the transparency plane
-			if (hit)
-			{
-				const double Tr = plane_at(e.x2t, x, y);
-				double T_B = 0;
-				if (e.kind == KIND_TEXTURED)
-				{ // H.h:2006-2021
-					Tap etap;
-					double eL, eUV[2], L_B = 0, e_B[2] = {0, 0};
-					textured_tap(ep, x, y, false, 0.0, p.tex_w, p.tex_h, C, etap, eL, eUV);
+					prev[cc] = base[cc];
+				if (hit && !need_replay)
+				{
+					Tap utap;
+					double uL = 0, uUV[2];
+					if (e.kind == KIND_TEXTURED)
+						textured_tap(ep, x, y, false, 0.0, p.tex_w, p.tex_h, C, utap, uL, uUV);
 #pragma unroll
 					for (int cc = 0; cc < CH; cc++)
 						if (cc < C)
 						{
-							const double i00 = ldp(texture, etap.idx[0] + cc), i10 = ldp(texture, etap.idx[1] + cc);
-							const double i01 = ldp(texture, etap.idx[2] + cc), i11 = ldp(texture, etap.idx[3] + cc);
-							const double A = bilinear_mix(etap, i00, i10, i01, i11);
-							T_B += g[cc] * (prev[cc] - A * eL);
-							L_B += g[cc] * (1 - Tr) * A;
-							double wgt[4];
-							bilinear_mix_adjoint(etap, eL * (1 - Tr) * g[cc], i00, i10, i01, i11, wgt, e_B);
-							if (texture_b)
-								texture_scatter(texture_b, etap, cc, wgt);
-							g[cc] *= Tr;
-						}
-					pb[0] = etap.out[0] ? 0.0 : e_B[0];
-					pb[1] = etap.out[1] ? 0.0 : e_B[1];
-					pb[2] = L_B;
-				}
-				else
-				{ // H.h:1726-1746
-#pragma unroll
-					for (int cc = 0; cc < CH; cc++)
-						if (cc < C)
-						{
-							const double A = interp_channel(ep, cc, x, y, false, 0.0);
-							T_B += g[cc] * (prev[cc] - A);
-							pb[cc] = (1 - Tr) * g[cc];
-							g[cc] *= Tr;
+							prev[cc] = (cur[cc] - (1 - Tr_here) * edge_channel(e, ep, texture, utap, uL, cc, x, y, false, 0.0)) / Tr_here;
+							cur[cc] = prev[cc];
 						}
 				}
-				pb[4] = T_B;
-			}
-			// ... reduced over the tile on the VALU (DPP), one global atomic per moment
-			double *eacc = w.edge_acc + (size_t)S.ids[j] * (3 * P + 3);
-			double esum = 0; // lane 3 * pl + m keeps moment m of plane pl: 15 lanes then issue ONE atomic instruction
+				if (__ballot(need_replay))
+				{ // measure-zero event (pixel centre within 1e-6 sigma of the edge line): records straight from memory
+					const int upto = first + r;
+					for (int q = 0; q < upto; q++)
+					{
+						uint32_t tq = 0;
 #pragma unroll
-			for (int pl = 0; pl < 5; pl++)
-			{
-				if (pl < 4 && pl >= P)
-					continue;
-				const double mx = wave_sum_dpp(pb[pl] * x), my = wave_sum_dpp(pb[pl] * y), m1 = wave_sum_dpp(pb[pl]);
-				esum = lane == 3 * pl ? mx : (lane == 3 * pl + 1 ? my : (lane == 3 * pl + 2 ? m1 : esum));
-			}
-			if (lane < 15 && esum != 0)
-			{
-				const int pl = lane / 3, m = lane - 3 * pl;
-				atomic_add_f64(eacc + (pl == 4 ? 3 * P : 3 * pl) + m, esum);
+						for (int bb = 0; bb < EMAX / TB; bb++)
+							tq = bb == (q / TB) ? tm[bb] : tq;
+						if (!need_replay || !((tq >> (q % TB)) & 1u))
+							continue;
+						const uint32_t sq = es.sorted[q];
+						const EdgeRec &eq = w.edge_rec[sq];
+						const double *qp = w.edge_planes + (size_t)sq * 3 * P;
+						const double Tq = plane_at(eq.x2t, x, y);
+						Tap qtap;
+						double qL = 0, qUV[2];
+						if (eq.kind == KIND_TEXTURED)
+							textured_tap(qp, x, y, false, 0.0, p.tex_w, p.tex_h, C, qtap, qL, qUV);
+#pragma unroll
+						for (int cc = 0; cc < CH; cc++)
+							if (cc < C)
+							{
+								prev[cc] *= Tq;
+								prev[cc] += (1 - Tq) * edge_channel(eq, qp, texture, qtap, qL, cc, x, y, false, 0.0);
+							}
+					}
+					if (need_replay)
+					{
+#pragma unroll
+						for (int cc = 0; cc < CH; cc++)
+							cur[cc] = prev[cc];
+					}
+				}
+				// per-pixel plane adjoints of this edge (0 where it does not touch the pixel) ...
+				double pb[5] = {0, 0, 0, 0, 0}; // planes 0..3 (colours, or u, v, shade) and the transparency plane
+				if (hit)
+				{
+					const double Tr = Tr_here;
+					double T_B = 0;
+					if (e.kind == KIND_TEXTURED)
+					{ // H.h:2006-2021
+						Tap etap;
+						double eL, eUV[2], L_B = 0, e_B[2] = {0, 0};
+						textured_tap(ep, x, y, false, 0.0, p.tex_w, p.tex_h, C, etap, eL, eUV);
+#pragma unroll
+						for (int cc = 0; cc < CH; cc++)
+							if (cc < C)
+							{
+								const double i00 = ldp(texture, etap.idx[0] + cc), i10 = ldp(texture, etap.idx[1] + cc);
+								const double i01 = ldp(texture, etap.idx[2] + cc), i11 = ldp(texture, etap.idx[3] + cc);
+								const double A = bilinear_mix(etap, i00, i10, i01, i11);
+								T_B += g[cc] * (prev[cc] - A * eL);
+								L_B += g[cc] * (1 - Tr) * A;
+								double wgt[4];
+								bilinear_mix_adjoint(etap, eL * (1 - Tr) * g[cc], i00, i10, i01, i11, wgt, e_B);
+								if (texture_b)
+									texture_scatter(texture_b, etap, cc, wgt);
+								g[cc] *= Tr;
+							}
+						pb[0] = etap.out[0] ? 0.0 : e_B[0];
+						pb[1] = etap.out[1] ? 0.0 : e_B[1];
+						pb[2] = L_B;
+					}
+					else
+					{ // H.h:1726-1746
+#pragma unroll
+						for (int cc = 0; cc < CH; cc++)
+							if (cc < C)
+							{
+								const double A = interp_channel(ep, cc, x, y, false, 0.0);
+								T_B += g[cc] * (prev[cc] - A);
+								pb[cc] = (1 - Tr) * g[cc];
+								g[cc] *= Tr;
+							}
+					}
+					pb[4] = T_B;
+				}
+				// ... reduced over the tile on the VALU (DPP), then ONE atomic instruction (15 lanes) per edge and tile
+				double *eacc = w.edge_acc + (size_t)S.ids[r] * (3 * P + 3);
+				double esum = 0; // lane 3 * pl + m keeps moment m of plane pl
+#pragma unroll
+				for (int pl = 0; pl < 5; pl++)
+				{
+					if (pl < 4 && pl >= P)
+						continue;
+					const double mx = wave_sum_dpp(pb[pl] * x), my = wave_sum_dpp(pb[pl] * y), m1 = wave_sum_dpp(pb[pl]);
+					esum = lane == 3 * pl ? mx : (lane == 3 * pl + 1 ? my : (lane == 3 * pl + 2 ? m1 : esum));
+				}
+				if (lane < 15 && esum != 0)
+				{
+					const int pl = lane / 3, m = lane - 3 * pl;
+					atomic_add_f64(eacc + (pl == 4 ? 3 * P : 3 * pl) + m, esum);
+				}
 			}
 		}
 	}

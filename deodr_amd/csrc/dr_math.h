@@ -142,6 +142,25 @@ DR_HD double plane_coef(int nv, const double a[3], const double *x2b, int j)
 
 #define DR_SHRT_MAX 32767
 
+// The reference's fallback for |a / b| beyond the 16-bit range (or b == 0) walks x upward from x_min while a predicate
+// P(x) holds (H.h:459-477, 499-517): up to `width` iterations.  P(x) compares the correctly rounded product (x + 1) * b
+// with a, which is monotone in x, so the first x where P fails is found by bisection with the identical result -- a
+// 1000-iteration data-dependent loop in one lane would stall its whole wavefront.
+template <class Pred>
+DR_HD int first_failing(int x_min, int x_max, Pred holds)
+{
+	int lo = x_min, hi = x_max; // the walk stops at x_max whatever P says there
+	while (lo < hi)
+	{
+		const int mid = lo + ((hi - lo) >> 1);
+		if (holds(mid))
+			lo = mid + 1;
+		else
+			hi = mid;
+	}
+	return lo;
+}
+
 DR_HD int floor_div(double a, double b, int x_min, int x_max) // H.h:440-479
 {
 	int x;
@@ -153,16 +172,12 @@ DR_HD int floor_div(double a, double b, int x_min, int x_max) // H.h:440-479
 		if (x > x_max)
 			x = x_max;
 	}
-	else
-	{ // |a/b| is huge or b == 0: the reference searches upward from x_min
+	else if (x_min >= x_max)
 		x = x_min;
-		if (b > 0)
-			while (((x + 1) * b <= a) && (x < x_max))
-				x++;
-		else
-			while (((x + 1) * b >= a) && (x < x_max))
-				x++;
-	}
+	else if (b > 0)
+		x = first_failing(x_min, x_max, [=](int t) { return (t + 1) * b <= a; });
+	else
+		x = first_failing(x_min, x_max, [=](int t) { return (t + 1) * b >= a; });
 	return x;
 }
 
@@ -177,16 +192,12 @@ DR_HD int ceil_div(double a, double b, int x_min, int x_max) // H.h:481-519
 		if (x > x_max)
 			x = x_max;
 	}
-	else
-	{
+	else if (x_min >= x_max)
 		x = x_min;
-		if (b > 0)
-			while (((x + 1) * b < a) && (x < x_max))
-				x++;
-		else
-			while (((x + 1) * b > a) && (x < x_max))
-				x++;
-	}
+	else if (b > 0)
+		x = first_failing(x_min, x_max, [=](int t) { return (t + 1) * b < a; });
+	else
+		x = first_failing(x_min, x_max, [=](int t) { return (t + 1) * b > a; });
 	return x;
 }
 

@@ -1,0 +1,57 @@
+"""CPU checks of the kernels' per-primitive arithmetic (deodr_amd/csrc/dr_math.h, dr_prims.h instantiated on the host by
+tests/sim/tile_sim.cpp): coverage of single primitives through the SAME span functions the HIP kernels use must equal the
+coverage the CPU oracle draws -- including degenerate slopes where the reference falls back to its incremental search."""
+
+import numpy as np
+import pytest
+
+import sim_util
+from deodr_amd.differentiable_renderer import Scene2D
+
+
+def one_triangle_scene(ij, W=40, H=32, strict=True, edgeflags=(True, True, True)):
+    ij = np.asarray(ij, dtype=np.float64)
+    cr = (ij[1, 0] - ij[0, 0]) * (ij[2, 1] - ij[0, 1]) - (ij[1, 1] - ij[0, 1]) * (ij[2, 0] - ij[0, 0])
+    return Scene2D(
+        faces=np.array([[0, 1, 2]], dtype=np.uint32), faces_uv=np.array([[0, 1, 2]], dtype=np.uint32), ij=ij,
+        depths=np.array([1.0, 1.0, 1.0]), textured=np.zeros(1, dtype=bool), uv=np.zeros((3, 2)), shade=np.zeros(3),
+        colors=np.ones((3, 1)), shaded=np.zeros(1, dtype=bool), edgeflags=np.array([edgeflags], dtype=bool), height=H, width=W,
+        nb_colors=1, texture=np.zeros((0, 0)), background_color=np.zeros(1), clockwise=bool(cr > 0), backface_culling=True,
+        strict_edge=strict,
+    )  # fmt: skip
+
+
+CASES = [
+    [[3.2, 4.1], [30.7, 6.3], [12.4, 27.9]],
+    [[5, 5], [30, 5], [18, 25]],  # exactly horizontal edge: the reference's b == 0 fallback
+    [[5, 5], [5, 28], [31, 17]],  # exactly vertical edge
+    [[2, 10], [38, 10.0000001], [20, 30]],  # almost horizontal: quotient beyond the 16-bit range
+    [[10, 2], [10.0000001, 30], [30, 16]],  # almost vertical
+    [[-20, -10], [70, 5], [10, 60]],  # larger than the image
+    [[7, 7], [9, 7.5], [8, 9]],  # tiny
+]
+
+
+@pytest.mark.parametrize("strict", [True, False])
+@pytest.mark.parametrize("case", range(len(CASES)))
+def test_span_functions_match_oracle_coverage(oracle_api, case, strict):
+    import ctypes as C
+
+    s = one_triangle_scene(CASES[case], strict=strict)
+    lib = sim_util.lib()
+    c, keep = sim_util.sim_scene(s, sigma=1.5)
+    rnd = oracle_api.ref() or oracle_api.port()
+    # triangle coverage == pixels whose z-buffer the oracle wrote
+    image, z = rnd.render(s, 0.0)
+    mask = np.zeros((s.height, s.width), dtype=np.uint8)
+    lib.sim_tri_coverage(C.byref(c), 0, mask.ctypes.data)
+    assert np.array_equal(mask.astype(bool), np.isfinite(z))
+    # edge-band coverage == pixels the oracle's edge pass changes (colour 1 blended over background 0), edge by edge
+    for n in range(3):
+        s1 = one_triangle_scene(CASES[case], strict=strict, edgeflags=tuple(i == n for i in range(3)))
+        image1, z1 = rnd.render(s1, 1.5)
+        band = (np.abs(image1[:, :, 0] - image[:, :, 0]) > 0) & ~np.isfinite(z)
+        emask = np.zeros((s.height, s.width), dtype=np.uint8)
+        lib.sim_edge_coverage(C.byref(c), 0, n, emask.ctypes.data)
+        # the band also extends over the triangle itself only where Z_edge < z (never here: same depth), so compare outside
+        assert np.array_equal(emask.astype(bool) & ~np.isfinite(z), band), n
