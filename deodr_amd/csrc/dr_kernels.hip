@@ -192,6 +192,18 @@ __device__ __forceinline__ SceneView scene_view(const KParams &p, int view)
 	return s;
 }
 
+// owner buffer: triangle index in the low 30 bits, its PrimKind in the top 2 (3 = no owner), so that the adjoint does not
+// have to gather the kind from the 128-byte record of every pixel's owner
+__device__ __forceinline__ int32_t pack_owner(int k, int kind) { return k < 0 ? -1 : (int32_t)((uint32_t)k | ((uint32_t)kind << 30)); }
+__device__ __forceinline__ void unpack_owner(int32_t raw, int &owner, int &kind)
+{
+	const uint32_t u = (uint32_t)raw;
+	kind = (int)(u >> 30);
+	owner = kind == 3 ? -1 : (int)(u & 0x3fffffffu);
+	if (kind == 3)
+		kind = KIND_NONE;
+}
+
 // ------------------------------------------------------------------------------------------------ wave primitives
 
 __device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
@@ -649,7 +661,7 @@ __global__ __launch_bounds__(256) void raster_fwd_kernel(KParams p)
 		{
 			if (p.zbuf)
 				((PixT *)p.zbuf)[vpix] = (PixT)zbest;
-			w.face_id[pix] = kbest;
+			w.face_id[pix] = pack_owner(kbest, kind);
 		}
 	}
 	if (blockIdx.x == 0 && threadIdx.x == 0)
@@ -930,6 +942,8 @@ __global__ __launch_bounds__(256) void raster_fwd_fast_kernel(KParams p)
 		const size_t pix = (size_t)py * W + px;
 		const size_t vpix = (size_t)view * H * W + pix;
 		const double x = px, y = py;
+		// the inline triangle list is fetched together with the counters (one memory round trip instead of two)
+		const uint32_t list_entry = w.tri_list[(size_t)tile * K_TRI + (lane & (K_TRI - 1))];
 		int ntri = uniform((int)w.tri_cnt[tile]);
 		int nedge = uniform((int)w.edge_cnt[tile]);
 		if (p.debug & 1)
@@ -955,7 +969,7 @@ __global__ __launch_bounds__(256) void raster_fwd_fast_kernel(KParams p)
 		{
 			const int n_inline = ntri < K_TRI ? ntri : K_TRI;
 			if (lane < n_inline)
-				S.ids[lane] = w.tri_list[(size_t)tile * K_TRI + lane];
+				S.ids[lane] = list_entry;
 			lds_sync();
 			stage_batch(S, w.tri_rec, w.tri_planes, P, n_inline, lane);
 			lds_sync();
@@ -1121,7 +1135,7 @@ __global__ __launch_bounds__(256) void raster_fwd_fast_kernel(KParams p)
 			}
 			if (p.zbuf)
 				((PixT *)p.zbuf)[vpix] = (PixT)st.zbest;
-			w.face_id[pix] = st.kbest;
+			w.face_id[pix] = pack_owner(st.kbest, st.kind);
 		}
 	}
 	if (blockIdx.x == 0 && threadIdx.x == 0)
@@ -1178,14 +1192,15 @@ __device__ __noinline__ void bwd_tile_generic(const KParams &p, int view, int tx
 	int nedge = uniform((int)w.edge_saved[tile]);
 	if (p.debug & 32)
 		nedge = 0;
-	int owner = inb ? w.face_id[pix] : -1;
+	int owner = -1, kind = KIND_NONE;
+	if (inb)
+		unpack_owner(w.face_id[pix], owner, kind);
 	if (p.debug & 16)
 		owner = -1;
 	if (__ballot(owner >= 0) == 0 && nedge == 0)
 		return;
 
 	// what pass 1 left at this pixel
-	int kind = KIND_NONE;
 	const double *planes = nullptr;
 	double zown = INFINITY;
 	Tap tap;
@@ -1193,7 +1208,6 @@ __device__ __noinline__ void bwd_tile_generic(const KParams &p, int view, int tx
 	if (owner >= 0)
 	{
 		const TriRec &r = w.tri_rec[owner];
-		kind = r.kind;
 		planes = w.tri_planes + (size_t)owner * 3 * P;
 		zown = plane_at(r.xZ, x, y);
 		if (kind == KIND_TEXTURED)
@@ -1639,7 +1653,9 @@ __global__ __launch_bounds__(256, 3) void raster_bwd_fast_kernel(KParams p)
 			w.heavy_list[atomicAdd(&w.hdr->heavy_count[w.hdr->cur], 1u)] = (uint32_t)tile;
 		return;
 	}
-	int owner = inb ? w.face_id[pix] : -1;
+	int owner = -1, kind = KIND_NONE;
+	if (inb)
+		unpack_owner(w.face_id[pix], owner, kind);
 	if (p.debug & 16)
 		owner = -1;
 	if (__ballot(owner >= 0) == 0 && nedge == 0)
@@ -1653,14 +1669,12 @@ __global__ __launch_bounds__(256, 3) void raster_bwd_fast_kernel(KParams p)
 			g[cc] = (cc < C && inb) ? (double)gin[cc] : 0.0;
 	}
 	// what pass 1 left at this pixel
-	int kind = KIND_NONE;
 	const double *planes = nullptr;
 	double zown = INFINITY;
 	Tap tap;
 	double L = 0, UV[2] = {0, 0};
 	if (owner >= 0)
 	{
-		kind = w.tri_rec[owner].kind;
 		planes = w.tri_planes + (size_t)owner * 3 * P;
 		if (kind == KIND_TEXTURED)
 			textured_tap(planes, x, y, false, 0.0, p.tex_w, p.tex_h, C, tap, L, UV);
@@ -2046,6 +2060,8 @@ int fill_params(const DeodrHipScene *sc, double sigma, void *workspace, size_t w
 		return fail("invalid scene dimensions");
 	if (sc->nb_colors <= 0 || sc->nb_colors > DEODR_HIP_MAX_COLORS)
 		return fail("nb_colors out of range");
+	if (sc->nb_triangles >= (1 << 30))
+		return fail("more than 2^30 triangles");
 	if (sc->height > 32767 || sc->width > 32767)
 		return fail("image larger than 32767 pixels (pixel coordinates are 16-bit, as in the reference)");
 	if ((sc->vertex_dtype != DEODR_HIP_F32 && sc->vertex_dtype != DEODR_HIP_F64) || (sc->pixel_dtype != DEODR_HIP_F32 && sc->pixel_dtype != DEODR_HIP_F64))
