@@ -684,7 +684,7 @@ __global__ __launch_bounds__(256) void raster_fwd_kernel(KParams p)
 // the depth test and shading then read plane coefficients as LDS broadcasts.  Handles nb_colors <= 4 without
 // antialiase_error; everything else runs on raster_fwd_kernel.
 
-constexpr int TB = 32; // triangles (or edges) staged per batch
+constexpr int TB = 16; // triangles (or edges) staged per batch: small, so that LDS never limits the number of resident waves
 
 struct alignas(16) WaveLds
 {
@@ -722,11 +722,16 @@ __device__ __forceinline__ uint32_t column_mask(int xb, int xe, int x0)
 // bit j of the result = bit `lx` of byte j of the 32-byte row `bytes` (coverage of my column by primitive j)
 __device__ __forceinline__ uint32_t gather_column_bits(const uint8_t *row_bytes, int lx)
 {
-	const uint4 a = ((const uint4 *)row_bytes)[0], b = ((const uint4 *)row_bytes)[1];
-	const uint32_t wd[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+	uint32_t wd[TB / 4];
+#pragma unroll
+	for (int i = 0; i < TB / 16; i++)
+	{
+		const uint4 a = ((const uint4 *)row_bytes)[i];
+		wd[4 * i] = a.x, wd[4 * i + 1] = a.y, wd[4 * i + 2] = a.z, wd[4 * i + 3] = a.w;
+	}
 	uint32_t m = 0;
 #pragma unroll
-	for (int i = 0; i < 8; i++)
+	for (int i = 0; i < TB / 4; i++)
 	{
 		uint32_t t = (wd[i] >> lx) & 0x01010101u;
 		m |= (((t * 0x01020408u) >> 24) & 0xfu) << (4 * i);
@@ -828,7 +833,7 @@ __device__ __forceinline__ void tri_batch(const KParams &p, WaveLds &S, int nb, 
 	lds_sync(); // the next batch overwrites the staging area
 }
 
-constexpr int EMAX = 128; // silhouette edges of one tile the staged kernels can order; more -> generic / deferred path
+constexpr int EMAX = 64; // silhouette edges of one tile the staged kernels can order; more -> generic / deferred path
 
 struct EdgeSort
 {
@@ -917,17 +922,17 @@ __device__ __forceinline__ uint32_t stage_edge_batch(WaveLds &S, const EdgeSort 
 	return inb ? gather_column_bits(&S.cover[lane >> 3][0], lane & 7) : 0u;
 }
 
-template <class PixT>
-__global__ __launch_bounds__(256) void raster_fwd_fast_kernel(KParams p)
+template <class PixT, int WPB> // WPB wavefronts (= tiles) per workgroup
+__global__ __launch_bounds__(64 * WPB) void raster_fwd_fast_kernel(KParams p)
 {
-	__shared__ WaveLds s_lds[4];
-	__shared__ EdgeSort s_es[4];
+	__shared__ WaveLds s_lds[WPB];
+	__shared__ EdgeSort s_es[WPB];
 	const int view = blockIdx.y;
 	const int wave = uniform(threadIdx.x >> 6), lane = threadIdx.x & 63;
 	const ViewPtrs w = view_ptrs(p, view);
-	const int strips_x = (p.L.tiles_x + 3) / 4;
+	const int strips_x = (p.L.tiles_x + WPB - 1) / WPB;
 	const int b = xcd_band(blockIdx.x, gridDim.x);
-	const int ty = b / strips_x, tx = (b % strips_x) * 4 + wave;
+	const int ty = b / strips_x, tx = (b % strips_x) * WPB + wave;
 	const int W = p.W, H = p.H, C = p.C, P = p.L.P;
 	const bool persp = p.persp;
 	const PixT *texture = (const PixT *)p.texture;
@@ -968,12 +973,16 @@ __global__ __launch_bounds__(256) void raster_fwd_fast_kernel(KParams p)
 		if (ntri > 0)
 		{
 			const int n_inline = ntri < K_TRI ? ntri : K_TRI;
-			if (lane < n_inline)
-				S.ids[lane] = list_entry;
-			lds_sync();
-			stage_batch(S, w.tri_rec, w.tri_planes, P, n_inline, lane);
-			lds_sync();
-			tri_batch(p, S, n_inline, lane, x0, y0, inb, st);
+			for (int base = 0; base < n_inline; base += TB)
+			{
+				const int nb = n_inline - base < TB ? n_inline - base : TB;
+				if (lane >= base && lane < base + nb)
+					S.ids[lane - base] = list_entry;
+				lds_sync();
+				stage_batch(S, w.tri_rec, w.tri_planes, P, nb, lane);
+				lds_sync();
+				tri_batch(p, S, nb, lane, x0, y0, inb, st);
+			}
 			if (ntri > K_TRI)
 			{ // spilled pairs of this tile: compact them out of the pool, TB at a time
 				uint32_t spill_n = w.hdr->tri_spill[w.hdr->cur];
@@ -1617,17 +1626,17 @@ __device__ __forceinline__ void lds_add(double *slot, double v)
 		unsafeAtomicAdd(slot, v);
 }
 
-template <class PixT>
-__global__ __launch_bounds__(256, 3) void raster_bwd_fast_kernel(KParams p)
+template <class PixT, int WPB>
+__global__ __launch_bounds__(64 * WPB, 3) void raster_bwd_fast_kernel(KParams p)
 {
-	__shared__ BwdLds s_lds[4];
-	__shared__ EdgeSort s_es[4];
+	__shared__ BwdLds s_lds[WPB];
+	__shared__ EdgeSort s_es[WPB];
 	const int view = blockIdx.y;
 	const int wave = uniform(threadIdx.x >> 6), lane = threadIdx.x & 63;
 	const ViewPtrs w = view_ptrs(p, view);
-	const int strips_x = (p.L.tiles_x + 3) / 4;
+	const int strips_x = (p.L.tiles_x + WPB - 1) / WPB;
 	const int b = xcd_band(blockIdx.x, gridDim.x);
-	const int ty = b / strips_x, tx = (b % strips_x) * 4 + wave;
+	const int ty = b / strips_x, tx = (b % strips_x) * WPB + wave;
 	const int W = p.W, H = p.H, C = p.C, P = p.L.P;
 	const PixT *texture = (const PixT *)p.texture;
 	PixT *texture_b = (PixT *)p.texture_b;
@@ -1704,6 +1713,7 @@ __global__ __launch_bounds__(256, 3) void raster_bwd_fast_kernel(KParams p)
 		// pass A, far -> near: which edges are drawn over this pixel (bit j of tm[b] = edge 32 b + j in blending order)
 		// and the antialiased colour they leave
 		uint32_t tm[EMAX / TB] = {0, 0, 0, 0};
+		static_assert(EMAX / TB == 4, "tm[] initialiser");
 		double cur[CH];
 #pragma unroll
 		for (int cc = 0; cc < CH; cc++)
@@ -1949,28 +1959,36 @@ __global__ __launch_bounds__(256, 3) void raster_bwd_fast_kernel(KParams p)
 	// Run totals go through LDS so that the global atomics are issued moment-major by 64 lanes at once: the cost of an atomic
 	// instruction is per distinct cache line it touches, and the 3P moments of one owner are contiguous.
 	const bool emit = tail && oid >= 0;
-	const unsigned long long emask = __ballot(emit);
-	const int nrun = __popcll(emask);
-	const int my_run = __popcll(emask & ((1ull << lane) - 1ull));
-	double *tab = (double *)&S.rec[0];	  // staging area of the edge phase, free by now: 64 runs x 12 moments = 6 KB
-	uint32_t *own = (uint32_t *)&S.cover[0][0]; // 64 owner ids
-	lds_sync();
-	if (emit)
+	constexpr int RUNS = 32; // run totals flushed per pass: 32 x 12 doubles fit in the (now idle) record staging area
+	static_assert(RUNS * NMOM * sizeof(double) <= sizeof(S.rec) + sizeof(S.planes) && RUNS * 4 <= sizeof(S.cover), "LDS reuse");
+	double *tab = (double *)&S.rec[0];
+	uint32_t *own = (uint32_t *)&S.cover[0][0];
+	unsigned long long emask = __ballot(emit);
+	while (emask)
 	{
-		own[my_run] = (uint32_t)oid;
-#pragma unroll
-		for (int i = 0; i < NMOM; i++)
-			tab[my_run * NMOM + i] = mom[i];
-	}
-	lds_sync();
-	if (!(p.debug & 128))
-		for (int idx = lane; idx < nrun * NMOM; idx += 64)
+		const int my_run = __popcll(emask & ((1ull << lane) - 1ull));
+		const bool sel = ((emask >> lane) & 1ull) && my_run < RUNS;
+		const int total = __popcll(emask);
+		const int nrun = total < RUNS ? total : RUNS;
+		lds_sync();
+		if (sel)
 		{
-			const int r = idx / NMOM, m = idx - r * NMOM;
-			const double v = tab[idx];
-			if (m < nm && v != 0)
-				atomic_add_f64(w.tri_acc + (size_t)own[r] * nm + m, v);
+			own[my_run] = (uint32_t)oid;
+#pragma unroll
+			for (int i = 0; i < NMOM; i++)
+				tab[my_run * NMOM + i] = mom[i];
 		}
+		lds_sync();
+		if (!(p.debug & 128))
+			for (int idx = lane; idx < nrun * NMOM; idx += 64)
+			{
+				const int r = idx / NMOM, m = idx - r * NMOM;
+				const double v = tab[idx];
+				if (m < nm && v != 0)
+					atomic_add_f64(w.tri_acc + (size_t)own[r] * nm + m, v);
+			}
+		emask &= ~__ballot(sel);
+	}
 }
 
 template <class PixT>
@@ -2152,6 +2170,7 @@ struct ProfEvent
 };
 bool g_profile = false;
 bool g_force_generic = false; // DEODR_HIP_FORCE_GENERIC=1: run the un-staged kernels (tests cover both)
+const int g_wpb = getenv("DEODR_HIP_WPB") ? atoi(getenv("DEODR_HIP_WPB")) : 1; // wavefronts per workgroup of the staged kernels: 1 or 4
 std::vector<ProfEvent> g_prof_events;
 std::vector<std::pair<hipEvent_t, hipEvent_t>> g_prof_free;
 
@@ -2196,22 +2215,27 @@ int launch_forward(const DeodrHipScene *sc, KParams &p, hipStream_t stream)
 		ScopedKernelTimer t(KID_SETUP, stream);
 		hipLaunchKernelGGL(setup_bin_kernel, grid, dim3(256), 0, stream, p);
 	}
-	const int strips_x = (p.L.tiles_x + 3) / 4;
+	const bool fast = !p.aa_err && p.C <= CH && !g_force_generic;
+	const int wpb = fast ? g_wpb : 4; // wavefronts (tiles) per workgroup of the staged kernels (tuning knob DEODR_HIP_WPB)
+	const int strips_x = (p.L.tiles_x + wpb - 1) / wpb;
 	dim3 grid(strips_x * p.L.tiles_y, n_views);
 	{
 		ScopedKernelTimer t(KID_RASTER_FWD, stream);
-		const bool fast = !p.aa_err && p.C <= CH && !g_force_generic;
 		if (sc->pixel_dtype == DEODR_HIP_F64)
 		{
-			if (fast)
-				hipLaunchKernelGGL(raster_fwd_fast_kernel<double>, grid, dim3(256), 0, stream, p);
+			if (fast && wpb == 1)
+				hipLaunchKernelGGL((raster_fwd_fast_kernel<double, 1>), grid, dim3(64), 0, stream, p);
+			else if (fast)
+				hipLaunchKernelGGL((raster_fwd_fast_kernel<double, 4>), grid, dim3(256), 0, stream, p);
 			else
 				hipLaunchKernelGGL(raster_fwd_kernel<double>, grid, dim3(256), 0, stream, p);
 		}
 		else
 		{
-			if (fast)
-				hipLaunchKernelGGL(raster_fwd_fast_kernel<float>, grid, dim3(256), 0, stream, p);
+			if (fast && wpb == 1)
+				hipLaunchKernelGGL((raster_fwd_fast_kernel<float, 1>), grid, dim3(64), 0, stream, p);
+			else if (fast)
+				hipLaunchKernelGGL((raster_fwd_fast_kernel<float, 4>), grid, dim3(256), 0, stream, p);
 			else
 				hipLaunchKernelGGL(raster_fwd_kernel<float>, grid, dim3(256), 0, stream, p);
 		}
@@ -2315,22 +2339,27 @@ int deodr_hip_render_scene_b(const DeodrHipScene *sc, const void *image, const v
 	p.obs = obs;
 	p.err_b = err_buffer_b;
 	p.aa_err = antialiase_error != 0;
-	const int strips_x = (p.L.tiles_x + 3) / 4;
+	const bool fast = !p.aa_err && p.C <= CH && !g_force_generic;
+	const int wpb = fast ? g_wpb : 4;
+	const int strips_x = (p.L.tiles_x + wpb - 1) / wpb;
 	dim3 grid(strips_x * p.L.tiles_y, sc->n_views);
 	{
 		ScopedKernelTimer t(KID_RASTER_BWD, st);
-		const bool fast = !p.aa_err && p.C <= CH && !g_force_generic;
 		if (sc->pixel_dtype == DEODR_HIP_F64)
 		{
-			if (fast)
-				hipLaunchKernelGGL(raster_bwd_fast_kernel<double>, grid, dim3(256), 0, st, p);
+			if (fast && wpb == 1)
+				hipLaunchKernelGGL((raster_bwd_fast_kernel<double, 1>), grid, dim3(64), 0, st, p);
+			else if (fast)
+				hipLaunchKernelGGL((raster_bwd_fast_kernel<double, 4>), grid, dim3(256), 0, st, p);
 			else
 				hipLaunchKernelGGL(raster_bwd_kernel<double>, grid, dim3(256), 0, st, p);
 		}
 		else
 		{
-			if (fast)
-				hipLaunchKernelGGL(raster_bwd_fast_kernel<float>, grid, dim3(256), 0, st, p);
+			if (fast && wpb == 1)
+				hipLaunchKernelGGL((raster_bwd_fast_kernel<float, 1>), grid, dim3(64), 0, st, p);
+			else if (fast)
+				hipLaunchKernelGGL((raster_bwd_fast_kernel<float, 4>), grid, dim3(256), 0, st, p);
 			else
 				hipLaunchKernelGGL(raster_bwd_kernel<float>, grid, dim3(256), 0, st, p);
 		}
