@@ -312,6 +312,12 @@ __global__ __launch_bounds__(256) void setup_bin_kernel(KParams p)
 	TriRec rec;
 	EdgeRec erec[3];
 	setup_triangle(s, k, rec, w.tri_planes + (size_t)k * 3 * s.P, erec, w.edge_planes + (size_t)k * 9 * s.P);
+	if (rec.kind == KIND_NONE && !rec.front)
+	{ // culled: only the two flags of the record are ever read again (finalize_kernel skips its edge slots too)
+		w.tri_rec[k].kind = KIND_NONE;
+		w.tri_rec[k].front = 0;
+		return;
+	}
 	w.tri_rec[k] = rec;
 	for (int n = 0; n < 3; n++)
 		w.edge_rec[3 * (size_t)k + n] = erec[n];
@@ -2027,7 +2033,9 @@ __global__ __launch_bounds__(256) void finalize_kernel(KParams p)
 	if (k == 0)
 		w.hdr->heavy_count[w.hdr->cur] = 0; // the deferred-tile queue of this adjoint has been drained
 	const TriRec rec = w.tri_rec[k];
-	if (rec.front && rec.kind != KIND_NONE)
+	if (!rec.front)
+		return; // culled triangles own no accumulators and no edges (their edge slots may hold stale records)
+	if (rec.kind != KIND_NONE)
 	{
 		double *acc = w.tri_acc + (size_t)k * 3 * P;
 		finalize_triangle(s, g, k, rec, acc, DeviceAdd());

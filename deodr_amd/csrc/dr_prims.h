@@ -110,6 +110,13 @@ DR_HD void setup_triangle(const SceneView &s, int k, TriRec &rec, double *tri_pl
 	const uint32_t *face = s.faces + 3 * (size_t)k, *face_uv = s.faces_uv + 3 * (size_t)k;
 	double sum_depth, area;
 	tri_cull(s, k, sum_depth, area);
+	if (s.culling && !(area > 0))
+	{ // culled: neither pass 1 (H.h:2786) nor pass 2 (H.h:2847) nor the adjoint (H.h:3063) touches it -- no stencil needed
+		rec.kind = KIND_NONE;
+		rec.front = 0;
+		erec[0].kind = erec[1].kind = erec[2].kind = KIND_NONE;
+		return;
+	}
 	const bool tex = s.textured[k] != 0, both = tex && s.shaded[k] != 0;
 	double V[3][2], Zv[3];
 	for (int i = 0; i < 3; i++)
