@@ -184,8 +184,8 @@ def main():
         dom = max(KERNELS, key=lambda k: per_kernel[k]["avg_ms"])
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
-        if os.path.exists(tpath):
-            traffic = json.load(open(tpath)).get(dom)
+        if os.path.exists(tpath):  # HBM bytes per launch from the last PMC run (tools/profile_round.sh), gfx950 correction applied
+            traffic = (json.load(open(tpath)).get(dom) or {}).get("bytes_per_launch")
         kernel_ms = sum(v["avg_ms"] for v in per_kernel.values())
         out = {
             "metric": "Mpixels/s forward+backward, 1024^2 20k-tri scene", "value": px / dt / 1e6, "unit": "Mpixels/s",
