@@ -309,18 +309,13 @@ __global__ __launch_bounds__(256) void setup_bin_kernel(KParams p)
 		w.hdr->edge_spill[1 - cur] = 0;
 		w.hdr->heavy_count[1 - cur] = 0;
 	}
-	TriRec rec;
-	EdgeRec erec[3];
+	// records are built in place in HBM: a culled triangle only gets its two flags written, an edge slot that is not a
+	// silhouette edge only its kind byte (no 128-byte stores of unused records, no private-memory copies)
+	TriRec &rec = w.tri_rec[k];
+	EdgeRec *erec = w.edge_rec + 3 * (size_t)k;
 	setup_triangle(s, k, rec, w.tri_planes + (size_t)k * 3 * s.P, erec, w.edge_planes + (size_t)k * 9 * s.P);
 	if (rec.kind == KIND_NONE && !rec.front)
-	{ // culled: only the two flags of the record are ever read again (finalize_kernel skips its edge slots too)
-		w.tri_rec[k].kind = KIND_NONE;
-		w.tri_rec[k].front = 0;
 		return;
-	}
-	w.tri_rec[k] = rec;
-	for (int n = 0; n < 3; n++)
-		w.edge_rec[3 * (size_t)k + n] = erec[n];
 	if (rec.kind != KIND_NONE)
 	{
 		int x0 = rec.x_min < 0 ? 0 : rec.x_min, x1 = rec.x_max > s.W - 1 ? s.W - 1 : rec.x_max;

@@ -101,15 +101,71 @@ DR_HD void attr_planes(const SceneView &s, int kind, int nv, const uint32_t vid[
 		}
 }
 
+// attribute planes from attributes already in registers: att[v][c] (c < C colour channels, or u, v, shade for textured)
+DR_HD void attr_planes_reg(const SceneView &s, int kind, int nv, const double att[3][4], const double Zv[3], const double *x2b,
+						   double *planes)
+{
+	const int np = kind == KIND_TEXTURED ? 3 : s.C;
+	for (int c = 0; c < np; c++)
+	{
+		double a[3];
+		for (int i = 0; i < nv; i++)
+		{
+			a[i] = att[i][c];
+			if (s.persp)
+			{
+				const double w = 1 / Zv[i];
+				a[i] = (kind == KIND_TEXTURED && c == 2) ? w * a[i] : a[i] * w;
+			}
+		}
+		for (int j = 0; j < 3; j++)
+			planes[3 * c + j] = plane_coef(nv, a, x2b, j);
+	}
+}
+
 // Set up triangle k: its record, its attribute planes and its (up to) three silhouette-edge records.
 // Returns through `rec` / `erec[3]`; planes are written straight to the arrays.  Pass-1 kind follows H.h:2785-2819,
 // edge eligibility H.h:2847-2853, edge kind H.h:2868-2895.
+// Every input of the triangle is fetched up front (two dependent memory round trips: indices, then vertex data); the
+// thread is one long dependent chain, and each further round trip in the middle of it costs the whole kernel its latency.
 DR_HD void setup_triangle(const SceneView &s, int k, TriRec &rec, double *tri_planes /*[3P]*/, EdgeRec erec[3],
 						  double *edge_planes /*[3][3P]*/)
 {
 	const uint32_t *face = s.faces + 3 * (size_t)k, *face_uv = s.faces_uv + 3 * (size_t)k;
-	double sum_depth, area;
-	tri_cull(s, k, sum_depth, area);
+	const uint32_t f[3] = {face[0], face[1], face[2]}, fuv[3] = {face_uv[0], face_uv[1], face_uv[2]};
+	const bool tex = s.textured[k] != 0, both = tex && s.shaded[k] != 0;
+	const bool eflag[3] = {s.edgeflags[3 * (size_t)k] != 0, s.edgeflags[3 * (size_t)k + 1] != 0, s.edgeflags[3 * (size_t)k + 2] != 0};
+	double Vraw[3][2], Zv[3];
+	for (int i = 0; i < 3; i++)
+	{
+		Vraw[i][0] = ldv(s.ij, 2 * (size_t)f[i], s.vtx_f64);
+		Vraw[i][1] = ldv(s.ij, 2 * (size_t)f[i] + 1, s.vtx_f64);
+		Zv[i] = ldv(s.depths, f[i], s.vtx_f64);
+	}
+	const bool small_c = s.C <= 4;
+	double att[3][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+	if (both)
+		for (int i = 0; i < 3; i++)
+		{
+			att[i][0] = ldv(s.uv, 2 * (size_t)fuv[i], s.vtx_f64);
+			att[i][1] = ldv(s.uv, 2 * (size_t)fuv[i] + 1, s.vtx_f64);
+			att[i][2] = ldv(s.shade, f[i], s.vtx_f64);
+		}
+	else if (small_c)
+		for (int i = 0; i < 3; i++)
+			for (int c = 0; c < 4; c++)
+				if (c < s.C)
+					att[i][c] = ldv(s.colors, (size_t)f[i] * s.C + c, s.vtx_f64);
+	// prologue of renderScene (H.h:2751-2779)
+	double sum_depth = 0;
+	bool front = true;
+	for (int i = 0; i < 3; i++)
+	{
+		if (Zv[i] < 0)
+			front = false;
+		sum_depth += Zv[i];
+	}
+	const double area = front ? signed_area(Vraw, s.clockwise) : 0.0;
 	if (s.culling && !(area > 0))
 	{ // culled: neither pass 1 (H.h:2786) nor pass 2 (H.h:2847) nor the adjoint (H.h:3063) touches it -- no stencil needed
 		rec.kind = KIND_NONE;
@@ -117,13 +173,11 @@ DR_HD void setup_triangle(const SceneView &s, int k, TriRec &rec, double *tri_pl
 		erec[0].kind = erec[1].kind = erec[2].kind = KIND_NONE;
 		return;
 	}
-	const bool tex = s.textured[k] != 0, both = tex && s.shaded[k] != 0;
-	double V[3][2], Zv[3];
+	double V[3][2];
 	for (int i = 0; i < 3; i++)
 	{
-		V[i][0] = ldv(s.ij, 2 * (size_t)face[i], s.vtx_f64) - s.offset;
-		V[i][1] = ldv(s.ij, 2 * (size_t)face[i] + 1, s.vtx_f64) - s.offset;
-		Zv[i] = ldv(s.depths, face[i], s.vtx_f64);
+		V[i][0] = Vraw[i][0] - s.offset;
+		V[i][1] = Vraw[i][1] - s.offset;
 	}
 	double x2b[9];
 	tri_stencil(V, s.strict, rec, x2b);
@@ -139,24 +193,44 @@ DR_HD void setup_triangle(const SceneView &s, int k, TriRec &rec, double *tri_pl
 			rec.xZ[j] = plane_coef(3, zz, x2b, j);
 	}
 	if (rec.kind != KIND_NONE)
-		attr_planes(s, rec.kind, 3, face, face_uv, Zv, x2b, tri_planes);
+	{
+		if (both || small_c)
+			attr_planes_reg(s, rec.kind, 3, att, Zv, x2b, tri_planes);
+		else
+			attr_planes(s, rec.kind, 3, f, fuv, Zv, x2b, tri_planes);
+	}
 	for (int n = 0; n < 3; n++)
 	{
 		EdgeRec &e = erec[n];
 		e.kind = KIND_NONE;
-		if (!(s.sigma > 0) || !(area > 0) || !s.edgeflags[3 * (size_t)k + n])
+		if (!(s.sigma > 0) || !(area > 0) || !eflag[n])
 			continue;
 		const int *sub = LIST_SUB[n];
 		double EV[2][2] = {{V[sub[0]][0], V[sub[0]][1]}, {V[sub[1]][0], V[sub[1]][1]}};
 		double EZ[3] = {Zv[sub[0]], Zv[sub[1]], 0};
-		uint32_t vid[3] = {face[sub[0]], face[sub[1]], 0}, uvid[3] = {face_uv[sub[0]], face_uv[sub[1]], 0};
 		edge_stencil(EV, s.H, s.W, s.sigma, s.clockwise, e);
 		e.kind = both ? KIND_TEXTURED : KIND_INTERP; // textured && !shaded edges are drawn interpolated (H.h:2884)
 		e.key = sum_depth;
 		double zz[2] = {s.persp ? 1 / EZ[0] : EZ[0], s.persp ? 1 / EZ[1] : EZ[1]};
 		for (int j = 0; j < 3; j++)
 			e.xZ[j] = plane_coef(2, zz, e.x2b, j);
-		attr_planes(s, e.kind, 2, vid, uvid, EZ, e.x2b, edge_planes + (size_t)n * 3 * s.P);
+		double *ep = edge_planes + (size_t)n * 3 * s.P;
+		if (both || (small_c && !tex))
+		{
+			double eatt[3][4];
+			for (int c = 0; c < 4; c++)
+			{
+				eatt[0][c] = att[sub[0]][c];
+				eatt[1][c] = att[sub[1]][c];
+				eatt[2][c] = 0;
+			}
+			attr_planes_reg(s, e.kind, 2, eatt, EZ, e.x2b, ep);
+		}
+		else
+		{ // many channels, or a textured-but-unshaded triangle whose edges use the vertex colours
+			uint32_t vid[3] = {f[sub[0]], f[sub[1]], 0}, uvid[3] = {fuv[sub[0]], fuv[sub[1]], 0};
+			attr_planes(s, e.kind, 2, vid, uvid, EZ, e.x2b, ep);
+		}
 	}
 }
 
