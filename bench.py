@@ -124,21 +124,20 @@ def main():
     grads = ds.zero_grads()
     shared = torch.zeros(V * (2 + Cc), dtype=torch.float64, device=dev)  # packed shared-parameter gradient
 
-    image_b = torch.empty_like(image)
+    obs_views = obs.expand(B, S, S, Cc).contiguous()  # one observation per view (here the same synthetic image)
+    pending = [None]
 
     def step():
         r.render(ds, 1.0, out=(image, z), check_overflow=False)
-        # dL/dimage of L = sum (image - obs)^2 is 2 (image - obs): one elementwise kernel for the residual; the factor 2
-        # commutes with the (linear) adjoint and is applied to the small per-vertex gradients instead of to 33 Mpixel
-        torch.sub(image, obs, out=image_b)
         grads["ij_b"].zero_()
         grads["colors_b"].zero_()
-        r.render_backward(ds, image_b=image_b, grads=grads)
-        grads["ij_b"].mul_(2)
-        grads["colors_b"].mul_(2)
+        # adjoint of L = sum (image - obs)^2: dL/dimage = 2 (image - obs) is formed inside the adjoint kernel (residual mode)
+        r.render_backward(ds, residual_obs=obs_views, grads=grads)
         if dist is not None:
+            if pending[0] is not None:
+                pending[0].wait()  # the previous step's all-reduce overlapped this step's rendering
             torch.cat((grads["ij_b"].sum(0).reshape(-1), grads["colors_b"].sum(0).reshape(-1)), out=shared)
-            dist.all_reduce(shared)
+            pending[0] = dist.all_reduce(shared, async_op=True)
 
     # first call checks the spill pool once (synchronises), then nothing in the loop does
     r.render(ds, 1.0, out=(image, z), check_overflow=True)
@@ -147,6 +146,9 @@ def main():
 
     def barrier():
         if dist is not None:
+            if pending[0] is not None:
+                pending[0].wait()
+                pending[0] = None
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -201,7 +203,7 @@ def main():
                          "kernel_time_fraction_of_step": kernel_ms / (dt / args.steps * 1e3), "per_kernel": per_kernel},
         }  # fmt: skip
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(views[0], 2 * image_b[0].cpu().numpy().astype(np.float64))
+            out["cpu_baseline"] = cpu_baseline(views[0], 2 * (image[0] - obs).cpu().numpy().astype(np.float64))
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()

@@ -1397,7 +1397,8 @@ __device__ __noinline__ void bwd_tile_generic(const KParams &p, int view, int tx
 					if (p.aa_err) // image_b = -2 (obs - image) err_buffer_b, H.h:3054-3060
 						g[j] = -2 * ((double)((const PixT *)p.obs)[vpix * C + c0 + j] - base_channel(c0 + j)) * eb;
 					else
-						g[j] = (double)((const PixT *)p.image_b)[vpix * C + c0 + j];
+						g[j] = p.image_b ? (double)((const PixT *)p.image_b)[vpix * C + c0 + j]
+										 : 2 * ((double)((const PixT *)p.image_in)[vpix * C + c0 + j] - (double)((const PixT *)p.obs)[vpix * C + c0 + j]);
 				}
 			}
 			if (nedge > 0 && !p.aa_err)
@@ -1673,10 +1674,20 @@ __global__ __launch_bounds__(64 * WPB, 3) void raster_bwd_fast_kernel(KParams p)
 
 	double g[CH];
 	{
-		const PixT *gin = (const PixT *)p.image_b + vpix * C;
+		if (p.image_b)
+		{
+			const PixT *gin = (const PixT *)p.image_b + vpix * C;
 #pragma unroll
-		for (int cc = 0; cc < CH; cc++)
-			g[cc] = (cc < C && inb) ? (double)gin[cc] : 0.0;
+			for (int cc = 0; cc < CH; cc++)
+				g[cc] = (cc < C && inb) ? (double)gin[cc] : 0.0;
+		}
+		else
+		{ // residual mode: dL/dimage of L = sum (image - obs)^2 formed on the fly from the rendered image and the observation
+			const PixT *im = (const PixT *)p.image_in + vpix * C, *ob = (const PixT *)p.obs + vpix * C;
+#pragma unroll
+			for (int cc = 0; cc < CH; cc++)
+				g[cc] = (cc < C && inb) ? 2 * ((double)im[cc] - (double)ob[cc]) : 0.0;
+		}
 	}
 	// what pass 1 left at this pixel
 	const double *planes = nullptr;
@@ -2325,8 +2336,8 @@ int deodr_hip_render_scene_b(const DeodrHipScene *sc, const void *image, const v
 		if (!obs || !err_buffer_b)
 			return fail("antialiase_error needs obs and err_buffer_b");
 	}
-	else if (!image_b)
-		return fail("image_b == NULL");
+	else if (!image_b && !(image && obs))
+		return fail("image_b == NULL (or, for the residual mode, image and obs)");
 	hipStream_t st = (hipStream_t)stream;
 	if (!have_forward_state)
 	{ // stateless use: rebuild records, tile lists and the owner buffer (no image / z written)

@@ -222,9 +222,12 @@ class HipRasterizer:
         self._last = (ds, float(sigma), bool(antialiase_error), obs_t, image, err)
         return (image, z, err) if antialiase_error else (image, z)
 
-    def render_backward(self, ds, image_b=None, err_buffer_b=None, grads=None, have_forward_state=True):
+    def render_backward(self, ds, image_b=None, err_buffer_b=None, grads=None, have_forward_state=True, residual_obs=None):
         """Adjoint of the last :meth:`render` of ``ds``; returns the dict of gradient tensors (accumulated into ``grads``
-        when given, fresh zeros otherwise).  Nothing passed in is mutated."""
+        when given, fresh zeros otherwise).  Nothing passed in is mutated.
+
+        ``residual_obs`` (instead of ``image_b``): propagate the gradient of ``sum((image - residual_obs)**2)`` where
+        ``image`` is the output of the last render; ``2 (image - obs)`` is formed inside the kernel."""
         last_ds, sigma, aa, obs_t, image, _ = self._last
         n, H, W, Cc = ds.n_views, ds.height, ds.width, ds.nb_colors
         pd = ds.pixel_dtype
@@ -234,6 +237,10 @@ class HipRasterizer:
         ib = eb = None
         if aa:
             eb = err_buffer_b.to(device=ds.device, dtype=pd).reshape(n, H, W).contiguous()
+        elif residual_obs is not None:
+            obs_t = residual_obs.to(device=ds.device, dtype=pd)
+            if tuple(obs_t.shape) != (n, H, W, Cc) or not obs_t.is_contiguous():  # pass [n,H,W,C] to avoid this copy
+                obs_t = obs_t.expand(n, H, W, Cc).contiguous()
         else:
             ib = image_b.to(device=ds.device, dtype=pd).reshape(n, H, W, Cc).contiguous()
         _check(lib().deodr_hip_render_scene_b(C.byref(sc), _ptr(image), None, _ptr(ib), sigma, int(aa), _ptr(obs_t), None, _ptr(eb),

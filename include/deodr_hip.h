@@ -90,6 +90,10 @@ int deodr_hip_render_scene(const DeodrHipScene *scene, void *image, void *z_buff
 						   const void *obs, void *err_buffer, void *workspace, size_t workspace_bytes, void *stream);
 
 /* renderScene_B.  Requires backface_culling and !perspective_correct like the reference (H.h:2922, 810).
+ * Extension ("residual mode", antialiase_error == 0 only): with image_b == NULL and image, obs given, the adjoint of the
+ * sum-of-squares loss L = sum (image - obs)^2 is propagated, i.e. image_b = 2 (image - obs) is formed inside the kernel
+ * from the rendered image (what Scene2D.render_compare_and_backward does on the host, dr.py:728-732) instead of being
+ * written to and read back from HBM.
  * have_forward_state != 0: the workspace still holds the state of the matching deodr_hip_render_scene call (same scene
  * arrays, same sigma) and is reused; 0: the forward state is recomputed first (stateless use, as the reference). */
 int deodr_hip_render_scene_b(const DeodrHipScene *scene, const void *image, const void *z_buffer, const void *image_b,

@@ -286,3 +286,23 @@ def test_autograd_batched_views(oracle_api):
         g_ref = ref.grads(v, 1.0, img_ref, z_ref, w[i].cpu().numpy().astype(np.float64))
         assert rel_err(ij.grad[i].cpu().numpy(), g_ref["ij_b"]) < 1e-4
         assert rel_err(colors.grad[i].cpu().numpy(), g_ref["colors_b"]) < 1e-4
+
+
+def test_residual_mode_equals_explicit_image_b(oracle_api):
+    """Extension of the C ABI: image_b == NULL + obs -> 2 (image - obs) is formed inside the adjoint kernel."""
+    from hip_util import device_scene
+    from deodr_amd.hip_renderer import HipRasterizer
+
+    s = random_scene(400)
+    s.backface_culling = True
+    for force_generic_colors in (False,):
+        ds = device_scene(s, F32)
+        r = HipRasterizer.for_scene(ds)
+        image, z = r.render(ds, 1.0)
+        obs = torch.as_tensor(np.random.RandomState(2).rand(1, s.height, s.width, 3).astype(np.float32), device=image.device)
+        g_a = r.render_backward(ds, image_b=2 * (image - obs))
+        g_b = r.render_backward(ds, residual_obs=obs)
+        from hip_util import rel_err
+
+        for k in ("ij_b", "colors_b", "uv_b", "shade_b", "texture_b"):  # image_b is rounded to float32 in one of the two paths
+            assert rel_err(g_b[k].cpu().numpy(), g_a[k].cpu().numpy()) < 1e-5, k
