@@ -82,6 +82,7 @@ def main():
     ap.add_argument("--views", type=int, default=8, help="views rendered per GPU per step")
     ap.add_argument("--size", type=int, default=1024)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed even for one rank (exercises the RCCL path)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0))
@@ -91,11 +92,27 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or args.force_dist:
         import torch.distributed as dist
 
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)  # RCCL over xGMI
+        # RCCL writes a banner to the C stdout when the communicator is created; send it to stderr so that the JSON result
+        # stays the only (and last) line on stdout
+        saved_fd = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group(backend="nccl", device_id=dev)  # RCCL over xGMI
+            warm = torch.zeros(1, device=dev)
+            dist.all_reduce(warm)  # creates the communicator now
+            torch.cuda.synchronize()
+        finally:
+            C.CDLL(None).fflush(None)
+            os.dup2(saved_fd, 1)
+            os.close(saved_fd)
 
     import __graft_entry__ as g
 
@@ -204,9 +221,14 @@ def main():
         }  # fmt: skip
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(views[0], 2 * (image[0] - obs).cpu().numpy().astype(np.float64))
-        print(json.dumps(out))
+        result_line = json.dumps(out)
+    else:
+        result_line = None
     if dist is not None:
         dist.destroy_process_group()
+    if result_line is not None:  # the ONE JSON line, last thing on stdout
+        sys.stdout.flush()
+        print(result_line, flush=True)
 
 
 if __name__ == "__main__":

@@ -306,3 +306,10 @@ def test_residual_mode_equals_explicit_image_b(oracle_api):
 
         for k in ("ij_b", "colors_b", "uv_b", "shade_b", "texture_b"):  # image_b is rounded to float32 in one of the two paths
             assert rel_err(g_b[k].cpu().numpy(), g_a[k].cpu().numpy()) < 1e-5, k
+
+
+def test_config5_shape_textured_2048(oracle_api):
+    """One view of BASELINE configs[4]: 2048x2048, 100 352-triangle sphere, 1024x1024 texture (uv_b / shade_b / texture_b)."""
+    s = scenes.sphere_scene(size=2048, nu=224, n_rings=224, nb_colors=3, textured=True, texture_size=1024)
+    assert s.faces.shape[0] == 100352
+    compare_backward(oracle_api, s, 1.0, F32)
