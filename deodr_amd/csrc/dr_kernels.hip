@@ -1127,25 +1127,24 @@ __global__ __launch_bounds__(64 * WPB) void raster_fwd_fast_kernel(KParams p)
 			if (p.image)
 			{
 				PixT *out = (PixT *)p.image + vpix * C;
+				// streaming (non-temporal) stores: the frame is written once and not re-read by this kernel, keep L2 for records
 				if (C == 4)
 				{
-					struct alignas(4 * sizeof(PixT)) V4
-					{
-						PixT a, b, c, d;
-					};
-					*(V4 *)out = V4{(PixT)col[0], (PixT)col[1], (PixT)col[2], (PixT)col[3]};
+					typedef PixT V4 __attribute__((ext_vector_type(4)));
+					const V4 v = {(PixT)col[0], (PixT)col[1], (PixT)col[2], (PixT)col[3]};
+					__builtin_nontemporal_store(v, (V4 *)out);
 				}
 				else
 				{
 #pragma unroll
 					for (int cc = 0; cc < CH; cc++)
 						if (cc < C)
-							out[cc] = (PixT)col[cc];
+							__builtin_nontemporal_store((PixT)col[cc], out + cc);
 				}
 			}
 			if (p.zbuf)
-				((PixT *)p.zbuf)[vpix] = (PixT)st.zbest;
-			w.face_id[pix] = pack_owner(st.kbest, st.kind);
+				__builtin_nontemporal_store((PixT)st.zbest, (PixT *)p.zbuf + vpix);
+			__builtin_nontemporal_store(pack_owner(st.kbest, st.kind), w.face_id + pix);
 		}
 	}
 	if (blockIdx.x == 0 && threadIdx.x == 0)
