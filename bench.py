@@ -81,6 +81,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--views", type=int, default=8, help="views rendered per GPU per step")
     ap.add_argument("--size", type=int, default=1024)
+    ap.add_argument("--sigma", type=float, default=1.0, help="edge-overdraw width (the metric configuration uses 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed even for one rank (exercises the RCCL path)")
     args = ap.parse_args()
@@ -145,7 +146,7 @@ def main():
     pending = [None]
 
     def step():
-        r.render(ds, 1.0, out=(image, z), check_overflow=False)
+        r.render(ds, args.sigma, out=(image, z), check_overflow=False)
         grads["ij_b"].zero_()
         grads["colors_b"].zero_()
         # adjoint of L = sum (image - obs)^2: dL/dimage = 2 (image - obs) is formed inside the adjoint kernel (residual mode)
@@ -157,7 +158,7 @@ def main():
             pending[0] = dist.all_reduce(shared, async_op=True)
 
     # first call checks the spill pool once (synchronises), then nothing in the loop does
-    r.render(ds, 1.0, out=(image, z), check_overflow=True)
+    r.render(ds, args.sigma, out=(image, z), check_overflow=True)
     for _ in range(args.warmup):
         step()
 

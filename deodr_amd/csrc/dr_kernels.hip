@@ -294,15 +294,16 @@ __device__ __forceinline__ bool tile_outside_halfplanes(const double *eq, int n,
 }
 
 __global__ __launch_bounds__(256) void setup_bin_kernel(KParams p)
-{
+{ // work items: [0, T) triangles, [T, 4T) silhouette-edge slots (k, n) -- separate threads, so that the few triangles
+  // that own silhouette edges do not stretch the dependent chain of their whole wavefront
 	const int view = blockIdx.y;
-	const int k = blockIdx.x * blockDim.x + threadIdx.x;
-	if (k >= p.T)
+	const int item = blockIdx.x * blockDim.x + threadIdx.x;
+	if (item >= 4 * p.T)
 		return;
 	const SceneView s = scene_view(p, view);
 	const ViewPtrs w = view_ptrs(p, view);
 	const uint32_t cur = w.hdr->epoch & 1u; // stable during this kernel: only the forward raster advances the epoch
-	if (k == 0)
+	if (item == 0)
 	{
 		w.hdr->cur = cur;
 		w.hdr->tri_spill[1 - cur] = 0;
@@ -311,34 +312,44 @@ __global__ __launch_bounds__(256) void setup_bin_kernel(KParams p)
 	}
 	// records are built in place in HBM: a culled triangle only gets its two flags written, an edge slot that is not a
 	// silhouette edge only its kind byte (no 128-byte stores of unused records, no private-memory copies)
-	TriRec &rec = w.tri_rec[k];
-	EdgeRec *erec = w.edge_rec + 3 * (size_t)k;
-	setup_triangle(s, k, rec, w.tri_planes + (size_t)k * 3 * s.P, erec, w.edge_planes + (size_t)k * 9 * s.P);
-	if (rec.kind == KIND_NONE && !rec.front)
-		return;
-	if (rec.kind != KIND_NONE)
+	if (item < p.T)
 	{
+		const int k = item;
+		TriInputs t;
+		load_triangle(s, k, t, true);
+		TriRec &rec = w.tri_rec[k];
+		setup_tri_only(s, t, rec, w.tri_planes + (size_t)k * 3 * s.P);
+		if (rec.kind == KIND_NONE)
+			return;
 		int x0 = rec.x_min < 0 ? 0 : rec.x_min, x1 = rec.x_max > s.W - 1 ? s.W - 1 : rec.x_max;
 		int y0 = rec.y_begin[0] < 0 ? 0 : rec.y_begin[0], y1 = rec.y_end[1] > s.H - 1 ? s.H - 1 : rec.y_end[1];
 		if (x0 <= x1 && y0 <= y1)
 			for (int ty = y0 / TILE; ty <= y1 / TILE; ty++)
 				for (int tx = x0 / TILE; tx <= x1 / TILE; tx++)
 					if (!tile_outside_halfplanes(&rec.eq[0][0], 3, tx, ty))
-					push_tile(w.tri_cnt, w.tri_list, K_TRI, w.tri_pool, p.L.tri_pool_cap, &w.hdr->tri_spill[cur], ty * p.L.tiles_x + tx, (uint32_t)k);
+						push_tile(w.tri_cnt, w.tri_list, K_TRI, w.tri_pool, p.L.tri_pool_cap, &w.hdr->tri_spill[cur], ty * p.L.tiles_x + tx,
+								  (uint32_t)k);
+		return;
 	}
-	for (int n = 0; n < 3; n++)
+	const int slot = item - p.T, k = slot / 3, n = slot - 3 * k;
+	EdgeRec &e = w.edge_rec[slot];
+	if (!(s.sigma > 0) || !s.edgeflags[slot])
 	{
-		const EdgeRec &e = erec[n];
-		if (e.kind == KIND_NONE || e.x_begin > e.x_end || e.y_begin > e.y_end)
-			continue;
-		const double band[12] = {e.x2b[0], e.x2b[1], e.x2b[2], e.x2b[3], e.x2b[4], e.x2b[5], e.x2t[0], e.x2t[1], e.x2t[2],
-								 -e.x2t[0], -e.x2t[1], 1 - e.x2t[2]}; // the four half-planes of the band, H.h:1418-1435
-		for (int ty = e.y_begin / TILE; ty <= e.y_end / TILE; ty++)
-			for (int tx = e.x_begin / TILE; tx <= e.x_end / TILE; tx++)
-				if (!tile_outside_halfplanes(band, 4, tx, ty))
-				push_tile(w.edge_cnt, w.edge_list, K_EDGE, w.edge_pool, p.L.edge_pool_cap, &w.hdr->edge_spill[cur], ty * p.L.tiles_x + tx,
-						  (uint32_t)(3 * k + n));
+		e.kind = KIND_NONE;
+		return;
 	}
+	TriInputs t;
+	load_triangle(s, k, t, true);
+	setup_edge_only(s, t, k, n, e, w.edge_planes + (size_t)slot * 3 * s.P);
+	if (e.kind == KIND_NONE || e.x_begin > e.x_end || e.y_begin > e.y_end)
+		return;
+	const double band[12] = {e.x2b[0], e.x2b[1], e.x2b[2], e.x2b[3], e.x2b[4], e.x2b[5], e.x2t[0], e.x2t[1], e.x2t[2],
+							 -e.x2t[0], -e.x2t[1], 1 - e.x2t[2]}; // the four half-planes of the band, H.h:1418-1435
+	for (int ty = e.y_begin / TILE; ty <= e.y_end / TILE; ty++)
+		for (int tx = e.x_begin / TILE; tx <= e.x_end / TILE; tx++)
+			if (!tile_outside_halfplanes(band, 4, tx, ty))
+				push_tile(w.edge_cnt, w.edge_list, K_EDGE, w.edge_pool, p.L.edge_pool_cap, &w.hdr->edge_spill[cur], ty * p.L.tiles_x + tx,
+						  (uint32_t)slot);
 }
 
 // ------------------------------------------------------------------------------------------- tile-level edge ordering
@@ -2021,10 +2032,10 @@ __global__ __launch_bounds__(256) void raster_bwd_heavy_kernel(KParams p)
 // ------------------------------------------------------------------------------------------------------- finalize
 
 __global__ __launch_bounds__(256) void finalize_kernel(KParams p)
-{
+{ // work items as in setup_bin_kernel: [0, T) triangles, [T, 4T) edge slots
 	const int view = blockIdx.y;
-	const int k = blockIdx.x * blockDim.x + threadIdx.x;
-	if (k >= p.T)
+	const int item = blockIdx.x * blockDim.x + threadIdx.x;
+	if (item >= 4 * p.T)
 		return;
 	const SceneView s = scene_view(p, view);
 	const ViewPtrs w = view_ptrs(p, view);
@@ -2035,28 +2046,30 @@ __global__ __launch_bounds__(256) void finalize_kernel(KParams p)
 	g.shade_b = (char *)p.shade_b + (size_t)view * p.V * es;
 	g.uv_b = p.uv_b;
 	const int P = s.P;
-	if (k == 0)
+	if (item == 0)
 		w.hdr->heavy_count[w.hdr->cur] = 0; // the deferred-tile queue of this adjoint has been drained
-	const TriRec rec = w.tri_rec[k];
-	if (!rec.front)
-		return; // culled triangles own no accumulators and no edges (their edge slots may hold stale records)
-	if (rec.kind != KIND_NONE)
+	if (item < p.T)
 	{
+		const int k = item;
+		const TriRec &rec = w.tri_rec[k];
+		if (!rec.front || rec.kind == KIND_NONE)
+			return; // culled triangles own no accumulators
 		double *acc = w.tri_acc + (size_t)k * 3 * P;
 		finalize_triangle(s, g, k, rec, acc, DeviceAdd());
 		for (int i = 0; i < 3 * P; i++)
 			acc[i] = 0; // self-cleaning accumulators
+		return;
 	}
-	for (int n = 0; n < 3; n++)
-	{
-		const EdgeRec e = w.edge_rec[3 * (size_t)k + n];
-		if (e.kind == KIND_NONE)
-			continue;
-		double *acc = w.edge_acc + (3 * (size_t)k + n) * (3 * P + 3);
-		finalize_edge(s, g, k, n, e, acc, DeviceAdd());
-		for (int i = 0; i < 3 * P + 3; i++)
-			acc[i] = 0;
-	}
+	const int slot = item - p.T, k = slot / 3, n = slot - 3 * k;
+	if (!(s.sigma > 0) || !s.edgeflags[slot] || !w.tri_rec[k].front)
+		return; // not a silhouette edge of a front-facing triangle in this forward (its slot may hold a stale record)
+	const EdgeRec &e = w.edge_rec[slot];
+	if (e.kind == KIND_NONE)
+		return;
+	double *acc = w.edge_acc + (size_t)slot * (3 * P + 3);
+	finalize_edge(s, g, k, n, e, acc, DeviceAdd());
+	for (int i = 0; i < 3 * P + 3; i++)
+		acc[i] = 0;
 }
 
 // ------------------------------------------------------------------------------------------------------ host side
@@ -2224,7 +2237,7 @@ int launch_forward(const DeodrHipScene *sc, KParams &p, hipStream_t stream)
 	const int n_views = sc->n_views;
 	if (p.T > 0)
 	{
-		dim3 grid((p.T + 255) / 256, n_views);
+		dim3 grid((4 * p.T + 255) / 256, n_views);
 		ScopedKernelTimer t(KID_SETUP, stream);
 		hipLaunchKernelGGL(setup_bin_kernel, grid, dim3(256), 0, stream, p);
 	}
@@ -2387,7 +2400,7 @@ int deodr_hip_render_scene_b(const DeodrHipScene *sc, const void *image, const v
 	}
 	if (p.T > 0)
 	{
-		dim3 g2((p.T + 255) / 256, sc->n_views);
+		dim3 g2((4 * p.T + 255) / 256, sc->n_views);
 		ScopedKernelTimer t(KID_FINALIZE, st);
 		hipLaunchKernelGGL(finalize_kernel, g2, dim3(256), 0, st, p);
 	}

@@ -123,115 +123,144 @@ DR_HD void attr_planes_reg(const SceneView &s, int kind, int nv, const double at
 	}
 }
 
-// Set up triangle k: its record, its attribute planes and its (up to) three silhouette-edge records.
-// Returns through `rec` / `erec[3]`; planes are written straight to the arrays.  Pass-1 kind follows H.h:2785-2819,
-// edge eligibility H.h:2847-2853, edge kind H.h:2868-2895.
-// Every input of the triangle is fetched up front (two dependent memory round trips: indices, then vertex data); the
-// thread is one long dependent chain, and each further round trip in the middle of it costs the whole kernel its latency.
-DR_HD void setup_triangle(const SceneView &s, int k, TriRec &rec, double *tri_planes /*[3P]*/, EdgeRec erec[3],
-						  double *edge_planes /*[3][3P]*/)
+// Inputs of one triangle, fetched up front (two dependent memory round trips: indices, then vertex data; each further
+// round trip in the middle of the thread's long dependent chain would cost the whole kernel its latency).
+struct TriInputs
+{
+	uint32_t f[3], fuv[3];
+	bool tex, both;
+	double Vraw[3][2], Zv[3];
+	double att[3][4]; // colours (C <= 4) or (u, v, shade)
+	double sum_depth, area;
+};
+
+DR_HD void load_triangle(const SceneView &s, int k, TriInputs &t, bool with_attributes)
 {
 	const uint32_t *face = s.faces + 3 * (size_t)k, *face_uv = s.faces_uv + 3 * (size_t)k;
-	const uint32_t f[3] = {face[0], face[1], face[2]}, fuv[3] = {face_uv[0], face_uv[1], face_uv[2]};
-	const bool tex = s.textured[k] != 0, both = tex && s.shaded[k] != 0;
-	const bool eflag[3] = {s.edgeflags[3 * (size_t)k] != 0, s.edgeflags[3 * (size_t)k + 1] != 0, s.edgeflags[3 * (size_t)k + 2] != 0};
-	double Vraw[3][2], Zv[3];
 	for (int i = 0; i < 3; i++)
 	{
-		Vraw[i][0] = ldv(s.ij, 2 * (size_t)f[i], s.vtx_f64);
-		Vraw[i][1] = ldv(s.ij, 2 * (size_t)f[i] + 1, s.vtx_f64);
-		Zv[i] = ldv(s.depths, f[i], s.vtx_f64);
+		t.f[i] = face[i];
+		t.fuv[i] = face_uv[i];
 	}
-	const bool small_c = s.C <= 4;
-	double att[3][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
-	if (both)
-		for (int i = 0; i < 3; i++)
-		{
-			att[i][0] = ldv(s.uv, 2 * (size_t)fuv[i], s.vtx_f64);
-			att[i][1] = ldv(s.uv, 2 * (size_t)fuv[i] + 1, s.vtx_f64);
-			att[i][2] = ldv(s.shade, f[i], s.vtx_f64);
-		}
-	else if (small_c)
-		for (int i = 0; i < 3; i++)
-			for (int c = 0; c < 4; c++)
-				if (c < s.C)
-					att[i][c] = ldv(s.colors, (size_t)f[i] * s.C + c, s.vtx_f64);
-	// prologue of renderScene (H.h:2751-2779)
-	double sum_depth = 0;
+	t.tex = s.textured[k] != 0;
+	t.both = t.tex && s.shaded[k] != 0;
+	for (int i = 0; i < 3; i++)
+	{
+		t.Vraw[i][0] = ldv(s.ij, 2 * (size_t)t.f[i], s.vtx_f64);
+		t.Vraw[i][1] = ldv(s.ij, 2 * (size_t)t.f[i] + 1, s.vtx_f64);
+		t.Zv[i] = ldv(s.depths, t.f[i], s.vtx_f64);
+	}
+	for (int i = 0; i < 3; i++)
+		for (int c = 0; c < 4; c++)
+			t.att[i][c] = 0;
+	if (with_attributes)
+	{
+		if (t.both)
+			for (int i = 0; i < 3; i++)
+			{
+				t.att[i][0] = ldv(s.uv, 2 * (size_t)t.fuv[i], s.vtx_f64);
+				t.att[i][1] = ldv(s.uv, 2 * (size_t)t.fuv[i] + 1, s.vtx_f64);
+				t.att[i][2] = ldv(s.shade, t.f[i], s.vtx_f64);
+			}
+		else if (s.C <= 4)
+			for (int i = 0; i < 3; i++)
+				for (int c = 0; c < 4; c++)
+					if (c < s.C)
+						t.att[i][c] = ldv(s.colors, (size_t)t.f[i] * s.C + c, s.vtx_f64);
+	}
+	// prologue of renderScene (H.h:2751-2779): depth sum (sort key of the edges) and signed area (0 behind the camera)
+	t.sum_depth = 0;
 	bool front = true;
 	for (int i = 0; i < 3; i++)
 	{
-		if (Zv[i] < 0)
+		if (t.Zv[i] < 0)
 			front = false;
-		sum_depth += Zv[i];
+		t.sum_depth += t.Zv[i];
 	}
-	const double area = front ? signed_area(Vraw, s.clockwise) : 0.0;
-	if (s.culling && !(area > 0))
+	t.area = front ? signed_area(t.Vraw, s.clockwise) : 0.0;
+}
+
+// Triangle part of the set-up: record + attribute planes.  Pass-1 kind follows H.h:2785-2819.
+DR_HD void setup_tri_only(const SceneView &s, const TriInputs &t, TriRec &rec, double *tri_planes /*[3P]*/)
+{
+	if (s.culling && !(t.area > 0))
 	{ // culled: neither pass 1 (H.h:2786) nor pass 2 (H.h:2847) nor the adjoint (H.h:3063) touches it -- no stencil needed
 		rec.kind = KIND_NONE;
 		rec.front = 0;
-		erec[0].kind = erec[1].kind = erec[2].kind = KIND_NONE;
 		return;
 	}
 	double V[3][2];
 	for (int i = 0; i < 3; i++)
 	{
-		V[i][0] = Vraw[i][0] - s.offset;
-		V[i][1] = Vraw[i][1] - s.offset;
+		V[i][0] = t.Vraw[i][0] - s.offset;
+		V[i][1] = t.Vraw[i][1] - s.offset;
 	}
 	double x2b[9];
 	tri_stencil(V, s.strict, rec, x2b);
-	rec.front = area > 0;
+	rec.front = t.area > 0;
 	rec.kind = KIND_NONE;
-	if (area > 0 || !s.culling)
-		rec.kind = both ? KIND_TEXTURED : (tex ? KIND_NONE : KIND_INTERP);
-	{
-		double zz[3];
-		for (int i = 0; i < 3; i++)
-			zz[i] = s.persp ? 1 / Zv[i] : Zv[i];
-		for (int j = 0; j < 3; j++)
-			rec.xZ[j] = plane_coef(3, zz, x2b, j);
-	}
+	if (t.area > 0 || !s.culling)
+		rec.kind = t.both ? KIND_TEXTURED : (t.tex ? KIND_NONE : KIND_INTERP);
+	double zz[3];
+	for (int i = 0; i < 3; i++)
+		zz[i] = s.persp ? 1 / t.Zv[i] : t.Zv[i];
+	for (int j = 0; j < 3; j++)
+		rec.xZ[j] = plane_coef(3, zz, x2b, j);
 	if (rec.kind != KIND_NONE)
 	{
-		if (both || small_c)
-			attr_planes_reg(s, rec.kind, 3, att, Zv, x2b, tri_planes);
+		if (t.both || s.C <= 4)
+			attr_planes_reg(s, rec.kind, 3, t.att, t.Zv, x2b, tri_planes);
 		else
-			attr_planes(s, rec.kind, 3, f, fuv, Zv, x2b, tri_planes);
+			attr_planes(s, rec.kind, 3, t.f, t.fuv, t.Zv, x2b, tri_planes);
 	}
-	for (int n = 0; n < 3; n++)
+}
+
+// Edge n of triangle k: eligibility H.h:2847-2853, kind H.h:2868-2895, stencil H.h:1366-1460.
+DR_HD void setup_edge_only(const SceneView &s, const TriInputs &t, int k, int n, EdgeRec &e, double *ep /*[3P]*/)
+{
+	e.kind = KIND_NONE;
+	if (!(s.sigma > 0) || !(t.area > 0) || !s.edgeflags[3 * (size_t)k + n])
+		return;
+	const int *sub = LIST_SUB[n];
+	double EV[2][2], EZ[3] = {t.Zv[sub[0]], t.Zv[sub[1]], 0};
+	for (int i = 0; i < 2; i++)
 	{
-		EdgeRec &e = erec[n];
-		e.kind = KIND_NONE;
-		if (!(s.sigma > 0) || !(area > 0) || !eflag[n])
-			continue;
-		const int *sub = LIST_SUB[n];
-		double EV[2][2] = {{V[sub[0]][0], V[sub[0]][1]}, {V[sub[1]][0], V[sub[1]][1]}};
-		double EZ[3] = {Zv[sub[0]], Zv[sub[1]], 0};
-		edge_stencil(EV, s.H, s.W, s.sigma, s.clockwise, e);
-		e.kind = both ? KIND_TEXTURED : KIND_INTERP; // textured && !shaded edges are drawn interpolated (H.h:2884)
-		e.key = sum_depth;
-		double zz[2] = {s.persp ? 1 / EZ[0] : EZ[0], s.persp ? 1 / EZ[1] : EZ[1]};
-		for (int j = 0; j < 3; j++)
-			e.xZ[j] = plane_coef(2, zz, e.x2b, j);
-		double *ep = edge_planes + (size_t)n * 3 * s.P;
-		if (both || (small_c && !tex))
-		{
-			double eatt[3][4];
-			for (int c = 0; c < 4; c++)
-			{
-				eatt[0][c] = att[sub[0]][c];
-				eatt[1][c] = att[sub[1]][c];
-				eatt[2][c] = 0;
-			}
-			attr_planes_reg(s, e.kind, 2, eatt, EZ, e.x2b, ep);
-		}
-		else
-		{ // many channels, or a textured-but-unshaded triangle whose edges use the vertex colours
-			uint32_t vid[3] = {f[sub[0]], f[sub[1]], 0}, uvid[3] = {fuv[sub[0]], fuv[sub[1]], 0};
-			attr_planes(s, e.kind, 2, vid, uvid, EZ, e.x2b, ep);
-		}
+		EV[i][0] = t.Vraw[sub[i]][0] - s.offset;
+		EV[i][1] = t.Vraw[sub[i]][1] - s.offset;
 	}
+	edge_stencil(EV, s.H, s.W, s.sigma, s.clockwise, e);
+	e.kind = t.both ? KIND_TEXTURED : KIND_INTERP; // textured && !shaded edges are drawn interpolated (H.h:2884)
+	e.key = t.sum_depth;
+	double zz[2] = {s.persp ? 1 / EZ[0] : EZ[0], s.persp ? 1 / EZ[1] : EZ[1]};
+	for (int j = 0; j < 3; j++)
+		e.xZ[j] = plane_coef(2, zz, e.x2b, j);
+	if (t.both || (s.C <= 4 && !t.tex))
+	{
+		double eatt[3][4];
+		for (int c = 0; c < 4; c++)
+		{
+			eatt[0][c] = t.att[sub[0]][c];
+			eatt[1][c] = t.att[sub[1]][c];
+			eatt[2][c] = 0;
+		}
+		attr_planes_reg(s, e.kind, 2, eatt, EZ, e.x2b, ep);
+	}
+	else
+	{ // many channels, or a textured-but-unshaded triangle whose edges use the vertex colours
+		uint32_t vid[3] = {t.f[sub[0]], t.f[sub[1]], 0}, uvid[3] = {t.fuv[sub[0]], t.fuv[sub[1]], 0};
+		attr_planes(s, e.kind, 2, vid, uvid, EZ, e.x2b, ep);
+	}
+}
+
+// Whole set-up of triangle k (record, planes, three edge slots) in one call: used by the host simulator.
+DR_HD void setup_triangle(const SceneView &s, int k, TriRec &rec, double *tri_planes /*[3P]*/, EdgeRec erec[3],
+						  double *edge_planes /*[3][3P]*/)
+{
+	TriInputs t;
+	load_triangle(s, k, t, true);
+	setup_tri_only(s, t, rec, tri_planes);
+	for (int n = 0; n < 3; n++)
+		setup_edge_only(s, t, k, n, erec[n], edge_planes + (size_t)n * 3 * s.P);
 }
 
 // ------------------------------------------------------------------------------------------------------- finalize
