@@ -40,6 +40,8 @@ constexpr int K_TRI = 32;	// inline triangle slots per tile; more spill to the p
 constexpr int K_EDGE = 32;	// inline edge slots per tile (== TB: one staged batch)
 constexpr int CH = 4;		// colour channels kept in registers at a time
 constexpr int MAX_SORTED = 64; // edges of a tile whose blending order is cached in LDS
+constexpr int NSUB = 8;		// sub-lists of the per-view list of tiles that hold silhouette edges (tile % NSUB: bounded, 8 append counters)
+constexpr int CNT_STRIDE = 32; // uint32 between two append counters (one 128-byte line each)
 
 struct WsHeader // 64 bytes per view at the start of the view's workspace
 {
@@ -58,9 +60,9 @@ static_assert(sizeof(WsHeader) == 64, "");
 struct Layout
 {
 	size_t hdr, tri_rec, tri_planes, tri_acc, edge_rec, edge_planes, edge_acc, tri_cnt, edge_cnt, edge_saved, tri_list, edge_list, tri_pool,
-		edge_pool, face_id, heavy_list, view_bytes;
+		edge_pool, face_id, heavy_list, edge_tile_cnt, edge_tiles, view_bytes;
 	uint32_t tri_pool_cap, edge_pool_cap;
-	int tiles_x, tiles_y, ntiles, P;
+	int tiles_x, tiles_y, ntiles, P, sub_cap;
 };
 
 size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -98,6 +100,9 @@ Layout make_layout(int T, int H, int W, int C, size_t pool_pairs)
 	L.edge_pool = take(sizeof(uint2) * (size_t)L.edge_pool_cap);
 	L.face_id = take(sizeof(int32_t) * (size_t)H * W);
 	L.heavy_list = take(sizeof(uint32_t) * L.ntiles);
+	L.sub_cap = (L.ntiles + NSUB - 1) / NSUB;
+	L.edge_tile_cnt = take(sizeof(uint32_t) * 2 * NSUB * CNT_STRIDE);
+	L.edge_tiles = take(sizeof(uint32_t) * NSUB * (size_t)L.sub_cap);
 	L.view_bytes = o;
 	return L;
 }
@@ -134,6 +139,7 @@ struct ViewPtrs
 	uint2 *tri_pool, *edge_pool;
 	int32_t *face_id;
 	uint32_t *heavy_list;
+	uint32_t *edge_tile_cnt, *edge_tiles; // tiles with silhouette edges: NSUB counters per epoch parity, NSUB sub-lists of sub_cap tiles
 };
 
 __device__ __forceinline__ ViewPtrs view_ptrs(const KParams &p, int view)
@@ -156,6 +162,8 @@ __device__ __forceinline__ ViewPtrs view_ptrs(const KParams &p, int view)
 	v.edge_pool = (uint2 *)(b + p.L.edge_pool);
 	v.face_id = (int32_t *)(b + p.L.face_id);
 	v.heavy_list = (uint32_t *)(b + p.L.heavy_list);
+	v.edge_tile_cnt = (uint32_t *)(b + p.L.edge_tile_cnt);
+	v.edge_tiles = (uint32_t *)(b + p.L.edge_tiles);
 	return v;
 }
 
@@ -239,6 +247,42 @@ __device__ __forceinline__ double wave_sum_dpp(double v)
 // NOTE: must be called with all 64 lanes enabled (a DPP move reads 0 from a disabled lane)
 __device__ __forceinline__ double wave_sum(double v) { return wave_sum_dpp(v); }
 
+// Sixteen wave sums for the price of about three: a transposing butterfly.  At step b the lanes whose bit b is clear keep the
+// even member of every pair of values and receive it from a lane whose bit b is set, and vice versa, so the number of live
+// values halves at each step while the number of lanes that share a value halves too (15 exchanges instead of 16 x 6).
+// Lane l returns  sum over the wave of v[l & 15].  v is clobbered.  All 64 lanes must be enabled.
+template <int N, int CTRL>
+__device__ __forceinline__ void reduce_halve(double *v, bool bit)
+{
+#pragma unroll
+	for (int j = 0; j < N / 2; j++)
+	{
+		const double keep = bit ? v[2 * j + 1] : v[2 * j];
+		const double send = bit ? v[2 * j] : v[2 * j + 1];
+		v[j] = keep + dpp_d<CTRL>(send);
+	}
+}
+__device__ __forceinline__ double wave_sum16(double *v, int lane)
+{
+	reduce_halve<16, 0xB1>(v, lane & 1);	// quad_perm [1,0,3,2]: lane ^ 1
+	reduce_halve<8, 0x4E>(v, lane & 2);		// quad_perm [2,3,0,1]: lane ^ 2
+	reduce_halve<4, 0x124>(v, lane & 4);	// row_ror:4: a source whose bit 2 differs (each lane is a source exactly once)
+	reduce_halve<2, 0x128>(v, lane & 8);	// row_ror:8: lane ^ 8
+	// v[0]: the 16-lane row's sum of value (lane & 15); add the four rows (gfx950 row swaps: no LDS, no readlane)
+	double r = v[0];
+	{
+		const auto h = __builtin_amdgcn_permlane16_swap(__double2hiint(r), __double2hiint(r), false, false);
+		const auto l = __builtin_amdgcn_permlane16_swap(__double2loint(r), __double2loint(r), false, false);
+		r = __hiloint2double(h[0], l[0]) + __hiloint2double(h[1], l[1]);
+	}
+	{
+		const auto h = __builtin_amdgcn_permlane32_swap(__double2hiint(r), __double2hiint(r), false, false);
+		const auto l = __builtin_amdgcn_permlane32_swap(__double2loint(r), __double2loint(r), false, false);
+		r = __hiloint2double(h[0], l[0]) + __hiloint2double(h[1], l[1]);
+	}
+	return r;
+}
+
 struct DeviceAdd // accumulate a vertex gradient (the reference's `+=` into scene.*_b)
 {
 	__device__ __forceinline__ void operator()(void *arr, size_t i, bool f64, double v) const
@@ -262,7 +306,7 @@ __device__ __forceinline__ int xcd_band(int b, int n)
 
 // ----------------------------------------------------------------------------------------------------- set-up + bin
 
-__device__ __forceinline__ void push_tile(uint32_t *cnt, uint32_t *list, int cap_inline, uint2 *pool, uint32_t pool_cap, uint32_t *spill,
+__device__ __forceinline__ uint32_t push_tile(uint32_t *cnt, uint32_t *list, int cap_inline, uint2 *pool, uint32_t pool_cap, uint32_t *spill,
 										  int tile, uint32_t prim)
 {
 	uint32_t slot = atomicAdd(&cnt[tile], 1u);
@@ -274,6 +318,7 @@ __device__ __forceinline__ void push_tile(uint32_t *cnt, uint32_t *list, int cap
 		if (o < pool_cap)
 			pool[o] = make_uint2((uint32_t)tile, prim);
 	}
+	return slot; // 0: first primitive of the tile
 }
 
 // Conservative rejection for binning: a primitive covers a pixel only where every one of its half-plane functions
@@ -310,6 +355,8 @@ __global__ __launch_bounds__(256) void setup_bin_kernel(KParams p)
 		w.hdr->edge_spill[1 - cur] = 0;
 		w.hdr->heavy_count[1 - cur] = 0;
 	}
+	if (item < NSUB)
+		w.edge_tile_cnt[((1 - cur) * NSUB + item) * CNT_STRIDE] = 0;
 	// records are built in place in HBM: a culled triangle only gets its two flags written, an edge slot that is not a
 	// silhouette edge only its kind byte (no 128-byte stores of unused records, no private-memory copies)
 	if (item < p.T)
@@ -348,8 +395,15 @@ __global__ __launch_bounds__(256) void setup_bin_kernel(KParams p)
 	for (int ty = e.y_begin / TILE; ty <= e.y_end / TILE; ty++)
 		for (int tx = e.x_begin / TILE; tx <= e.x_end / TILE; tx++)
 			if (!tile_outside_halfplanes(band, 4, tx, ty))
-				push_tile(w.edge_cnt, w.edge_list, K_EDGE, w.edge_pool, p.L.edge_pool_cap, &w.hdr->edge_spill[cur], ty * p.L.tiles_x + tx,
-						  (uint32_t)slot);
+			{
+				const int tile = ty * p.L.tiles_x + tx;
+				if (push_tile(w.edge_cnt, w.edge_list, K_EDGE, w.edge_pool, p.L.edge_pool_cap, &w.hdr->edge_spill[cur], tile, (uint32_t)slot) == 0)
+				{ // first edge of the tile: the tile joins the list the adjoint's edge kernel walks
+					const int sub = tile % NSUB;
+					const uint32_t at = atomicAdd(&w.edge_tile_cnt[(cur * NSUB + sub) * CNT_STRIDE], 1u);
+					w.edge_tiles[(size_t)sub * p.L.sub_cap + at] = (uint32_t)tile;
+				}
+			}
 }
 
 // ------------------------------------------------------------------------------------------- tile-level edge ordering
@@ -1638,23 +1692,14 @@ __device__ __forceinline__ void lds_add(double *slot, double v)
 		unsafeAtomicAdd(slot, v);
 }
 
-template <class PixT, int WPB>
-__global__ __launch_bounds__(64 * WPB, 3) void raster_bwd_fast_kernel(KParams p)
+// One tile of the adjoint.  EDGES = false: tiles without silhouette edges (the edge code is compiled out: half the
+// registers, twice the resident waves to hide the memory latency); EDGES = true: the tiles that have some.
+template <class PixT, bool EDGES>
+__device__ __forceinline__ void bwd_fast_tile(const KParams &p, const ViewPtrs &w, int view, int tx, int ty, int lane, BwdLds &S, EdgeSort &es)
 {
-	__shared__ BwdLds s_lds[WPB];
-	__shared__ EdgeSort s_es[WPB];
-	const int view = blockIdx.y;
-	const int wave = uniform(threadIdx.x >> 6), lane = threadIdx.x & 63;
-	const ViewPtrs w = view_ptrs(p, view);
-	const int strips_x = (p.L.tiles_x + WPB - 1) / WPB;
-	const int b = xcd_band(blockIdx.x, gridDim.x);
-	const int ty = b / strips_x, tx = (b % strips_x) * WPB + wave;
 	const int W = p.W, H = p.H, C = p.C, P = p.L.P;
 	const PixT *texture = (const PixT *)p.texture;
 	PixT *texture_b = (PixT *)p.texture_b;
-	BwdLds &S = s_lds[wave];
-	if (tx >= p.L.tiles_x)
-		return;
 	const int tile = ty * p.L.tiles_x + tx;
 	const int x0 = tx * TILE, y0 = ty * TILE;
 	const int px = x0 + (lane & 7), py = y0 + (lane >> 3);
@@ -1667,10 +1712,20 @@ __global__ __launch_bounds__(64 * WPB, 3) void raster_bwd_fast_kernel(KParams p)
 	int nedge = uniform((int)w.edge_saved[tile]);
 	if (p.debug & 32)
 		nedge = 0;
+	if ((nedge > 0) != EDGES)
+		return; // the other kernel's tile
+#ifdef DR_TILE_TRACE
+	uint32_t tr[8] = {0x7fc0beefu, (uint32_t)nedge, 0, 0, 0, 0, 0, 0};
+	const uint64_t tr0 = __builtin_readcyclecounter();
+#define DR_TRACE(i) tr[i] = (uint32_t)(__builtin_readcyclecounter() - tr0)
+#else
+#define DR_TRACE(i)
+#endif
 	int n_edges = 0;
-	if (nedge > 0)
-		n_edges = gather_sorted_edges(s_es[wave], w, p, tile, nedge, lane);
-	if (n_edges < 0)
+	if (EDGES)
+		n_edges = gather_sorted_edges(es, w, p, tile, nedge, lane);
+	DR_TRACE(2);
+	if (EDGES && n_edges < 0)
 	{ // more than EMAX edges in one tile (or pool overflow) -> queued for raster_bwd_heavy_kernel
 		if (lane == 0)
 			w.heavy_list[atomicAdd(&w.hdr->heavy_count[w.hdr->cur], 1u)] = (uint32_t)tile;
@@ -1678,6 +1733,10 @@ __global__ __launch_bounds__(64 * WPB, 3) void raster_bwd_fast_kernel(KParams p)
 	}
 	int owner = -1, kind = KIND_NONE;
 	unpack_owner(raw_owner, owner, kind);
+#ifdef DR_TILE_TRACE
+	if (raw_owner == 0x12345678) tr[1] = 9;
+	DR_TRACE(3);
+#endif
 	if (p.debug & 16)
 		owner = -1;
 	if (__ballot(owner >= 0) == 0 && nedge == 0)
@@ -1700,6 +1759,10 @@ __global__ __launch_bounds__(64 * WPB, 3) void raster_bwd_fast_kernel(KParams p)
 				g[cc] = (cc < C && inb) ? 2 * ((double)im[cc] - (double)ob[cc]) : 0.0;
 		}
 	}
+#ifdef DR_TILE_TRACE
+	if (g[0] + g[1] + g[2] + g[3] == 12345.678) tr[1] = 8;
+	DR_TRACE(4);
+#endif
 	// what pass 1 left at this pixel
 	const double *planes = nullptr;
 	double zown = INFINITY;
@@ -1713,14 +1776,17 @@ __global__ __launch_bounds__(64 * WPB, 3) void raster_bwd_fast_kernel(KParams p)
 	}
 
 	// ---- adjoint of pass 2 (near -> far), TB staged edges at a time
-	if (n_edges > 0)
+	if (EDGES && n_edges > 0)
 	{
-		EdgeSort &es = s_es[wave];
 		// depth and un-antialiased colour of the pixel
 		double base[CH] = {0, 0, 0, 0};
 		if (owner >= 0)
 		{
 			zown = plane_at(w.tri_rec[owner].xZ, x, y);
+#ifdef DR_TILE_TRACE
+			if (zown == 12345.678) tr[1] = 8;
+			DR_TRACE(5);
+#endif
 #pragma unroll
 			for (int cc = 0; cc < CH; cc++)
 				if (cc < C)
@@ -1737,6 +1803,11 @@ __global__ __launch_bounds__(64 * WPB, 3) void raster_bwd_fast_kernel(KParams p)
 		// and the antialiased colour they leave
 		uint32_t tm[EMAX / TB] = {0, 0, 0, 0};
 		static_assert(EMAX / TB == 4, "tm[] initialiser");
+#ifdef DR_TILE_TRACE
+		if (base[0] + base[1] + base[2] + base[3] + g[0] + g[1] + g[2] + g[3] == 12345.678)
+			tr[1] = 7; // forces the loads behind base[] and g[] to complete here
+		DR_TRACE(6);
+#endif
 		double cur[CH];
 #pragma unroll
 		for (int cc = 0; cc < CH; cc++)
@@ -1746,6 +1817,10 @@ __global__ __launch_bounds__(64 * WPB, 3) void raster_bwd_fast_kernel(KParams p)
 		{
 			const int first = b * TB, nb = n_edges - first < TB ? n_edges - first : TB;
 			const uint32_t ecov = stage_edge_batch(*(WaveLds *)&S, es, w, P, first, nb, lane, x0, y0, W, inb);
+#ifdef DR_TILE_TRACE
+			if (b == 0)
+				DR_TRACE(7);
+#endif
 			uint32_t tmb = 0;
 			for (int j = 0; j < nb; j++)
 			{
@@ -1901,16 +1976,17 @@ __global__ __launch_bounds__(64 * WPB, 3) void raster_bwd_fast_kernel(KParams p)
 				}
 				// ... reduced over the tile on the VALU (DPP), then ONE atomic instruction (15 lanes) per edge and tile
 				double *eacc = w.edge_acc + (size_t)S.ids[r] * (3 * P + 3);
-				double esum = 0; // lane 3 * pl + m keeps moment m of plane pl
+				double mv[16]; // lane 3 * pl + m ends up with moment m of plane pl
 #pragma unroll
 				for (int pl = 0; pl < 5; pl++)
 				{
-					if (pl < 4 && pl >= P)
-						continue;
-					const double mx = wave_sum_dpp(pb[pl] * x), my = wave_sum_dpp(pb[pl] * y), m1 = wave_sum_dpp(pb[pl]);
-					esum = lane == 3 * pl ? mx : (lane == 3 * pl + 1 ? my : (lane == 3 * pl + 2 ? m1 : esum));
+					mv[3 * pl] = pb[pl] * x;
+					mv[3 * pl + 1] = pb[pl] * y;
+					mv[3 * pl + 2] = pb[pl];
 				}
-				if (lane < 15 && esum != 0)
+				mv[15] = 0;
+				const double esum = wave_sum16(mv, lane);
+				if (lane < 15 && esum != 0 && (lane >= 12 || lane < 3 * P))
 				{
 					const int pl = lane / 3, m = lane - 3 * pl;
 					atomic_add_f64(eacc + (pl == 4 ? 3 * P : 3 * pl) + m, esum);
@@ -2002,15 +2078,92 @@ __global__ __launch_bounds__(64 * WPB, 3) void raster_bwd_fast_kernel(KParams p)
 				tab[my_run * NMOM + i] = mom[i];
 		}
 		lds_sync();
-		if (!(p.debug & 128))
-			for (int idx = lane; idx < nrun * NMOM; idx += 64)
+		// Runs of the same owner (one per pixel row it crosses) are merged before they leave the tile: lane 12 j + m sums moment m
+		// over the runs of the j-th distinct owner, five owners per atomic instruction.
+		const uint32_t own_l = lane < nrun ? own[lane] : 0xffffffffu;
+		uint32_t rem = (uint32_t)__ballot(lane < nrun);
+		while (rem)
+		{
+			constexpr int G = 5;
+			uint32_t gid[G], gmask[G];
+#pragma unroll
+			for (int j = 0; j < G; j++)
 			{
-				const int r = idx / NMOM, m = idx - r * NMOM;
-				const double v = tab[idx];
-				if (m < nm && v != 0)
-					atomic_add_f64(w.tri_acc + (size_t)own[r] * nm + m, v);
+				gid[j] = 0;
+				gmask[j] = 0;
+				if (rem)
+				{
+					const int lead = __ffs((int)rem) - 1;
+					gid[j] = (uint32_t)__builtin_amdgcn_readlane((int)own_l, lead);
+					gmask[j] = (uint32_t)__ballot(own_l == gid[j]) & rem;
+					rem &= ~gmask[j];
+				}
 			}
+			const int j = lane / NMOM, m = lane - j * NMOM;
+			uint32_t o = 0, mask = 0;
+#pragma unroll
+			for (int q = 0; q < G; q++)
+			{
+				o = j == q ? gid[q] : o;
+				mask = j == q ? gmask[q] : mask;
+			}
+			double acc = 0;
+			while (mask)
+			{
+				const int r = __ffs((int)mask) - 1;
+				mask &= mask - 1;
+				acc += tab[r * NMOM + m];
+			}
+			if (m < nm && acc != 0 && !(p.debug & 128))
+				atomic_add_f64(w.tri_acc + (size_t)o * nm + m, acc);
+		}
 		emask &= ~__ballot(sel);
+	}
+#ifdef DR_TILE_TRACE
+	if (EDGES && lane < 8)
+	{
+		uint32_t v = 0;
+		for (int i = 0; i < 8; i++)
+			v = lane == i ? tr[i] : v;
+		((uint32_t *)p.image_in)[((size_t)view * H * W + (size_t)y0 * W + x0) * C + lane] = v; // C == 4: the first two pixels of the tile
+	}
+#endif
+#undef DR_TRACE
+}
+
+template <class PixT, int WPB>
+__global__ __launch_bounds__(64 * WPB, 6) void raster_bwd_fast_kernel(KParams p)
+{ // every tile of the frame; those with silhouette edges are left to raster_bwd_edge_kernel
+	__shared__ BwdLds s_lds[WPB];
+	const int view = blockIdx.y;
+	const int wave = uniform(threadIdx.x >> 6), lane = threadIdx.x & 63;
+	const ViewPtrs w = view_ptrs(p, view);
+	const int strips_x = (p.L.tiles_x + WPB - 1) / WPB;
+	const int b = xcd_band(blockIdx.x, gridDim.x);
+	const int ty = b / strips_x, tx = (b % strips_x) * WPB + wave;
+	if (tx >= p.L.tiles_x)
+		return;
+	bwd_fast_tile<PixT, false>(p, w, view, tx, ty, lane, s_lds[wave], *(EdgeSort *)nullptr);
+}
+
+template <class PixT>
+__global__ __launch_bounds__(64, 3) void raster_bwd_edge_kernel(KParams p)
+{ // persistent waves over the list of tiles that hold silhouette edges (built by setup_bin_kernel); wave g walks
+  // sub-list g % NSUB from entry g / NSUB in steps of gridDim.x / NSUB
+	__shared__ BwdLds s_lds;
+	__shared__ EdgeSort s_es;
+	const int view = blockIdx.y;
+	const int lane = threadIdx.x;
+	const ViewPtrs w = view_ptrs(p, view);
+	const int sub = blockIdx.x % NSUB, stride = gridDim.x / NSUB;
+	const uint32_t n = w.edge_tile_cnt[(w.hdr->cur * NSUB + sub) * CNT_STRIDE];
+	const uint32_t *list = w.edge_tiles + (size_t)sub * p.L.sub_cap;
+#pragma nounroll
+	for (uint32_t i = blockIdx.x / NSUB; i < n; i += stride)
+	{
+		const int tile = uniform((int)list[i]);
+		bwd_fast_tile<PixT, true>(p, w, view, tile % p.L.tiles_x, tile / p.L.tiles_x, lane, s_lds, s_es);
+		lds_sync();
 	}
 }
 
@@ -2197,7 +2350,26 @@ struct ProfEvent
 };
 bool g_profile = false;
 bool g_force_generic = false; // DEODR_HIP_FORCE_GENERIC=1: run the un-staged kernels (tests cover both)
+const int g_edge_waves = getenv("DEODR_HIP_EDGE_WAVES") ? atoi(getenv("DEODR_HIP_EDGE_WAVES")) : 1024; // persistent waves per view of the adjoint's edge kernel
 const int g_wpb = getenv("DEODR_HIP_WPB") ? atoi(getenv("DEODR_HIP_WPB")) : 1; // wavefronts per workgroup of the staged kernels: 1 or 4
+
+template <class PixT>
+void launch_adjoint_raster(const KParams &p, bool fast, int wpb, dim3 grid, dim3 edge_grid, hipStream_t st)
+{
+	if (!fast)
+	{
+		hipLaunchKernelGGL(raster_bwd_kernel<PixT>, grid, dim3(256), 0, st, p);
+		return;
+	}
+	if (wpb == 1)
+		hipLaunchKernelGGL((raster_bwd_fast_kernel<PixT, 1>), grid, dim3(64), 0, st, p);
+	else
+		hipLaunchKernelGGL((raster_bwd_fast_kernel<PixT, 4>), grid, dim3(256), 0, st, p);
+	// (running the two kernels side by side on a forked stream was measured: no gain, the edge kernel just stretches)
+	if (p.sigma > 0 && !(p.debug & 32))
+		hipLaunchKernelGGL(raster_bwd_edge_kernel<PixT>, edge_grid, dim3(64), 0, st, p);
+}
+
 std::vector<ProfEvent> g_prof_events;
 std::vector<std::pair<hipEvent_t, hipEvent_t>> g_prof_free;
 
@@ -2370,26 +2542,17 @@ int deodr_hip_render_scene_b(const DeodrHipScene *sc, const void *image, const v
 	const int wpb = fast ? g_wpb : 4;
 	const int strips_x = (p.L.tiles_x + wpb - 1) / wpb;
 	dim3 grid(strips_x * p.L.tiles_y, sc->n_views);
+	// persistent waves of the edge kernel: enough to cover a silhouette-heavy single view, few enough that with many views
+	// the waves that find their sub-list exhausted cost nothing
+	int edge_waves = p.L.ntiles < g_edge_waves ? p.L.ntiles : g_edge_waves;
+	edge_waves = (edge_waves + NSUB - 1) / NSUB * NSUB;
+	dim3 edge_grid(edge_waves, sc->n_views);
 	{
 		ScopedKernelTimer t(KID_RASTER_BWD, st);
 		if (sc->pixel_dtype == DEODR_HIP_F64)
-		{
-			if (fast && wpb == 1)
-				hipLaunchKernelGGL((raster_bwd_fast_kernel<double, 1>), grid, dim3(64), 0, st, p);
-			else if (fast)
-				hipLaunchKernelGGL((raster_bwd_fast_kernel<double, 4>), grid, dim3(256), 0, st, p);
-			else
-				hipLaunchKernelGGL(raster_bwd_kernel<double>, grid, dim3(256), 0, st, p);
-		}
+			launch_adjoint_raster<double>(p, fast, wpb, grid, edge_grid, st);
 		else
-		{
-			if (fast && wpb == 1)
-				hipLaunchKernelGGL((raster_bwd_fast_kernel<float, 1>), grid, dim3(64), 0, st, p);
-			else if (fast)
-				hipLaunchKernelGGL((raster_bwd_fast_kernel<float, 4>), grid, dim3(256), 0, st, p);
-			else
-				hipLaunchKernelGGL(raster_bwd_kernel<float>, grid, dim3(256), 0, st, p);
-		}
+			launch_adjoint_raster<float>(p, fast, wpb, grid, edge_grid, st);
 		if (fast)
 		{ // a few blocks per view drain the deferred-tile queue (usually empty); finalize_kernel resets it
 			dim3 gh(16, sc->n_views);

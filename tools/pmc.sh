@@ -15,7 +15,7 @@ for name in ('sq1','sq2','fetch','write'):
     agg = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = collections.Counter()
     for f in files:
         for row in csv.DictReader(open(f)):
-            k = row['Kernel_Name'].split('(')[0][-40:]
+            import re; m = re.search(r'(raster_\w+|setup_bin_kernel|finalize_kernel)', row['Kernel_Name']); k = m.group(1) if m else ''
             if 'raster' not in k and 'setup' not in k and 'finalize' not in k: continue
             agg[k][row['Counter_Name']] += float(row['Counter_Value']); cnt[(k,row['Counter_Name'])] += 1
     for k, d in agg.items():
