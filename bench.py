@@ -83,6 +83,7 @@ def main():
     ap.add_argument("--size", type=int, default=1024)
     ap.add_argument("--sigma", type=float, default=1.0, help="edge-overdraw width (the metric configuration uses 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--two-pass", action="store_true", help="render and render_backward as two calls (default: the fused fit step, same outputs)")
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed even for one rank (exercises the RCCL path)")
     args = ap.parse_args()
 
@@ -146,11 +147,15 @@ def main():
     pending = [None]
 
     def step():
-        r.render(ds, args.sigma, out=(image, z), check_overflow=False)
         grads["ij_b"].zero_()
         grads["colors_b"].zero_()
-        # adjoint of L = sum (image - obs)^2: dL/dimage = 2 (image - obs) is formed inside the adjoint kernel (residual mode)
-        r.render_backward(ds, residual_obs=obs_views, grads=grads)
+        if args.two_pass:
+            r.render(ds, args.sigma, out=(image, z), check_overflow=False)
+            # adjoint of L = sum (image - obs)^2: dL/dimage = 2 (image - obs) is formed inside the adjoint kernel (residual mode)
+            r.render_backward(ds, residual_obs=obs_views, grads=grads)
+        else:
+            # same outputs in one call: the forward raster back-propagates through the tiles without silhouette edges itself
+            r.render_fit(ds, obs_views, args.sigma, grads=grads, out=(image, z), check_overflow=False)
         if dist is not None:
             if pending[0] is not None:
                 pending[0].wait()  # the previous step's all-reduce overlapped this step's rendering

@@ -358,7 +358,7 @@ __global__ __launch_bounds__(256) void setup_bin_kernel(KParams p)
 	if (item < NSUB)
 		w.edge_tile_cnt[((1 - cur) * NSUB + item) * CNT_STRIDE] = 0;
 	// records are built in place in HBM: a culled triangle only gets its two flags written, an edge slot that is not a
-	// silhouette edge only its kind byte (no 128-byte stores of unused records, no private-memory copies)
+	// silhouette edge nothing at all (no 128-byte stores of unused records, no private-memory copies)
 	if (item < p.T)
 	{
 		const int k = item;
@@ -381,10 +381,8 @@ __global__ __launch_bounds__(256) void setup_bin_kernel(KParams p)
 	const int slot = item - p.T, k = slot / 3, n = slot - 3 * k;
 	EdgeRec &e = w.edge_rec[slot];
 	if (!(s.sigma > 0) || !s.edgeflags[slot])
-	{
-		e.kind = KIND_NONE;
-		return;
-	}
+		return; // nothing is written for the ~90 % of slots that are not silhouette edges: records are only reached through the
+				// tile lists, and finalize_kernel re-checks the flag (a one-byte store per 128-byte record was 60 MB of HBM writes)
 	TriInputs t;
 	load_triangle(s, k, t, true);
 	setup_edge_only(s, t, k, n, e, w.edge_planes + (size_t)slot * 3 * s.P);
@@ -988,7 +986,14 @@ __device__ __forceinline__ uint32_t stage_edge_batch(WaveLds &S, const EdgeSort 
 	return inb ? gather_column_bits(&S.cover[lane >> 3][0], lane & 7) : 0u;
 }
 
-template <class PixT, int WPB> // WPB wavefronts (= tiles) per workgroup
+template <class PixT>
+__device__ __forceinline__ void owner_adjoint(const KParams &p, const ViewPtrs &w, int lane, double x, double y, int owner, int kind, const double *g,
+											  const Tap &tap, double L, double *tab, uint32_t *own);
+
+// FUSED: the forward of a fit step.  The loss is L = sum (image - obs)^2, so dL/dimage is known the moment a pixel is
+// resolved: tiles without silhouette edges back-propagate into their owners' accumulators right here (no second pass over the
+// frame, no owner buffer round trip); tiles with edges are left to raster_bwd_edge_kernel.
+template <class PixT, int WPB, bool FUSED> // WPB wavefronts (= tiles) per workgroup
 __global__ __launch_bounds__(64 * WPB) void raster_fwd_fast_kernel(KParams p)
 {
 	__shared__ WaveLds s_lds[WPB];
@@ -1028,6 +1033,15 @@ __global__ __launch_bounds__(64 * WPB) void raster_fwd_fast_kernel(KParams p)
 		}
 		if (lane == 0)
 			w.edge_saved[tile] = (uint32_t)nedge;
+		PixT ob[CH] = {0, 0, 0, 0};
+		if (FUSED && ntri > 0 && nedge == 0 && inb)
+		{ // requested now, used after the last triangle
+			const PixT *o = (const PixT *)p.obs + vpix * C;
+#pragma unroll
+			for (int cc = 0; cc < CH; cc++)
+				if (cc < C)
+					ob[cc] = o[cc];
+		}
 		PixState st;
 		st.zbest = INFINITY;
 		st.kbest = -1;
@@ -1101,11 +1115,12 @@ __global__ __launch_bounds__(64 * WPB) void raster_fwd_fast_kernel(KParams p)
 			for (int cc = 0; cc < CH; cc++)
 				col[cc] = (cc < C && inb) ? background_channel<PixT>(p, view, pix, cc) : 0.0;
 		}
-		else if (st.kind == KIND_TEXTURED)
+		Tap tap;
+		double L = 0;
+		if (st.kbest >= 0 && st.kind == KIND_TEXTURED)
 		{
-			Tap tap;
 			bilinear_tap(p.tex_w, p.tex_h, st.v[0], st.v[1], C, tap);
-			const double L = st.v[2];
+			L = st.v[2];
 #pragma unroll
 			for (int cc = 0; cc < CH; cc++)
 				col[cc] = cc < C ? textured_channel(texture, tap, cc) * L : 0.0;
@@ -1210,6 +1225,16 @@ __global__ __launch_bounds__(64 * WPB) void raster_fwd_fast_kernel(KParams p)
 			if (p.zbuf)
 				__builtin_nontemporal_store((PixT)st.zbest, (PixT *)p.zbuf + vpix);
 			__builtin_nontemporal_store(pack_owner(st.kbest, st.kind), w.face_id + pix);
+		}
+		if (FUSED && nedge == 0 && __ballot(st.kbest >= 0) != 0)
+		{ // same residual as raster_bwd_fast_kernel forms from the stored frame: the colour is rounded to the pixel type first
+			double g[CH];
+#pragma unroll
+			for (int cc = 0; cc < CH; cc++)
+				g[cc] = (cc < C && inb) ? 2 * ((double)(PixT)col[cc] - (double)ob[cc]) : 0.0;
+			lds_sync();
+			owner_adjoint<PixT>(p, w, lane, x, y, st.kbest, st.kbest >= 0 ? st.kind : (int)KIND_NONE, g, tap, L, (double *)&S.rec[0],
+								(uint32_t *)&S.cover[0][0]);
 		}
 	}
 	if (blockIdx.x == 0 && threadIdx.x == 0)
@@ -1692,6 +1717,139 @@ __device__ __forceinline__ void lds_add(double *slot, double v)
 		unsafeAtomicAdd(slot, v);
 }
 
+constexpr int RUNS = 32; // run totals flushed per pass: 32 x 12 doubles fit in the (by then idle) record staging area of the wave
+static_assert(RUNS * NMOM * sizeof(double) <= sizeof(WaveLds::rec) + sizeof(WaveLds::planes) && RUNS * 4 <= sizeof(WaveLds::cover), "LDS reuse");
+
+// Adjoint of pass 1 for one tile: g = dL/d(colour written by pass 1) of this lane's pixel, owned by triangle `owner`.
+// tab (RUNS * NMOM doubles) and own (RUNS words) are LDS scratch of this wave.  All 64 lanes must call it.
+template <class PixT>
+__device__ __forceinline__ void owner_adjoint(const KParams &p, const ViewPtrs &w, int lane, double x, double y, int owner, int kind, const double *g,
+											  const Tap &tap, double L, double *tab, uint32_t *own)
+{
+	const int C = p.C, P = p.L.P;
+	const PixT *texture = (const PixT *)p.texture;
+	PixT *texture_b = (PixT *)p.texture_b;
+	double mom[NMOM];
+#pragma unroll
+	for (int i = 0; i < NMOM; i++)
+		mom[i] = 0;
+	if (kind == KIND_TEXTURED)
+	{ // H.h:1320-1353
+		double L_B = 0, e_B[2] = {0, 0};
+#pragma unroll
+		for (int cc = 0; cc < CH; cc++)
+			if (cc < C)
+			{
+				const double i00 = ldp(texture, tap.idx[0] + cc), i10 = ldp(texture, tap.idx[1] + cc);
+				const double i01 = ldp(texture, tap.idx[2] + cc), i11 = ldp(texture, tap.idx[3] + cc);
+				L_B += g[cc] * bilinear_mix(tap, i00, i10, i01, i11);
+				double wgt[4];
+				bilinear_mix_adjoint(tap, g[cc] * L, i00, i10, i01, i11, wgt, e_B);
+				if (texture_b)
+					texture_scatter(texture_b, tap, cc, wgt);
+			}
+		const double ub = tap.out[0] ? 0.0 : e_B[0], vb = tap.out[1] ? 0.0 : e_B[1];
+		mom[0] = ub * x, mom[1] = ub * y, mom[2] = ub;
+		mom[3] = vb * x, mom[4] = vb * y, mom[5] = vb;
+		mom[6] = L_B * x, mom[7] = L_B * y, mom[8] = L_B;
+	}
+	else if (kind == KIND_INTERP)
+	{ // H.h:1024-1037
+#pragma unroll
+		for (int cc = 0; cc < CH; cc++)
+			if (cc < C)
+			{
+				mom[3 * cc + 0] = g[cc] * x;
+				mom[3 * cc + 1] = g[cc] * y;
+				mom[3 * cc + 2] = g[cc];
+			}
+	}
+	// Segmented reduction over the pixels of each owner.  Inside a pixel row a triangle's pixels are runs of consecutive
+	// lanes, so: head-flag segmented inclusive scan over the 8 lanes of every row (3 DPP steps on the VALU, no LDS),
+	// then the last lane of each run adds the run total to the owner's accumulator (one global atomic per moment and run).
+	const int nm = 3 * P; // moments per owner in the global accumulator (P = max(C, 3) planes)
+	const int lx = lane & 7;
+	const int oid = (owner >= 0 && kind != KIND_NONE) ? owner : -1;
+	const int left_oid = dpp_i<0x111>(oid); // evaluated by ALL lanes: a DPP move under a divergent branch reads 0 from disabled lanes
+	const bool head = (lx == 0) | (left_oid != oid);
+	int f = head ? 1 : 0;
+#define DR_SEG_STEP(CTRL)                                                                                                    \
+	{                                                                                                                        \
+		const int tf = dpp_i<CTRL>(f);                                                                                       \
+		double t[NMOM];                                                                                                      \
+		_Pragma("unroll") for (int i = 0; i < NMOM; i++) t[i] = dpp_d<CTRL>(mom[i]);                                         \
+		/* branch-free on purpose: a DPP move must run with every lane enabled (a disabled source lane reads as 0) */       \
+		_Pragma("unroll") for (int i = 0; i < NMOM; i++) mom[i] += f ? 0.0 : t[i];                                           \
+		f = f ? f : tf;                                                                                                      \
+	}
+	DR_SEG_STEP(0x111)
+	DR_SEG_STEP(0x112)
+	DR_SEG_STEP(0x114)
+#undef DR_SEG_STEP
+	const int right_head = dpp_i<0x101>(head ? 1 : 0);
+	const bool tail = (lx == 7) | (right_head != 0);
+	// Run totals go through LDS so that the global atomics are issued moment-major by 64 lanes at once: the cost of an atomic
+	// instruction is per distinct cache line it touches, and the 3P moments of one owner are contiguous.
+	const bool emit = tail && oid >= 0;
+	unsigned long long emask = __ballot(emit);
+	while (emask)
+	{
+		const int my_run = __popcll(emask & ((1ull << lane) - 1ull));
+		const bool sel = ((emask >> lane) & 1ull) && my_run < RUNS;
+		const int total = __popcll(emask);
+		const int nrun = total < RUNS ? total : RUNS;
+		lds_sync();
+		if (sel)
+		{
+			own[my_run] = (uint32_t)oid;
+#pragma unroll
+			for (int i = 0; i < NMOM; i++)
+				tab[my_run * NMOM + i] = mom[i];
+		}
+		lds_sync();
+		// Runs of the same owner (one per pixel row it crosses) are merged before they leave the tile: lane 12 j + m sums moment m
+		// over the runs of the j-th distinct owner, five owners per atomic instruction.
+		const uint32_t own_l = lane < nrun ? own[lane] : 0xffffffffu;
+		uint32_t rem = (uint32_t)__ballot(lane < nrun);
+		while (rem)
+		{
+			constexpr int G = 5;
+			uint32_t gid[G], gmask[G];
+#pragma unroll
+			for (int j = 0; j < G; j++)
+			{
+				gid[j] = 0;
+				gmask[j] = 0;
+				if (rem)
+				{
+					const int lead = __ffs((int)rem) - 1;
+					gid[j] = (uint32_t)__builtin_amdgcn_readlane((int)own_l, lead);
+					gmask[j] = (uint32_t)__ballot(own_l == gid[j]) & rem;
+					rem &= ~gmask[j];
+				}
+			}
+			const int j = lane / NMOM, m = lane - j * NMOM;
+			uint32_t o = 0, mask = 0;
+#pragma unroll
+			for (int q = 0; q < G; q++)
+			{
+				o = j == q ? gid[q] : o;
+				mask = j == q ? gmask[q] : mask;
+			}
+			double acc = 0;
+			while (mask)
+			{
+				const int r = __ffs((int)mask) - 1;
+				mask &= mask - 1;
+				acc += tab[r * NMOM + m];
+			}
+			if (m < nm && acc != 0 && !(p.debug & 128))
+				atomic_add_f64(w.tri_acc + (size_t)o * nm + m, acc);
+		}
+		emask &= ~__ballot(sel);
+	}
+}
+
 // One tile of the adjoint.  EDGES = false: tiles without silhouette edges (the edge code is compiled out: half the
 // registers, twice the resident waves to hide the memory latency); EDGES = true: the tiles that have some.
 template <class PixT, bool EDGES>
@@ -1733,10 +1891,6 @@ __device__ __forceinline__ void bwd_fast_tile(const KParams &p, const ViewPtrs &
 	}
 	int owner = -1, kind = KIND_NONE;
 	unpack_owner(raw_owner, owner, kind);
-#ifdef DR_TILE_TRACE
-	if (raw_owner == 0x12345678) tr[1] = 9;
-	DR_TRACE(3);
-#endif
 	if (p.debug & 16)
 		owner = -1;
 	if (__ballot(owner >= 0) == 0 && nedge == 0)
@@ -1759,10 +1913,6 @@ __device__ __forceinline__ void bwd_fast_tile(const KParams &p, const ViewPtrs &
 				g[cc] = (cc < C && inb) ? 2 * ((double)im[cc] - (double)ob[cc]) : 0.0;
 		}
 	}
-#ifdef DR_TILE_TRACE
-	if (g[0] + g[1] + g[2] + g[3] == 12345.678) tr[1] = 8;
-	DR_TRACE(4);
-#endif
 	// what pass 1 left at this pixel
 	const double *planes = nullptr;
 	double zown = INFINITY;
@@ -1783,10 +1933,6 @@ __device__ __forceinline__ void bwd_fast_tile(const KParams &p, const ViewPtrs &
 		if (owner >= 0)
 		{
 			zown = plane_at(w.tri_rec[owner].xZ, x, y);
-#ifdef DR_TILE_TRACE
-			if (zown == 12345.678) tr[1] = 8;
-			DR_TRACE(5);
-#endif
 #pragma unroll
 			for (int cc = 0; cc < CH; cc++)
 				if (cc < C)
@@ -1803,11 +1949,6 @@ __device__ __forceinline__ void bwd_fast_tile(const KParams &p, const ViewPtrs &
 		// and the antialiased colour they leave
 		uint32_t tm[EMAX / TB] = {0, 0, 0, 0};
 		static_assert(EMAX / TB == 4, "tm[] initialiser");
-#ifdef DR_TILE_TRACE
-		if (base[0] + base[1] + base[2] + base[3] + g[0] + g[1] + g[2] + g[3] == 12345.678)
-			tr[1] = 7; // forces the loads behind base[] and g[] to complete here
-		DR_TRACE(6);
-#endif
 		double cur[CH];
 #pragma unroll
 		for (int cc = 0; cc < CH; cc++)
@@ -1817,10 +1958,6 @@ __device__ __forceinline__ void bwd_fast_tile(const KParams &p, const ViewPtrs &
 		{
 			const int first = b * TB, nb = n_edges - first < TB ? n_edges - first : TB;
 			const uint32_t ecov = stage_edge_batch(*(WaveLds *)&S, es, w, P, first, nb, lane, x0, y0, W, inb);
-#ifdef DR_TILE_TRACE
-			if (b == 0)
-				DR_TRACE(7);
-#endif
 			uint32_t tmb = 0;
 			for (int j = 0; j < nb; j++)
 			{
@@ -1850,6 +1987,7 @@ __device__ __forceinline__ void bwd_fast_tile(const KParams &p, const ViewPtrs &
 			for (int bb = 0; bb < EMAX / TB; bb++)
 				tm[bb] = bb == b ? tmb : tm[bb];
 		}
+		DR_TRACE(3);
 		// pass B, near -> far (H.h:2961-3052)
 		for (int b = nbatch - 1; b >= 0; b--)
 		{
@@ -1995,131 +2133,11 @@ __device__ __forceinline__ void bwd_fast_tile(const KParams &p, const ViewPtrs &
 		}
 	}
 
+	DR_TRACE(4);
 	// ---- adjoint of pass 1: g now belongs to the triangle that owns the pixel
-	double mom[NMOM];
-#pragma unroll
-	for (int i = 0; i < NMOM; i++)
-		mom[i] = 0;
-	if (kind == KIND_TEXTURED)
-	{ // H.h:1320-1353
-		double L_B = 0, e_B[2] = {0, 0};
-#pragma unroll
-		for (int cc = 0; cc < CH; cc++)
-			if (cc < C)
-			{
-				const double i00 = ldp(texture, tap.idx[0] + cc), i10 = ldp(texture, tap.idx[1] + cc);
-				const double i01 = ldp(texture, tap.idx[2] + cc), i11 = ldp(texture, tap.idx[3] + cc);
-				L_B += g[cc] * bilinear_mix(tap, i00, i10, i01, i11);
-				double wgt[4];
-				bilinear_mix_adjoint(tap, g[cc] * L, i00, i10, i01, i11, wgt, e_B);
-				if (texture_b)
-					texture_scatter(texture_b, tap, cc, wgt);
-			}
-		const double ub = tap.out[0] ? 0.0 : e_B[0], vb = tap.out[1] ? 0.0 : e_B[1];
-		mom[0] = ub * x, mom[1] = ub * y, mom[2] = ub;
-		mom[3] = vb * x, mom[4] = vb * y, mom[5] = vb;
-		mom[6] = L_B * x, mom[7] = L_B * y, mom[8] = L_B;
-	}
-	else if (kind == KIND_INTERP)
-	{ // H.h:1024-1037
-#pragma unroll
-		for (int cc = 0; cc < CH; cc++)
-			if (cc < C)
-			{
-				mom[3 * cc + 0] = g[cc] * x;
-				mom[3 * cc + 1] = g[cc] * y;
-				mom[3 * cc + 2] = g[cc];
-			}
-	}
-	// Segmented reduction over the pixels of each owner.  Inside a pixel row a triangle's pixels are runs of consecutive
-	// lanes, so: head-flag segmented inclusive scan over the 8 lanes of every row (3 DPP steps on the VALU, no LDS),
-	// then the last lane of each run adds the run total to the owner's accumulator (one global atomic per moment and run).
-	const int nm = 3 * P; // moments per owner in the global accumulator (P = max(C, 3) planes)
-	const int lx = lane & 7;
-	const int oid = (owner >= 0 && kind != KIND_NONE) ? owner : -1;
-	const int left_oid = dpp_i<0x111>(oid); // evaluated by ALL lanes: a DPP move under a divergent branch reads 0 from disabled lanes
-	const bool head = (lx == 0) | (left_oid != oid);
-	int f = head ? 1 : 0;
-#define DR_SEG_STEP(CTRL)                                                                                                    \
-	{                                                                                                                        \
-		const int tf = dpp_i<CTRL>(f);                                                                                       \
-		double t[NMOM];                                                                                                      \
-		_Pragma("unroll") for (int i = 0; i < NMOM; i++) t[i] = dpp_d<CTRL>(mom[i]);                                         \
-		/* branch-free on purpose: a DPP move must run with every lane enabled (a disabled source lane reads as 0) */       \
-		_Pragma("unroll") for (int i = 0; i < NMOM; i++) mom[i] += f ? 0.0 : t[i];                                           \
-		f = f ? f : tf;                                                                                                      \
-	}
-	DR_SEG_STEP(0x111)
-	DR_SEG_STEP(0x112)
-	DR_SEG_STEP(0x114)
-#undef DR_SEG_STEP
-	const int right_head = dpp_i<0x101>(head ? 1 : 0);
-	const bool tail = (lx == 7) | (right_head != 0);
-	// Run totals go through LDS so that the global atomics are issued moment-major by 64 lanes at once: the cost of an atomic
-	// instruction is per distinct cache line it touches, and the 3P moments of one owner are contiguous.
-	const bool emit = tail && oid >= 0;
-	constexpr int RUNS = 32; // run totals flushed per pass: 32 x 12 doubles fit in the (now idle) record staging area
-	static_assert(RUNS * NMOM * sizeof(double) <= sizeof(S.rec) + sizeof(S.planes) && RUNS * 4 <= sizeof(S.cover), "LDS reuse");
-	double *tab = (double *)&S.rec[0];
-	uint32_t *own = (uint32_t *)&S.cover[0][0];
-	unsigned long long emask = __ballot(emit);
-	while (emask)
-	{
-		const int my_run = __popcll(emask & ((1ull << lane) - 1ull));
-		const bool sel = ((emask >> lane) & 1ull) && my_run < RUNS;
-		const int total = __popcll(emask);
-		const int nrun = total < RUNS ? total : RUNS;
-		lds_sync();
-		if (sel)
-		{
-			own[my_run] = (uint32_t)oid;
-#pragma unroll
-			for (int i = 0; i < NMOM; i++)
-				tab[my_run * NMOM + i] = mom[i];
-		}
-		lds_sync();
-		// Runs of the same owner (one per pixel row it crosses) are merged before they leave the tile: lane 12 j + m sums moment m
-		// over the runs of the j-th distinct owner, five owners per atomic instruction.
-		const uint32_t own_l = lane < nrun ? own[lane] : 0xffffffffu;
-		uint32_t rem = (uint32_t)__ballot(lane < nrun);
-		while (rem)
-		{
-			constexpr int G = 5;
-			uint32_t gid[G], gmask[G];
-#pragma unroll
-			for (int j = 0; j < G; j++)
-			{
-				gid[j] = 0;
-				gmask[j] = 0;
-				if (rem)
-				{
-					const int lead = __ffs((int)rem) - 1;
-					gid[j] = (uint32_t)__builtin_amdgcn_readlane((int)own_l, lead);
-					gmask[j] = (uint32_t)__ballot(own_l == gid[j]) & rem;
-					rem &= ~gmask[j];
-				}
-			}
-			const int j = lane / NMOM, m = lane - j * NMOM;
-			uint32_t o = 0, mask = 0;
-#pragma unroll
-			for (int q = 0; q < G; q++)
-			{
-				o = j == q ? gid[q] : o;
-				mask = j == q ? gmask[q] : mask;
-			}
-			double acc = 0;
-			while (mask)
-			{
-				const int r = __ffs((int)mask) - 1;
-				mask &= mask - 1;
-				acc += tab[r * NMOM + m];
-			}
-			if (m < nm && acc != 0 && !(p.debug & 128))
-				atomic_add_f64(w.tri_acc + (size_t)o * nm + m, acc);
-		}
-		emask &= ~__ballot(sel);
-	}
+	owner_adjoint<PixT>(p, w, lane, x, y, owner, kind, g, tap, L, (double *)&S.rec[0], (uint32_t *)&S.cover[0][0]);
 #ifdef DR_TILE_TRACE
+	DR_TRACE(5);
 	if (EDGES && lane < 8)
 	{
 		uint32_t v = 0;
@@ -2354,14 +2372,16 @@ const int g_edge_waves = getenv("DEODR_HIP_EDGE_WAVES") ? atoi(getenv("DEODR_HIP
 const int g_wpb = getenv("DEODR_HIP_WPB") ? atoi(getenv("DEODR_HIP_WPB")) : 1; // wavefronts per workgroup of the staged kernels: 1 or 4
 
 template <class PixT>
-void launch_adjoint_raster(const KParams &p, bool fast, int wpb, dim3 grid, dim3 edge_grid, hipStream_t st)
+void launch_adjoint_raster(const KParams &p, bool fast, bool owner_tiles, int wpb, dim3 grid, dim3 edge_grid, hipStream_t st)
 {
 	if (!fast)
 	{
 		hipLaunchKernelGGL(raster_bwd_kernel<PixT>, grid, dim3(256), 0, st, p);
 		return;
 	}
-	if (wpb == 1)
+	if (!owner_tiles)
+		; // a fused forward has already back-propagated through the tiles without edges
+	else if (wpb == 1)
 		hipLaunchKernelGGL((raster_bwd_fast_kernel<PixT, 1>), grid, dim3(64), 0, st, p);
 	else
 		hipLaunchKernelGGL((raster_bwd_fast_kernel<PixT, 4>), grid, dim3(256), 0, st, p);
@@ -2405,7 +2425,24 @@ struct ScopedKernelTimer
 	}
 };
 
-int launch_forward(const DeodrHipScene *sc, KParams &p, hipStream_t stream)
+template <class PixT>
+void launch_forward_raster(const KParams &p, bool fast, bool fused, int wpb, dim3 grid, hipStream_t stream)
+{
+	if (!fast)
+		hipLaunchKernelGGL(raster_fwd_kernel<PixT>, grid, dim3(256), 0, stream, p);
+	else if (wpb == 1 && fused)
+		hipLaunchKernelGGL((raster_fwd_fast_kernel<PixT, 1, true>), grid, dim3(64), 0, stream, p);
+	else if (wpb == 1)
+		hipLaunchKernelGGL((raster_fwd_fast_kernel<PixT, 1, false>), grid, dim3(64), 0, stream, p);
+	else if (fused)
+		hipLaunchKernelGGL((raster_fwd_fast_kernel<PixT, 4, true>), grid, dim3(256), 0, stream, p);
+	else
+		hipLaunchKernelGGL((raster_fwd_fast_kernel<PixT, 4, false>), grid, dim3(256), 0, stream, p);
+}
+
+// fused: the forward also back-propagates L = sum (image - obs)^2 through the tiles that have no silhouette edge (staged
+// kernels only; the caller checks `staged_path`)
+int launch_forward(const DeodrHipScene *sc, KParams &p, hipStream_t stream, bool fused = false)
 {
 	const int n_views = sc->n_views;
 	if (p.T > 0)
@@ -2421,28 +2458,50 @@ int launch_forward(const DeodrHipScene *sc, KParams &p, hipStream_t stream)
 	{
 		ScopedKernelTimer t(KID_RASTER_FWD, stream);
 		if (sc->pixel_dtype == DEODR_HIP_F64)
-		{
-			if (fast && wpb == 1)
-				hipLaunchKernelGGL((raster_fwd_fast_kernel<double, 1>), grid, dim3(64), 0, stream, p);
-			else if (fast)
-				hipLaunchKernelGGL((raster_fwd_fast_kernel<double, 4>), grid, dim3(256), 0, stream, p);
-			else
-				hipLaunchKernelGGL(raster_fwd_kernel<double>, grid, dim3(256), 0, stream, p);
-		}
+			launch_forward_raster<double>(p, fast, fused && fast, wpb, grid, stream);
 		else
-		{
-			if (fast && wpb == 1)
-				hipLaunchKernelGGL((raster_fwd_fast_kernel<float, 1>), grid, dim3(64), 0, stream, p);
-			else if (fast)
-				hipLaunchKernelGGL((raster_fwd_fast_kernel<float, 4>), grid, dim3(256), 0, stream, p);
-			else
-				hipLaunchKernelGGL(raster_fwd_kernel<float>, grid, dim3(256), 0, stream, p);
-		}
+			launch_forward_raster<float>(p, fast, fused && fast, wpb, grid, stream);
 	}
 	return check_hip(hipGetLastError(), "forward launch");
 }
 
 } // namespace
+
+// adjoint raster (+ deferred tiles) and the per-primitive finalize; owner_tiles = false after a fused forward
+int launch_adjoint(const DeodrHipScene *sc, KParams &p, hipStream_t st, bool owner_tiles)
+{
+	const bool fast = !p.aa_err && p.C <= CH && !g_force_generic;
+	const int wpb = fast ? g_wpb : 4;
+	const int strips_x = (p.L.tiles_x + wpb - 1) / wpb;
+	dim3 grid(strips_x * p.L.tiles_y, sc->n_views);
+	// persistent waves of the edge kernel: enough to cover a silhouette-heavy single view, few enough that with many views
+	// the waves that find their sub-list exhausted cost nothing
+	int edge_waves = p.L.ntiles < g_edge_waves ? p.L.ntiles : g_edge_waves;
+	edge_waves = (edge_waves + NSUB - 1) / NSUB * NSUB;
+	dim3 edge_grid(edge_waves, sc->n_views);
+	{
+		ScopedKernelTimer t(KID_RASTER_BWD, st);
+		if (sc->pixel_dtype == DEODR_HIP_F64)
+			launch_adjoint_raster<double>(p, fast, owner_tiles, wpb, grid, edge_grid, st);
+		else
+			launch_adjoint_raster<float>(p, fast, owner_tiles, wpb, grid, edge_grid, st);
+		if (fast)
+		{ // a few blocks per view drain the deferred-tile queue (usually empty); finalize_kernel resets it
+			dim3 gh(16, sc->n_views);
+			if (sc->pixel_dtype == DEODR_HIP_F64)
+				hipLaunchKernelGGL(raster_bwd_heavy_kernel<double>, gh, dim3(256), 0, st, p);
+			else
+				hipLaunchKernelGGL(raster_bwd_heavy_kernel<float>, gh, dim3(256), 0, st, p);
+		}
+	}
+	if (p.T > 0)
+	{
+		dim3 g2((4 * p.T + 255) / 256, sc->n_views);
+		ScopedKernelTimer t(KID_FINALIZE, st);
+		hipLaunchKernelGGL(finalize_kernel, g2, dim3(256), 0, st, p);
+	}
+	return check_hip(hipGetLastError(), "backward launch");
+}
 
 extern "C" {
 
@@ -2538,37 +2597,26 @@ int deodr_hip_render_scene_b(const DeodrHipScene *sc, const void *image, const v
 	p.obs = obs;
 	p.err_b = err_buffer_b;
 	p.aa_err = antialiase_error != 0;
-	const bool fast = !p.aa_err && p.C <= CH && !g_force_generic;
-	const int wpb = fast ? g_wpb : 4;
-	const int strips_x = (p.L.tiles_x + wpb - 1) / wpb;
-	dim3 grid(strips_x * p.L.tiles_y, sc->n_views);
-	// persistent waves of the edge kernel: enough to cover a silhouette-heavy single view, few enough that with many views
-	// the waves that find their sub-list exhausted cost nothing
-	int edge_waves = p.L.ntiles < g_edge_waves ? p.L.ntiles : g_edge_waves;
-	edge_waves = (edge_waves + NSUB - 1) / NSUB * NSUB;
-	dim3 edge_grid(edge_waves, sc->n_views);
-	{
-		ScopedKernelTimer t(KID_RASTER_BWD, st);
-		if (sc->pixel_dtype == DEODR_HIP_F64)
-			launch_adjoint_raster<double>(p, fast, wpb, grid, edge_grid, st);
-		else
-			launch_adjoint_raster<float>(p, fast, wpb, grid, edge_grid, st);
-		if (fast)
-		{ // a few blocks per view drain the deferred-tile queue (usually empty); finalize_kernel resets it
-			dim3 gh(16, sc->n_views);
-			if (sc->pixel_dtype == DEODR_HIP_F64)
-				hipLaunchKernelGGL(raster_bwd_heavy_kernel<double>, gh, dim3(256), 0, st, p);
-			else
-				hipLaunchKernelGGL(raster_bwd_heavy_kernel<float>, gh, dim3(256), 0, st, p);
-		}
-	}
-	if (p.T > 0)
-	{
-		dim3 g2((4 * p.T + 255) / 256, sc->n_views);
-		ScopedKernelTimer t(KID_FINALIZE, st);
-		hipLaunchKernelGGL(finalize_kernel, g2, dim3(256), 0, st, p);
-	}
-	return check_hip(hipGetLastError(), "backward launch");
+	return launch_adjoint(sc, p, st, true);
+}
+
+int deodr_hip_render_scene_fit(const DeodrHipScene *sc, void *image, void *z_buffer, double sigma, const void *obs, void *workspace,
+							   size_t workspace_bytes, void *stream)
+{
+	KParams p;
+	if (fill_params(sc, sigma, workspace, workspace_bytes, p, true))
+		return 1;
+	if (!image || !obs)
+		return fail("render_scene_fit needs image and obs");
+	hipStream_t st = (hipStream_t)stream;
+	p.image = image;
+	p.zbuf = z_buffer;
+	p.obs = obs;
+	p.image_in = image;
+	const bool fused = p.C <= CH && !g_force_generic && !(p.debug & 256);
+	if (launch_forward(sc, p, st, fused))
+		return 1;
+	return launch_adjoint(sc, p, st, !fused);
 }
 
 int deodr_hip_workspace_status(const DeodrHipScene *sc, void *workspace, size_t workspace_bytes, void *stream, int *overflowed,

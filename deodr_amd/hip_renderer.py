@@ -59,6 +59,9 @@ def lib():
         L.deodr_hip_render_scene_b.restype = C.c_int
         L.deodr_hip_render_scene_b.argtypes = [C.POINTER(_SceneC), C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_int, C.c_void_p,
                                                C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]  # fmt: skip
+        L.deodr_hip_render_scene_fit.restype = C.c_int
+        L.deodr_hip_render_scene_fit.argtypes = [C.POINTER(_SceneC), C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p, C.c_size_t,
+                                                 C.c_void_p]  # fmt: skip
         L.deodr_hip_workspace_status.restype = C.c_int
         L.deodr_hip_workspace_status.argtypes = [C.POINTER(_SceneC), C.c_void_p, C.c_size_t, C.c_void_p, C.POINTER(C.c_int),
                                                  C.POINTER(C.c_ulonglong)]  # fmt: skip
@@ -221,6 +224,33 @@ class HipRasterizer:
             self._alloc(max(2 * int(need.value), 1024))  # regrow (zero-filled) and render again
         self._last = (ds, float(sigma), bool(antialiase_error), obs_t, image, err)
         return (image, z, err) if antialiase_error else (image, z)
+
+    def render_fit(self, ds, obs, sigma=1.0, grads=None, out=None, check_overflow=None):
+        """One fit step in one call: render ``ds`` and back-propagate ``sum((image - obs)**2)``; -> (image, z_buffer, grads).
+
+        Same results as :meth:`render` followed by ``render_backward(residual_obs=obs)`` (what the reference's
+        ``Scene2D.render_compare_and_backward`` does with ``antialiase_error=False``), but the forward raster already
+        back-propagates through every tile without silhouette edges, so the frame is traversed once."""
+        n, H, W, Cc = ds.n_views, ds.height, ds.width, ds.nb_colors
+        assert (ds.nb_triangles, H, W, Cc, n) == self.dims, "scene shape differs from the workspace shape"
+        pd = ds.pixel_dtype
+        if out is None:
+            image = torch.empty((n, H, W, Cc), dtype=pd, device=ds.device)
+            z = torch.empty((n, H, W), dtype=pd, device=ds.device)
+        else:
+            image, z = out
+        obs_t = obs.to(device=ds.device, dtype=pd)
+        if tuple(obs_t.shape) != (n, H, W, Cc) or not obs_t.is_contiguous():  # pass [n,H,W,C] to avoid this copy
+            obs_t = obs_t.expand(n, H, W, Cc).contiguous()
+        if check_overflow or (check_overflow is None and not self._checked):
+            self.render(ds, sigma, out=(image, z), check_overflow=True)  # sizes the spill pool once (synchronises)
+        if grads is None:
+            grads = ds.zero_grads()
+        sc = ds.c_struct(grads)
+        _check(lib().deodr_hip_render_scene_fit(C.byref(sc), _ptr(image), _ptr(z), float(sigma), _ptr(obs_t), _ptr(self.workspace),
+                                                self.nbytes, _stream()))  # fmt: skip
+        self._last = (ds, float(sigma), False, obs_t, image, None)
+        return image, z, grads
 
     def render_backward(self, ds, image_b=None, err_buffer_b=None, grads=None, have_forward_state=True, residual_obs=None):
         """Adjoint of the last :meth:`render` of ``ds``; returns the dict of gradient tensors (accumulated into ``grads``

@@ -101,6 +101,15 @@ int deodr_hip_render_scene_b(const DeodrHipScene *scene, const void *image, cons
 							 const void *err_buffer_b, void *workspace, size_t workspace_bytes, int have_forward_state,
 							 void *stream);
 
+/* One step of a fit: renderScene followed by renderScene_B for the sum-of-squares loss L = sum (image - obs)^2, i.e. what
+ * Scene2D.render_compare_and_backward (dr.py:700-740, antialiase_error = False branch) does with two calls and a host
+ * subtraction in between.  Outputs are exactly those of deodr_hip_render_scene (image, z_buffer) followed by
+ * deodr_hip_render_scene_b in residual mode (the scene's *_b arrays are accumulated into).  Because dL/dimage of a pixel
+ * is known as soon as the pixel is resolved, the forward raster back-propagates through the tiles that have no silhouette
+ * edge in the same pass; only the tiles with edges are visited again.  Same preconditions as deodr_hip_render_scene_b. */
+int deodr_hip_render_scene_fit(const DeodrHipScene *scene, void *image, void *z_buffer, double sigma, const void *obs,
+							   void *workspace, size_t workspace_bytes, void *stream);
+
 /* Synchronises `stream` and reports whether any forward since the workspace was zero-filled overflowed the spill pool
  * (then that result was incomplete and the call must be repeated with a workspace sized for a larger `pool_pairs`):
  * *needed_pairs receives the largest number of spilled pairs seen in any view.  Costs a device synchronisation: call it

@@ -313,3 +313,63 @@ def test_config5_shape_textured_2048(oracle_api):
     s = scenes.sphere_scene(size=2048, nu=224, n_rings=224, nb_colors=3, textured=True, texture_size=1024)
     assert s.faces.shape[0] == 100352
     compare_backward(oracle_api, s, 1.0, F32)
+
+
+def compare_fit_step(api, views, sigma, dt, seed=11):
+    """deodr_hip_render_scene_fit (fused forward + adjoint of sum (image - obs)^2) against the CPU checker fed with
+    image_b = 2 (image - obs), and against the two-call path of the same library."""
+    from hip_util import device_scene, rel_err
+
+    if not isinstance(views, (list, tuple)):
+        views = [views]
+    ds = device_scene(views, dt)
+    r = HipRasterizer_for(ds)
+    n, H, W, Cc = ds.n_views, ds.height, ds.width, ds.nb_colors
+    obs = np.random.RandomState(seed).rand(n, H, W, Cc)
+    obs_t = torch.as_tensor(obs, device=ds.device, dtype=dt)
+    image, z, g = r.render_fit(ds, obs_t, sigma, check_overflow=True)
+    image2, z2 = r.render(ds, sigma)
+    g2 = r.render_backward(ds, residual_obs=obs_t)
+    torch.cuda.synchronize()
+    assert torch.equal(image, image2) and torch.equal(z, z2), "the fused forward writes the same frame"
+    tol_img, tol = TOL[dt]
+    for i, s in enumerate(views):
+        ref = checker(api)
+        img_ref, z_ref = ref.render(s, sigma)
+        assert np.abs(image[i].cpu().numpy() - img_ref).max() < tol_img
+        image_b = 2 * (image[i].cpu().numpy().astype(np.float64) - obs_t[i].cpu().numpy().astype(np.float64))
+        g_ref = ref.grads(s, sigma, img_ref, z_ref, image_b)
+        g_fix = checker(api, fixed=True).grads(s, sigma, img_ref, z_ref, image_b)
+        for k in ("ij_b", "colors_b", "shade_b"):
+            assert rel_err(g[k][i].cpu().numpy(), g_ref[k]) < tol, (k, "vs checker")
+            assert rel_err(g[k][i].cpu().numpy(), g2[k][i].cpu().numpy()) < 1e-9, (k, "vs two calls")
+        if n == 1:
+            assert rel_err(g["uv_b"].cpu().numpy(), g_ref["uv_b"]) < tol, "uv_b"
+            if g["texture_b"] is not None and np.size(s.texture):
+                assert rel_err(g["texture_b"].cpu().numpy(), g_fix["texture_b"]) < tol, "texture_b"
+    assert rel_err(g["uv_b"].cpu().numpy(), g2["uv_b"].cpu().numpy()) < 1e-9
+
+
+def HipRasterizer_for(ds):
+    from deodr_amd.hip_renderer import HipRasterizer
+
+    return HipRasterizer.for_scene(ds)
+
+
+@pytest.mark.parametrize("dt", [F32, F64])
+@pytest.mark.parametrize("case", [0, 1, 3])
+@pytest.mark.parametrize("sigma", [0.0, 1.0, 2.5])
+def test_fit_step_flag_space(oracle_api, case, sigma, dt):
+    s = random_scene(300 + case, **FLAG_CASES[case])
+    s.backface_culling = True
+    compare_fit_step(oracle_api, s, sigma, dt)
+
+
+def test_fit_step_sphere_20k(oracle_api):
+    compare_fit_step(oracle_api, scenes.sphere_scene(), 1.0, F32)
+
+
+def test_fit_step_hand_textured_views(oracle_api):
+    path = os.path.join(GOLDEN, "hand_mesh.npz")
+    compare_fit_step(oracle_api, scenes.hand_scene(path, size=256, angle=0.2, textured=True), 1.0, F32)
+    compare_fit_step(oracle_api, [scenes.hand_scene(path, size=256, angle=a, textured=False) for a in (-0.4, 0.1, 0.5)], 1.0, F32)

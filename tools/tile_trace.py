@@ -36,9 +36,7 @@ d = np.diff(np.concatenate([np.zeros((len(t), 1), np.int64), t], 1), axis=1)
 for i, n in enumerate(names):
     print("%-12s cycles: mean %8.0f  p50 %8.0f  p90 %8.0f  max %8.0f" % (n, d[:, i].mean(), *np.percentile(d[:, i], [50, 90]), d[:, i].max()))
 print("total        cycles: mean %8.0f  p50 %8.0f  p90 %8.0f  max %8.0f" % (t[:, 3].mean(), *np.percentile(t[:, 3], [50, 90]), t[:, 3].max()))
-print("inside passA: owner colour + g ready at %.0f, first batch staged at %.0f (mean cycles from tile start; gather ends at %.0f)" % (rows[:, 6].mean(), rows[:, 7].mean(), rows[:, 2].mean()))
 for lo, hi in [(1, 2), (3, 4), (5, 8), (9, 16), (17, 32), (33, 64)]:
     m = (ne >= lo) & (ne <= hi)
     if m.any():
         print("n_edges %2d-%2d: %5d tiles, total mean %8.0f, passB mean %8.0f" % (lo, hi, m.sum(), t[m, 3].mean(), d[m, 2].mean()))
-print("v2 trace points (mean cycles from tile start): gather %.0f  face_id %.0f  g %.0f  zown %.0f  base %.0f  staged %.0f" % tuple(rows[:, i].mean() for i in (2, 3, 4, 5, 6, 7)))
