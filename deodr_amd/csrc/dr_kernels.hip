@@ -838,13 +838,20 @@ __device__ __forceinline__ void tri_batch(const KParams &p, WaveLds &S, int nb, 
 			const TriRec &rec = S.rec[j];
 			if (rec.kind != KIND_NONE)
 			{
+				// A row lies in one half of the triangle (above or below its middle vertex), so one span (two divisions, not
+				// four) per (triangle, row); only the non-strict fill rule puts the middle-vertex row in both halves.
 				const int yy = y0 + r;
-#pragma unroll
-				for (int half = 0; half < 2; half++)
+				const bool in0 = yy >= rec.y_begin[0] && yy <= rec.y_end[0], in1 = yy >= rec.y_begin[1] && yy <= rec.y_end[1];
+				int xb, xe;
+				tri_half_span(rec, in0 ? 0 : 1, yy, W, H, strict, xb, xe);
+				m = column_mask(xb, xe, x0);
+				if (__ballot(in0 && in1))
 				{
-					int xb, xe;
-					tri_half_span(rec, half, yy, W, H, strict, xb, xe);
-					m |= column_mask(xb, xe, x0);
+					if (in0 && in1)
+					{
+						tri_half_span(rec, 1, yy, W, H, strict, xb, xe);
+						m |= column_mask(xb, xe, x0);
+					}
 				}
 			}
 		}
@@ -1729,10 +1736,9 @@ __device__ __forceinline__ void owner_adjoint(const KParams &p, const ViewPtrs &
 	const int C = p.C, P = p.L.P;
 	const PixT *texture = (const PixT *)p.texture;
 	PixT *texture_b = (PixT *)p.texture_b;
-	double mom[NMOM];
-#pragma unroll
-	for (int i = 0; i < NMOM; i++)
-		mom[i] = 0;
+	// per-pixel adjoint of the owner's (up to four) attribute planes; its moments  sum v * [x, y, 1]  over the owner's pixels
+	// are what the per-triangle finalize needs
+	double val[CH] = {0, 0, 0, 0};
 	if (kind == KIND_TEXTURED)
 	{ // H.h:1320-1353
 		double L_B = 0, e_B[2] = {0, 0};
@@ -1748,21 +1754,25 @@ __device__ __forceinline__ void owner_adjoint(const KParams &p, const ViewPtrs &
 				if (texture_b)
 					texture_scatter(texture_b, tap, cc, wgt);
 			}
-		const double ub = tap.out[0] ? 0.0 : e_B[0], vb = tap.out[1] ? 0.0 : e_B[1];
-		mom[0] = ub * x, mom[1] = ub * y, mom[2] = ub;
-		mom[3] = vb * x, mom[4] = vb * y, mom[5] = vb;
-		mom[6] = L_B * x, mom[7] = L_B * y, mom[8] = L_B;
+		val[0] = tap.out[0] ? 0.0 : e_B[0];
+		val[1] = tap.out[1] ? 0.0 : e_B[1];
+		val[2] = L_B;
 	}
 	else if (kind == KIND_INTERP)
 	{ // H.h:1024-1037
 #pragma unroll
 		for (int cc = 0; cc < CH; cc++)
 			if (cc < C)
-			{
-				mom[3 * cc + 0] = g[cc] * x;
-				mom[3 * cc + 1] = g[cc] * y;
-				mom[3 * cc + 2] = g[cc];
-			}
+				val[cc] = g[cc];
+	}
+	// a run lies in one pixel row, so its y moment is y times its plain sum: two scanned values per plane, not three
+	constexpr int NSCAN = 2 * CH;
+	double sc[NSCAN];
+#pragma unroll
+	for (int q = 0; q < CH; q++)
+	{
+		sc[2 * q] = val[q] * x;
+		sc[2 * q + 1] = val[q];
 	}
 	// Segmented reduction over the pixels of each owner.  Inside a pixel row a triangle's pixels are runs of consecutive
 	// lanes, so: head-flag segmented inclusive scan over the 8 lanes of every row (3 DPP steps on the VALU, no LDS),
@@ -1776,10 +1786,10 @@ __device__ __forceinline__ void owner_adjoint(const KParams &p, const ViewPtrs &
 #define DR_SEG_STEP(CTRL)                                                                                                    \
 	{                                                                                                                        \
 		const int tf = dpp_i<CTRL>(f);                                                                                       \
-		double t[NMOM];                                                                                                      \
-		_Pragma("unroll") for (int i = 0; i < NMOM; i++) t[i] = dpp_d<CTRL>(mom[i]);                                         \
+		double t[NSCAN];                                                                                                     \
+		_Pragma("unroll") for (int i = 0; i < NSCAN; i++) t[i] = dpp_d<CTRL>(sc[i]);                                         \
 		/* branch-free on purpose: a DPP move must run with every lane enabled (a disabled source lane reads as 0) */       \
-		_Pragma("unroll") for (int i = 0; i < NMOM; i++) mom[i] += f ? 0.0 : t[i];                                           \
+		_Pragma("unroll") for (int i = 0; i < NSCAN; i++) sc[i] += f ? 0.0 : t[i];                                           \
 		f = f ? f : tf;                                                                                                      \
 	}
 	DR_SEG_STEP(0x111)
@@ -1803,8 +1813,12 @@ __device__ __forceinline__ void owner_adjoint(const KParams &p, const ViewPtrs &
 		{
 			own[my_run] = (uint32_t)oid;
 #pragma unroll
-			for (int i = 0; i < NMOM; i++)
-				tab[my_run * NMOM + i] = mom[i];
+			for (int q = 0; q < CH; q++)
+			{
+				tab[my_run * NMOM + 3 * q] = sc[2 * q];
+				tab[my_run * NMOM + 3 * q + 1] = sc[2 * q + 1] * y;
+				tab[my_run * NMOM + 3 * q + 2] = sc[2 * q + 1];
+			}
 		}
 		lds_sync();
 		// Runs of the same owner (one per pixel row it crosses) are merged before they leave the tile: lane 12 j + m sums moment m
@@ -2026,11 +2040,12 @@ __device__ __forceinline__ void bwd_fast_tile(const KParams &p, const ViewPtrs &
 					double uL = 0, uUV[2];
 					if (e.kind == KIND_TEXTURED)
 						textured_tap(ep, x, y, false, 0.0, p.tex_w, p.tex_h, C, utap, uL, uUV);
+					const double inv_T = 1 / Tr_here; // one division for the C channels (the reference divides each: 1 ulp apart)
 #pragma unroll
 					for (int cc = 0; cc < CH; cc++)
 						if (cc < C)
 						{
-							prev[cc] = (cur[cc] - (1 - Tr_here) * edge_channel(e, ep, texture, utap, uL, cc, x, y, false, 0.0)) / Tr_here;
+							prev[cc] = (cur[cc] - (1 - Tr_here) * edge_channel(e, ep, texture, utap, uL, cc, x, y, false, 0.0)) * inv_T;
 							cur[cc] = prev[cc];
 						}
 				}

@@ -432,19 +432,12 @@ DR_HD void edge_row_span(const EdgeRec &r, int y, int width, int &xb, int &xe)
 			b = -r.x2t[1];
 			c = (1 - r.x2t[2]);
 		}
-		double num = -(b * y + c);
+		const double num = -(b * y + c);
+		const int t = floor_div(num, a, xb - 1, xe + 1); // one division whatever the sign of a (on the GPU both sides of a branch run)
 		if (a < 0)
-		{
-			int t = floor_div(num, a, xb - 1, xe + 1);
-			if (t < xe)
-				xe = t;
-		}
+			xe = t < xe ? t : xe;
 		else
-		{
-			int t = 1 + floor_div(num, a, xb - 1, xe + 1);
-			if (t > xb)
-				xb = t;
-		}
+			xb = t + 1 > xb ? t + 1 : xb;
 	}
 }
 
