@@ -306,10 +306,9 @@ __device__ __forceinline__ int xcd_band(int b, int n)
 
 // ----------------------------------------------------------------------------------------------------- set-up + bin
 
-__device__ __forceinline__ uint32_t push_tile(uint32_t *cnt, uint32_t *list, int cap_inline, uint2 *pool, uint32_t pool_cap, uint32_t *spill,
-										  int tile, uint32_t prim)
+__device__ __forceinline__ void place_in_tile(uint32_t *list, int cap_inline, uint2 *pool, uint32_t pool_cap, uint32_t *spill, int tile,
+											  uint32_t prim, uint32_t slot)
 {
-	uint32_t slot = atomicAdd(&cnt[tile], 1u);
 	if (slot < (uint32_t)cap_inline)
 		list[(size_t)tile * cap_inline + slot] = prim;
 	else
@@ -318,16 +317,25 @@ __device__ __forceinline__ uint32_t push_tile(uint32_t *cnt, uint32_t *list, int
 		if (o < pool_cap)
 			pool[o] = make_uint2((uint32_t)tile, prim);
 	}
+}
+
+__device__ __forceinline__ uint32_t push_tile(uint32_t *cnt, uint32_t *list, int cap_inline, uint2 *pool, uint32_t pool_cap, uint32_t *spill,
+											  int tile, uint32_t prim)
+{
+	const uint32_t slot = atomicAdd(&cnt[tile], 1u);
+	place_in_tile(list, cap_inline, pool, pool_cap, spill, tile, prim, slot);
 	return slot; // 0: first primitive of the tile
 }
 
 // Conservative rejection for binning: a primitive covers a pixel only where every one of its half-plane functions
 // E = a x + b y + c is >= 0 (or > 0); if some E is clearly negative on all four corner pixels of the tile, no pixel of the
 // tile can be covered.  The slack keeps the test safe against the rounding of the exact span arithmetic used later.
-__device__ __forceinline__ bool tile_outside_halfplanes(const double *eq, int n, int tx, int ty)
+template <int N>
+__device__ __forceinline__ bool tile_outside_halfplanes(const double *eq, int tx, int ty)
 {
 	const double xa = tx * TILE, xb = tx * TILE + (TILE - 1), ya = ty * TILE, yb = ty * TILE + (TILE - 1);
-	for (int k = 0; k < n; k++)
+#pragma unroll
+	for (int k = 0; k < N; k++)
 	{
 		const double a = eq[3 * k], b = eq[3 * k + 1], c = eq[3 * k + 2];
 		const double emax = a * (a > 0 ? xb : xa) + b * (b > 0 ? yb : ya) + c;
@@ -357,50 +365,116 @@ __global__ __launch_bounds__(256) void setup_bin_kernel(KParams p)
 	}
 	if (item < NSUB)
 		w.edge_tile_cnt[((1 - cur) * NSUB + item) * CNT_STRIDE] = 0;
-	// records are built in place in HBM: a culled triangle only gets its two flags written, an edge slot that is not a
-	// silhouette edge nothing at all (no 128-byte stores of unused records, no private-memory copies)
+	// Records are built in registers and leave with one 128-byte store: the binning below reads the local copy (reading a
+	// record back from HBM right after writing it costs a full memory round trip per field), a culled triangle only gets its two
+	// flags written, an edge slot that is not a silhouette edge nothing at all.
 	if (item < p.T)
 	{
 		const int k = item;
 		TriInputs t;
 		load_triangle(s, k, t, true);
-		TriRec &rec = w.tri_rec[k];
+		TriRec rec;
 		setup_tri_only(s, t, rec, w.tri_planes + (size_t)k * 3 * s.P);
+		TriRec &out = w.tri_rec[k];
 		if (rec.kind == KIND_NONE)
+		{
+			out.kind = KIND_NONE;
+			out.front = rec.front;
 			return;
-		int x0 = rec.x_min < 0 ? 0 : rec.x_min, x1 = rec.x_max > s.W - 1 ? s.W - 1 : rec.x_max;
-		int y0 = rec.y_begin[0] < 0 ? 0 : rec.y_begin[0], y1 = rec.y_end[1] > s.H - 1 ? s.H - 1 : rec.y_end[1];
-		if (x0 <= x1 && y0 <= y1)
-			for (int ty = y0 / TILE; ty <= y1 / TILE; ty++)
-				for (int tx = x0 / TILE; tx <= x1 / TILE; tx++)
-					if (!tile_outside_halfplanes(&rec.eq[0][0], 3, tx, ty))
-						push_tile(w.tri_cnt, w.tri_list, K_TRI, w.tri_pool, p.L.tri_pool_cap, &w.hdr->tri_spill[cur], ty * p.L.tiles_x + tx,
-								  (uint32_t)k);
+		}
+		rec.pad0[0] = rec.pad0[1] = 0;
+		rec.pad1[0] = rec.pad1[1] = rec.pad1[2] = 0;
+		out = rec;
+		const int x0 = rec.x_min < 0 ? 0 : rec.x_min, x1 = rec.x_max > s.W - 1 ? s.W - 1 : rec.x_max;
+		const int y0 = rec.y_begin[0] < 0 ? 0 : rec.y_begin[0], y1 = rec.y_end[1] > s.H - 1 ? s.H - 1 : rec.y_end[1];
+		if (x0 > x1 || y0 > y1)
+			return;
+		const double eq[9] = {rec.eq[0][0], rec.eq[0][1], rec.eq[0][2], rec.eq[1][0], rec.eq[1][1], rec.eq[1][2], rec.eq[2][0], rec.eq[2][1], rec.eq[2][2]};
+		const int tx0 = x0 / TILE, ty0 = y0 / TILE, ntx = x1 / TILE - tx0 + 1, nty = y1 / TILE - ty0 + 1;
+		if (ntx <= 3 && nty <= 3)
+		{ // the usual small triangle: its slot requests are all in flight together (one memory round trip, not one per tile)
+			uint32_t slot[9];
+			bool use[9];
+#pragma unroll
+			for (int q = 0; q < 9; q++)
+			{
+				const int dx = q % 3, dy = q / 3;
+				use[q] = dx < ntx && dy < nty && !tile_outside_halfplanes<3>(eq, tx0 + dx, ty0 + dy);
+				slot[q] = 0;
+				if (use[q])
+					slot[q] = atomicAdd(&w.tri_cnt[(ty0 + dy) * p.L.tiles_x + tx0 + dx], 1u);
+			}
+#pragma unroll
+			for (int q = 0; q < 9; q++)
+				if (use[q])
+					place_in_tile(w.tri_list, K_TRI, w.tri_pool, p.L.tri_pool_cap, &w.hdr->tri_spill[cur], (ty0 + q / 3) * p.L.tiles_x + tx0 + q % 3,
+								  (uint32_t)k, slot[q]);
+			return;
+		}
+		for (int ty = ty0; ty < ty0 + nty; ty++)
+			for (int tx = tx0; tx < tx0 + ntx; tx++)
+				if (!tile_outside_halfplanes<3>(eq, tx, ty))
+					push_tile(w.tri_cnt, w.tri_list, K_TRI, w.tri_pool, p.L.tri_pool_cap, &w.hdr->tri_spill[cur], ty * p.L.tiles_x + tx, (uint32_t)k);
 		return;
 	}
 	const int slot = item - p.T, k = slot / 3, n = slot - 3 * k;
-	EdgeRec &e = w.edge_rec[slot];
 	if (!(s.sigma > 0) || !s.edgeflags[slot])
 		return; // nothing is written for the ~90 % of slots that are not silhouette edges: records are only reached through the
 				// tile lists, and finalize_kernel re-checks the flag (a one-byte store per 128-byte record was 60 MB of HBM writes)
 	TriInputs t;
 	load_triangle(s, k, t, true);
+	EdgeRec e;
 	setup_edge_only(s, t, k, n, e, w.edge_planes + (size_t)slot * 3 * s.P);
-	if (e.kind == KIND_NONE || e.x_begin > e.x_end || e.y_begin > e.y_end)
+	EdgeRec &eout = w.edge_rec[slot];
+	if (e.kind == KIND_NONE)
+	{
+		eout.kind = KIND_NONE;
+		return;
+	}
+	for (int i = 0; i < 7; i++)
+		e.pad0[i] = 0;
+	eout = e;
+	if (e.x_begin > e.x_end || e.y_begin > e.y_end)
 		return;
 	const double band[12] = {e.x2b[0], e.x2b[1], e.x2b[2], e.x2b[3], e.x2b[4], e.x2b[5], e.x2t[0], e.x2t[1], e.x2t[2],
 							 -e.x2t[0], -e.x2t[1], 1 - e.x2t[2]}; // the four half-planes of the band, H.h:1418-1435
-	for (int ty = e.y_begin / TILE; ty <= e.y_end / TILE; ty++)
-		for (int tx = e.x_begin / TILE; tx <= e.x_end / TILE; tx++)
-			if (!tile_outside_halfplanes(band, 4, tx, ty))
+	const int tx0 = e.x_begin / TILE, ty0 = e.y_begin / TILE, ntx = e.x_end / TILE - tx0 + 1, nty = e.y_end / TILE - ty0 + 1;
+	auto first_edge_of = [&](int tile) { // the tile joins the list the adjoint's edge kernel walks
+		const int sub = tile % NSUB;
+		const uint32_t at = atomicAdd(&w.edge_tile_cnt[(cur * NSUB + sub) * CNT_STRIDE], 1u);
+		w.edge_tiles[(size_t)sub * p.L.sub_cap + at] = (uint32_t)tile;
+	};
+	if (ntx <= 3 && nty <= 3)
+	{
+		uint32_t got[9];
+		bool use[9];
+#pragma unroll
+		for (int q = 0; q < 9; q++)
+		{
+			const int dx = q % 3, dy = q / 3;
+			use[q] = dx < ntx && dy < nty && !tile_outside_halfplanes<4>(band, tx0 + dx, ty0 + dy);
+			got[q] = 1;
+			if (use[q])
+				got[q] = atomicAdd(&w.edge_cnt[(ty0 + dy) * p.L.tiles_x + tx0 + dx], 1u);
+		}
+#pragma unroll
+		for (int q = 0; q < 9; q++)
+			if (use[q])
+			{
+				const int tile = (ty0 + q / 3) * p.L.tiles_x + tx0 + q % 3;
+				place_in_tile(w.edge_list, K_EDGE, w.edge_pool, p.L.edge_pool_cap, &w.hdr->edge_spill[cur], tile, (uint32_t)slot, got[q]);
+				if (got[q] == 0)
+					first_edge_of(tile);
+			}
+		return;
+	}
+	for (int ty = ty0; ty < ty0 + nty; ty++)
+		for (int tx = tx0; tx < tx0 + ntx; tx++)
+			if (!tile_outside_halfplanes<4>(band, tx, ty))
 			{
 				const int tile = ty * p.L.tiles_x + tx;
 				if (push_tile(w.edge_cnt, w.edge_list, K_EDGE, w.edge_pool, p.L.edge_pool_cap, &w.hdr->edge_spill[cur], tile, (uint32_t)slot) == 0)
-				{ // first edge of the tile: the tile joins the list the adjoint's edge kernel walks
-					const int sub = tile % NSUB;
-					const uint32_t at = atomicAdd(&w.edge_tile_cnt[(cur * NSUB + sub) * CNT_STRIDE], 1u);
-					w.edge_tiles[(size_t)sub * p.L.sub_cap + at] = (uint32_t)tile;
-				}
+					first_edge_of(tile);
 			}
 }
 

@@ -278,8 +278,10 @@ DR_HD void tri_stencil(const double V[3][2], bool strict, TriRec &r, double x2b[
 	r.y_end[0] = (int16_t)floor(sy[1]);
 	r.y_begin[1] = strict ? (int16_t)((int16_t)floor(sy[1]) + 1) : (int16_t)ceil(sy[1]);
 	r.y_end[1] = (int16_t)floor(sy[2]);
+	// (selects instead of r.eq[id][0]: a record kept in registers must not be indexed dynamically)
 	int id = oy[0];
-	if (r.eq[id % 3][0] > 0)
+	const double ea0 = r.eq[0][0], ea1 = r.eq[1][0], ea2 = r.eq[2][0]; // values, not lvalues: see pick3 in dr_prims.h
+	if ((id == 0 ? ea0 : (id == 1 ? ea1 : ea2)) > 0)
 	{
 		r.right[0] = (uint8_t)((id + 2) % 3);
 		r.left[0] = (uint8_t)(id % 3);
@@ -290,7 +292,7 @@ DR_HD void tri_stencil(const double V[3][2], bool strict, TriRec &r, double x2b[
 		r.left[0] = (uint8_t)((id + 2) % 3);
 	}
 	id = oy[2];
-	if (r.eq[id % 3][0] < 0)
+	if ((id == 0 ? ea0 : (id == 1 ? ea1 : ea2)) < 0)
 	{
 		r.right[1] = (uint8_t)(id % 3);
 		r.left[1] = (uint8_t)((id + 2) % 3);

@@ -106,21 +106,31 @@ DR_HD void attr_planes_reg(const SceneView &s, int kind, int nv, const double at
 						   double *planes)
 {
 	const int np = kind == KIND_TEXTURED ? 3 : s.C;
-	for (int c = 0; c < np; c++)
-	{
-		double a[3];
-		for (int i = 0; i < nv; i++)
+	// fully unrolled with a guard: a loop with a run-time trip count would index att[][c] dynamically, which sends the
+	// caller's register-resident inputs to scratch memory
+#pragma unroll
+	for (int c = 0; c < 4; c++)
+		if (c < np)
 		{
-			a[i] = att[i][c];
-			if (s.persp)
+			double a[3];
+#pragma unroll
+			for (int i = 0; i < 3; i++)
 			{
-				const double w = 1 / Zv[i];
-				a[i] = (kind == KIND_TEXTURED && c == 2) ? w * a[i] : a[i] * w;
+				a[i] = 0;
+				if (i < nv)
+				{
+					a[i] = att[i][c];
+					if (s.persp)
+					{
+						const double w = 1 / Zv[i];
+						a[i] = (kind == KIND_TEXTURED && c == 2) ? w * a[i] : a[i] * w;
+					}
+				}
 			}
+#pragma unroll
+			for (int j = 0; j < 3; j++)
+				planes[3 * c + j] = plane_coef(nv, a, x2b, j);
 		}
-		for (int j = 0; j < 3; j++)
-			planes[3 * c + j] = plane_coef(nv, a, x2b, j);
-	}
 }
 
 // Inputs of one triangle, fetched up front (two dependent memory round trips: indices, then vertex data; each further
@@ -215,19 +225,29 @@ DR_HD void setup_tri_only(const SceneView &s, const TriInputs &t, TriRec &rec, d
 	}
 }
 
+template <class T>
+DR_HD T pick3(T v0, T v1, T v2, int i)
+{
+	return i == 0 ? v0 : (i == 1 ? v1 : v2);
+}
+
 // Edge n of triangle k: eligibility H.h:2847-2853, kind H.h:2868-2895, stencil H.h:1366-1460.
 DR_HD void setup_edge_only(const SceneView &s, const TriInputs &t, int k, int n, EdgeRec &e, double *ep /*[3P]*/)
 {
 	e.kind = KIND_NONE;
 	if (!(s.sigma > 0) || !(t.area > 0) || !s.edgeflags[3 * (size_t)k + n])
 		return;
-	const int *sub = LIST_SUB[n];
-	double EV[2][2], EZ[3] = {t.Zv[sub[0]], t.Zv[sub[1]], 0};
-	for (int i = 0; i < 2; i++)
-	{
-		EV[i][0] = t.Vraw[sub[i]][0] - s.offset;
-		EV[i][1] = t.Vraw[sub[i]][1] - s.offset;
-	}
+	// vertices LIST_SUB[n] = {1,0}, {2,1}, {0,2} of the triangle, picked with selects: indexing the register-resident
+	// TriInputs with a run-time n would push the whole structure to scratch memory
+	const int a = n == 0 ? 1 : (n == 1 ? 2 : 0), b = n == 0 ? 0 : (n == 1 ? 1 : 2);
+	// (pick3 takes VALUES: `i == 0 ? arr[0] : arr[1]` on lvalues selects an address and loads through it afterwards)
+#define DR_PICK(arr, i) pick3(arr[0], arr[1], arr[2], i)
+#define DR_PICK2(arr, i, c) pick3(arr[0][c], arr[1][c], arr[2][c], i)
+	double EV[2][2], EZ[3] = {DR_PICK(t.Zv, a), DR_PICK(t.Zv, b), 0};
+	EV[0][0] = DR_PICK2(t.Vraw, a, 0) - s.offset;
+	EV[0][1] = DR_PICK2(t.Vraw, a, 1) - s.offset;
+	EV[1][0] = DR_PICK2(t.Vraw, b, 0) - s.offset;
+	EV[1][1] = DR_PICK2(t.Vraw, b, 1) - s.offset;
 	edge_stencil(EV, s.H, s.W, s.sigma, s.clockwise, e);
 	e.kind = t.both ? KIND_TEXTURED : KIND_INTERP; // textured && !shaded edges are drawn interpolated (H.h:2884)
 	e.key = t.sum_depth;
@@ -239,17 +259,19 @@ DR_HD void setup_edge_only(const SceneView &s, const TriInputs &t, int k, int n,
 		double eatt[3][4];
 		for (int c = 0; c < 4; c++)
 		{
-			eatt[0][c] = t.att[sub[0]][c];
-			eatt[1][c] = t.att[sub[1]][c];
+			eatt[0][c] = DR_PICK2(t.att, a, c);
+			eatt[1][c] = DR_PICK2(t.att, b, c);
 			eatt[2][c] = 0;
 		}
 		attr_planes_reg(s, e.kind, 2, eatt, EZ, e.x2b, ep);
 	}
 	else
 	{ // many channels, or a textured-but-unshaded triangle whose edges use the vertex colours
-		uint32_t vid[3] = {t.f[sub[0]], t.f[sub[1]], 0}, uvid[3] = {t.fuv[sub[0]], t.fuv[sub[1]], 0};
+		uint32_t vid[3] = {DR_PICK(t.f, a), DR_PICK(t.f, b), 0}, uvid[3] = {DR_PICK(t.fuv, a), DR_PICK(t.fuv, b), 0};
 		attr_planes(s, e.kind, 2, vid, uvid, EZ, e.x2b, ep);
 	}
+#undef DR_PICK
+#undef DR_PICK2
 }
 
 // Whole set-up of triangle k (record, planes, three edge slots) in one call: used by the host simulator.
