@@ -1114,6 +1114,35 @@ __global__ __launch_bounds__(64 * WPB) void raster_fwd_fast_kernel(KParams p)
 		}
 		if (lane == 0)
 			w.edge_saved[tile] = (uint32_t)nedge;
+		if ((ntri | nedge) == 0)
+		{ // two tiles out of three hold no primitive: background, no depth, no owner -- and nothing else to run through
+			if (inb && !(p.debug & 4))
+			{
+				if (p.image)
+				{
+					PixT *out = (PixT *)p.image + vpix * C;
+					if (C == 4)
+					{
+						typedef PixT V4 __attribute__((ext_vector_type(4)));
+						const V4 v = {(PixT)background_channel<PixT>(p, view, pix, 0), (PixT)background_channel<PixT>(p, view, pix, 1),
+									  (PixT)background_channel<PixT>(p, view, pix, 2), (PixT)background_channel<PixT>(p, view, pix, 3)};
+						__builtin_nontemporal_store(v, (V4 *)out);
+					}
+					else
+					{
+#pragma unroll
+						for (int cc = 0; cc < CH; cc++)
+							if (cc < C)
+								__builtin_nontemporal_store((PixT)background_channel<PixT>(p, view, pix, cc), out + cc);
+					}
+				}
+				if (p.zbuf)
+					__builtin_nontemporal_store((PixT)INFINITY, (PixT *)p.zbuf + vpix);
+				__builtin_nontemporal_store((int32_t)-1, w.face_id + pix);
+			}
+		}
+		else
+		{
 		PixT ob[CH] = {0, 0, 0, 0};
 		if (FUSED && ntri > 0 && nedge == 0 && inb)
 		{ // requested now, used after the last triangle
@@ -1317,6 +1346,7 @@ __global__ __launch_bounds__(64 * WPB) void raster_fwd_fast_kernel(KParams p)
 			owner_adjoint<PixT>(p, w, lane, x, y, st.kbest, st.kbest >= 0 ? st.kind : (int)KIND_NONE, g, tap, L, (double *)&S.rec[0],
 								(uint32_t *)&S.cover[0][0]);
 		}
+			}
 	}
 	if (blockIdx.x == 0 && threadIdx.x == 0)
 	{ // one thread per view closes the epoch; nobody else reads `epoch` or `needed_max` during this kernel

@@ -328,6 +328,24 @@ DR_HD void finalize_triangle(const SceneView &s, const GradView &g, int k, const
 		for (int i = 0; i < 3; i++)
 			add(g.shade_b, face[i], s.vtx_f64, a_B[i]);
 	}
+	else if (s.C <= 4)
+	{ // same as below, unrolled under a guard: every colour load is in flight before the first one is used (a rolled loop
+	  // pays one memory round trip per channel)
+		double a[4][3];
+#pragma unroll
+		for (int c = 0; c < 4; c++)
+			for (int i = 0; i < 3; i++)
+				a[c][i] = c < s.C ? ldv(s.colors, (size_t)face[i] * s.C + c, s.vtx_f64) : 0.0;
+#pragma unroll
+		for (int c = 0; c < 4; c++)
+			if (c < s.C)
+			{
+				double a_B[3] = {0, 0, 0};
+				plane_adjoint(3, acc + 3 * c, a[c], a_B, x2b, x2b_B);
+				for (int i = 0; i < 3; i++)
+					add(g.colors_b, (size_t)face[i] * s.C + c, s.vtx_f64, a_B[i]);
+			}
+	}
 	else
 		for (int c = 0; c < s.C; c++)
 		{ // H.h:841-851
@@ -350,8 +368,8 @@ DR_HD void finalize_edge(const SceneView &s, const GradView &g, int k, int n, co
 	if (e.kind == KIND_NONE)
 		return;
 	const uint32_t *face = s.faces + 3 * (size_t)k, *face_uv = s.faces_uv + 3 * (size_t)k;
-	const int *sub = LIST_SUB[n];
-	const uint32_t vid[2] = {face[sub[0]], face[sub[1]]}, uvid[2] = {face_uv[sub[0]], face_uv[sub[1]]};
+	const int ia = n == 0 ? 1 : (n == 1 ? 2 : 0), ib = n == 0 ? 0 : (n == 1 ? 1 : 2); // LIST_SUB[n]
+	const uint32_t vid[2] = {face[ia], face[ib]}, uvid[2] = {face_uv[ia], face_uv[ib]};
 	double V[2][2];
 	for (int i = 0; i < 2; i++)
 	{
@@ -376,6 +394,26 @@ DR_HD void finalize_edge(const SceneView &s, const GradView &g, int k, int n, co
 		plane_adjoint(2, acc + 6, a, a_B, e.x2b, x2b_B);
 		for (int i = 0; i < 2; i++)
 			add(g.shade_b, vid[i], s.vtx_f64, a_B[i]);
+	}
+	else if (s.C <= 4)
+	{ // unrolled under a guard, loads first (see finalize_triangle)
+		double a[4][3];
+#pragma unroll
+		for (int c = 0; c < 4; c++)
+		{
+			for (int i = 0; i < 2; i++)
+				a[c][i] = c < s.C ? ldv(s.colors, (size_t)vid[i] * s.C + c, s.vtx_f64) : 0.0;
+			a[c][2] = 0;
+		}
+#pragma unroll
+		for (int c = 0; c < 4; c++)
+			if (c < s.C)
+			{
+				double a_B[3] = {0, 0, 0};
+				plane_adjoint(2, acc + 3 * c, a[c], a_B, e.x2b, x2b_B);
+				for (int i = 0; i < 2; i++)
+					add(g.colors_b, (size_t)vid[i] * s.C + c, s.vtx_f64, a_B[i]);
+			}
 	}
 	else
 		for (int c = 0; c < s.C; c++)
