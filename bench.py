@@ -147,15 +147,16 @@ def main():
     pending = [None]
 
     def step():
-        grads["ij_b"].zero_()
-        grads["colors_b"].zero_()
         if args.two_pass:
+            grads["ij_b"].zero_()
+            grads["colors_b"].zero_()
             r.render(ds, args.sigma, out=(image, z), check_overflow=False)
             # adjoint of L = sum (image - obs)^2: dL/dimage = 2 (image - obs) is formed inside the adjoint kernel (residual mode)
             r.render_backward(ds, residual_obs=obs_views, grads=grads)
         else:
             # same outputs in one call: the forward raster back-propagates through the tiles without silhouette edges itself
-            r.render_fit(ds, obs_views, args.sigma, grads=grads, out=(image, z), check_overflow=False)
+            # (and zeroes the gradient arrays of the previous step on the way)
+            r.render_fit(ds, obs_views, args.sigma, grads=grads, out=(image, z), check_overflow=False, clear_grads=True)
         if dist is not None:
             if pending[0] is not None:
                 pending[0].wait()  # the previous step's all-reduce overlapped this step's rendering

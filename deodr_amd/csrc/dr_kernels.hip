@@ -122,6 +122,7 @@ struct KParams
 	void *image, *zbuf, *err;
 	const void *image_b, *obs, *err_b, *image_in;
 	int aa_err;
+	int clear_grads; // the set-up kernel zeroes the per-view gradient arrays (a fit step that wants fresh gradients: no separate fills)
 	int debug; // ablation switches for profiling (DEODR_HIP_DEBUG), 0 in production
 	// workspace
 	char *ws;
@@ -365,6 +366,31 @@ __global__ __launch_bounds__(256) void setup_bin_kernel(KParams p)
 	}
 	if (item < NSUB)
 		w.edge_tile_cnt[((1 - cur) * NSUB + item) * CNT_STRIDE] = 0;
+	if (p.clear_grads)
+		for (int v = item; v < p.V; v += gridDim.x * blockDim.x)
+		{ // nothing accumulates into them before finalize_kernel, two kernels later
+			const size_t at = (size_t)view * p.V + v;
+			if (p.vtx_f64)
+			{
+				if (p.ij_b)
+					((double2 *)p.ij_b)[at] = make_double2(0, 0);
+				if (p.shade_b)
+					((double *)p.shade_b)[at] = 0;
+				if (p.colors_b)
+					for (int c = 0; c < p.C; c++)
+						((double *)p.colors_b)[at * p.C + c] = 0;
+			}
+			else
+			{
+				if (p.ij_b)
+					((float2 *)p.ij_b)[at] = make_float2(0, 0);
+				if (p.shade_b)
+					((float *)p.shade_b)[at] = 0;
+				if (p.colors_b)
+					for (int c = 0; c < p.C; c++)
+						((float *)p.colors_b)[at * p.C + c] = 0;
+			}
+		}
 	// Records are built in registers and leave with one 128-byte store: the binning below reads the local copy (reading a
 	// record back from HBM right after writing it costs a full memory round trip per field), a culled triangle only gets its two
 	// flags written, an edge slot that is not a silhouette edge nothing at all.
@@ -2719,8 +2745,8 @@ int deodr_hip_render_scene_b(const DeodrHipScene *sc, const void *image, const v
 	return launch_adjoint(sc, p, st, true);
 }
 
-int deodr_hip_render_scene_fit(const DeodrHipScene *sc, void *image, void *z_buffer, double sigma, const void *obs, void *workspace,
-							   size_t workspace_bytes, void *stream)
+int deodr_hip_render_scene_fit(const DeodrHipScene *sc, void *image, void *z_buffer, double sigma, const void *obs, int clear_gradients,
+							   void *workspace, size_t workspace_bytes, void *stream)
 {
 	KParams p;
 	if (fill_params(sc, sigma, workspace, workspace_bytes, p, true))
@@ -2732,6 +2758,15 @@ int deodr_hip_render_scene_fit(const DeodrHipScene *sc, void *image, void *z_buf
 	p.zbuf = z_buffer;
 	p.obs = obs;
 	p.image_in = image;
+	if (clear_gradients)
+	{
+		p.clear_grads = 1; // per-view arrays: zeroed by the set-up kernel; the two shared ones by a fill
+		const size_t es = p.vtx_f64 ? 8 : 4, ps = sc->pixel_dtype == DEODR_HIP_F64 ? 8 : 4;
+		if (p.uv_b && check_hip(hipMemsetAsync(p.uv_b, 0, (size_t)p.Vuv * 2 * es, st), "clear uv_b"))
+			return 1;
+		if (p.texture_b && check_hip(hipMemsetAsync(p.texture_b, 0, (size_t)p.tex_h * p.tex_w * p.C * ps, st), "clear texture_b"))
+			return 1;
+	}
 	const bool fused = p.C <= CH && !g_force_generic && !(p.debug & 256);
 	if (launch_forward(sc, p, st, fused))
 		return 1;

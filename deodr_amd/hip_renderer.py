@@ -20,7 +20,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libdeodr_hip.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 
 class _SceneC(C.Structure):
@@ -60,8 +60,8 @@ def lib():
         L.deodr_hip_render_scene_b.argtypes = [C.POINTER(_SceneC), C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_int, C.c_void_p,
                                                C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]  # fmt: skip
         L.deodr_hip_render_scene_fit.restype = C.c_int
-        L.deodr_hip_render_scene_fit.argtypes = [C.POINTER(_SceneC), C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p, C.c_size_t,
-                                                 C.c_void_p]  # fmt: skip
+        L.deodr_hip_render_scene_fit.argtypes = [C.POINTER(_SceneC), C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, C.c_int, C.c_void_p,
+                                                 C.c_size_t, C.c_void_p]  # fmt: skip
         L.deodr_hip_workspace_status.restype = C.c_int
         L.deodr_hip_workspace_status.argtypes = [C.POINTER(_SceneC), C.c_void_p, C.c_size_t, C.c_void_p, C.POINTER(C.c_int),
                                                  C.POINTER(C.c_ulonglong)]  # fmt: skip
@@ -225,12 +225,13 @@ class HipRasterizer:
         self._last = (ds, float(sigma), bool(antialiase_error), obs_t, image, err)
         return (image, z, err) if antialiase_error else (image, z)
 
-    def render_fit(self, ds, obs, sigma=1.0, grads=None, out=None, check_overflow=None):
+    def render_fit(self, ds, obs, sigma=1.0, grads=None, out=None, check_overflow=None, clear_grads=False):
         """One fit step in one call: render ``ds`` and back-propagate ``sum((image - obs)**2)``; -> (image, z_buffer, grads).
 
         Same results as :meth:`render` followed by ``render_backward(residual_obs=obs)`` (what the reference's
         ``Scene2D.render_compare_and_backward`` does with ``antialiase_error=False``), but the forward raster already
-        back-propagates through every tile without silhouette edges, so the frame is traversed once."""
+        back-propagates through every tile without silhouette edges, so the frame is traversed once.  ``clear_grads``: zero
+        ``grads`` first, inside the same kernel launches (otherwise they are accumulated into)."""
         n, H, W, Cc = ds.n_views, ds.height, ds.width, ds.nb_colors
         assert (ds.nb_triangles, H, W, Cc, n) == self.dims, "scene shape differs from the workspace shape"
         pd = ds.pixel_dtype
@@ -247,8 +248,8 @@ class HipRasterizer:
         if grads is None:
             grads = ds.zero_grads()
         sc = ds.c_struct(grads)
-        _check(lib().deodr_hip_render_scene_fit(C.byref(sc), _ptr(image), _ptr(z), float(sigma), _ptr(obs_t), _ptr(self.workspace),
-                                                self.nbytes, _stream()))  # fmt: skip
+        _check(lib().deodr_hip_render_scene_fit(C.byref(sc), _ptr(image), _ptr(z), float(sigma), _ptr(obs_t), int(bool(clear_grads)),
+                                                _ptr(self.workspace), self.nbytes, _stream()))  # fmt: skip
         self._last = (ds, float(sigma), False, obs_t, image, None)
         return image, z, grads
 

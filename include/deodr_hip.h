@@ -106,9 +106,11 @@ int deodr_hip_render_scene_b(const DeodrHipScene *scene, const void *image, cons
  * subtraction in between.  Outputs are exactly those of deodr_hip_render_scene (image, z_buffer) followed by
  * deodr_hip_render_scene_b in residual mode (the scene's *_b arrays are accumulated into).  Because dL/dimage of a pixel
  * is known as soon as the pixel is resolved, the forward raster back-propagates through the tiles that have no silhouette
- * edge in the same pass; only the tiles with edges are visited again.  Same preconditions as deodr_hip_render_scene_b. */
+ * edge in the same pass; only the tiles with edges are visited again.  Same preconditions as deodr_hip_render_scene_b.
+ * clear_gradients != 0: the scene's *_b arrays are zeroed first (Scene2D.clear_gradients, dr.py) inside the same launches,
+ * so that a fit loop needs no separate fills; 0: they are accumulated into, as renderScene_B does. */
 int deodr_hip_render_scene_fit(const DeodrHipScene *scene, void *image, void *z_buffer, double sigma, const void *obs,
-							   void *workspace, size_t workspace_bytes, void *stream);
+							   int clear_gradients, void *workspace, size_t workspace_bytes, void *stream);
 
 /* Synchronises `stream` and reports whether any forward since the workspace was zero-filled overflowed the spill pool
  * (then that result was incomplete and the call must be repeated with a workspace sized for a larger `pool_pairs`):
@@ -133,7 +135,7 @@ const char *deodr_hip_last_error(void);
 
 /* ABI version of this header; bumped on any incompatible change. */
 int deodr_hip_abi_version(void);
-#define DEODR_HIP_ABI_VERSION 1
+#define DEODR_HIP_ABI_VERSION 2
 
 #ifdef __cplusplus
 }

@@ -327,7 +327,11 @@ def compare_fit_step(api, views, sigma, dt, seed=11):
     n, H, W, Cc = ds.n_views, ds.height, ds.width, ds.nb_colors
     obs = np.random.RandomState(seed).rand(n, H, W, Cc)
     obs_t = torch.as_tensor(obs, device=ds.device, dtype=dt)
-    image, z, g = r.render_fit(ds, obs_t, sigma, check_overflow=True)
+    stale = ds.zero_grads()
+    for v in stale.values():
+        if v is not None:
+            v.fill_(123.0)  # clear_grads must wipe whatever a previous step left
+    image, z, g = r.render_fit(ds, obs_t, sigma, grads=stale, check_overflow=True, clear_grads=True)
     image2, z2 = r.render(ds, sigma)
     g2 = r.render_backward(ds, residual_obs=obs_t)
     torch.cuda.synchronize()
