@@ -42,6 +42,7 @@ constexpr int CH = 4;		// colour channels kept in registers at a time
 constexpr int MAX_SORTED = 64; // edges of a tile whose blending order is cached in LDS
 constexpr int NSUB = 8;		// sub-lists of the per-view list of tiles that hold silhouette edges (tile % NSUB: bounded, 8 append counters)
 constexpr int CNT_STRIDE = 32; // uint32 between two append counters (one 128-byte line each)
+constexpr int PRIO_EDGES = 16; // tiles with more edges than this are also listed apart: the adjoint's edge kernel starts with them
 
 struct WsHeader // 64 bytes per view at the start of the view's workspace
 {
@@ -101,8 +102,8 @@ Layout make_layout(int T, int H, int W, int C, size_t pool_pairs)
 	L.face_id = take(sizeof(int32_t) * (size_t)H * W);
 	L.heavy_list = take(sizeof(uint32_t) * L.ntiles);
 	L.sub_cap = (L.ntiles + NSUB - 1) / NSUB;
-	L.edge_tile_cnt = take(sizeof(uint32_t) * 2 * NSUB * CNT_STRIDE);
-	L.edge_tiles = take(sizeof(uint32_t) * NSUB * (size_t)L.sub_cap);
+	L.edge_tile_cnt = take(sizeof(uint32_t) * 2 * 2 * NSUB * CNT_STRIDE); // [epoch parity][all | many-edged][sub-list]
+	L.edge_tiles = take(sizeof(uint32_t) * 2 * NSUB * (size_t)L.sub_cap);  // [all | many-edged][sub-list][sub_cap]
 	L.view_bytes = o;
 	return L;
 }
@@ -364,8 +365,8 @@ __global__ __launch_bounds__(256) void setup_bin_kernel(KParams p)
 		w.hdr->edge_spill[1 - cur] = 0;
 		w.hdr->heavy_count[1 - cur] = 0;
 	}
-	if (item < NSUB)
-		w.edge_tile_cnt[((1 - cur) * NSUB + item) * CNT_STRIDE] = 0;
+	if (item < 2 * NSUB)
+		w.edge_tile_cnt[((1 - cur) * 2 * NSUB + item) * CNT_STRIDE] = 0;
 	if (p.clear_grads)
 		for (int v = item; v < p.V; v += gridDim.x * blockDim.x)
 		{ // nothing accumulates into them before finalize_kernel, two kernels later
@@ -465,9 +466,13 @@ __global__ __launch_bounds__(256) void setup_bin_kernel(KParams p)
 	const double band[12] = {e.x2b[0], e.x2b[1], e.x2b[2], e.x2b[3], e.x2b[4], e.x2b[5], e.x2t[0], e.x2t[1], e.x2t[2],
 							 -e.x2t[0], -e.x2t[1], 1 - e.x2t[2]}; // the four half-planes of the band, H.h:1418-1435
 	const int tx0 = e.x_begin / TILE, ty0 = e.y_begin / TILE, ntx = e.x_end / TILE - tx0 + 1, nty = e.y_end / TILE - ty0 + 1;
-	auto first_edge_of = [&](int tile) { // the tile joins the list the adjoint's edge kernel walks
-		const int sub = tile % NSUB;
-		const uint32_t at = atomicAdd(&w.edge_tile_cnt[(cur * NSUB + sub) * CNT_STRIDE], 1u);
+	// on its first edge the tile joins the list the adjoint's edge kernel walks; on its (PRIO_EDGES + 1)-th also the list of
+	// the long tiles that kernel starts with (the kernel lasts as long as its slowest tile)
+	auto listed = [&](int tile, uint32_t got) {
+		if (got != 0 && got != (uint32_t)PRIO_EDGES)
+			return;
+		const int sub = (got ? NSUB : 0) + tile % NSUB;
+		const uint32_t at = atomicAdd(&w.edge_tile_cnt[(cur * 2 * NSUB + sub) * CNT_STRIDE], 1u);
 		w.edge_tiles[(size_t)sub * p.L.sub_cap + at] = (uint32_t)tile;
 	};
 	if (ntx <= 3 && nty <= 3)
@@ -489,8 +494,7 @@ __global__ __launch_bounds__(256) void setup_bin_kernel(KParams p)
 			{
 				const int tile = (ty0 + q / 3) * p.L.tiles_x + tx0 + q % 3;
 				place_in_tile(w.edge_list, K_EDGE, w.edge_pool, p.L.edge_pool_cap, &w.hdr->edge_spill[cur], tile, (uint32_t)slot, got[q]);
-				if (got[q] == 0)
-					first_edge_of(tile);
+				listed(tile, got[q]);
 			}
 		return;
 	}
@@ -499,8 +503,7 @@ __global__ __launch_bounds__(256) void setup_bin_kernel(KParams p)
 			if (!tile_outside_halfplanes<4>(band, tx, ty))
 			{
 				const int tile = ty * p.L.tiles_x + tx;
-				if (push_tile(w.edge_cnt, w.edge_list, K_EDGE, w.edge_pool, p.L.edge_pool_cap, &w.hdr->edge_spill[cur], tile, (uint32_t)slot) == 0)
-					first_edge_of(tile);
+				listed(tile, push_tile(w.edge_cnt, w.edge_list, K_EDGE, w.edge_pool, p.L.edge_pool_cap, &w.hdr->edge_spill[cur], tile, (uint32_t)slot));
 			}
 }
 
@@ -1997,7 +2000,8 @@ __device__ __forceinline__ void owner_adjoint(const KParams &p, const ViewPtrs &
 // One tile of the adjoint.  EDGES = false: tiles without silhouette edges (the edge code is compiled out: half the
 // registers, twice the resident waves to hide the memory latency); EDGES = true: the tiles that have some.
 template <class PixT, bool EDGES>
-__device__ __forceinline__ void bwd_fast_tile(const KParams &p, const ViewPtrs &w, int view, int tx, int ty, int lane, BwdLds &S, EdgeSort &es)
+__device__ __forceinline__ void bwd_fast_tile(const KParams &p, const ViewPtrs &w, int view, int tx, int ty, int lane, BwdLds &S, EdgeSort &es,
+											  int skip_above = 0x7fffffff)
 {
 	const int W = p.W, H = p.H, C = p.C, P = p.L.P;
 	const PixT *texture = (const PixT *)p.texture;
@@ -2014,8 +2018,8 @@ __device__ __forceinline__ void bwd_fast_tile(const KParams &p, const ViewPtrs &
 	int nedge = uniform((int)w.edge_saved[tile]);
 	if (p.debug & 32)
 		nedge = 0;
-	if ((nedge > 0) != EDGES)
-		return; // the other kernel's tile
+	if ((nedge > 0) != EDGES || nedge > skip_above)
+		return; // the other kernel's tile (or one this kernel has already taken from its list of long tiles)
 #ifdef DR_TILE_TRACE
 	uint32_t tr[8] = {0x7fc0beefu, (uint32_t)nedge, 0, 0, 0, 0, 0, 0};
 	const uint64_t tr0 = __builtin_readcyclecounter();
@@ -2311,21 +2315,25 @@ __global__ __launch_bounds__(64 * WPB, 6) void raster_bwd_fast_kernel(KParams p)
 
 template <class PixT>
 __global__ __launch_bounds__(64, 3) void raster_bwd_edge_kernel(KParams p)
-{ // persistent waves over the list of tiles that hold silhouette edges (built by setup_bin_kernel); wave g walks
-  // sub-list g % NSUB from entry g / NSUB in steps of gridDim.x / NSUB
+{ // persistent waves over the lists of tiles that hold silhouette edges (built by setup_bin_kernel).  Grid (views, waves):
+  // the first waves dispatched are wave 0 of every view, and every wave starts with the many-edged tiles -- the kernel
+  // lasts as long as its slowest tile, so those must not start late.  Wave g walks sub-list g % NSUB from entry g / NSUB
+  // in steps of gridDim.y / NSUB.
 	__shared__ BwdLds s_lds;
 	__shared__ EdgeSort s_es;
-	const int view = blockIdx.y;
+	const int view = blockIdx.x;
 	const int lane = threadIdx.x;
 	const ViewPtrs w = view_ptrs(p, view);
-	const int sub = blockIdx.x % NSUB, stride = gridDim.x / NSUB;
-	const uint32_t n = w.edge_tile_cnt[(w.hdr->cur * NSUB + sub) * CNT_STRIDE];
-	const uint32_t *list = w.edge_tiles + (size_t)sub * p.L.sub_cap;
+	const int sub = blockIdx.y % NSUB, stride = gridDim.y / NSUB;
+	const uint32_t *cnt = w.edge_tile_cnt + (size_t)w.hdr->cur * 2 * NSUB * CNT_STRIDE;
+	const uint32_t n_all = cnt[sub * CNT_STRIDE], n_long = cnt[(NSUB + sub) * CNT_STRIDE];
+	const uint32_t *all = w.edge_tiles + (size_t)sub * p.L.sub_cap, *longs = w.edge_tiles + (size_t)(NSUB + sub) * p.L.sub_cap;
 #pragma nounroll
-	for (uint32_t i = blockIdx.x / NSUB; i < n; i += stride)
+	for (uint32_t i = blockIdx.y / NSUB; i < n_long + n_all; i += stride)
 	{
-		const int tile = uniform((int)list[i]);
-		bwd_fast_tile<PixT, true>(p, w, view, tile % p.L.tiles_x, tile / p.L.tiles_x, lane, s_lds, s_es);
+		const bool from_long = i < n_long;
+		const int tile = uniform((int)(from_long ? longs[i] : all[i - n_long]));
+		bwd_fast_tile<PixT, true>(p, w, view, tile % p.L.tiles_x, tile / p.L.tiles_x, lane, s_lds, s_es, from_long ? 0x7fffffff : PRIO_EDGES);
 		lds_sync();
 	}
 }
@@ -2623,7 +2631,7 @@ int launch_adjoint(const DeodrHipScene *sc, KParams &p, hipStream_t st, bool own
 	// the waves that find their sub-list exhausted cost nothing
 	int edge_waves = p.L.ntiles < g_edge_waves ? p.L.ntiles : g_edge_waves;
 	edge_waves = (edge_waves + NSUB - 1) / NSUB * NSUB;
-	dim3 edge_grid(edge_waves, sc->n_views);
+	dim3 edge_grid(sc->n_views, edge_waves);
 	{
 		ScopedKernelTimer t(KID_RASTER_BWD, st);
 		if (sc->pixel_dtype == DEODR_HIP_F64)
