@@ -2314,7 +2314,7 @@ __global__ __launch_bounds__(64 * WPB, 6) void raster_bwd_fast_kernel(KParams p)
 }
 
 template <class PixT>
-__global__ __launch_bounds__(64, 3) void raster_bwd_edge_kernel(KParams p)
+__global__ __launch_bounds__(64, 2) void raster_bwd_edge_kernel(KParams p)
 { // persistent waves over the lists of tiles that hold silhouette edges (built by setup_bin_kernel).  Grid (views, waves):
   // the first waves dispatched are wave 0 of every view, and every wave starts with the many-edged tiles -- the kernel
   // lasts as long as its slowest tile, so those must not start late.  Wave g walks sub-list g % NSUB from entry g / NSUB
