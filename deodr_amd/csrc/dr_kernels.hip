@@ -321,6 +321,36 @@ __device__ __forceinline__ void place_in_tile(uint32_t *list, int cap_inline, ui
 	}
 }
 
+// The same rejection for the 3 x 3 block of tiles whose first tile is (tx0, ty0): bit 3 dy + dx of the result is set when tile
+// (tx0 + dx, ty0 + dy) is clearly outside one of the N half-planes.  The corner where a half-plane function is largest
+// is the same in every tile, so a x and b y are formed once per column / row of tiles (the per-tile form above costs
+// ~20 operations per half-plane and tile, and binning was half of the arithmetic of the set-up kernel).  The slack uses the
+// largest scale of the block, i.e. it is at least as cautious as the per-tile test.
+template <int N>
+__device__ __forceinline__ uint32_t tiles3x3_outside_halfplanes(const double *eq, int tx0, int ty0)
+{
+	uint32_t out = 0;
+	const double xmax = (tx0 + 2) * TILE + (TILE - 1), ymax = (ty0 + 2) * TILE + (TILE - 1);
+#pragma unroll
+	for (int k = 0; k < N; k++)
+	{
+		const double a = eq[3 * k], b = eq[3 * k + 1], c = eq[3 * k + 2];
+		const double limit = -1e-9 * (fabs(a) * xmax + fabs(b) * ymax + fabs(c)) - 1e-12;
+		const double cx = tx0 * TILE + (a > 0 ? TILE - 1 : 0), cy = ty0 * TILE + (b > 0 ? TILE - 1 : 0);
+		double ax[3], by[3];
+#pragma unroll
+		for (int d = 0; d < 3; d++)
+		{
+			ax[d] = a * (cx + d * TILE);
+			by[d] = b * (cy + d * TILE) + c;
+		}
+#pragma unroll
+		for (int q = 0; q < 9; q++)
+			out |= (ax[q % 3] + by[q / 3] < limit) ? (1u << q) : 0u;
+	}
+	return out;
+}
+
 __device__ __forceinline__ uint32_t push_tile(uint32_t *cnt, uint32_t *list, int cap_inline, uint2 *pool, uint32_t pool_cap, uint32_t *spill,
 											  int tile, uint32_t prim)
 {
@@ -348,13 +378,73 @@ __device__ __forceinline__ bool tile_outside_halfplanes(const double *eq, int tx
 	return false;
 }
 
-__global__ __launch_bounds__(256) void setup_bin_kernel(KParams p)
-{ // work items: [0, T) triangles, [T, 4T) silhouette-edge slots (k, n) -- separate threads, so that the few triangles
-  // that own silhouette edges do not stretch the dependent chain of their whole wavefront
+// Work split of the per-primitive kernels (set-up, finalize).  Blocks [0, tri_blocks) take PRIM_BLOCK triangles each.  The
+// other blocks take PRIM_BLOCK edge slots (3 k + n) each, of which only the few per cent flagged as silhouette edges need
+// work: the block compacts them through LDS so that they fill the lanes of its first wavefront(s) and the others retire at
+// once (one thread per slot left ~2 busy lanes in almost every wavefront of the long edge path).
+constexpr int PRIM_BLOCK = 256;
+
+__host__ __device__ inline int prim_tri_blocks(int T) { return (T + PRIM_BLOCK - 1) / PRIM_BLOCK; }
+__host__ __device__ inline int prim_blocks(int T) { return prim_tri_blocks(T) + (3 * T + PRIM_BLOCK - 1) / PRIM_BLOCK; }
+
+// -> the slot this thread works on, or -1.  Called by every thread of an edge block.
+__device__ __forceinline__ int compact_flagged_slots(const KParams &p, const uint8_t *edgeflags)
+{
+	__shared__ uint32_t s_slots[PRIM_BLOCK];
+	__shared__ uint32_t s_count[PRIM_BLOCK / 64];
+	const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+	const int slot = (blockIdx.x - prim_tri_blocks(p.T)) * PRIM_BLOCK + tid;
+	const bool flagged = p.sigma > 0 && slot < 3 * p.T && edgeflags[slot] != 0;
+	const unsigned long long m = __ballot(flagged);
+	if (lane == 0)
+		s_count[wave] = (uint32_t)__popcll(m);
+	__syncthreads();
+	uint32_t before = 0, total = 0;
+#pragma unroll
+	for (int i = 0; i < PRIM_BLOCK / 64; i++)
+	{
+		const uint32_t c = s_count[i];
+		before += i < wave ? c : 0u;
+		total += c;
+	}
+	if (flagged)
+		s_slots[before + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)slot;
+	__syncthreads();
+	return (uint32_t)tid < total ? (int)s_slots[tid] : -1;
+}
+
+#ifdef DR_WAVE_TRACE
+// timeline of the per-primitive kernels: [wave slot] = (start, end) in 10 ns ticks of the constant 100 MHz counter
+__device__ unsigned long long g_wave_trace[2][1 << 16][2];
+struct WaveTrace
+{
+	int which;
+	unsigned long long t0;
+	__device__ WaveTrace(int w) : which(w), t0(__builtin_amdgcn_s_memrealtime()) {}
+	__device__ ~WaveTrace()
+	{
+		if ((threadIdx.x & 63) == 0)
+		{
+			const unsigned id = (blockIdx.y * gridDim.x + blockIdx.x) * (blockDim.x >> 6) + (threadIdx.x >> 6);
+			if (id < (1u << 16))
+			{
+				g_wave_trace[which][id][0] = t0;
+				g_wave_trace[which][id][1] = __builtin_amdgcn_s_memrealtime();
+			}
+		}
+	}
+};
+#define DR_WAVE_TRACE_SCOPE(w) WaveTrace wave_trace_scope(w)
+#else
+#define DR_WAVE_TRACE_SCOPE(w)
+#endif
+
+__global__ __launch_bounds__(PRIM_BLOCK) void setup_bin_kernel(KParams p)
+{
+	DR_WAVE_TRACE_SCOPE(0);
 	const int view = blockIdx.y;
-	const int item = blockIdx.x * blockDim.x + threadIdx.x;
-	if (item >= 4 * p.T)
-		return;
+	const int item = blockIdx.x * PRIM_BLOCK + threadIdx.x; // only an id for the housekeeping below
+	const bool tri_block = (int)blockIdx.x < prim_tri_blocks(p.T);
 	const SceneView s = scene_view(p, view);
 	const ViewPtrs w = view_ptrs(p, view);
 	const uint32_t cur = w.hdr->epoch & 1u; // stable during this kernel: only the forward raster advances the epoch
@@ -395,9 +485,11 @@ __global__ __launch_bounds__(256) void setup_bin_kernel(KParams p)
 	// Records are built in registers and leave with one 128-byte store: the binning below reads the local copy (reading a
 	// record back from HBM right after writing it costs a full memory round trip per field), a culled triangle only gets its two
 	// flags written, an edge slot that is not a silhouette edge nothing at all.
-	if (item < p.T)
+	if (tri_block)
 	{
 		const int k = item;
+		if (k >= p.T)
+			return;
 		TriInputs t;
 		load_triangle(s, k, t, true);
 		TriRec rec;
@@ -422,11 +514,12 @@ __global__ __launch_bounds__(256) void setup_bin_kernel(KParams p)
 		{ // the usual small triangle: its slot requests are all in flight together (one memory round trip, not one per tile)
 			uint32_t slot[9];
 			bool use[9];
+			const uint32_t outside = tiles3x3_outside_halfplanes<3>(eq, tx0, ty0);
 #pragma unroll
 			for (int q = 0; q < 9; q++)
 			{
 				const int dx = q % 3, dy = q / 3;
-				use[q] = dx < ntx && dy < nty && !tile_outside_halfplanes<3>(eq, tx0 + dx, ty0 + dy);
+				use[q] = dx < ntx && dy < nty && !((outside >> q) & 1u);
 				slot[q] = 0;
 				if (use[q])
 					slot[q] = atomicAdd(&w.tri_cnt[(ty0 + dy) * p.L.tiles_x + tx0 + dx], 1u);
@@ -444,10 +537,12 @@ __global__ __launch_bounds__(256) void setup_bin_kernel(KParams p)
 					push_tile(w.tri_cnt, w.tri_list, K_TRI, w.tri_pool, p.L.tri_pool_cap, &w.hdr->tri_spill[cur], ty * p.L.tiles_x + tx, (uint32_t)k);
 		return;
 	}
-	const int slot = item - p.T, k = slot / 3, n = slot - 3 * k;
-	if (!(s.sigma > 0) || !s.edgeflags[slot])
-		return; // nothing is written for the ~90 % of slots that are not silhouette edges: records are only reached through the
-				// tile lists, and finalize_kernel re-checks the flag (a one-byte store per 128-byte record was 60 MB of HBM writes)
+	// nothing is written for the ~97 % of slots that are not silhouette edges: records are only reached through the tile
+	// lists, and finalize_kernel works from the same flags
+	const int slot = compact_flagged_slots(p, s.edgeflags);
+	if (slot < 0)
+		return;
+	const int k = slot / 3, n = slot - 3 * k;
 	TriInputs t;
 	load_triangle(s, k, t, true);
 	EdgeRec e;
@@ -479,11 +574,12 @@ __global__ __launch_bounds__(256) void setup_bin_kernel(KParams p)
 	{
 		uint32_t got[9];
 		bool use[9];
+		const uint32_t outside = tiles3x3_outside_halfplanes<4>(band, tx0, ty0);
 #pragma unroll
 		for (int q = 0; q < 9; q++)
 		{
 			const int dx = q % 3, dy = q / 3;
-			use[q] = dx < ntx && dy < nty && !tile_outside_halfplanes<4>(band, tx0 + dx, ty0 + dy);
+			use[q] = dx < ntx && dy < nty && !((outside >> q) & 1u);
 			got[q] = 1;
 			if (use[q])
 				got[q] = atomicAdd(&w.edge_cnt[(ty0 + dy) * p.L.tiles_x + tx0 + dx], 1u);
@@ -1921,8 +2017,11 @@ __device__ __forceinline__ void owner_adjoint(const KParams &p, const ViewPtrs &
 		const int tf = dpp_i<CTRL>(f);                                                                                       \
 		double t[NSCAN];                                                                                                     \
 		_Pragma("unroll") for (int i = 0; i < NSCAN; i++) t[i] = dpp_d<CTRL>(sc[i]);                                         \
-		/* branch-free on purpose: a DPP move must run with every lane enabled (a disabled source lane reads as 0) */       \
-		_Pragma("unroll") for (int i = 0; i < NSCAN; i++) sc[i] += f ? 0.0 : t[i];                                           \
+		/* the DPP moves above run with every lane enabled (a disabled source lane reads as 0); only the adds are masked */   \
+		if (!f)                                                                                                              \
+		{                                                                                                                    \
+			_Pragma("unroll") for (int i = 0; i < NSCAN; i++) sc[i] += t[i];                                                 \
+		}                                                                                                                    \
 		f = f ? f : tf;                                                                                                      \
 	}
 	DR_SEG_STEP(0x111)
@@ -2356,12 +2455,11 @@ __global__ __launch_bounds__(256) void raster_bwd_heavy_kernel(KParams p)
 
 // ------------------------------------------------------------------------------------------------------- finalize
 
-__global__ __launch_bounds__(256) void finalize_kernel(KParams p)
-{ // work items as in setup_bin_kernel: [0, T) triangles, [T, 4T) edge slots
+__global__ __launch_bounds__(PRIM_BLOCK) void finalize_kernel(KParams p)
+{ // same split as setup_bin_kernel: triangle blocks, then edge-slot blocks compacted to the flagged slots
+	DR_WAVE_TRACE_SCOPE(1);
 	const int view = blockIdx.y;
-	const int item = blockIdx.x * blockDim.x + threadIdx.x;
-	if (item >= 4 * p.T)
-		return;
+	const bool tri_block = (int)blockIdx.x < prim_tri_blocks(p.T);
 	const SceneView s = scene_view(p, view);
 	const ViewPtrs w = view_ptrs(p, view);
 	const size_t es = p.vtx_f64 ? 8 : 4;
@@ -2371,22 +2469,36 @@ __global__ __launch_bounds__(256) void finalize_kernel(KParams p)
 	g.shade_b = (char *)p.shade_b + (size_t)view * p.V * es;
 	g.uv_b = p.uv_b;
 	const int P = s.P;
-	if (item == 0)
+	if (blockIdx.x == 0 && threadIdx.x == 0)
 		w.hdr->heavy_count[w.hdr->cur] = 0; // the deferred-tile queue of this adjoint has been drained
-	if (item < p.T)
+	if (tri_block)
 	{
-		const int k = item;
+		const int k = blockIdx.x * PRIM_BLOCK + threadIdx.x;
+		if (k >= p.T)
+			return;
 		const TriRec &rec = w.tri_rec[k];
+		double *acc = w.tri_acc + (size_t)k * 3 * P;
+		// the accumulators are requested together with the record's flags (one memory round trip less for the triangles that
+		// go on; the culled half wastes a 96-byte read)
+		double acc_local[12];
+#pragma unroll
+		for (int i = 0; i < 12; i++)
+			acc_local[i] = i < 3 * P ? acc[i] : 0.0;
 		if (!rec.front || rec.kind == KIND_NONE)
 			return; // culled triangles own no accumulators
-		double *acc = w.tri_acc + (size_t)k * 3 * P;
-		finalize_triangle(s, g, k, rec, acc, DeviceAdd());
+		if (P <= 4)
+			finalize_triangle(s, g, k, rec, acc_local, DeviceAdd());
+		else
+			finalize_triangle(s, g, k, rec, acc, DeviceAdd());
 		for (int i = 0; i < 3 * P; i++)
 			acc[i] = 0; // self-cleaning accumulators
 		return;
 	}
-	const int slot = item - p.T, k = slot / 3, n = slot - 3 * k;
-	if (!(s.sigma > 0) || !s.edgeflags[slot] || !w.tri_rec[k].front)
+	const int slot = compact_flagged_slots(p, s.edgeflags);
+	if (slot < 0)
+		return;
+	const int k = slot / 3, n = slot - 3 * k;
+	if (!w.tri_rec[k].front)
 		return; // not a silhouette edge of a front-facing triangle in this forward (its slot may hold a stale record)
 	const EdgeRec &e = w.edge_rec[slot];
 	if (e.kind == KIND_NONE)
@@ -2600,9 +2712,9 @@ int launch_forward(const DeodrHipScene *sc, KParams &p, hipStream_t stream, bool
 	const int n_views = sc->n_views;
 	if (p.T > 0)
 	{
-		dim3 grid((4 * p.T + 255) / 256, n_views);
+		dim3 grid(prim_blocks(p.T), n_views);
 		ScopedKernelTimer t(KID_SETUP, stream);
-		hipLaunchKernelGGL(setup_bin_kernel, grid, dim3(256), 0, stream, p);
+		hipLaunchKernelGGL(setup_bin_kernel, grid, dim3(PRIM_BLOCK), 0, stream, p);
 	}
 	const bool fast = !p.aa_err && p.C <= CH && !g_force_generic;
 	const int wpb = fast ? g_wpb : 4; // wavefronts (tiles) per workgroup of the staged kernels (tuning knob DEODR_HIP_WPB)
@@ -2649,9 +2761,9 @@ int launch_adjoint(const DeodrHipScene *sc, KParams &p, hipStream_t st, bool own
 	}
 	if (p.T > 0)
 	{
-		dim3 g2((4 * p.T + 255) / 256, sc->n_views);
+		dim3 g2(prim_blocks(p.T), sc->n_views);
 		ScopedKernelTimer t(KID_FINALIZE, st);
-		hipLaunchKernelGGL(finalize_kernel, g2, dim3(256), 0, st, p);
+		hipLaunchKernelGGL(finalize_kernel, g2, dim3(PRIM_BLOCK), 0, st, p);
 	}
 	return check_hip(hipGetLastError(), "backward launch");
 }
@@ -2780,6 +2892,13 @@ int deodr_hip_render_scene_fit(const DeodrHipScene *sc, void *image, void *z_buf
 		return 1;
 	return launch_adjoint(sc, p, st, !fused);
 }
+
+#ifdef DR_WAVE_TRACE
+int deodr_hip_debug_wave_trace(void *dst, size_t bytes) // tools/wave_trace.py
+{
+	return check_hip(hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_wave_trace), bytes < sizeof(g_wave_trace) ? bytes : sizeof(g_wave_trace)), "wave trace");
+}
+#endif
 
 int deodr_hip_workspace_status(const DeodrHipScene *sc, void *workspace, size_t workspace_bytes, void *stream, int *overflowed,
 							   unsigned long long *needed_pairs)

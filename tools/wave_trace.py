@@ -1,0 +1,41 @@
+"""Timeline of the waves of setup_bin_kernel / finalize_kernel (library built with -DDR_WAVE_TRACE).  Run on the GPU box."""
+import sys, os, ctypes as C
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from deodr_amd import scenes, hip_renderer as hr
+from deodr_amd.hip_renderer import DeviceScene, HipRasterizer
+
+dev = torch.device("cuda:0")
+S, B = 1024, 8
+views = [scenes.sphere_scene(size=S, angle=float(a)) for a in np.linspace(-0.5, 0.5, B)]
+s0 = views[0]
+stack = lambda name: np.stack([np.asarray(getattr(v, name)) for v in views])
+ds = DeviceScene(s0.faces, s0.faces_uv, s0.textured, s0.shaded, s0.uv, stack("ij"), stack("depths"), stack("colors"), stack("shade"),
+                 stack("edgeflags"), S, S, texture=None, background_color=s0.background_color, clockwise=s0.clockwise,
+                 vertex_dtype=torch.float64, pixel_dtype=torch.float32, device=dev)
+r = HipRasterizer.for_scene(ds)
+obs = torch.rand((B, S, S, ds.nb_colors), dtype=torch.float32, device=dev)
+grads = ds.zero_grads()
+for _ in range(4):
+    r.render_fit(ds, obs, 1.0, grads=grads, clear_grads=True)
+torch.cuda.synchronize()
+buf = np.zeros((2, 1 << 16, 2), dtype=np.uint64)
+L = hr.lib()
+L.deodr_hip_debug_wave_trace.argtypes = [C.c_void_p, C.c_size_t]
+assert L.deodr_hip_debug_wave_trace(buf.ctypes.data, buf.nbytes) == 0
+T = ds.nb_triangles
+for which, name in enumerate(("setup_bin_kernel", "finalize_kernel")):
+    t = buf[which].astype(np.int64)
+    ok = t[:, 1] > 0
+    t = t[ok]
+    t0 = t[:, 0].min()
+    start, end = (t[:, 0] - t0) * 0.01, (t[:, 1] - t0) * 0.01  # microseconds
+    dur = end - start
+    print(f"{name}: {len(t)} waves, kernel span {end.max():.1f} us; wave start p50 {np.percentile(start,50):.1f} p90 {np.percentile(start,90):.1f} max {start.max():.1f};"
+          f" wave life mean {dur.mean():.2f} p50 {np.percentile(dur,50):.2f} p90 {np.percentile(dur,90):.2f} p99 {np.percentile(dur,99):.2f} max {dur.max():.2f}")
+    hist, edges = np.histogram(end, bins=10, range=(0, end.max()))
+    print("   waves ending per tenth of the span:", hist.tolist())
+    hist, edges = np.histogram(start, bins=10, range=(0, end.max()))
+    print("   waves starting per tenth of the span:", hist.tolist())
+    long = np.argsort(-dur)[:5]
+    print("   longest waves (start, life):", [(round(float(start[i]), 1), round(float(dur[i]), 1)) for i in long])
