@@ -4,8 +4,10 @@
 
 Workload (config.workload): BASELINE configs[2], the configuration the metric is quoted on -- 1024x1024, 20 000-triangle
 bumpy sphere, C = 4 channels (RGB + depth), sigma = 1, ~33 % coverage, ~650 drawn silhouette edges -- rendered as
-`--views` (default 8) poses per GPU per step.  One step = renderScene + renderScene_B over the whole view batch with all
-inputs resident in HBM (+, for N > 1, ONE RCCL all-reduce of the shared-parameter gradient, the reduction the reference's
+`--views` (default 8) poses per GPU per step.  One step = renderScene + renderScene_B for the loss sum (image - obs)^2 over
+the whole view batch -- by default through the one-call fit step (deodr_hip_render_scene_fit: same outputs, the forward raster
+back-propagates through the tiles without silhouette edges itself), with --two-pass as two calls -- with all inputs resident
+in HBM (+, for N > 1, ONE RCCL all-reduce of the shared-parameter gradient, the reduction the reference's
 multi-view fitter does on the host at deodr/mesh_fitter.py:518-527).  Views shard across ranks with no data-path
 collective, per-GPU work is fixed as N grows ("weak").
 
@@ -33,16 +35,18 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/
 KERNELS = ["setup_bin_kernel", "raster_fwd_kernel", "raster_bwd_kernel", "finalize_kernel"]
 
 
-def algorithmic_bytes(H, W, C, T, V, n_views):
+def algorithmic_bytes(H, W, C, T, V, n_views, fused):
     """Per LAUNCH algorithmic HBM bytes of each kernel, float32 buffers (untextured, colour background).
 
     B_fwd = 4 [H W (C+1) + V (2+1+C) + 3T]      B_bwd = 4 [H W C + H W + V (2+1+C) + 3T + V (2+C)]
-    split by the kernel that has to move them."""
+    split by the kernel that has to move them.  In the fused fit step the forward raster also does the frame-sized part of
+    the adjoint (it reads the observation where the two-pass adjoint reads image_b), so it is charged both frame terms and
+    the adjoint's edge kernel, which only revisits the ~3 % of tiles that hold silhouette edges, none."""
     px = H * W
     per_view = {
         "setup_bin_kernel": 4 * (V * (3 + C) + 3 * T),
-        "raster_fwd_kernel": 4 * px * (C + 1),
-        "raster_bwd_kernel": 4 * px * (C + 1),
+        "raster_fwd_kernel": 4 * px * (C + 1) * (2 if fused else 1),
+        "raster_bwd_kernel": 0 if fused else 4 * px * (C + 1),
         "finalize_kernel": 4 * (V * (3 + C) + 3 * T + V * (2 + C)),
     }
     return {k: v * n_views for k, v in per_view.items()}
@@ -200,13 +204,13 @@ def main():
 
     if rank == 0:
         px = world * B * S * S * args.steps
-        alg = algorithmic_bytes(S, S, Cc, T, V, B)
+        alg = algorithmic_bytes(S, S, Cc, T, V, B, fused=not args.two_pass)
         per_kernel = {}
         for i, k in enumerate(KERNELS):
             n = max(int(launches[i]), 1)
             avg_ms = ms_sum[i] / n
             per_kernel[k] = {"avg_ms": avg_ms, "launches": int(launches[i]), "alg_bytes": alg[k],
-                             "GBps": alg[k] / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else None}  # fmt: skip
+                             "GBps": alg[k] / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 and alg[k] else None}  # fmt: skip
         dom = max(KERNELS, key=lambda k: per_kernel[k]["avg_ms"])
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
@@ -219,6 +223,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"BASELINE configs[2]: {S}x{S}, {T}-triangle bumpy sphere, C={Cc} (RGB+depth), sigma=1, "
                                    f"{B} views per GPU per step, float32 pixel buffers / float64 vertex arrays, all-double arithmetic",
+                       "step": "renderScene + renderScene_B (two calls)" if args.two_pass else "deodr_hip_render_scene_fit (forward + adjoint of sum (image - obs)^2, one call)",
                        "views_per_gpu": B, "global_views": B * world,
                        "parallelism": f"views sharded {B}/GPU" + (", 1 RCCL all-reduce of the shared gradient per step" if world > 1 else "")},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": per_kernel[dom]["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",

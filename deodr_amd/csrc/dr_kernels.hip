@@ -457,6 +457,14 @@ __global__ __launch_bounds__(PRIM_BLOCK) void setup_bin_kernel(KParams p)
 	}
 	if (item < 2 * NSUB)
 		w.edge_tile_cnt[((1 - cur) * 2 * NSUB + item) * CNT_STRIDE] = 0;
+	if (p.clear_grads && view == 0 && p.uv_b)
+		for (int v = item; v < 2 * p.Vuv; v += gridDim.x * blockDim.x)
+		{ // shared by the views: zeroed once
+			if (p.vtx_f64)
+				((double *)p.uv_b)[v] = 0;
+			else
+				((float *)p.uv_b)[v] = 0;
+		}
 	if (p.clear_grads)
 		for (int v = item; v < p.V; v += gridDim.x * blockDim.x)
 		{ // nothing accumulates into them before finalize_kernel, two kernels later
@@ -2880,10 +2888,8 @@ int deodr_hip_render_scene_fit(const DeodrHipScene *sc, void *image, void *z_buf
 	p.image_in = image;
 	if (clear_gradients)
 	{
-		p.clear_grads = 1; // per-view arrays: zeroed by the set-up kernel; the two shared ones by a fill
-		const size_t es = p.vtx_f64 ? 8 : 4, ps = sc->pixel_dtype == DEODR_HIP_F64 ? 8 : 4;
-		if (p.uv_b && check_hip(hipMemsetAsync(p.uv_b, 0, (size_t)p.Vuv * 2 * es, st), "clear uv_b"))
-			return 1;
+		p.clear_grads = 1; // vertex arrays: zeroed by the set-up kernel; the texture gradient (large, if any) by a fill
+		const size_t ps = sc->pixel_dtype == DEODR_HIP_F64 ? 8 : 4;
 		if (p.texture_b && check_hip(hipMemsetAsync(p.texture_b, 0, (size_t)p.tex_h * p.tex_w * p.C * ps, st), "clear texture_b"))
 			return 1;
 	}

@@ -14,7 +14,7 @@ rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/write -o p
 python - <<PY
 import csv, glob, json, collections
 out = "$OUT"
-names = {"setup_bin_kernel": "setup_bin_kernel", "raster_fwd": "raster_fwd_kernel", "raster_bwd_fast": "raster_bwd_kernel", "raster_bwd_kernel": "raster_bwd_kernel", "finalize_kernel": "finalize_kernel"}
+names = {"setup_bin_kernel": "setup_bin_kernel", "raster_fwd": "raster_fwd_kernel", "raster_bwd_edge": "raster_bwd_edge_kernel", "raster_bwd_fast": "raster_bwd_kernel", "raster_bwd_kernel": "raster_bwd_kernel", "finalize_kernel": "finalize_kernel"}
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for c in ("fetch", "write"):
     for f in glob.glob(f"{out}/{c}/*counter_collection.csv"):
