@@ -5,4 +5,6 @@ from .differentiable_renderer_pytorch import (  # noqa: F401
     TorchDifferentiableRenderer2DFunc,
     TorchDifferentiableRenderViews,
     TorchDifferentiableRenderViewsFunc,
+    TorchRenderViewsL2Loss,
+    TorchRenderViewsL2LossFunc,
 )

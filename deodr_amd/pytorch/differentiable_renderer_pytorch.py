@@ -91,3 +91,30 @@ class TorchDifferentiableRenderViewsFunc(torch.autograd.Function):
 
 def TorchDifferentiableRenderViews(ij, colors, device_scene, rasterizer, sigma=1.0):
     return TorchDifferentiableRenderViewsFunc.apply(ij, colors, device_scene, rasterizer, sigma)
+
+
+class TorchRenderViewsL2LossFunc(torch.autograd.Function):
+    """sum((render(ij, colors) - obs)**2) over ``n_views`` views as ONE op: (ij [n,V,2], colors [n,V,C]) -> scalar loss.
+
+    What the reference's fitters write as ``image = render(...); loss = ((image - obs) ** 2).sum(); loss.backward()``
+    (deodr/pytorch/mesh_fitter_pytorch.py, dr.py:701-740): here the forward is one ``deodr_hip_render_scene_fit`` call that
+    renders AND back-propagates the residual (the gradient of the loss w.r.t. the image is known as soon as a pixel is
+    resolved), so ``backward`` only scales the stored gradients.  ``image`` and ``z_buffer`` of the last call are kept on
+    the context owner (``rasterizer.last_fit``) for display."""
+
+    @staticmethod
+    def forward(ctx, ij, colors, obs, device_scene, rasterizer, sigma):
+        device_scene.set_views(ij=ij.detach(), colors=colors.detach())
+        image, z, g = rasterizer.render_fit(device_scene, obs, sigma, clear_grads=False)
+        rasterizer.last_fit = (image, z)
+        ctx.save_for_backward(g["ij_b"].to(ij.dtype), g["colors_b"].to(colors.dtype))
+        return ((image.double() - obs.to(image.device).double()) ** 2).sum()
+
+    @staticmethod
+    def backward(ctx, loss_b):
+        ij_b, colors_b = ctx.saved_tensors
+        return loss_b.to(ij_b.dtype) * ij_b, loss_b.to(colors_b.dtype) * colors_b, None, None, None, None
+
+
+def TorchRenderViewsL2Loss(ij, colors, obs, device_scene, rasterizer, sigma=1.0):
+    return TorchRenderViewsL2LossFunc.apply(ij, colors, obs, device_scene, rasterizer, sigma)

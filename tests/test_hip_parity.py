@@ -377,3 +377,28 @@ def test_fit_step_hand_textured_views(oracle_api):
     path = os.path.join(GOLDEN, "hand_mesh.npz")
     compare_fit_step(oracle_api, scenes.hand_scene(path, size=256, angle=0.2, textured=True), 1.0, F32)
     compare_fit_step(oracle_api, [scenes.hand_scene(path, size=256, angle=a, textured=False) for a in (-0.4, 0.1, 0.5)], 1.0, F32)
+
+
+def test_autograd_l2_loss_op_equals_render_then_loss(oracle_api):
+    """TorchRenderViewsL2Loss (one fused call) against TorchDifferentiableRenderViews + a torch loss (two passes)."""
+    from hip_util import device_scene, rel_err
+    from deodr_amd.hip_renderer import HipRasterizer
+    from deodr_amd.pytorch import TorchDifferentiableRenderViews, TorchRenderViewsL2Loss
+
+    path = os.path.join(GOLDEN, "hand_mesh.npz")
+    views = [scenes.hand_scene(path, size=128, angle=a, textured=False) for a in (-0.3, 0.4)]
+    ds = device_scene(views, F32)
+    r = HipRasterizer.for_scene(ds)
+    obs = torch.as_tensor(np.random.RandomState(4).rand(2, 128, 128, 3).astype(np.float32), device=ds.device)
+    grads = []
+    for fused in (True, False):
+        ij = ds.ij.clone().requires_grad_(True)
+        colors = ds.colors.clone().requires_grad_(True)
+        if fused:
+            loss = TorchRenderViewsL2Loss(ij, colors, obs, ds, r, 1.0)
+        else:
+            loss = ((TorchDifferentiableRenderViews(ij, colors, ds, r, 1.0).double() - obs.double()) ** 2).sum()
+        (3.0 * loss).backward()
+        grads.append((float(loss), ij.grad.cpu().numpy(), colors.grad.cpu().numpy()))
+    assert abs(grads[0][0] - grads[1][0]) <= 1e-9 * abs(grads[1][0])
+    assert rel_err(grads[0][1], grads[1][1]) < 1e-5 and rel_err(grads[0][2], grads[1][2]) < 1e-5
