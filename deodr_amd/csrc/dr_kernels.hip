@@ -123,6 +123,7 @@ struct KParams
 	void *image, *zbuf, *err;
 	const void *image_b, *obs, *err_b, *image_in;
 	int aa_err;
+	int row_group;	 // tile rows per strip dealt to an XCD by the raster kernels (xcd_strip_row); 0: one band per XCD
 	int clear_grads; // the set-up kernel zeroes the per-view gradient arrays (a fit step that wants fresh gradients: no separate fills)
 	int debug; // ablation switches for profiling (DEODR_HIP_DEBUG), 0 in production
 	// workspace
@@ -304,6 +305,18 @@ __device__ __forceinline__ int xcd_band(int b, int n)
 {
 	int q = n >> 3, r = n & 7, xcd = b & 7, idx = b >> 3;
 	return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
+// The bands are then dealt to the XCDs in strips of `group` tile rows (band-ordered row pr = band * rows_per_band + i becomes
+// row (i / group) * 8 * group + band * group + i % group): one contiguous band per XCD leaves the XCDs that own the top and
+// the bottom of the frame -- usually background -- idle while the others rasterize the object in the middle, and blocks are
+// dispatched in order.  Needs tiles_y % (8 * group) == 0, otherwise the bands stay whole (any bijection is correct).
+__device__ __forceinline__ int xcd_strip_row(int pr, int tiles_y, int group)
+{
+	if (group <= 0 || tiles_y % (8 * group) != 0)
+		return pr;
+	const int per_band = tiles_y / 8, band = pr / per_band, i = pr - band * per_band;
+	return (i / group) * 8 * group + band * group + i % group;
 }
 
 // ----------------------------------------------------------------------------------------------------- set-up + bin
@@ -708,7 +721,7 @@ __global__ __launch_bounds__(256) void raster_fwd_kernel(KParams p)
 	const ViewPtrs w = view_ptrs(p, view);
 	const int strips_x = (p.L.tiles_x + 3) / 4;
 	const int b = xcd_band(blockIdx.x, gridDim.x);
-	const int ty = b / strips_x, tx = (b % strips_x) * 4 + wave;
+	const int ty = xcd_strip_row(b / strips_x, p.L.tiles_y, p.row_group), tx = (b % strips_x) * 4 + wave;
 	const int W = p.W, H = p.H, C = p.C, P = p.L.P;
 	const bool persp = p.persp, strict = p.strict;
 	const PixT *texture = (const PixT *)p.texture;
@@ -1212,12 +1225,20 @@ __global__ __launch_bounds__(64 * WPB) void raster_fwd_fast_kernel(KParams p)
 {
 	__shared__ WaveLds s_lds[WPB];
 	__shared__ EdgeSort s_es[WPB];
+#ifdef DR_FWD_TRACE
+	// per-tile phase timing (tools/fwd_trace.py): eight counters over the first row of the tile in the z buffer
+	uint32_t ftr[8] = {0x7fc0f00du, 0, 0, 0, 0, 0, 0, 0};
+	const uint64_t ftr0 = __builtin_readcyclecounter();
+#define DR_FTRACE(i) ftr[i] = (uint32_t)(__builtin_readcyclecounter() - ftr0)
+#else
+#define DR_FTRACE(i)
+#endif
 	const int view = blockIdx.y;
 	const int wave = uniform(threadIdx.x >> 6), lane = threadIdx.x & 63;
 	const ViewPtrs w = view_ptrs(p, view);
 	const int strips_x = (p.L.tiles_x + WPB - 1) / WPB;
 	const int b = xcd_band(blockIdx.x, gridDim.x);
-	const int ty = b / strips_x, tx = (b % strips_x) * WPB + wave;
+	const int ty = xcd_strip_row(b / strips_x, p.L.tiles_y, p.row_group), tx = (b % strips_x) * WPB + wave;
 	const int W = p.W, H = p.H, C = p.C, P = p.L.P;
 	const bool persp = p.persp;
 	const PixT *texture = (const PixT *)p.texture;
@@ -1292,6 +1313,10 @@ __global__ __launch_bounds__(64 * WPB) void raster_fwd_fast_kernel(KParams p)
 #pragma unroll
 		for (int cc = 0; cc < CH; cc++)
 			st.v[cc] = 0;
+#ifdef DR_FWD_TRACE
+		ftr[1] = (uint32_t)ntri | ((uint32_t)nedge << 16);
+#endif
+		DR_FTRACE(2); // counters arrived
 		// ---- pass 1
 		if (ntri > 0)
 		{
@@ -1347,6 +1372,7 @@ __global__ __launch_bounds__(64 * WPB) void raster_fwd_fast_kernel(KParams p)
 				}
 			}
 		}
+		DR_FTRACE(3); // pass 1 done
 		// ---- resolve the winner's colour
 		double col[CH];
 #pragma unroll
@@ -1444,6 +1470,7 @@ __global__ __launch_bounds__(64 * WPB) void raster_fwd_fast_kernel(KParams p)
 				}
 			}
 		}
+		DR_FTRACE(4); // colour resolved, edges blended
 		// ---- one write per pixel
 		if (inb && !(p.debug & 4))
 		{
@@ -1469,6 +1496,7 @@ __global__ __launch_bounds__(64 * WPB) void raster_fwd_fast_kernel(KParams p)
 				__builtin_nontemporal_store((PixT)st.zbest, (PixT *)p.zbuf + vpix);
 			__builtin_nontemporal_store(pack_owner(st.kbest, st.kind), w.face_id + pix);
 		}
+		DR_FTRACE(5); // frame stores issued
 		if (FUSED && nedge == 0 && __ballot(st.kbest >= 0) != 0)
 		{ // same residual as raster_bwd_fast_kernel forms from the stored frame: the colour is rounded to the pixel type first
 			double g[CH];
@@ -1479,6 +1507,16 @@ __global__ __launch_bounds__(64 * WPB) void raster_fwd_fast_kernel(KParams p)
 			owner_adjoint<PixT>(p, w, lane, x, y, st.kbest, st.kbest >= 0 ? st.kind : (int)KIND_NONE, g, tap, L, (double *)&S.rec[0],
 								(uint32_t *)&S.cover[0][0]);
 		}
+#ifdef DR_FWD_TRACE
+		DR_FTRACE(6); // adjoint of pass 1 issued
+		if (lane < 8 && p.zbuf)
+		{
+			uint32_t v = 0;
+			for (int i = 0; i < 8; i++)
+				v = lane == i ? ftr[i] : v;
+			((uint32_t *)p.zbuf)[(size_t)view * H * W + (size_t)y0 * W + x0 + lane] = v;
+		}
+#endif
 			}
 	}
 	if (blockIdx.x == 0 && threadIdx.x == 0)
@@ -1931,7 +1969,7 @@ __global__ __launch_bounds__(256) void raster_bwd_kernel(KParams p)
 	const int wave = uniform(threadIdx.x >> 6), lane = threadIdx.x & 63;
 	const int strips_x = (p.L.tiles_x + 3) / 4;
 	const int b = xcd_band(blockIdx.x, gridDim.x);
-	const int ty = b / strips_x, tx = (b % strips_x) * 4 + wave;
+	const int ty = xcd_strip_row(b / strips_x, p.L.tiles_y, p.row_group), tx = (b % strips_x) * 4 + wave;
 	if (tx < p.L.tiles_x)
 		bwd_tile_generic<PixT>(p, blockIdx.y, tx, ty, lane, s_order[wave]);
 }
@@ -2414,7 +2452,7 @@ __global__ __launch_bounds__(64 * WPB, 6) void raster_bwd_fast_kernel(KParams p)
 	const ViewPtrs w = view_ptrs(p, view);
 	const int strips_x = (p.L.tiles_x + WPB - 1) / WPB;
 	const int b = xcd_band(blockIdx.x, gridDim.x);
-	const int ty = b / strips_x, tx = (b % strips_x) * WPB + wave;
+	const int ty = xcd_strip_row(b / strips_x, p.L.tiles_y, p.row_group), tx = (b % strips_x) * WPB + wave;
 	if (tx >= p.L.tiles_x)
 		return;
 	bwd_fast_tile<PixT, false>(p, w, view, tx, ty, lane, s_lds[wave], *(EdgeSort *)nullptr);
@@ -2621,6 +2659,8 @@ int fill_params(const DeodrHipScene *sc, double sigma, void *workspace, size_t w
 	{
 		static const int dbg = getenv("DEODR_HIP_DEBUG") ? atoi(getenv("DEODR_HIP_DEBUG")) : 0;
 		p.debug = dbg;
+		static const int row_group = getenv("DEODR_HIP_ROWGROUP") ? atoi(getenv("DEODR_HIP_ROWGROUP")) : 2;
+		p.row_group = row_group;
 	}
 	return 0;
 }
