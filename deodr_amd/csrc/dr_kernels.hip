@@ -43,6 +43,13 @@ constexpr int MAX_SORTED = 64; // edges of a tile whose blending order is cached
 constexpr int NSUB = 8;		// sub-lists of the per-view list of tiles that hold silhouette edges (tile % NSUB: bounded, 8 append counters)
 constexpr int CNT_STRIDE = 32; // uint32 between two append counters (one 128-byte line each)
 constexpr int PRIO_EDGES = 16; // tiles with more edges than this are also listed apart: the adjoint's edge kernel starts with them
+// Tiles that receive more than FIRST_PRIMS triangles (or edges) are the long poles of the forward raster: the first
+// FWD_FIRST of them per view are flagged (`first_flag`) and listed, and the staged forward kernel dispatches them before
+// anything else -- otherwise the many-primitive tiles of the last view end 30 us after every other wave of the kernel.
+// The block that finds its own tile flagged leaves it alone and clears the flag (nobody else reads it).
+constexpr int FIRST_PRIMS = 16;
+constexpr int FWD_FIRST = 64; // listed tiles per view (NSUB sub-lists of FWD_FIRST / NSUB)
+constexpr int LIST_KINDS = 3; // edge tiles, many-edged tiles, first tiles of the forward
 
 struct WsHeader // 64 bytes per view at the start of the view's workspace
 {
@@ -61,7 +68,7 @@ static_assert(sizeof(WsHeader) == 64, "");
 struct Layout
 {
 	size_t hdr, tri_rec, tri_planes, tri_acc, edge_rec, edge_planes, edge_acc, tri_cnt, edge_cnt, edge_saved, tri_list, edge_list, tri_pool,
-		edge_pool, face_id, heavy_list, edge_tile_cnt, edge_tiles, view_bytes;
+		edge_pool, face_id, heavy_list, edge_tile_cnt, edge_tiles, first_flag, view_bytes;
 	uint32_t tri_pool_cap, edge_pool_cap;
 	int tiles_x, tiles_y, ntiles, P, sub_cap;
 };
@@ -102,8 +109,9 @@ Layout make_layout(int T, int H, int W, int C, size_t pool_pairs)
 	L.face_id = take(sizeof(int32_t) * (size_t)H * W);
 	L.heavy_list = take(sizeof(uint32_t) * L.ntiles);
 	L.sub_cap = (L.ntiles + NSUB - 1) / NSUB;
-	L.edge_tile_cnt = take(sizeof(uint32_t) * 2 * 2 * NSUB * CNT_STRIDE); // [epoch parity][all | many-edged][sub-list]
-	L.edge_tiles = take(sizeof(uint32_t) * 2 * NSUB * (size_t)L.sub_cap);  // [all | many-edged][sub-list][sub_cap]
+	L.edge_tile_cnt = take(sizeof(uint32_t) * 2 * LIST_KINDS * NSUB * CNT_STRIDE); // [epoch parity][kind][sub-list]
+	L.edge_tiles = take(sizeof(uint32_t) * LIST_KINDS * NSUB * (size_t)L.sub_cap);	// [kind][sub-list][sub_cap]
+	L.first_flag = take(sizeof(uint32_t) * L.ntiles);
 	L.view_bytes = o;
 	return L;
 }
@@ -123,6 +131,8 @@ struct KParams
 	void *image, *zbuf, *err;
 	const void *image_b, *obs, *err_b, *image_in;
 	int aa_err;
+	int n_views;
+	int first_tiles; // the staged forward with one tile per workgroup follows: flag and list the many-primitive tiles (FWD_FIRST)
 	int row_group;	 // tile rows per strip dealt to an XCD by the raster kernels (xcd_strip_row); 0: one band per XCD
 	int clear_grads; // the set-up kernel zeroes the per-view gradient arrays (a fit step that wants fresh gradients: no separate fills)
 	int debug; // ablation switches for profiling (DEODR_HIP_DEBUG), 0 in production
@@ -142,6 +152,7 @@ struct ViewPtrs
 	uint2 *tri_pool, *edge_pool;
 	int32_t *face_id;
 	uint32_t *heavy_list;
+	uint32_t *first_flag;				  // 1: the tile is on the list of tiles the forward rasterizes first
 	uint32_t *edge_tile_cnt, *edge_tiles; // tiles with silhouette edges: NSUB counters per epoch parity, NSUB sub-lists of sub_cap tiles
 };
 
@@ -167,6 +178,7 @@ __device__ __forceinline__ ViewPtrs view_ptrs(const KParams &p, int view)
 	v.heavy_list = (uint32_t *)(b + p.L.heavy_list);
 	v.edge_tile_cnt = (uint32_t *)(b + p.L.edge_tile_cnt);
 	v.edge_tiles = (uint32_t *)(b + p.L.edge_tiles);
+	v.first_flag = (uint32_t *)(b + p.L.first_flag);
 	return v;
 }
 
@@ -321,6 +333,20 @@ __device__ __forceinline__ int xcd_strip_row(int pr, int tiles_y, int group)
 
 // ----------------------------------------------------------------------------------------------------- set-up + bin
 
+// The (FIRST_PRIMS + 1)-th triangle or edge of a tile claims the tile for the head of the forward's dispatch order: whoever
+// sets the flag first lists the tile; if the view's list is full the flag is withdrawn (the tile is rasterized in place).
+__device__ __forceinline__ void claim_first_tile(const KParams &p, const ViewPtrs &w, uint32_t cur, int tile)
+{
+	if (atomicOr(&w.first_flag[tile], 1u))
+		return;
+	const int sub = 2 * NSUB + tile % NSUB;
+	const uint32_t at = atomicAdd(&w.edge_tile_cnt[(cur * LIST_KINDS * NSUB + sub) * CNT_STRIDE], 1u);
+	if (at < (uint32_t)(FWD_FIRST / NSUB))
+		w.edge_tiles[(size_t)sub * p.L.sub_cap + at] = (uint32_t)tile;
+	else
+		atomicAnd(&w.first_flag[tile], 0u);
+}
+
 __device__ __forceinline__ void place_in_tile(uint32_t *list, int cap_inline, uint2 *pool, uint32_t pool_cap, uint32_t *spill, int tile,
 											  uint32_t prim, uint32_t slot)
 {
@@ -468,8 +494,8 @@ __global__ __launch_bounds__(PRIM_BLOCK) void setup_bin_kernel(KParams p)
 		w.hdr->edge_spill[1 - cur] = 0;
 		w.hdr->heavy_count[1 - cur] = 0;
 	}
-	if (item < 2 * NSUB)
-		w.edge_tile_cnt[((1 - cur) * 2 * NSUB + item) * CNT_STRIDE] = 0;
+	if (item < LIST_KINDS * NSUB)
+		w.edge_tile_cnt[((1 - cur) * LIST_KINDS * NSUB + item) * CNT_STRIDE] = 0;
 	if (p.clear_grads && view == 0 && p.uv_b)
 		for (int v = item; v < 2 * p.Vuv; v += gridDim.x * blockDim.x)
 		{ // shared by the views: zeroed once
@@ -548,14 +574,24 @@ __global__ __launch_bounds__(PRIM_BLOCK) void setup_bin_kernel(KParams p)
 #pragma unroll
 			for (int q = 0; q < 9; q++)
 				if (use[q])
-					place_in_tile(w.tri_list, K_TRI, w.tri_pool, p.L.tri_pool_cap, &w.hdr->tri_spill[cur], (ty0 + q / 3) * p.L.tiles_x + tx0 + q % 3,
-								  (uint32_t)k, slot[q]);
+				{
+					const int tile = (ty0 + q / 3) * p.L.tiles_x + tx0 + q % 3;
+					place_in_tile(w.tri_list, K_TRI, w.tri_pool, p.L.tri_pool_cap, &w.hdr->tri_spill[cur], tile, (uint32_t)k, slot[q]);
+					if (p.first_tiles && slot[q] == (uint32_t)FIRST_PRIMS)
+						claim_first_tile(p, w, cur, tile);
+				}
 			return;
 		}
 		for (int ty = ty0; ty < ty0 + nty; ty++)
 			for (int tx = tx0; tx < tx0 + ntx; tx++)
 				if (!tile_outside_halfplanes<3>(eq, tx, ty))
-					push_tile(w.tri_cnt, w.tri_list, K_TRI, w.tri_pool, p.L.tri_pool_cap, &w.hdr->tri_spill[cur], ty * p.L.tiles_x + tx, (uint32_t)k);
+				{
+					const int tile = ty * p.L.tiles_x + tx;
+					if (push_tile(w.tri_cnt, w.tri_list, K_TRI, w.tri_pool, p.L.tri_pool_cap, &w.hdr->tri_spill[cur], tile, (uint32_t)k) ==
+							(uint32_t)FIRST_PRIMS &&
+						p.first_tiles)
+						claim_first_tile(p, w, cur, tile);
+				}
 		return;
 	}
 	// nothing is written for the ~97 % of slots that are not silhouette edges: records are only reached through the tile
@@ -588,8 +624,11 @@ __global__ __launch_bounds__(PRIM_BLOCK) void setup_bin_kernel(KParams p)
 		if (got != 0 && got != (uint32_t)PRIO_EDGES)
 			return;
 		const int sub = (got ? NSUB : 0) + tile % NSUB;
-		const uint32_t at = atomicAdd(&w.edge_tile_cnt[(cur * 2 * NSUB + sub) * CNT_STRIDE], 1u);
+		const uint32_t at = atomicAdd(&w.edge_tile_cnt[(cur * LIST_KINDS * NSUB + sub) * CNT_STRIDE], 1u);
 		w.edge_tiles[(size_t)sub * p.L.sub_cap + at] = (uint32_t)tile;
+		static_assert(PRIO_EDGES == FIRST_PRIMS, "one threshold for both lists");
+		if (got && p.first_tiles)
+			claim_first_tile(p, w, cur, tile);
 	};
 	if (ntx <= 3 && nty <= 3)
 	{
@@ -1233,12 +1272,51 @@ __global__ __launch_bounds__(64 * WPB) void raster_fwd_fast_kernel(KParams p)
 #else
 #define DR_FTRACE(i)
 #endif
-	const int view = blockIdx.y;
+	// Block roles.  WPB == 1 (the default): 1-D grid; with p.first_tiles its first n_views * FWD_FIRST blocks each take one
+	// entry of a view's list of many-primitive tiles (views fastest, so that every view's long tiles start at once), the
+	// others map to (view, tile) and leave the flagged tiles alone.  WPB == 4: grid (strips, views), no list.
 	const int wave = uniform(threadIdx.x >> 6), lane = threadIdx.x & 63;
+	int view, tx, ty;
+	bool listed_tile = false, closes_epoch;
+	if (WPB == 1)
+	{
+		const int per_view = p.L.ntiles, nfirst = p.first_tiles ? p.n_views * FWD_FIRST : 0;
+		int bid = blockIdx.x;
+		if (bid < nfirst)
+		{
+			view = bid % p.n_views;
+			const int slot = bid / p.n_views, sub = 2 * NSUB + slot % NSUB, idx = slot / NSUB;
+			const ViewPtrs wl = view_ptrs(p, view);
+			const uint32_t n = wl.edge_tile_cnt[(wl.hdr->cur * LIST_KINDS * NSUB + sub) * CNT_STRIDE];
+			if ((uint32_t)idx >= (n < (uint32_t)(FWD_FIRST / NSUB) ? n : (uint32_t)(FWD_FIRST / NSUB)))
+				return;
+			const int t = uniform((int)wl.edge_tiles[(size_t)sub * p.L.sub_cap + idx]);
+			tx = t % p.L.tiles_x;
+			ty = t / p.L.tiles_x;
+			listed_tile = true;
+			closes_epoch = false;
+		}
+		else
+		{
+			bid -= nfirst;
+			view = bid / per_view;
+			const int bx = bid - view * per_view;
+			const int b = xcd_band(bx, per_view);
+			ty = xcd_strip_row(b / p.L.tiles_x, p.L.tiles_y, p.row_group);
+			tx = b % p.L.tiles_x;
+			closes_epoch = bx == 0;
+		}
+	}
+	else
+	{
+		view = blockIdx.y;
+		const int strips_x = (p.L.tiles_x + WPB - 1) / WPB;
+		const int b = xcd_band(blockIdx.x, gridDim.x);
+		ty = xcd_strip_row(b / strips_x, p.L.tiles_y, p.row_group);
+		tx = (b % strips_x) * WPB + wave;
+		closes_epoch = blockIdx.x == 0;
+	}
 	const ViewPtrs w = view_ptrs(p, view);
-	const int strips_x = (p.L.tiles_x + WPB - 1) / WPB;
-	const int b = xcd_band(blockIdx.x, gridDim.x);
-	const int ty = xcd_strip_row(b / strips_x, p.L.tiles_y, p.row_group), tx = (b % strips_x) * WPB + wave;
 	const int W = p.W, H = p.H, C = p.C, P = p.L.P;
 	const bool persp = p.persp;
 	const PixT *texture = (const PixT *)p.texture;
@@ -1257,6 +1335,11 @@ __global__ __launch_bounds__(64 * WPB) void raster_fwd_fast_kernel(KParams p)
 		const uint32_t list_entry = w.tri_list[(size_t)tile * K_TRI + (lane & (K_TRI - 1))];
 		int ntri = uniform((int)w.tri_cnt[tile]);
 		int nedge = uniform((int)w.edge_cnt[tile]);
+		const bool taken = WPB == 1 && p.first_tiles && !listed_tile && uniform((int)w.first_flag[tile]) != 0;
+		if (taken && lane == 0)
+			w.first_flag[tile] = 0; // a block at the head of the grid rasterizes this tile; the flag has served
+		if (!taken)
+		{
 		if (p.debug & 1)
 			ntri = 0;
 		if (p.debug & 2)
@@ -1518,8 +1601,9 @@ __global__ __launch_bounds__(64 * WPB) void raster_fwd_fast_kernel(KParams p)
 		}
 #endif
 			}
+		} // not left to a block at the head of the grid
 	}
-	if (blockIdx.x == 0 && threadIdx.x == 0)
+	if (closes_epoch && threadIdx.x == 0)
 	{ // one thread per view closes the epoch; nobody else reads `epoch` or `needed_max` during this kernel
 		const uint32_t cur = w.hdr->cur;
 		const uint32_t a = w.hdr->tri_spill[cur], bq = w.hdr->edge_spill[cur];
@@ -2470,7 +2554,7 @@ __global__ __launch_bounds__(64, 2) void raster_bwd_edge_kernel(KParams p)
 	const int lane = threadIdx.x;
 	const ViewPtrs w = view_ptrs(p, view);
 	const int sub = blockIdx.y % NSUB, stride = gridDim.y / NSUB;
-	const uint32_t *cnt = w.edge_tile_cnt + (size_t)w.hdr->cur * 2 * NSUB * CNT_STRIDE;
+	const uint32_t *cnt = w.edge_tile_cnt + (size_t)w.hdr->cur * LIST_KINDS * NSUB * CNT_STRIDE;
 	const uint32_t n_all = cnt[sub * CNT_STRIDE], n_long = cnt[(NSUB + sub) * CNT_STRIDE];
 	const uint32_t *all = w.edge_tiles + (size_t)sub * p.L.sub_cap, *longs = w.edge_tiles + (size_t)(NSUB + sub) * p.L.sub_cap;
 #pragma nounroll
@@ -2682,6 +2766,7 @@ struct ProfEvent
 bool g_profile = false;
 bool g_force_generic = false; // DEODR_HIP_FORCE_GENERIC=1: run the un-staged kernels (tests cover both)
 const int g_edge_waves = getenv("DEODR_HIP_EDGE_WAVES") ? atoi(getenv("DEODR_HIP_EDGE_WAVES")) : 1024; // persistent waves per view of the adjoint's edge kernel
+const int g_first_tiles = getenv("DEODR_HIP_FIRST_TILES") ? atoi(getenv("DEODR_HIP_FIRST_TILES")) : 1; // 0: no many-primitive-tiles-first order
 const int g_wpb = getenv("DEODR_HIP_WPB") ? atoi(getenv("DEODR_HIP_WPB")) : 1; // wavefronts per workgroup of the staged kernels: 1 or 4
 
 template <class PixT>
@@ -2741,12 +2826,14 @@ struct ScopedKernelTimer
 template <class PixT>
 void launch_forward_raster(const KParams &p, bool fast, bool fused, int wpb, dim3 grid, hipStream_t stream)
 {
+	// one tile per workgroup: 1-D grid, the listed many-primitive tiles of every view first (see the kernel)
+	const dim3 flat((unsigned)p.n_views * (unsigned)((p.first_tiles ? FWD_FIRST : 0) + p.L.ntiles));
 	if (!fast)
 		hipLaunchKernelGGL(raster_fwd_kernel<PixT>, grid, dim3(256), 0, stream, p);
 	else if (wpb == 1 && fused)
-		hipLaunchKernelGGL((raster_fwd_fast_kernel<PixT, 1, true>), grid, dim3(64), 0, stream, p);
+		hipLaunchKernelGGL((raster_fwd_fast_kernel<PixT, 1, true>), flat, dim3(64), 0, stream, p);
 	else if (wpb == 1)
-		hipLaunchKernelGGL((raster_fwd_fast_kernel<PixT, 1, false>), grid, dim3(64), 0, stream, p);
+		hipLaunchKernelGGL((raster_fwd_fast_kernel<PixT, 1, false>), flat, dim3(64), 0, stream, p);
 	else if (fused)
 		hipLaunchKernelGGL((raster_fwd_fast_kernel<PixT, 4, true>), grid, dim3(256), 0, stream, p);
 	else
@@ -2758,6 +2845,8 @@ void launch_forward_raster(const KParams &p, bool fast, bool fused, int wpb, dim
 int launch_forward(const DeodrHipScene *sc, KParams &p, hipStream_t stream, bool fused = false)
 {
 	const int n_views = sc->n_views;
+	p.n_views = n_views;
+	p.first_tiles = !p.aa_err && p.C <= CH && !g_force_generic && g_wpb == 1 && g_first_tiles;
 	if (p.T > 0)
 	{
 		dim3 grid(prim_blocks(p.T), n_views);
