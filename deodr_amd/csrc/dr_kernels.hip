@@ -42,13 +42,13 @@ constexpr int CH = 4;		// colour channels kept in registers at a time
 constexpr int MAX_SORTED = 64; // edges of a tile whose blending order is cached in LDS
 constexpr int NSUB = 8;		// sub-lists of the per-view list of tiles that hold silhouette edges (tile % NSUB: bounded, 8 append counters)
 constexpr int CNT_STRIDE = 32; // uint32 between two append counters (one 128-byte line each)
-constexpr int PRIO_EDGES = 16; // tiles with more edges than this are also listed apart: the adjoint's edge kernel starts with them
+constexpr int PRIO_EDGES = 8; // tiles with more edges than this are also listed apart: the adjoint's edge kernel starts with them
 // Tiles that receive more than FIRST_PRIMS triangles (or edges) are the long poles of the forward raster: the first
 // FWD_FIRST of them per view are flagged (`first_flag`) and listed, and the staged forward kernel dispatches them before
 // anything else -- otherwise the many-primitive tiles of the last view end 30 us after every other wave of the kernel.
 // The block that finds its own tile flagged leaves it alone and clears the flag (nobody else reads it).
-constexpr int FIRST_PRIMS = 16;
-constexpr int FWD_FIRST = 64; // listed tiles per view (NSUB sub-lists of FWD_FIRST / NSUB)
+constexpr int FIRST_PRIMS = 8;
+constexpr int FWD_FIRST = 512; // listed tiles per view (NSUB sub-lists of FWD_FIRST / NSUB)
 constexpr int LIST_KINDS = 3; // edge tiles, many-edged tiles, first tiles of the forward
 
 struct WsHeader // 64 bytes per view at the start of the view's workspace
@@ -454,7 +454,7 @@ __device__ __forceinline__ int compact_flagged_slots(const KParams &p, const uin
 
 #ifdef DR_WAVE_TRACE
 // timeline of the per-primitive kernels: [wave slot] = (start, end) in 10 ns ticks of the constant 100 MHz counter
-__device__ unsigned long long g_wave_trace[2][1 << 16][2];
+__device__ unsigned long long g_wave_trace[3][1 << 18][2]; // 0 set-up, 1 finalize, 2 forward raster
 struct WaveTrace
 {
 	int which;
@@ -465,7 +465,7 @@ struct WaveTrace
 		if ((threadIdx.x & 63) == 0)
 		{
 			const unsigned id = (blockIdx.y * gridDim.x + blockIdx.x) * (blockDim.x >> 6) + (threadIdx.x >> 6);
-			if (id < (1u << 16))
+			if (id < (1u << 18))
 			{
 				g_wave_trace[which][id][0] = t0;
 				g_wave_trace[which][id][1] = __builtin_amdgcn_s_memrealtime();
@@ -1262,6 +1262,7 @@ __device__ __forceinline__ void owner_adjoint(const KParams &p, const ViewPtrs &
 template <class PixT, int WPB, bool FUSED> // WPB wavefronts (= tiles) per workgroup
 __global__ __launch_bounds__(64 * WPB) void raster_fwd_fast_kernel(KParams p)
 {
+	DR_WAVE_TRACE_SCOPE(2);
 	__shared__ WaveLds s_lds[WPB];
 	__shared__ EdgeSort s_es[WPB];
 #ifdef DR_FWD_TRACE

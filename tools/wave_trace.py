@@ -19,12 +19,12 @@ grads = ds.zero_grads()
 for _ in range(4):
     r.render_fit(ds, obs, 1.0, grads=grads, clear_grads=True)
 torch.cuda.synchronize()
-buf = np.zeros((2, 1 << 16, 2), dtype=np.uint64)
+buf = np.zeros((3, 1 << 18, 2), dtype=np.uint64)
 L = hr.lib()
 L.deodr_hip_debug_wave_trace.argtypes = [C.c_void_p, C.c_size_t]
 assert L.deodr_hip_debug_wave_trace(buf.ctypes.data, buf.nbytes) == 0
 T = ds.nb_triangles
-for which, name in enumerate(("setup_bin_kernel", "finalize_kernel")):
+for which, name in enumerate(("setup_bin_kernel", "finalize_kernel", "raster_fwd_fast_kernel")):
     t = buf[which].astype(np.int64)
     ok = t[:, 1] > 0
     t = t[ok]
@@ -39,3 +39,7 @@ for which, name in enumerate(("setup_bin_kernel", "finalize_kernel")):
     print("   waves starting per tenth of the span:", hist.tolist())
     long = np.argsort(-dur)[:5]
     print("   longest waves (start, life):", [(round(float(start[i]), 1), round(float(dur[i]), 1)) for i in long])
+    ts = np.linspace(0, end.max(), 41)[1:-1]  # waves in flight over time
+    print("   waves in flight at 39 instants:", [int(((start <= x) & (end > x)).sum()) for x in ts])
+    late = np.argsort(-end)[:8]
+    print("   last waves to end (start, life):", [(round(float(start[i]), 1), round(float(dur[i]), 1)) for i in late])
