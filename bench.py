@@ -87,6 +87,7 @@ def main():
     ap.add_argument("--size", type=int, default=1024)
     ap.add_argument("--sigma", type=float, default=1.0, help="edge-overdraw width (the metric configuration uses 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--time-every", type=int, default=4, help="steps between two steps whose kernels are timed with hipEvents")
     ap.add_argument("--two-pass", action="store_true", help="render and render_backward as two calls (default: the fused fit step, same outputs)")
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed even for one rank (exercises the RCCL path)")
     args = ap.parse_args()
@@ -180,7 +181,9 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    hr.lib().deodr_hip_profile_enable(1)
+    # per-kernel hipEvents on every 4th step of the timed region (an event pair takes ~3 us of stream time: timing all
+    # five launches of every step would add ~10 % to the step being measured)
+    hr.lib().deodr_hip_profile_enable(0 if os.environ.get("DEODR_BENCH_NO_EVENTS") else args.time_every)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):

@@ -2767,7 +2767,9 @@ struct ProfEvent
 	hipEvent_t start, stop;
 	int kid;
 };
-bool g_profile = false;
+bool g_profile = false;	  // the launches of the current call are bracketed by events
+int g_profile_every = 0;	  // deodr_hip_profile_enable(n): 0 off, n > 0: every n-th forward (and the adjoint that follows it)
+unsigned g_profile_calls = 0; // forwards seen since profiling was enabled
 bool g_force_generic = false; // DEODR_HIP_FORCE_GENERIC=1: run the un-staged kernels (tests cover both)
 const int g_edge_waves = getenv("DEODR_HIP_EDGE_WAVES") ? atoi(getenv("DEODR_HIP_EDGE_WAVES")) : 1024; // persistent waves per view of the adjoint's edge kernel
 const int g_first_tiles = getenv("DEODR_HIP_FIRST_TILES") ? atoi(getenv("DEODR_HIP_FIRST_TILES")) : 1; // 0: no many-primitive-tiles-first order
@@ -2849,6 +2851,7 @@ void launch_forward_raster(const KParams &p, bool fast, bool fused, int wpb, dim
 int launch_forward(const DeodrHipScene *sc, KParams &p, hipStream_t stream, bool fused = false)
 {
 	const int n_views = sc->n_views;
+	g_profile = g_profile_every > 0 && (g_profile_calls++ % (unsigned)g_profile_every) == 0;
 	p.n_views = n_views;
 	p.first_tiles = !p.aa_err && p.C <= CH && !g_force_generic && g_wpb == 1 && g_first_tiles;
 	if (p.T > 0)
@@ -2919,9 +2922,11 @@ int deodr_hip_force_generic(int on)
 	return 0;
 }
 
-int deodr_hip_profile_enable(int on)
+int deodr_hip_profile_enable(int every)
 {
-	g_profile = on != 0;
+	g_profile_every = every > 0 ? every : 0;
+	g_profile_calls = 0;
+	g_profile = false;
 	return 0;
 }
 

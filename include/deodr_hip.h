@@ -119,11 +119,13 @@ int deodr_hip_render_scene_fit(const DeodrHipScene *scene, void *image, void *z_
 int deodr_hip_workspace_status(const DeodrHipScene *scene, void *workspace, size_t workspace_bytes, void *stream, int *overflowed,
 							   unsigned long long *needed_pairs);
 
-/* Measurement hooks (bench.py): while enabled, every kernel launch of this library is bracketed by hipEvents recorded on
- * the launch stream.  deodr_hip_profile_read waits for them and returns, per kernel
- *   [0] setup_bin_kernel  [1] raster_fwd_kernel  [2] raster_bwd_kernel  [3] finalize_kernel
- * the summed elapsed milliseconds and the number of launches since the previous read.  Not thread-safe. */
-int deodr_hip_profile_enable(int on);
+/* Measurement hooks (bench.py): deodr_hip_profile_enable(n), n > 0: the kernel launches of every n-th forward (and of the
+ * adjoint that follows it) are bracketed by hipEvents recorded on the launch stream; 0: off.  An event pair costs ~3 us of
+ * stream time on this part, i.e. ~10 % of a five-kernel step if every launch is timed, hence the sampling.
+ * deodr_hip_profile_read waits for the events and returns, per kernel
+ *   [0] setup_bin_kernel  [1] raster_fwd_kernel  [2] raster_bwd_kernel (all adjoint raster kernels)  [3] finalize_kernel
+ * the summed elapsed milliseconds and the number of timed launches since the previous read.  Not thread-safe. */
+int deodr_hip_profile_enable(int every);
 int deodr_hip_profile_read(double ms_sum[4], unsigned long long launches[4]);
 
 /* Test hook: non-zero makes every call use the generic (un-staged) kernels that otherwise only serve nb_colors > 4 and
