@@ -2578,8 +2578,9 @@ __global__ __launch_bounds__(256) void raster_bwd_heavy_kernel(KParams p)
 	const int view = blockIdx.y;
 	const int wave = uniform(threadIdx.x >> 6), lane = threadIdx.x & 63;
 	const ViewPtrs w = view_ptrs(p, view);
-	const uint32_t cur = w.hdr->cur;
-	const uint32_t n = w.hdr->heavy_count[cur];
+	// normally an empty launch: the three words are requested together so that it costs one memory round trip, not two
+	const uint32_t cur = w.hdr->cur, n0 = w.hdr->heavy_count[0], n1 = w.hdr->heavy_count[1];
+	const uint32_t n = cur ? n1 : n0;
 	for (uint32_t i = blockIdx.x * 4 + wave; i < n; i += gridDim.x * 4)
 	{
 		const int tile = (int)w.heavy_list[i];
