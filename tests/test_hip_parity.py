@@ -402,3 +402,22 @@ def test_autograd_l2_loss_op_equals_render_then_loss(oracle_api):
         grads.append((float(loss), ij.grad.cpu().numpy(), colors.grad.cpu().numpy()))
     assert abs(grads[0][0] - grads[1][0]) <= 1e-9 * abs(grads[1][0])
     assert rel_err(grads[0][1], grads[1][1]) < 1e-5 and rel_err(grads[0][2], grads[1][2]) < 1e-5
+
+
+@pytest.mark.parametrize("dt", [F32, F64])
+def test_partial_tiles_odd_frame_size(oracle_api, dt):
+    """Frame sizes that are not multiples of the 8 x 8 tile (the last tile row / column is partly outside the frame), two-call
+    path, fit step, and a 3-view batch whose tile rows cannot be dealt to the XCDs in strips (tiles_y = 5)."""
+    def scene(seed):
+        s = scenes.soup_scene(n_tri=30, width=53, height=37, seed=seed, textured_ratio=0.4, flat=False, texture_size=16)
+        s.depths = s.depths + 0.05 * np.random.RandomState(seed).rand(s.depths.shape[0]) + 0.2
+        return s
+
+    compare_backward(oracle_api, scene(5), 1.0, dt)
+    compare_fit_step(oracle_api, scene(6), 1.5, dt)
+    views = [scene(7) for _ in range(3)]
+    for i, v in enumerate(views):  # same topology / texture, different vertex positions and colours
+        rs = np.random.RandomState(70 + i)
+        v.ij = v.ij + rs.randn(*v.ij.shape)
+        v.colors = rs.rand(*v.colors.shape) * (v.colors != 0)
+    compare_fit_step(oracle_api, views, 1.0, dt)
