@@ -422,6 +422,7 @@ __device__ __forceinline__ bool tile_outside_halfplanes(const double *eq, int tx
 // work: the block compacts them through LDS so that they fill the lanes of its first wavefront(s) and the others retire at
 // once (one thread per slot left ~2 busy lanes in almost every wavefront of the long edge path).
 constexpr int PRIM_BLOCK = 256;
+constexpr int COOP_BLOCKS = 8; // 3 x 3-tile blocks of a bounding box one thread bins by itself
 
 __host__ __device__ inline int prim_tri_blocks(int T) { return (T + PRIM_BLOCK - 1) / PRIM_BLOCK; }
 __host__ __device__ inline int prim_blocks(int T) { return prim_tri_blocks(T) + (3 * T + PRIM_BLOCK - 1) / PRIM_BLOCK; }
@@ -532,93 +533,7 @@ __global__ __launch_bounds__(PRIM_BLOCK) void setup_bin_kernel(KParams p)
 	// Records are built in registers and leave with one 128-byte store: the binning below reads the local copy (reading a
 	// record back from HBM right after writing it costs a full memory round trip per field), a culled triangle only gets its two
 	// flags written, an edge slot that is not a silhouette edge nothing at all.
-	if (tri_block)
-	{
-		const int k = item;
-		if (k >= p.T)
-			return;
-		TriInputs t;
-		load_triangle(s, k, t, true);
-		TriRec rec;
-		setup_tri_only(s, t, rec, w.tri_planes + (size_t)k * 3 * s.P);
-		TriRec &out = w.tri_rec[k];
-		if (rec.kind == KIND_NONE)
-		{
-			out.kind = KIND_NONE;
-			out.front = rec.front;
-			return;
-		}
-		rec.pad0[0] = rec.pad0[1] = 0;
-		rec.pad1[0] = rec.pad1[1] = rec.pad1[2] = 0;
-		out = rec;
-		const int x0 = rec.x_min < 0 ? 0 : rec.x_min, x1 = rec.x_max > s.W - 1 ? s.W - 1 : rec.x_max;
-		const int y0 = rec.y_begin[0] < 0 ? 0 : rec.y_begin[0], y1 = rec.y_end[1] > s.H - 1 ? s.H - 1 : rec.y_end[1];
-		if (x0 > x1 || y0 > y1)
-			return;
-		const double eq[9] = {rec.eq[0][0], rec.eq[0][1], rec.eq[0][2], rec.eq[1][0], rec.eq[1][1], rec.eq[1][2], rec.eq[2][0], rec.eq[2][1], rec.eq[2][2]};
-		const int tx0 = x0 / TILE, ty0 = y0 / TILE, ntx = x1 / TILE - tx0 + 1, nty = y1 / TILE - ty0 + 1;
-		if (ntx <= 3 && nty <= 3)
-		{ // the usual small triangle: its slot requests are all in flight together (one memory round trip, not one per tile)
-			uint32_t slot[9];
-			bool use[9];
-			const uint32_t outside = tiles3x3_outside_halfplanes<3>(eq, tx0, ty0);
-#pragma unroll
-			for (int q = 0; q < 9; q++)
-			{
-				const int dx = q % 3, dy = q / 3;
-				use[q] = dx < ntx && dy < nty && !((outside >> q) & 1u);
-				slot[q] = 0;
-				if (use[q])
-					slot[q] = atomicAdd(&w.tri_cnt[(ty0 + dy) * p.L.tiles_x + tx0 + dx], 1u);
-			}
-#pragma unroll
-			for (int q = 0; q < 9; q++)
-				if (use[q])
-				{
-					const int tile = (ty0 + q / 3) * p.L.tiles_x + tx0 + q % 3;
-					place_in_tile(w.tri_list, K_TRI, w.tri_pool, p.L.tri_pool_cap, &w.hdr->tri_spill[cur], tile, (uint32_t)k, slot[q]);
-					if (p.first_tiles && slot[q] == (uint32_t)FIRST_PRIMS)
-						claim_first_tile(p, w, cur, tile);
-				}
-			return;
-		}
-		for (int ty = ty0; ty < ty0 + nty; ty++)
-			for (int tx = tx0; tx < tx0 + ntx; tx++)
-				if (!tile_outside_halfplanes<3>(eq, tx, ty))
-				{
-					const int tile = ty * p.L.tiles_x + tx;
-					if (push_tile(w.tri_cnt, w.tri_list, K_TRI, w.tri_pool, p.L.tri_pool_cap, &w.hdr->tri_spill[cur], tile, (uint32_t)k) ==
-							(uint32_t)FIRST_PRIMS &&
-						p.first_tiles)
-						claim_first_tile(p, w, cur, tile);
-				}
-		return;
-	}
-	// nothing is written for the ~97 % of slots that are not silhouette edges: records are only reached through the tile
-	// lists, and finalize_kernel works from the same flags
-	const int slot = compact_flagged_slots(p, s.edgeflags);
-	if (slot < 0)
-		return;
-	const int k = slot / 3, n = slot - 3 * k;
-	TriInputs t;
-	load_triangle(s, k, t, true);
-	EdgeRec e;
-	setup_edge_only(s, t, k, n, e, w.edge_planes + (size_t)slot * 3 * s.P);
-	EdgeRec &eout = w.edge_rec[slot];
-	if (e.kind == KIND_NONE)
-	{
-		eout.kind = KIND_NONE;
-		return;
-	}
-	for (int i = 0; i < 7; i++)
-		e.pad0[i] = 0;
-	eout = e;
-	if (e.x_begin > e.x_end || e.y_begin > e.y_end)
-		return;
-	const double band[12] = {e.x2b[0], e.x2b[1], e.x2b[2], e.x2b[3], e.x2b[4], e.x2b[5], e.x2t[0], e.x2t[1], e.x2t[2],
-							 -e.x2t[0], -e.x2t[1], 1 - e.x2t[2]}; // the four half-planes of the band, H.h:1418-1435
-	const int tx0 = e.x_begin / TILE, ty0 = e.y_begin / TILE, ntx = e.x_end / TILE - tx0 + 1, nty = e.y_end / TILE - ty0 + 1;
-	// on its first edge the tile joins the list the adjoint's edge kernel walks; on its (PRIO_EDGES + 1)-th also the list of
+	// on its first edge a tile joins the list the adjoint's edge kernel walks; on its (PRIO_EDGES + 1)-th also the list of
 	// the long tiles that kernel starts with (the kernel lasts as long as its slowest tile)
 	auto listed = [&](int tile, uint32_t got) {
 		if (got != 0 && got != (uint32_t)PRIO_EDGES)
@@ -630,37 +545,168 @@ __global__ __launch_bounds__(PRIM_BLOCK) void setup_bin_kernel(KParams p)
 		if (got && p.first_tiles)
 			claim_first_tile(p, w, cur, tile);
 	};
-	if (ntx <= 3 && nty <= 3)
+	// A primitive whose bounding box needs more than COOP_BLOCKS blocks of 3 x 3 tiles is not binned by its own thread
+	// (hundreds of dependent atomic round trips in one lane: 0.3 ms of set-up for a 1 000-triangle mesh filling a 1024^2
+	// frame) but handed to the whole wavefront below: its half-planes and box are kept here.  Smaller ones stay with their
+	// thread (all threads at once beat the wavefront working through its large primitives one after the other).
+	bool big = false;
+	double hp[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+	int btx0 = 0, bty0 = 0, bntx = 0, bnty = 0, bprim = 0;
+	if (tri_block)
 	{
-		uint32_t got[9];
-		bool use[9];
-		const uint32_t outside = tiles3x3_outside_halfplanes<4>(band, tx0, ty0);
-#pragma unroll
-		for (int q = 0; q < 9; q++)
+		do
 		{
-			const int dx = q % 3, dy = q / 3;
-			use[q] = dx < ntx && dy < nty && !((outside >> q) & 1u);
-			got[q] = 1;
-			if (use[q])
-				got[q] = atomicAdd(&w.edge_cnt[(ty0 + dy) * p.L.tiles_x + tx0 + dx], 1u);
-		}
+			const int k = item;
+			if (k >= p.T)
+				break;
+			TriInputs t;
+			load_triangle(s, k, t, true);
+			TriRec rec;
+			setup_tri_only(s, t, rec, w.tri_planes + (size_t)k * 3 * s.P);
+			TriRec &out = w.tri_rec[k];
+			if (rec.kind == KIND_NONE)
+			{
+				out.kind = KIND_NONE;
+				out.front = rec.front;
+				break;
+			}
+			rec.pad0[0] = rec.pad0[1] = 0;
+			rec.pad1[0] = rec.pad1[1] = rec.pad1[2] = 0;
+			out = rec;
+			const int x0 = rec.x_min < 0 ? 0 : rec.x_min, x1 = rec.x_max > s.W - 1 ? s.W - 1 : rec.x_max;
+			const int y0 = rec.y_begin[0] < 0 ? 0 : rec.y_begin[0], y1 = rec.y_end[1] > s.H - 1 ? s.H - 1 : rec.y_end[1];
+			if (x0 > x1 || y0 > y1)
+				break;
+			const double eq[9] = {rec.eq[0][0], rec.eq[0][1], rec.eq[0][2], rec.eq[1][0], rec.eq[1][1], rec.eq[1][2], rec.eq[2][0], rec.eq[2][1], rec.eq[2][2]};
+			const int tx0 = x0 / TILE, ty0 = y0 / TILE, ntx = x1 / TILE - tx0 + 1, nty = y1 / TILE - ty0 + 1;
+			if (((ntx + 2) / 3) * ((nty + 2) / 3) > COOP_BLOCKS)
+			{
+				big = true;
 #pragma unroll
-		for (int q = 0; q < 9; q++)
-			if (use[q])
-			{
-				const int tile = (ty0 + q / 3) * p.L.tiles_x + tx0 + q % 3;
-				place_in_tile(w.edge_list, K_EDGE, w.edge_pool, p.L.edge_pool_cap, &w.hdr->edge_spill[cur], tile, (uint32_t)slot, got[q]);
-				listed(tile, got[q]);
+				for (int i = 0; i < 9; i++)
+					hp[i] = eq[i];
+				btx0 = tx0, bty0 = ty0, bntx = ntx, bnty = nty, bprim = k;
+				break;
 			}
-		return;
+			// 3 x 3 tiles at a time (the usual small triangle: once), the slot requests of a block all in flight together: one
+			// memory round trip per block, not one per tile
+			for (int by = 0; by < nty; by += 3)
+				for (int bx = 0; bx < ntx; bx += 3)
+				{
+					uint32_t slot[9];
+					bool use[9];
+					const uint32_t outside = tiles3x3_outside_halfplanes<3>(eq, tx0 + bx, ty0 + by);
+#pragma unroll
+					for (int q = 0; q < 9; q++)
+					{
+						const int dx = bx + q % 3, dy = by + q / 3;
+						use[q] = dx < ntx && dy < nty && !((outside >> q) & 1u);
+						slot[q] = 0;
+						if (use[q])
+							slot[q] = atomicAdd(&w.tri_cnt[(ty0 + dy) * p.L.tiles_x + tx0 + dx], 1u);
+					}
+#pragma unroll
+					for (int q = 0; q < 9; q++)
+						if (use[q])
+						{
+							const int tile = (ty0 + by + q / 3) * p.L.tiles_x + tx0 + bx + q % 3;
+							place_in_tile(w.tri_list, K_TRI, w.tri_pool, p.L.tri_pool_cap, &w.hdr->tri_spill[cur], tile, (uint32_t)k, slot[q]);
+							if (p.first_tiles && slot[q] == (uint32_t)FIRST_PRIMS)
+								claim_first_tile(p, w, cur, tile);
+						}
+				}
+		} while (false);
 	}
-	for (int ty = ty0; ty < ty0 + nty; ty++)
-		for (int tx = tx0; tx < tx0 + ntx; tx++)
-			if (!tile_outside_halfplanes<4>(band, tx, ty))
+	else
+	{
+		do
+		{
+			// nothing is written for the ~97 % of slots that are not silhouette edges: records are only reached through the
+			// tile lists, and finalize_kernel works from the same flags
+			const int slot = compact_flagged_slots(p, s.edgeflags);
+			if (slot < 0)
+				break;
+			const int k = slot / 3, n = slot - 3 * k;
+			TriInputs t;
+			load_triangle(s, k, t, true);
+			EdgeRec e;
+			setup_edge_only(s, t, k, n, e, w.edge_planes + (size_t)slot * 3 * s.P);
+			EdgeRec &eout = w.edge_rec[slot];
+			if (e.kind == KIND_NONE)
 			{
-				const int tile = ty * p.L.tiles_x + tx;
-				listed(tile, push_tile(w.edge_cnt, w.edge_list, K_EDGE, w.edge_pool, p.L.edge_pool_cap, &w.hdr->edge_spill[cur], tile, (uint32_t)slot));
+				eout.kind = KIND_NONE;
+				break;
 			}
+			for (int i = 0; i < 7; i++)
+				e.pad0[i] = 0;
+			eout = e;
+			if (e.x_begin > e.x_end || e.y_begin > e.y_end)
+				break;
+			const double band[12] = {e.x2b[0], e.x2b[1], e.x2b[2], e.x2b[3], e.x2b[4], e.x2b[5], e.x2t[0], e.x2t[1], e.x2t[2],
+									 -e.x2t[0], -e.x2t[1], 1 - e.x2t[2]}; // the four half-planes of the band, H.h:1418-1435
+			const int tx0 = e.x_begin / TILE, ty0 = e.y_begin / TILE, ntx = e.x_end / TILE - tx0 + 1, nty = e.y_end / TILE - ty0 + 1;
+			if (((ntx + 2) / 3) * ((nty + 2) / 3) > COOP_BLOCKS)
+			{
+				big = true;
+#pragma unroll
+				for (int i = 0; i < 12; i++)
+					hp[i] = band[i];
+				btx0 = tx0, bty0 = ty0, bntx = ntx, bnty = nty, bprim = slot;
+				break;
+			}
+			for (int by = 0; by < nty; by += 3)
+				for (int bx = 0; bx < ntx; bx += 3)
+				{
+					uint32_t got[9];
+					bool use[9];
+					const uint32_t outside = tiles3x3_outside_halfplanes<4>(band, tx0 + bx, ty0 + by);
+#pragma unroll
+					for (int q = 0; q < 9; q++)
+					{
+						const int dx = bx + q % 3, dy = by + q / 3;
+						use[q] = dx < ntx && dy < nty && !((outside >> q) & 1u);
+						got[q] = 1;
+						if (use[q])
+							got[q] = atomicAdd(&w.edge_cnt[(ty0 + dy) * p.L.tiles_x + tx0 + dx], 1u);
+					}
+#pragma unroll
+					for (int q = 0; q < 9; q++)
+						if (use[q])
+						{
+							const int tile = (ty0 + by + q / 3) * p.L.tiles_x + tx0 + bx + q % 3;
+							place_in_tile(w.edge_list, K_EDGE, w.edge_pool, p.L.edge_pool_cap, &w.hdr->edge_spill[cur], tile, (uint32_t)slot, got[q]);
+							listed(tile, got[q]);
+						}
+				}
+		} while (false);
+	}
+	// ---- the large primitives of this wavefront, one after the other, 64 tiles of the bounding box at a time
+	const int lane = threadIdx.x & 63;
+	unsigned long long todo = __ballot(big);
+	while (todo)
+	{
+		const int src = __ffsll((long long)todo) - 1;
+		todo &= todo - 1;
+		double q[12];
+#pragma unroll
+		for (int i = 0; i < 12; i++)
+			q[i] = __shfl(hp[i], src, 64);
+		const int tx0 = __shfl(btx0, src, 64), ty0 = __shfl(bty0, src, 64), ntx = __shfl(bntx, src, 64), nty = __shfl(bnty, src, 64);
+		const uint32_t prim = (uint32_t)__shfl(bprim, src, 64);
+		for (int t = lane; t < ntx * nty; t += 64)
+		{
+			const int tx = tx0 + t % ntx, ty = ty0 + t / ntx, tile = ty * p.L.tiles_x + tx;
+			if (tri_block)
+			{
+				if (!tile_outside_halfplanes<3>(q, tx, ty) &&
+					push_tile(w.tri_cnt, w.tri_list, K_TRI, w.tri_pool, p.L.tri_pool_cap, &w.hdr->tri_spill[cur], tile, prim) == (uint32_t)FIRST_PRIMS &&
+					p.first_tiles)
+					claim_first_tile(p, w, cur, tile);
+			}
+			else if (!tile_outside_halfplanes<4>(q, tx, ty))
+				listed(tile, push_tile(w.edge_cnt, w.edge_list, K_EDGE, w.edge_pool, p.L.edge_pool_cap, &w.hdr->edge_spill[cur], tile, prim));
+		}
+	}
 }
 
 // ------------------------------------------------------------------------------------------- tile-level edge ordering
