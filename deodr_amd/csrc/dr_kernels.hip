@@ -1209,7 +1209,8 @@ __device__ __forceinline__ void tri_batch(const KParams &p, WaveLds &S, int nb, 
 	lds_sync(); // the next batch overwrites the staging area
 }
 
-constexpr int EMAX = 64; // silhouette edges of one tile the staged kernels can order; more -> generic / deferred path
+constexpr int EMAX = 128; // silhouette edges of one tile the staged kernels can order; more -> generic / deferred path (a
+						  // single 90-edge tile in the deferred kernel took 5 ms)
 
 struct EdgeSort
 {
@@ -2374,8 +2375,8 @@ __device__ __forceinline__ void bwd_fast_tile(const KParams &p, const ViewPtrs &
 		}
 		// pass A, far -> near: which edges are drawn over this pixel (bit j of tm[b] = edge 32 b + j in blending order)
 		// and the antialiased colour they leave
-		uint32_t tm[EMAX / TB] = {0, 0, 0, 0};
-		static_assert(EMAX / TB == 4, "tm[] initialiser");
+		uint32_t tm[EMAX / TB] = {0, 0, 0, 0, 0, 0, 0, 0};
+		static_assert(EMAX / TB == 8, "tm[] initialiser");
 		double cur[CH];
 #pragma unroll
 		for (int cc = 0; cc < CH; cc++)
