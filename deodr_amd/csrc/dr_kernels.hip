@@ -2149,9 +2149,44 @@ __device__ __forceinline__ void owner_adjoint(const KParams &p, const ViewPtrs &
 	// per-pixel adjoint of the owner's (up to four) attribute planes; its moments  sum v * [x, y, 1]  over the owner's pixels
 	// are what the per-triangle finalize needs
 	double val[CH] = {0, 0, 0, 0};
-	if (kind == KIND_TEXTURED)
+	// Texture gradient.  The taps of the 64 pixels of a tile fall into a small window of texels (a magnified texture: a
+	// dozen texels for 768 contributions), and atomics to one address serialise in the L2 at ~80 ns each: when the window
+	// fits the LDS scratch, the contributions are summed there (ds_add_f64) and each touched texel leaves with ONE global
+	// atomic -- "per-tile LDS partials before a single atomicAdd".
+	const bool textured = kind == KIND_TEXTURED;
+	int fu = 0, fv = 0, win_u0 = 0, win_v0 = 0, win_w = 0, win_h = 0;
+	bool windowed = false;
+	if (texture_b && __ballot(textured))
+	{
+		if (textured)
+		{
+			const int t0 = tap.idx[0] / C;
+			fv = t0 / p.tex_w;
+			fu = t0 - fv * p.tex_w;
+		}
+		int lo_u = textured ? fu : 0x7fffffff, lo_v = textured ? fv : 0x7fffffff, hi_u = textured ? fu : -1, hi_v = textured ? fv : -1;
+#pragma unroll
+		for (int d = 1; d < 64; d <<= 1)
+		{
+			lo_u = min(lo_u, __shfl_xor(lo_u, d, 64));
+			lo_v = min(lo_v, __shfl_xor(lo_v, d, 64));
+			hi_u = max(hi_u, __shfl_xor(hi_u, d, 64));
+			hi_v = max(hi_v, __shfl_xor(hi_v, d, 64));
+		}
+		win_u0 = lo_u, win_v0 = lo_v, win_w = hi_u - lo_u + 2, win_h = hi_v - lo_v + 2;
+		windowed = win_w * win_h * C <= RUNS * NMOM;
+		if (windowed)
+		{
+			lds_sync();
+			for (int i = lane; i < win_w * win_h * C; i += 64)
+				tab[i] = 0;
+			lds_sync();
+		}
+	}
+	if (textured)
 	{ // H.h:1320-1353
 		double L_B = 0, e_B[2] = {0, 0};
+		const int wbase = ((fv - win_v0) * win_w + (fu - win_u0)) * C;
 #pragma unroll
 		for (int cc = 0; cc < CH; cc++)
 			if (cc < C)
@@ -2161,14 +2196,35 @@ __device__ __forceinline__ void owner_adjoint(const KParams &p, const ViewPtrs &
 				L_B += g[cc] * bilinear_mix(tap, i00, i10, i01, i11);
 				double wgt[4];
 				bilinear_mix_adjoint(tap, g[cc] * L, i00, i10, i01, i11, wgt, e_B);
-				if (texture_b)
+				if (windowed)
+				{
+					lds_add(&tab[wbase + cc], wgt[0]);
+					lds_add(&tab[wbase + C + cc], wgt[1]);
+					lds_add(&tab[wbase + win_w * C + cc], wgt[2]);
+					lds_add(&tab[wbase + win_w * C + C + cc], wgt[3]);
+				}
+				else if (texture_b)
 					texture_scatter(texture_b, tap, cc, wgt);
 			}
 		val[0] = tap.out[0] ? 0.0 : e_B[0];
 		val[1] = tap.out[1] ? 0.0 : e_B[1];
 		val[2] = L_B;
 	}
-	else if (kind == KIND_INTERP)
+	if (windowed)
+	{
+		lds_sync();
+		for (int i = lane; i < win_w * win_h * C; i += 64)
+		{
+			const double v = tab[i];
+			if (v != 0)
+			{
+				const int texel = i / C, c = i - texel * C, jv = texel / win_w, ju = texel - jv * win_w;
+				unsafeAtomicAdd(texture_b + (size_t)C * ((win_u0 + ju) + (size_t)p.tex_w * (win_v0 + jv)) + c, (PixT)v);
+			}
+		}
+		lds_sync(); // tab is reused for the run totals below
+	}
+	if (kind == KIND_INTERP)
 	{ // H.h:1024-1037
 #pragma unroll
 		for (int cc = 0; cc < CH; cc++)
