@@ -1306,11 +1306,12 @@ __device__ __forceinline__ void owner_adjoint(const KParams &p, const ViewPtrs &
 // FUSED: the forward of a fit step.  The loss is L = sum (image - obs)^2, so dL/dimage is known the moment a pixel is
 // resolved: tiles without silhouette edges back-propagate into their owners' accumulators right here (no second pass over the
 // frame, no owner buffer round trip); tiles with edges are left to raster_bwd_edge_kernel.
-// Six waves per SIMD (80 VGPRs, some spills): the wave timeline shows the kernel slot-bound -- ~3 800 of the 4 096 slots that
+// Five waves per SIMD (96 VGPRs, a few spills): the wave timeline shows the kernel slot-bound -- ~3 800 of the 4 096 slots that
 // the natural 111 VGPRs allow are occupied throughout -- and more resident waves hide more of the dependent loads than the
-// spills cost (measured: 4 -> 156 us, 5 -> 151, 6 -> 149, 7 -> 154).
+// spills cost (measured: 4 -> 156 us, 5 -> 151, 6 -> 149, 7 -> 154; at 6 the spill traffic nearly doubles the HBM bytes of
+// the kernel for those last 2 us, so 5).
 template <class PixT, int WPB, bool FUSED> // WPB wavefronts (= tiles) per workgroup
-__global__ __launch_bounds__(64 * WPB, 6) void raster_fwd_fast_kernel(KParams p)
+__global__ __launch_bounds__(64 * WPB, 5) void raster_fwd_fast_kernel(KParams p)
 {
 	DR_WAVE_TRACE_SCOPE(2);
 	__shared__ WaveLds s_lds[WPB];
