@@ -1,21 +1,25 @@
 // deodr_amd/csrc/dr_kernels.hip -- HIP kernels (gfx950 / CDNA4, wave64) and the C ABI of libdeodr_hip.so.
 //
-// Pipeline of one renderScene + renderScene_B (n_views views per launch, blockIdx.y = view):
+// Kernels (n_views views per launch; DESIGN.md section 4 has the why of every choice below):
 //
-//   setup_bin_kernel   1 thread / triangle   cull, depth-sum, stencil + attribute planes in double (dr_prims.h),
-//                                            silhouette-edge records, binning of triangles and edges into 8x8 tiles
-//   raster_fwd_kernel  1 wavefront / tile    lane = pixel.  Pass 1 (z-buffered triangles, winner = min (Z, index)),
-//                                            shading of the winner, pass 2 (ordered edge overdraw) fused in registers;
-//                                            ONE coalesced write of image / z / owner id per pixel
-//   raster_bwd_kernel  1 wavefront / tile    adjoint of pass 2 (reverse order, forward chain replayed from the un-antialiased
-//                                            colour instead of the reference's un-blend by division) then of pass 1;
-//                                            per (tile, primitive): wave reduction of the image moments sum g [x, y, 1],
-//                                            one atomicAdd per moment into the per-primitive accumulators
-//   finalize_kernel    1 thread / triangle   moments -> plane adjoints -> 3x3-inverse adjoint -> vertex gradients
+//   setup_bin_kernel        blocks of 256 threads: one triangle per thread, or 256 edge slots compacted to the flagged ones.
+//                           Cull, depth sum, stencil + attribute planes in double and in registers (dr_prims.h), edge records,
+//                           binning into 8 x 8 tiles (all slot requests of a 3 x 3 block of tiles in flight; large boxes by
+//                           the whole wavefront), lists of edge tiles / many-primitive tiles, optional gradient clearing
+//   raster_fwd_fast_kernel  1 wavefront / tile, lane = pixel.  Pass 1 (z-buffered triangles staged 16 at a time through LDS,
+//                           exact scanline spans, winner = min (Z, index)), shading, pass 2 (ordered edge overdraw) fused in
+//                           registers, ONE write of image / z / owner per pixel.  FUSED: also the adjoint of pass 1 for the
+//                           sum-of-squares residual in tiles without edges (deodr_hip_render_scene_fit)
+//   raster_bwd_fast_kernel  (two-call path) adjoint of pass 1 in every tile without edges
+//   raster_bwd_edge_kernel  persistent waves over the listed edge tiles: adjoint of pass 2 (un-blend in reverse order, moments
+//                           by a transposing butterfly, one 15-lane atomic per edge and tile), then of pass 1
+//   raster_bwd_heavy_kernel the rare tiles with more than EMAX edges, generic code
+//   finalize_kernel         per primitive: moments -> plane adjoints -> 3x3-inverse adjoint -> vertex gradients
+//   raster_fwd_kernel / raster_bwd_kernel   the same algorithm without LDS staging: nb_colors > 4, antialiase_error
 //
-// No MFMA anywhere: the path is gather / scatter + streaming writes, bound by HBM and by launch latency.
-// The workspace is self-cleaning (tile counters are zeroed by the wave that consumed them, the spill counters by the
-// last block of the forward raster, the moment accumulators by finalize) so a call never needs a memset node.
+// No MFMA anywhere: the path is gather / scatter + streaming writes.  The workspace is self-cleaning (tile counters are
+// zeroed by the wave that consumed them, spill / list counters are double-buffered by the parity of the forward count,
+// the moment accumulators are zeroed by finalize) so a call never needs a memset node.
 #include <hip/hip_runtime.h>
 
 #include <math.h>
