@@ -31,14 +31,14 @@ def run(name, views, steps=20):
         r.render_fit(ds, obs, 1.0, grads=grads, out=(image, z), clear_grads=True)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
-    import ctypes as C
+    import ctypes
     from deodr_amd import hip_renderer as hr
     hr.lib().deodr_hip_profile_enable(1)
     for _ in range(4):
         r.render_fit(ds, obs, 1.0, grads=grads, out=(image, z), clear_grads=True)
     torch.cuda.synchronize()
     hr.lib().deodr_hip_profile_enable(0)
-    ms, ln = (C.c_double * 4)(), (C.c_ulonglong * 4)()
+    ms, ln = (ctypes.c_double * 4)(), (ctypes.c_ulonglong * 4)()
     hr.lib().deodr_hip_profile_read(ms, ln)
     per = [ms[i] / max(ln[i], 1) for i in range(4)]
     print(f"{name}: {n} view(s) {W}x{H} C={C} T={ds.nb_triangles} texture={'yes' if tex is not None else 'no'}: {dt*1e3:.3f} ms / fit step, {n*H*W/dt/1e6:.0f} Mpixel/s"
