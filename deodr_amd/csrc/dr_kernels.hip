@@ -2341,7 +2341,7 @@ __device__ __forceinline__ void owner_adjoint(const KParams &p, const ViewPtrs &
 // One tile of the adjoint.  EDGES = false: tiles without silhouette edges (the edge code is compiled out: half the
 // registers, twice the resident waves to hide the memory latency); EDGES = true: the tiles that have some.
 template <class PixT, bool EDGES>
-__device__ __forceinline__ void bwd_fast_tile(const KParams &p, const ViewPtrs &w, int view, int tx, int ty, int lane, BwdLds &S, EdgeSort &es,
+__device__ __forceinline__ void bwd_fast_tile(const KParams &p, const ViewPtrs &w, int view, int tx, int ty, int lane, BwdLds &S, EdgeSort *es, // es: only for EDGES
 											  int skip_above = 0x7fffffff)
 {
 	const int W = p.W, H = p.H, C = p.C, P = p.L.P;
@@ -2370,7 +2370,7 @@ __device__ __forceinline__ void bwd_fast_tile(const KParams &p, const ViewPtrs &
 #endif
 	int n_edges = 0;
 	if (EDGES)
-		n_edges = gather_sorted_edges(es, w, p, tile, nedge, lane);
+		n_edges = gather_sorted_edges(*es, w, p, tile, nedge, lane);
 	DR_TRACE(2);
 	if (EDGES && n_edges < 0)
 	{ // more than EMAX edges in one tile (or pool overflow) -> queued for raster_bwd_heavy_kernel
@@ -2446,7 +2446,7 @@ __device__ __forceinline__ void bwd_fast_tile(const KParams &p, const ViewPtrs &
 		for (int b = 0; b < nbatch; b++)
 		{
 			const int first = b * TB, nb = n_edges - first < TB ? n_edges - first : TB;
-			const uint32_t ecov = stage_edge_batch(*(WaveLds *)&S, es, w, P, first, nb, lane, x0, y0, W, inb);
+			const uint32_t ecov = stage_edge_batch(*(WaveLds *)&S, *es, w, P, first, nb, lane, x0, y0, W, inb);
 			uint32_t tmb = 0;
 			for (int j = 0; j < nb; j++)
 			{
@@ -2485,7 +2485,7 @@ __device__ __forceinline__ void bwd_fast_tile(const KParams &p, const ViewPtrs &
 			{
 				lds_sync();
 				if (lane < nb)
-					S.ids[lane] = es.sorted[first + lane];
+					S.ids[lane] = es->sorted[first + lane];
 				lds_sync();
 				stage_batch(*(WaveLds *)&S, w.edge_rec, w.edge_planes, P, nb, lane);
 				lds_sync();
@@ -2535,7 +2535,7 @@ __device__ __forceinline__ void bwd_fast_tile(const KParams &p, const ViewPtrs &
 							tq = bb == (q / TB) ? tm[bb] : tq;
 						if (!need_replay || !((tq >> (q % TB)) & 1u))
 							continue;
-						const uint32_t sq = es.sorted[q];
+						const uint32_t sq = es->sorted[q];
 						const EdgeRec &eq = w.edge_rec[sq];
 						const double *qp = w.edge_planes + (size_t)sq * 3 * P;
 						const double Tq = plane_at(eq.x2t, x, y);
@@ -2651,7 +2651,7 @@ __global__ __launch_bounds__(64 * WPB, 6) void raster_bwd_fast_kernel(KParams p)
 	const int ty = xcd_strip_row(b / strips_x, p.L.tiles_y, p.row_group), tx = (b % strips_x) * WPB + wave;
 	if (tx >= p.L.tiles_x)
 		return;
-	bwd_fast_tile<PixT, false>(p, w, view, tx, ty, lane, s_lds[wave], *(EdgeSort *)nullptr);
+	bwd_fast_tile<PixT, false>(p, w, view, tx, ty, lane, s_lds[wave], nullptr);
 }
 
 template <class PixT>
@@ -2674,7 +2674,7 @@ __global__ __launch_bounds__(64, 2) void raster_bwd_edge_kernel(KParams p)
 	{
 		const bool from_long = i < n_long;
 		const int tile = uniform((int)(from_long ? longs[i] : all[i - n_long]));
-		bwd_fast_tile<PixT, true>(p, w, view, tile % p.L.tiles_x, tile / p.L.tiles_x, lane, s_lds, s_es, from_long ? 0x7fffffff : PRIO_EDGES);
+		bwd_fast_tile<PixT, true>(p, w, view, tile % p.L.tiles_x, tile / p.L.tiles_x, lane, s_lds, &s_es, from_long ? 0x7fffffff : PRIO_EDGES);
 		lds_sync();
 	}
 }
