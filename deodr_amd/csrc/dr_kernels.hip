@@ -1343,7 +1343,8 @@ __global__ __launch_bounds__(64 * WPB, 5) void raster_fwd_fast_kernel(KParams p)
 			view = bid % p.n_views;
 			const int slot = bid / p.n_views, sub = 2 * NSUB + slot % NSUB, idx = slot / NSUB;
 			const ViewPtrs wl = view_ptrs(p, view);
-			const uint32_t n = wl.edge_tile_cnt[(wl.hdr->cur * LIST_KINDS * NSUB + sub) * CNT_STRIDE];
+			const uint32_t n0 = wl.edge_tile_cnt[sub * CNT_STRIDE], n1 = wl.edge_tile_cnt[(LIST_KINDS * NSUB + sub) * CNT_STRIDE];
+			const uint32_t n = wl.hdr->cur ? n1 : n0; // both parities requested with the parity: one round trip
 			if ((uint32_t)idx >= (n < (uint32_t)(FWD_FIRST / NSUB) ? n : (uint32_t)(FWD_FIRST / NSUB)))
 				return;
 			const int t = uniform((int)wl.edge_tiles[(size_t)sub * p.L.sub_cap + idx]);
@@ -2666,8 +2667,11 @@ __global__ __launch_bounds__(64, 2) void raster_bwd_edge_kernel(KParams p)
 	const int lane = threadIdx.x;
 	const ViewPtrs w = view_ptrs(p, view);
 	const int sub = blockIdx.y % NSUB, stride = gridDim.y / NSUB;
-	const uint32_t *cnt = w.edge_tile_cnt + (size_t)w.hdr->cur * LIST_KINDS * NSUB * CNT_STRIDE;
-	const uint32_t n_all = cnt[sub * CNT_STRIDE], n_long = cnt[(NSUB + sub) * CNT_STRIDE];
+	// the counters of both parities are requested together with the parity itself: one memory round trip, not two
+	const uint32_t *cnt0 = w.edge_tile_cnt, *cnt1 = w.edge_tile_cnt + (size_t)LIST_KINDS * NSUB * CNT_STRIDE;
+	const uint32_t cur = w.hdr->cur;
+	const uint32_t a0 = cnt0[sub * CNT_STRIDE], l0 = cnt0[(NSUB + sub) * CNT_STRIDE], a1 = cnt1[sub * CNT_STRIDE], l1 = cnt1[(NSUB + sub) * CNT_STRIDE];
+	const uint32_t n_all = cur ? a1 : a0, n_long = cur ? l1 : l0;
 	const uint32_t *all = w.edge_tiles + (size_t)sub * p.L.sub_cap, *longs = w.edge_tiles + (size_t)(NSUB + sub) * p.L.sub_cap;
 #pragma nounroll
 	for (uint32_t i = blockIdx.y / NSUB; i < n_long + n_all; i += stride)
