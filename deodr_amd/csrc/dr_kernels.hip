@@ -54,6 +54,12 @@ constexpr int PRIO_EDGES = 8; // tiles with more edges than this are also listed
 constexpr int FIRST_PRIMS = 8;
 constexpr int FWD_FIRST = 512; // listed tiles per view (NSUB sub-lists of FWD_FIRST / NSUB)
 constexpr int LIST_KINDS = 3; // edge tiles, many-edged tiles, first tiles of the forward
+// The forward sweep over a tile's edges (pass 2) leaves, per pixel, the antialiased colour in double and the mask of the
+// edges drawn: the forward raster saves both for the first SAVE_SUB edge tiles of every sub-list, so that the adjoint's edge
+// kernel starts with the reverse sweep instead of repeating the forward one (half of its time per tile).
+constexpr int SAVE_SUB = 512;
+constexpr uint32_t SWEEP_SAVED = 0x80000000u; // flag in edge_saved[tile]
+constexpr size_t SWEEP_BYTES = 64 * (CH * sizeof(double) + (128 / 16) * sizeof(uint16_t)); // 3 KB per tile: cur[CH][64], masks[8][64]
 
 struct WsHeader // 64 bytes per view at the start of the view's workspace
 {
@@ -72,9 +78,9 @@ static_assert(sizeof(WsHeader) == 64, "");
 struct Layout
 {
 	size_t hdr, tri_rec, tri_planes, tri_acc, edge_rec, edge_planes, edge_acc, tri_cnt, edge_cnt, edge_saved, tri_list, edge_list, tri_pool,
-		edge_pool, face_id, heavy_list, edge_tile_cnt, edge_tiles, first_flag, view_bytes;
+		edge_pool, face_id, heavy_list, edge_tile_cnt, edge_tiles, first_flag, edge_slot, edge_sweep, view_bytes;
 	uint32_t tri_pool_cap, edge_pool_cap;
-	int tiles_x, tiles_y, ntiles, P, sub_cap;
+	int tiles_x, tiles_y, ntiles, P, sub_cap, save_sub;
 };
 
 size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -116,6 +122,9 @@ Layout make_layout(int T, int H, int W, int C, size_t pool_pairs)
 	L.edge_tile_cnt = take(sizeof(uint32_t) * 2 * LIST_KINDS * NSUB * CNT_STRIDE); // [epoch parity][kind][sub-list]
 	L.edge_tiles = take(sizeof(uint32_t) * LIST_KINDS * NSUB * (size_t)L.sub_cap);	// [kind][sub-list][sub_cap]
 	L.first_flag = take(sizeof(uint32_t) * L.ntiles);
+	L.edge_slot = take(sizeof(uint32_t) * L.ntiles); // 1 + index of the tile's slot in edge_sweep, 0: none
+	L.save_sub = SAVE_SUB < L.sub_cap ? SAVE_SUB : L.sub_cap; // saved sweeps per sub-list
+	L.edge_sweep = take(SWEEP_BYTES * NSUB * (size_t)L.save_sub);
 	L.view_bytes = o;
 	return L;
 }
@@ -156,6 +165,8 @@ struct ViewPtrs
 	uint2 *tri_pool, *edge_pool;
 	int32_t *face_id;
 	uint32_t *heavy_list;
+	uint32_t *edge_slot;
+	char *edge_sweep;
 	uint32_t *first_flag;				  // 1: the tile is on the list of tiles the forward rasterizes first
 	uint32_t *edge_tile_cnt, *edge_tiles; // tiles with silhouette edges: NSUB counters per epoch parity, NSUB sub-lists of sub_cap tiles
 };
@@ -183,6 +194,8 @@ __device__ __forceinline__ ViewPtrs view_ptrs(const KParams &p, int view)
 	v.edge_tile_cnt = (uint32_t *)(b + p.L.edge_tile_cnt);
 	v.edge_tiles = (uint32_t *)(b + p.L.edge_tiles);
 	v.first_flag = (uint32_t *)(b + p.L.first_flag);
+	v.edge_slot = (uint32_t *)(b + p.L.edge_slot);
+	v.edge_sweep = b + p.L.edge_sweep;
 	return v;
 }
 
@@ -545,6 +558,8 @@ __global__ __launch_bounds__(PRIM_BLOCK) void setup_bin_kernel(KParams p)
 		const int sub = (got ? NSUB : 0) + tile % NSUB;
 		const uint32_t at = atomicAdd(&w.edge_tile_cnt[(cur * LIST_KINDS * NSUB + sub) * CNT_STRIDE], 1u);
 		w.edge_tiles[(size_t)sub * p.L.sub_cap + at] = (uint32_t)tile;
+		if (got == 0) // a place for the forward sweep of the tile (always written: a stale value must never be read)
+			w.edge_slot[tile] = at < (uint32_t)p.L.save_sub ? (uint32_t)sub * p.L.save_sub + at + 1u : 0u;
 		static_assert(PRIO_EDGES == FIRST_PRIMS, "one threshold for both lists");
 		if (got && p.first_tiles)
 			claim_first_tile(p, w, cur, tile);
@@ -1392,6 +1407,7 @@ __global__ __launch_bounds__(64 * WPB, 5) void raster_fwd_fast_kernel(KParams p)
 		const uint32_t list_entry = w.tri_list[(size_t)tile * K_TRI + (lane & (K_TRI - 1))];
 		int ntri = uniform((int)w.tri_cnt[tile]);
 		int nedge = uniform((int)w.edge_cnt[tile]);
+		const uint32_t slot_word = (uint32_t)uniform((int)w.edge_slot[tile]); // fresh whenever the tile has edges (set-up)
 		const bool taken = WPB == 1 && p.first_tiles && !listed_tile && uniform((int)w.first_flag[tile]) != 0;
 		if (taken && lane == 0)
 			w.first_flag[tile] = 0; // a block at the head of the grid rasterizes this tile; the flag has served
@@ -1406,8 +1422,10 @@ __global__ __launch_bounds__(64 * WPB, 5) void raster_fwd_fast_kernel(KParams p)
 			w.tri_cnt[tile] = 0;
 			w.edge_cnt[tile] = 0;
 		}
+		// the adjoint finds the edge count, and whether the forward sweep over the edges is saved (below), in edge_saved
+		const uint32_t sweep_slot = (nedge > 0 && nedge <= EMAX && !persp) ? slot_word : 0u;
 		if (lane == 0)
-			w.edge_saved[tile] = (uint32_t)nedge;
+			w.edge_saved[tile] = (uint32_t)nedge | (sweep_slot ? SWEEP_SAVED : 0u);
 		if ((ntri | nedge) == 0)
 		{ // two tiles out of three hold no primitive: background, no depth, no owner -- and nothing else to run through
 			if (inb && !(p.debug & 4))
@@ -1540,11 +1558,14 @@ __global__ __launch_bounds__(64 * WPB, 5) void raster_fwd_fast_kernel(KParams p)
 			n_edges = gather_sorted_edges(s_es[wave], w, p, tile, nedge, lane);
 		if (n_edges > 0)
 		{
+			static_assert(EMAX == 128 && TB == 16, "layout of the saved masks: one 16-bit word per batch of 16 edges");
+			uint16_t *sweep_masks = (uint16_t *)(w.edge_sweep + (size_t)(sweep_slot ? sweep_slot - 1 : 0) * SWEEP_BYTES + CH * 64 * sizeof(double));
 			const EdgeRec *erec = (const EdgeRec *)S.rec;
 			for (int first = 0; first < n_edges; first += TB)
 			{
 				const int nb = n_edges - first < TB ? n_edges - first : TB;
 				const uint32_t ecov = stage_edge_batch(S, s_es[wave], w, P, first, nb, lane, x0, y0, W, inb);
+				uint32_t drawn_batch = 0;
 				for (int j = 0; j < nb; j++)
 				{
 					const bool c = (ecov >> j) & 1u;
@@ -1556,6 +1577,7 @@ __global__ __launch_bounds__(64 * WPB, 5) void raster_fwd_fast_kernel(KParams p)
 						Ze = 1 / Ze;
 					if (c && Ze < st.zbest)
 					{
+						drawn_batch |= 1u << j;
 						const double *ep = &S.planes[j * 12];
 						const double Tr = plane_at(e.x2t, x, y);
 						Tap etap;
@@ -1572,6 +1594,15 @@ __global__ __launch_bounds__(64 * WPB, 5) void raster_fwd_fast_kernel(KParams p)
 							}
 					}
 				}
+				if (sweep_slot) // bit j: edge first + j of the blending order is drawn over this pixel
+					sweep_masks[(first / TB) * 64 + lane] = (uint16_t)drawn_batch;
+			}
+			if (sweep_slot)
+			{ // with the masks, what the adjoint's forward sweep would recompute: the antialiased colour in double
+				double *slot = (double *)(w.edge_sweep + (size_t)(sweep_slot - 1) * SWEEP_BYTES);
+#pragma unroll
+				for (int cc = 0; cc < CH; cc++)
+					slot[cc * 64 + lane] = col[cc];
 			}
 		}
 		else if (n_edges < 0)
@@ -1711,7 +1742,7 @@ __device__ __noinline__ void bwd_tile_generic(const KParams &p, int view, int tx
 	const size_t pix = (size_t)py * W + px;
 	const size_t vpix = (size_t)view * H * W + pix;
 	const double x = px, y = py;
-	int nedge = uniform((int)w.edge_saved[tile]);
+	int nedge = uniform((int)(w.edge_saved[tile] & ~SWEEP_SAVED));
 	if (p.debug & 32)
 		nedge = 0;
 	int owner = -1, kind = KIND_NONE;
@@ -2357,7 +2388,10 @@ __device__ __forceinline__ void bwd_fast_tile(const KParams &p, const ViewPtrs &
 	const double x = px, y = py;
 	// the owner ids are requested together with the tile's edge count (one memory round trip instead of two)
 	const int32_t raw_owner = inb ? w.face_id[pix] : -1;
-	int nedge = uniform((int)w.edge_saved[tile]);
+	const uint32_t raw_nedge = (uint32_t)uniform((int)w.edge_saved[tile]);
+	const uint32_t sweep_slot = EDGES ? (uint32_t)uniform((int)w.edge_slot[tile]) : 0u;
+	int nedge = (int)(raw_nedge & ~SWEEP_SAVED);
+	const bool sweep_saved = EDGES && (raw_nedge & SWEEP_SAVED) && sweep_slot && !(p.debug & 64);
 	if (p.debug & 32)
 		nedge = 0;
 	if ((nedge > 0) != EDGES || nedge > skip_above)
@@ -2418,33 +2452,50 @@ __device__ __forceinline__ void bwd_fast_tile(const KParams &p, const ViewPtrs &
 	// ---- adjoint of pass 2 (near -> far), TB staged edges at a time
 	if (EDGES && n_edges > 0)
 	{
-		// depth and un-antialiased colour of the pixel
+		// depth and un-antialiased colour of the pixel (only needed by the forward sweep and by the replay fallback)
 		double base[CH] = {0, 0, 0, 0};
-		if (owner >= 0)
-		{
-			zown = plane_at(w.tri_rec[owner].xZ, x, y);
+		auto pixel_base = [&]() {
+			if (owner >= 0)
+			{
+				zown = plane_at(w.tri_rec[owner].xZ, x, y);
 #pragma unroll
-			for (int cc = 0; cc < CH; cc++)
-				if (cc < C)
-					base[cc] = kind == KIND_TEXTURED ? textured_channel(texture, tap, cc) * L : interp_channel(planes, cc, x, y, false, 0.0);
-		}
-		else if (inb)
-		{
+				for (int cc = 0; cc < CH; cc++)
+					if (cc < C)
+						base[cc] = kind == KIND_TEXTURED ? textured_channel(texture, tap, cc) * L : interp_channel(planes, cc, x, y, false, 0.0);
+			}
+			else if (inb)
+			{
 #pragma unroll
-			for (int cc = 0; cc < CH; cc++)
-				if (cc < C)
-					base[cc] = background_channel<PixT>(p, view, pix, cc);
-		}
-		// pass A, far -> near: which edges are drawn over this pixel (bit j of tm[b] = edge 32 b + j in blending order)
-		// and the antialiased colour they leave
+				for (int cc = 0; cc < CH; cc++)
+					if (cc < C)
+						base[cc] = background_channel<PixT>(p, view, pix, cc);
+			}
+		};
+		// pass A, far -> near: which edges are drawn over this pixel (bit j of tm[b] = edge 16 b + j in blending order)
+		// and the antialiased colour they leave -- read back when the forward raster saved its own sweep of this tile
 		uint32_t tm[EMAX / TB] = {0, 0, 0, 0, 0, 0, 0, 0};
 		static_assert(EMAX / TB == 8, "tm[] initialiser");
-		double cur[CH];
-#pragma unroll
-		for (int cc = 0; cc < CH; cc++)
-			cur[cc] = base[cc];
+		double cur[CH] = {0, 0, 0, 0};
 		const int nbatch = (n_edges + TB - 1) / TB;
-		for (int b = 0; b < nbatch; b++)
+		bool have_base = !sweep_saved;
+		if (sweep_saved)
+		{
+			const char *slot = w.edge_sweep + (size_t)(sweep_slot - 1) * SWEEP_BYTES;
+#pragma unroll
+			for (int cc = 0; cc < CH; cc++)
+				cur[cc] = ((const double *)slot)[cc * 64 + lane];
+#pragma unroll
+			for (int q = 0; q < EMAX / TB; q++)
+				tm[q] = q < nbatch ? ((const uint16_t *)(slot + CH * 64 * sizeof(double)))[q * 64 + lane] : 0u;
+		}
+		else
+		{
+			pixel_base();
+#pragma unroll
+			for (int cc = 0; cc < CH; cc++)
+				cur[cc] = base[cc];
+		}
+		for (int b = 0; b < nbatch && !sweep_saved; b++)
 		{
 			const int first = b * TB, nb = n_edges - first < TB ? n_edges - first : TB;
 			const uint32_t ecov = stage_edge_batch(*(WaveLds *)&S, *es, w, P, first, nb, lane, x0, y0, W, inb);
@@ -2482,7 +2533,7 @@ __device__ __forceinline__ void bwd_fast_tile(const KParams &p, const ViewPtrs &
 		for (int b = nbatch - 1; b >= 0; b--)
 		{
 			const int first = b * TB, nb = n_edges - first < TB ? n_edges - first : TB;
-			if (nbatch > 1) // with a single batch the records staged by pass A are still in LDS
+			if (nbatch > 1 || sweep_saved) // with a single batch the records staged by pass A (if it ran) are still in LDS
 			{
 				lds_sync();
 				if (lane < nb)
@@ -2527,6 +2578,14 @@ __device__ __forceinline__ void bwd_fast_tile(const KParams &p, const ViewPtrs &
 				}
 				if (__ballot(need_replay))
 				{ // measure-zero event (pixel centre within 1e-6 sigma of the edge line): records straight from memory
+					if (!have_base)
+					{
+						pixel_base();
+						have_base = true;
+					}
+#pragma unroll
+					for (int cc = 0; cc < CH; cc++)
+						prev[cc] = need_replay ? base[cc] : prev[cc];
 					const int upto = first + r;
 					for (int q = 0; q < upto; q++)
 					{
