@@ -1559,7 +1559,6 @@ __global__ __launch_bounds__(64 * WPB, 5) void raster_fwd_fast_kernel(KParams p)
 		if (n_edges > 0)
 		{
 			static_assert(EMAX == 128 && TB == 16, "layout of the saved masks: one 16-bit word per batch of 16 edges");
-			uint16_t *sweep_masks = (uint16_t *)(w.edge_sweep + (size_t)(sweep_slot ? sweep_slot - 1 : 0) * SWEEP_BYTES + CH * 64 * sizeof(double));
 			const EdgeRec *erec = (const EdgeRec *)S.rec;
 			for (int first = 0; first < n_edges; first += TB)
 			{
@@ -1595,7 +1594,8 @@ __global__ __launch_bounds__(64 * WPB, 5) void raster_fwd_fast_kernel(KParams p)
 					}
 				}
 				if (sweep_slot) // bit j: edge first + j of the blending order is drawn over this pixel
-					sweep_masks[(first / TB) * 64 + lane] = (uint16_t)drawn_batch;
+					((uint16_t *)(w.edge_sweep + (size_t)(sweep_slot - 1) * SWEEP_BYTES + CH * 64 * sizeof(double)))[(first / TB) * 64 + lane] =
+						(uint16_t)drawn_batch;
 			}
 			if (sweep_slot)
 			{ // with the masks, what the adjoint's forward sweep would recompute: the antialiased colour in double
