@@ -2784,18 +2784,9 @@ __global__ __launch_bounds__(PRIM_BLOCK) void finalize_kernel(KParams p)
 			return;
 		const TriRec &rec = w.tri_rec[k];
 		double *acc = w.tri_acc + (size_t)k * 3 * P;
-		// the accumulators are requested together with the record's flags (one memory round trip less for the triangles that
-		// go on; the culled half wastes a 96-byte read)
-		double acc_local[12];
-#pragma unroll
-		for (int i = 0; i < 12; i++)
-			acc_local[i] = i < 3 * P ? acc[i] : 0.0;
 		if (!rec.front || rec.kind == KIND_NONE)
 			return; // culled triangles own no accumulators
-		if (P <= 4)
-			finalize_triangle(s, g, k, rec, acc_local, DeviceAdd());
-		else
-			finalize_triangle(s, g, k, rec, acc, DeviceAdd());
+		finalize_triangle(s, g, k, rec, acc, DeviceAdd());
 		for (int i = 0; i < 3 * P; i++)
 			acc[i] = 0; // self-cleaning accumulators
 		return;
