@@ -59,7 +59,8 @@ constexpr int LIST_KINDS = 3; // edge tiles, many-edged tiles, first tiles of th
 // kernel starts with the reverse sweep instead of repeating the forward one (half of its time per tile).
 constexpr int SAVE_SUB = 512;
 constexpr uint32_t SWEEP_SAVED = 0x80000000u; // flag in edge_saved[tile]
-constexpr size_t SWEEP_BYTES = 64 * (CH * sizeof(double) + (128 / 16) * sizeof(uint16_t)); // 3 KB per tile: cur[CH][64], masks[8][64]
+constexpr size_t SWEEP_ORDER = 64 * (CH * sizeof(double) + (128 / 16) * sizeof(uint16_t)); // offset of the saved blending order
+constexpr size_t SWEEP_BYTES = SWEEP_ORDER + 128 * sizeof(uint32_t); // 3.5 KB per tile: cur[CH][64], masks[8][64], order[128]
 
 struct WsHeader // 64 bytes per view at the start of the view's workspace
 {
@@ -1559,6 +1560,9 @@ __global__ __launch_bounds__(64 * WPB, 5) void raster_fwd_fast_kernel(KParams p)
 		if (n_edges > 0)
 		{
 			static_assert(EMAX == 128 && TB == 16, "layout of the saved masks: one 16-bit word per batch of 16 edges");
+			if (sweep_slot) // the blending order of the tile's edges: the adjoint need not gather and sort them again
+				for (int i = lane; i < n_edges; i += 64)
+					((uint32_t *)(w.edge_sweep + (size_t)(sweep_slot - 1) * SWEEP_BYTES + SWEEP_ORDER))[i] = s_es[wave].sorted[i];
 			const EdgeRec *erec = (const EdgeRec *)S.rec;
 			for (int first = 0; first < n_edges; first += TB)
 			{
@@ -2404,7 +2408,16 @@ __device__ __forceinline__ void bwd_fast_tile(const KParams &p, const ViewPtrs &
 #define DR_TRACE(i)
 #endif
 	int n_edges = 0;
-	if (EDGES)
+	if (EDGES && sweep_saved)
+	{ // the forward saved the blending order with its sweep
+		const uint32_t *order = (const uint32_t *)(w.edge_sweep + (size_t)(sweep_slot - 1) * SWEEP_BYTES + SWEEP_ORDER);
+		lds_sync();
+		for (int i = lane; i < nedge; i += 64)
+			es->sorted[i] = order[i];
+		lds_sync();
+		n_edges = nedge;
+	}
+	else if (EDGES)
 		n_edges = gather_sorted_edges(*es, w, p, tile, nedge, lane);
 	DR_TRACE(2);
 	if (EDGES && n_edges < 0)
