@@ -53,14 +53,22 @@ constexpr int PRIO_EDGES = 8; // tiles with more edges than this are also listed
 // The block that finds its own tile flagged leaves it alone and clears the flag (nobody else reads it).
 constexpr int FIRST_PRIMS = 8;
 constexpr int FWD_FIRST = 512; // listed tiles per view (NSUB sub-lists of FWD_FIRST / NSUB)
-constexpr int LIST_KINDS = 3; // edge tiles, many-edged tiles, first tiles of the forward
+constexpr int LIST_KINDS = 4; // edge tiles, tiles with > PRIO_EDGES edges, first tiles of the forward, tiles with > TB edges
 // The forward sweep over a tile's edges (pass 2) leaves, per pixel, the antialiased colour in double and the mask of the
 // edges drawn: the forward raster saves both for the first SAVE_SUB edge tiles of every sub-list, so that the adjoint's edge
 // kernel starts with the reverse sweep instead of repeating the forward one (half of its time per tile).
 constexpr int SAVE_SUB = 512;
 constexpr uint32_t SWEEP_SAVED = 0x80000000u; // flag in edge_saved[tile]
 constexpr size_t SWEEP_ORDER = 64 * (CH * sizeof(double) + (128 / 16) * sizeof(uint16_t)); // offset of the saved blending order
-constexpr size_t SWEEP_BYTES = SWEEP_ORDER + 128 * sizeof(uint32_t); // 3.5 KB per tile: cur[CH][64], masks[8][64], order[128]
+constexpr size_t SWEEP_SNAP = SWEEP_ORDER + 128 * sizeof(uint32_t);   // offset of the word: 1 + index of the tile's snapshots, 0: none
+constexpr size_t SWEEP_BYTES = SWEEP_SNAP + 64;						   // 3.6 KB per tile: cur[CH][64], masks[8][64], order[128], word
+// A tile with more than one batch of edges is the long pole of the adjoint's edge kernel (a 50-edge tile: 30 us of dependent
+// arithmetic).  For up to SNAP_CAP such tiles per view the forward also saves the colour after every batch, so that every
+// batch of the reverse sweep can be given to a wavefront of its own (it starts from the colour before its batch, and from the
+// gradient scaled by the transparencies of the nearer edges drawn over the pixel).
+constexpr int SNAP_CAP = 256;
+constexpr int CHUNKS = 128 / 16; // batches of a tile = wavefronts that may share its reverse sweep
+constexpr size_t SNAP_BYTES = (CHUNKS - 1) * CH * 64 * sizeof(double);
 
 struct WsHeader // 64 bytes per view at the start of the view's workspace
 {
@@ -72,14 +80,15 @@ struct WsHeader // 64 bytes per view at the start of the view's workspace
 	uint32_t cur;			// parity used by the forward whose state the workspace holds (written by its set-up kernel)
 	uint32_t needed_max;	// sticky: largest spill count ever seen (the host compares it with the pool capacity)
 	uint32_t heavy_count[2]; // tiles the fast adjoint kernel deferred to raster_bwd_heavy_kernel (parity of the adjoint's forward)
-	uint32_t pad[7];
+	uint32_t snap_count[2];	 // tiles whose forward sweep is also saved batch by batch (edge_snap), by forward parity
+	uint32_t pad[5];
 };
 static_assert(sizeof(WsHeader) == 64, "");
 
 struct Layout
 {
 	size_t hdr, tri_rec, tri_planes, tri_acc, edge_rec, edge_planes, edge_acc, tri_cnt, edge_cnt, edge_saved, tri_list, edge_list, tri_pool,
-		edge_pool, face_id, heavy_list, edge_tile_cnt, edge_tiles, first_flag, edge_slot, edge_sweep, view_bytes;
+		edge_pool, face_id, heavy_list, edge_tile_cnt, edge_tiles, first_flag, edge_slot, edge_sweep, edge_snap, view_bytes;
 	uint32_t tri_pool_cap, edge_pool_cap;
 	int tiles_x, tiles_y, ntiles, P, sub_cap, save_sub;
 };
@@ -126,6 +135,7 @@ Layout make_layout(int T, int H, int W, int C, size_t pool_pairs)
 	L.edge_slot = take(sizeof(uint32_t) * L.ntiles); // 1 + index of the tile's slot in edge_sweep, 0: none
 	L.save_sub = SAVE_SUB < L.sub_cap ? SAVE_SUB : L.sub_cap; // saved sweeps per sub-list
 	L.edge_sweep = take(SWEEP_BYTES * NSUB * (size_t)L.save_sub);
+	L.edge_snap = take(SNAP_BYTES * SNAP_CAP);
 	L.view_bytes = o;
 	return L;
 }
@@ -167,7 +177,7 @@ struct ViewPtrs
 	int32_t *face_id;
 	uint32_t *heavy_list;
 	uint32_t *edge_slot;
-	char *edge_sweep;
+	char *edge_sweep, *edge_snap;
 	uint32_t *first_flag;				  // 1: the tile is on the list of tiles the forward rasterizes first
 	uint32_t *edge_tile_cnt, *edge_tiles; // tiles with silhouette edges: NSUB counters per epoch parity, NSUB sub-lists of sub_cap tiles
 };
@@ -197,6 +207,7 @@ __device__ __forceinline__ ViewPtrs view_ptrs(const KParams &p, int view)
 	v.first_flag = (uint32_t *)(b + p.L.first_flag);
 	v.edge_slot = (uint32_t *)(b + p.L.edge_slot);
 	v.edge_sweep = b + p.L.edge_sweep;
+	v.edge_snap = b + p.L.edge_snap;
 	return v;
 }
 
@@ -512,6 +523,7 @@ __global__ __launch_bounds__(PRIM_BLOCK) void setup_bin_kernel(KParams p)
 		w.hdr->tri_spill[1 - cur] = 0;
 		w.hdr->edge_spill[1 - cur] = 0;
 		w.hdr->heavy_count[1 - cur] = 0;
+		w.hdr->snap_count[1 - cur] = 0;
 	}
 	if (item < LIST_KINDS * NSUB)
 		w.edge_tile_cnt[((1 - cur) * LIST_KINDS * NSUB + item) * CNT_STRIDE] = 0;
@@ -554,15 +566,15 @@ __global__ __launch_bounds__(PRIM_BLOCK) void setup_bin_kernel(KParams p)
 	// on its first edge a tile joins the list the adjoint's edge kernel walks; on its (PRIO_EDGES + 1)-th also the list of
 	// the long tiles that kernel starts with (the kernel lasts as long as its slowest tile)
 	auto listed = [&](int tile, uint32_t got) {
-		if (got != 0 && got != (uint32_t)PRIO_EDGES)
+		if (got != 0 && got != (uint32_t)PRIO_EDGES && got != 16u)
 			return;
-		const int sub = (got ? NSUB : 0) + tile % NSUB;
+		const int sub = (got == 0 ? 0 : (got == 16u ? 3 * NSUB : NSUB)) + tile % NSUB;
 		const uint32_t at = atomicAdd(&w.edge_tile_cnt[(cur * LIST_KINDS * NSUB + sub) * CNT_STRIDE], 1u);
 		w.edge_tiles[(size_t)sub * p.L.sub_cap + at] = (uint32_t)tile;
 		if (got == 0) // a place for the forward sweep of the tile (always written: a stale value must never be read)
 			w.edge_slot[tile] = at < (uint32_t)p.L.save_sub ? (uint32_t)sub * p.L.save_sub + at + 1u : 0u;
-		static_assert(PRIO_EDGES == FIRST_PRIMS, "one threshold for both lists");
-		if (got && p.first_tiles)
+		static_assert(PRIO_EDGES == FIRST_PRIMS && PRIO_EDGES != 16, "one threshold for both lists; 16 = TB, one batch of edges");
+		if (got == (uint32_t)PRIO_EDGES && p.first_tiles)
 			claim_first_tile(p, w, cur, tile);
 	};
 	// A primitive whose bounding box needs more than COOP_BLOCKS blocks of 3 x 3 tiles is not binned by its own thread
@@ -1560,9 +1572,22 @@ __global__ __launch_bounds__(64 * WPB, 5) void raster_fwd_fast_kernel(KParams p)
 		if (n_edges > 0)
 		{
 			static_assert(EMAX == 128 && TB == 16, "layout of the saved masks: one 16-bit word per batch of 16 edges");
-			if (sweep_slot) // the blending order of the tile's edges: the adjoint need not gather and sort them again
+			uint32_t snap = 0; // 1 + index of this tile's per-batch snapshots
+			if (sweep_slot)
+			{ // the blending order of the tile's edges: the adjoint need not gather and sort them again
 				for (int i = lane; i < n_edges; i += 64)
 					((uint32_t *)(w.edge_sweep + (size_t)(sweep_slot - 1) * SWEEP_BYTES + SWEEP_ORDER))[i] = s_es[wave].sorted[i];
+				if (n_edges > TB)
+				{
+					uint32_t at = 0;
+					if (lane == 0)
+						at = atomicAdd(&w.hdr->snap_count[w.hdr->cur], 1u);
+					at = (uint32_t)uniform((int)at);
+					snap = at < (uint32_t)SNAP_CAP ? at + 1 : 0u;
+				}
+				if (lane == 0)
+					*(uint32_t *)(w.edge_sweep + (size_t)(sweep_slot - 1) * SWEEP_BYTES + SWEEP_SNAP) = snap;
+			}
 			const EdgeRec *erec = (const EdgeRec *)S.rec;
 			for (int first = 0; first < n_edges; first += TB)
 			{
@@ -1600,6 +1625,13 @@ __global__ __launch_bounds__(64 * WPB, 5) void raster_fwd_fast_kernel(KParams p)
 				if (sweep_slot) // bit j: edge first + j of the blending order is drawn over this pixel
 					((uint16_t *)(w.edge_sweep + (size_t)(sweep_slot - 1) * SWEEP_BYTES + CH * 64 * sizeof(double)))[(first / TB) * 64 + lane] =
 						(uint16_t)drawn_batch;
+				if (snap && first + TB < n_edges)
+				{ // the colour after this batch: where the reverse sweep of the previous (farther) batches starts
+					double *shot = (double *)(w.edge_snap + (size_t)(snap - 1) * SNAP_BYTES) + (size_t)(first / TB) * CH * 64;
+#pragma unroll
+					for (int cc = 0; cc < CH; cc++)
+						shot[cc * 64 + lane] = col[cc];
+				}
 			}
 			if (sweep_slot)
 			{ // with the masks, what the adjoint's forward sweep would recompute: the antialiased colour in double
@@ -2378,8 +2410,8 @@ __device__ __forceinline__ void owner_adjoint(const KParams &p, const ViewPtrs &
 // registers, twice the resident waves to hide the memory latency); EDGES = true: the tiles that have some.
 template <class PixT, bool EDGES>
 __device__ __forceinline__ void bwd_fast_tile(const KParams &p, const ViewPtrs &w, int view, int tx, int ty, int lane, BwdLds &S, EdgeSort *es, // es: only for EDGES
-											  int skip_above = 0x7fffffff)
-{
+											  int skip_above = 0x7fffffff, int chunk = -1)
+{ // chunk >= 0: this wavefront is one of CHUNKS that may share the reverse sweep of a many-edged tile (batch `chunk` of it)
 	const int W = p.W, H = p.H, C = p.C, P = p.L.P;
 	const PixT *texture = (const PixT *)p.texture;
 	PixT *texture_b = (PixT *)p.texture_b;
@@ -2400,6 +2432,16 @@ __device__ __forceinline__ void bwd_fast_tile(const KParams &p, const ViewPtrs &
 		nedge = 0;
 	if ((nedge > 0) != EDGES || nedge > skip_above)
 		return; // the other kernel's tile (or one this kernel has already taken from its list of long tiles)
+	// batches of the reverse sweep this wavefront runs: all of them, or -- when the forward saved the colour after every batch
+	// -- only batch `chunk`
+	const int nbatch_all = (nedge + TB - 1) / TB;
+	uint32_t snap = 0;
+	if (EDGES && sweep_saved && chunk >= 0 && nbatch_all > 1)
+		snap = (uint32_t)uniform((int)*(const uint32_t *)(w.edge_sweep + (size_t)(sweep_slot - 1) * SWEEP_BYTES + SWEEP_SNAP));
+	const bool chunked = snap != 0;
+	if (EDGES && (chunked ? chunk >= nbatch_all : chunk > 0))
+		return; // nothing for this wavefront: the tile has fewer batches, or its sweep is not shared
+	const int b_hi = chunked ? chunk : nbatch_all - 1, b_lo = chunked ? chunk : 0;
 #ifdef DR_TILE_TRACE
 	uint32_t tr[8] = {0x7fc0beefu, (uint32_t)nedge, 0, 0, 0, 0, 0, 0};
 	const uint64_t tr0 = __builtin_readcyclecounter();
@@ -2494,9 +2536,13 @@ __device__ __forceinline__ void bwd_fast_tile(const KParams &p, const ViewPtrs &
 		if (sweep_saved)
 		{
 			const char *slot = w.edge_sweep + (size_t)(sweep_slot - 1) * SWEEP_BYTES;
+			// the colour after the last batch this wavefront un-blends: the tile's final colour, or a snapshot
+			const double *after = (chunked && b_hi < nbatch - 1)
+									  ? (const double *)(w.edge_snap + (size_t)(snap - 1) * SNAP_BYTES) + (size_t)b_hi * CH * 64
+									  : (const double *)slot;
 #pragma unroll
 			for (int cc = 0; cc < CH; cc++)
-				cur[cc] = ((const double *)slot)[cc * 64 + lane];
+				cur[cc] = after[cc * 64 + lane];
 #pragma unroll
 			for (int q = 0; q < EMAX / TB; q++)
 				tm[q] = q < nbatch ? ((const uint16_t *)(slot + CH * 64 * sizeof(double)))[q * 64 + lane] : 0u;
@@ -2542,11 +2588,28 @@ __device__ __forceinline__ void bwd_fast_tile(const KParams &p, const ViewPtrs &
 				tm[bb] = bb == b ? tmb : tm[bb];
 		}
 		DR_TRACE(3);
+		if (chunked && b_hi < nbatch - 1)
+		{ // the gradient that reaches batch b_hi has been attenuated by every nearer edge drawn over the pixel
+			for (int r = (b_hi + 1) * TB; r < n_edges; r++)
+			{
+				uint32_t bits = 0;
+#pragma unroll
+				for (int bb = 0; bb < EMAX / TB; bb++)
+					bits = bb == (r / TB) ? tm[bb] : bits;
+				const double Tq = plane_at(w.edge_rec[es->sorted[r]].x2t, x, y);
+				if ((bits >> (r % TB)) & 1u)
+				{
+#pragma unroll
+					for (int cc = 0; cc < CH; cc++)
+						g[cc] *= Tq;
+				}
+			}
+		}
 		// pass B, near -> far (H.h:2961-3052)
-		for (int b = nbatch - 1; b >= 0; b--)
+		for (int b = b_hi; b >= b_lo; b--)
 		{
 			const int first = b * TB, nb = n_edges - first < TB ? n_edges - first : TB;
-			if (nbatch > 1 || sweep_saved) // with a single batch the records staged by pass A (if it ran) are still in LDS
+			if (b < nbatch - 1 || sweep_saved) // the records of pass A's last batch (if it ran) are still in LDS
 			{
 				lds_sync();
 				if (lane < nb)
@@ -2697,6 +2760,8 @@ __device__ __forceinline__ void bwd_fast_tile(const KParams &p, const ViewPtrs &
 	}
 
 	DR_TRACE(4);
+	if (EDGES && b_lo > 0)
+		return; // the wavefront that ran batch 0 (the farthest edges) holds the gradient that reaches pass 1
 	// ---- adjoint of pass 1: g now belongs to the triangle that owns the pixel
 	owner_adjoint<PixT>(p, w, lane, x, y, owner, kind, g, tap, L, (double *)&S.rec[0], (uint32_t *)&S.cover[0][0]);
 #ifdef DR_TILE_TRACE
@@ -2743,14 +2808,26 @@ __global__ __launch_bounds__(64, 2) void raster_bwd_edge_kernel(KParams p)
 	const uint32_t *cnt0 = w.edge_tile_cnt, *cnt1 = w.edge_tile_cnt + (size_t)LIST_KINDS * NSUB * CNT_STRIDE;
 	const uint32_t cur = w.hdr->cur;
 	const uint32_t a0 = cnt0[sub * CNT_STRIDE], l0 = cnt0[(NSUB + sub) * CNT_STRIDE], a1 = cnt1[sub * CNT_STRIDE], l1 = cnt1[(NSUB + sub) * CNT_STRIDE];
-	const uint32_t n_all = cur ? a1 : a0, n_long = cur ? l1 : l0;
+	const uint32_t v0 = cnt0[(3 * NSUB + sub) * CNT_STRIDE], v1 = cnt1[(3 * NSUB + sub) * CNT_STRIDE];
+	const uint32_t n_all = cur ? a1 : a0, n_long = cur ? l1 : l0, n_multi = (cur ? v1 : v0) * CHUNKS;
 	const uint32_t *all = w.edge_tiles + (size_t)sub * p.L.sub_cap, *longs = w.edge_tiles + (size_t)(NSUB + sub) * p.L.sub_cap;
+	const uint32_t *multi = w.edge_tiles + (size_t)(3 * NSUB + sub) * p.L.sub_cap;
+	// Work items of a sub-list: first the tiles with more than one batch of edges, each offered to CHUNKS wavefronts (one per
+	// batch of its reverse sweep; those the tile has no use for return at once), then the other tiles with more than
+	// PRIO_EDGES edges, then the rest.
 #pragma nounroll
-	for (uint32_t i = blockIdx.y / NSUB; i < n_long + n_all; i += stride)
+	for (uint32_t i = blockIdx.y / NSUB; i < n_multi + n_long + n_all; i += stride)
 	{
-		const bool from_long = i < n_long;
-		const int tile = uniform((int)(from_long ? longs[i] : all[i - n_long]));
-		bwd_fast_tile<PixT, true>(p, w, view, tile % p.L.tiles_x, tile / p.L.tiles_x, lane, s_lds, &s_es, from_long ? 0x7fffffff : PRIO_EDGES);
+		int tile, lo, hi, chunk = -1; // the tile is processed when lo < its edge count <= hi
+		if (i < n_multi)
+			tile = (int)multi[i / CHUNKS], chunk = (int)(i % CHUNKS), lo = TB, hi = 0x7fffffff;
+		else if (i < n_multi + n_long)
+			tile = (int)longs[i - n_multi], lo = 0, hi = TB;
+		else
+			tile = (int)all[i - n_multi - n_long], lo = 0, hi = PRIO_EDGES;
+		tile = uniform(tile);
+		bwd_fast_tile<PixT, true>(p, w, view, tile % p.L.tiles_x, tile / p.L.tiles_x, lane, s_lds, &s_es, hi, chunk);
+		(void)lo; // a listed tile always has more edges than the threshold of its list
 		lds_sync();
 	}
 }
