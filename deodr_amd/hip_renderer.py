@@ -211,7 +211,7 @@ class HipRasterizer:
             obs_t = obs.to(device=ds.device, dtype=pd).reshape(n, H, W, Cc).contiguous()
             err = torch.empty((n, H, W), dtype=pd, device=ds.device)
         sc = ds.c_struct()
-        while True:
+        for _attempt in range(16):
             _check(lib().deodr_hip_render_scene(C.byref(sc), _ptr(image), _ptr(z), float(sigma), int(antialiase_error), _ptr(obs_t),
                                                 _ptr(err), _ptr(self.workspace), self.nbytes, _stream()))  # fmt: skip
             if check_overflow is False or (check_overflow is None and self._checked):
@@ -222,6 +222,8 @@ class HipRasterizer:
             if not over.value:
                 break
             self._alloc(max(2 * int(need.value), 1024))  # regrow (zero-filled) and render again
+        else:  # the pool doubles every time: this is not a scene that needs more room, something is wrong
+            raise RuntimeError("deodr_hip: the spill pool still overflows after 16 regrows")
         self._last = (ds, float(sigma), bool(antialiase_error), obs_t, image, err)
         return (image, z, err) if antialiase_error else (image, z)
 
