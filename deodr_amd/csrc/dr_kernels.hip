@@ -1709,6 +1709,10 @@ __global__ __launch_bounds__(64 * WPB, 5) void raster_fwd_fast_kernel(KParams p)
 			double g[CH];
 #pragma unroll
 			for (int cc = 0; cc < CH; cc++)
+				asm volatile("" : "+v"(ob[cc])); // the observation stays in the pixel type until here: converted to double right
+												 // after its load, it was spilled (four doubles per lane) through the whole of pass 1
+#pragma unroll
+			for (int cc = 0; cc < CH; cc++)
 				g[cc] = (cc < C && inb) ? 2 * ((double)(PixT)col[cc] - (double)ob[cc]) : 0.0;
 			lds_sync();
 			owner_adjoint<PixT>(p, w, lane, x, y, st.kbest, st.kbest >= 0 ? st.kind : (int)KIND_NONE, g, tap, L, (double *)&S.rec[0],
