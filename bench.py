@@ -11,11 +11,14 @@ in HBM (+, for N > 1, ONE RCCL all-reduce of the shared-parameter gradient, the 
 multi-view fitter does on the host at deodr/mesh_fitter.py:518-527).  Views shard across ranks with no data-path
 collective, per-GPU work is fixed as N grows ("weak").
 
-The JSON line carries two extra objects:
+The JSON line carries, besides the driver's contract:
   roofline      dominant kernel (largest summed time): achieved = algorithmic bytes per launch (float32
-                buffers) / average launch duration measured with hipEvents on the launch stream inside the timed region
-  cpu_baseline  the reference's own CPU path (oracle/_ref = unmodified header, g++ -O2, one thread) on the host of the GPU
-                box, timed on a bounded sample of the same workload (rank 0, N = 1 only)
+                buffers) / average launch duration measured with hipEvents on the launch stream inside the timed region;
+                `frac_necessary` = the same with the bytes that kernel itself has to move (counted from the tile bitmap of
+                the run); `whole_step` = all of SURVEY 8d's bytes / the step time -- the number the north star's 40 % is about
+  single_view   the same fit step for ONE view (latency case): eager and replayed from a captured HIP graph
+  cpu_baseline  the reference's own CPU path (oracle/_ref = unmodified header, g++ -O2) on the host of the GPU box: one
+                thread, and one process per view on min(views, cores) cores; bounded samples (rank 0, N = 1 only)
 """
 
 import argparse
@@ -52,14 +55,21 @@ def algorithmic_bytes(H, W, C, T, V, n_views, fused):
     return {k: v * n_views for k, v in per_view.items()}
 
 
-def cpu_baseline(scene, image_b, budget_s=12.0):
-    """The reference CPU path on this host: median-free throughput over a bounded sample (about `budget_s` of CPU work)."""
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def _cpu_fit_loop(scene, image_b, budget_s, copies):
+    """reps x (renderScene + renderScene_B) of one view on the reference CPU path -> (reps, seconds)."""
     from oracle import api
 
-    ref = api.ref()
-    kind = "reference"
-    if ref is None:
-        ref, kind = api.port(), "port"
+    ref = api.ref() or api.port()
     H, W, Cc = scene.height, scene.width, scene.nb_colors
     image, z = np.zeros((H, W, Cc)), np.zeros((H, W))
     ref.renderSceneCpp(scene, 1.0, image, z)  # warm-up (page-faults the buffers)
@@ -68,13 +78,101 @@ def cpu_baseline(scene, image_b, budget_s=12.0):
         scene.clear_gradients()
         t0 = time.perf_counter()
         ref.renderSceneCpp(scene, 1.0, image, z)
-        ref.renderSceneBCpp(scene, 1.0, image, z, image_b.copy())  # the adjoint un-antialiases `image` in place, as the reference
+        # the adjoint un-antialiases `image` and rescales `image_b` in place: the reference's Scene2D.render_backward hands it
+        # copies (make_copies=True, dr.py:665-699)
+        ref.renderSceneBCpp(scene, 1.0, image.copy() if copies else image, z, image_b.copy() if copies else image_b)
         t_used += time.perf_counter() - t0
         reps += 1
+    return reps, t_used
+
+
+def _cpu_worker(args):
+    angle, size, budget_s = args
+    sys.path.insert(0, ROOT)
+    from deodr_amd import scenes
+
+    scene = scenes.sphere_scene(size=size, angle=angle)
+    image_b = np.random.RandomState(3).rand(size, size, scene.nb_colors) - 0.5
+    return _cpu_fit_loop(scene, image_b, budget_s, True)
+
+
+def cpu_baseline(scene, image_b, poses, size):
+    """The reference CPU path on this host, bounded samples: one thread (the reference is single-threaded) with and without
+    the Python-side copies, then one process per view on min(views, cores) cores."""
+    from oracle import api
+
+    kind = "reference" if api.ref() is not None else "port"
+    H, W = scene.height, scene.width
+    reps, t = _cpu_fit_loop(scene, image_b, 8.0, True)
+    reps_nc, t_nc = _cpu_fit_loop(scene, image_b.copy(), 3.0, False)
+    out = {
+        "value": reps * H * W / t / 1e6, "unit": "Mpixels/s", "cores": 1, "kind": kind,
+        "sample": f"{reps} x (renderScene + renderScene_B) of ONE view of the same workload ({t:.1f} s, oracle/_ref = unmodified "
+                  f"reference header, g++ -O2 -fwrapv, single thread, with the image / image_b copies of Scene2D.render_backward)",
+        "without_copies_Mpixels_s": reps_nc * H * W / t_nc / 1e6,
+        "cpu_model": cpu_model(), "logical_cores": os.cpu_count(),
+    }  # fmt: skip
+    try:
+        import multiprocessing as mp
+
+        nproc = max(1, min(len(poses), os.cpu_count() or 1))
+        with mp.get_context("spawn").Pool(nproc) as pool:
+            res = pool.map(_cpu_worker, [(float(a), size, 5.0) for a in poses[:nproc]])
+        out["n_process"] = {
+            "value": sum(r for r, _ in res) * H * W / max(t for _, t in res) / 1e6, "unit": "Mpixels/s", "cores": nproc,
+            "sample": f"one process per view, {nproc} processes x ~5 s, views = the poses of the GPU batch",
+        }  # fmt: skip
+    except Exception as e:  # the single-thread figure is the contract; say why the other one is missing
+        out["n_process"] = {"value": None, "error": repr(e)}
+    return out
+
+
+def timed_steps(step, n):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        step()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / n
+
+
+def single_view_latency(scenes_mod, DeviceScene, HipRasterizer, dev, S, sigma, obs):
+    """One view per call: the latency case (a fit loop on a single image).  Eager launches and one HIP-graph replay per step."""
+    s = scenes_mod.sphere_scene(size=S, angle=0.0)
+    ds = DeviceScene(
+        s.faces, s.faces_uv, s.textured, s.shaded, s.uv, s.ij[None], s.depths[None], s.colors[None], s.shade[None],
+        s.edgeflags[None], S, S, texture=None, background_color=s.background_color, clockwise=s.clockwise,
+        vertex_dtype=torch.float64, pixel_dtype=torch.float32, device=dev,
+    )  # fmt: skip
+    Cc = ds.nb_colors
+    r = HipRasterizer.for_scene(ds)
+    image = torch.empty((1, S, S, Cc), dtype=torch.float32, device=dev)
+    z = torch.empty((1, S, S), dtype=torch.float32, device=dev)
+    grads = ds.zero_grads()
+    obs1 = obs[None].contiguous()
+    fit = lambda: r.render_fit(ds, obs1, sigma, grads=grads, out=(image, z), check_overflow=False, clear_grads=True)
+    r.render(ds, sigma, out=(image, z), check_overflow=True)
+    for _ in range(5):
+        fit()
+    eager = timed_steps(fit, 50)
+    graph = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        fit()
+    torch.cuda.current_stream().wait_stream(side)
+    with torch.cuda.graph(graph):
+        fit()
+    for _ in range(5):
+        graph.replay()
+    replay = timed_steps(graph.replay, 50)
+    T, V = ds.nb_triangles, int(ds.depths.shape[1])
+    alg = sum(algorithmic_bytes(S, S, Cc, T, V, 1, True).values())
+    best = min(eager, replay)
     return {
-        "value": reps * H * W / t_used / 1e6, "unit": "Mpixels/s", "cores": 1, "kind": kind,
-        "sample": f"{reps} x (renderScene + renderScene_B) of ONE view of the same workload ({t_used:.1f} s, "
-                  f"oracle/_ref = unmodified reference header, g++ -O2, single thread; host has {os.cpu_count()} logical cores)",
+        "workload": f"1 view {S}x{S} of the same scene per call (deodr_hip_render_scene_fit)", "ms_eager": eager * 1e3,
+        "ms_graph_replay": replay * 1e3, "Mpixels_s": S * S / best / 1e6, "alg_GBps": alg / best / 1e9,
+        "frac_of_hbm_peak": alg / best / 1e9 / HBM_PEAK_GBS,
     }  # fmt: skip
 
 
@@ -87,10 +185,16 @@ def main():
     ap.add_argument("--size", type=int, default=1024)
     ap.add_argument("--sigma", type=float, default=1.0, help="edge-overdraw width (the metric configuration uses 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--time-every", type=int, default=4, help="steps between two steps whose kernels are timed with hipEvents")
+    ap.add_argument("--no-single-view", action="store_true")
+    ap.add_argument("--time-every", type=int, default=4, help="steps between two steps whose kernels are timed with hipEvents (0: never)")
     ap.add_argument("--two-pass", action="store_true", help="render and render_backward as two calls (default: the fused fit step, same outputs)")
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed even for one rank (exercises the RCCL path)")
     args = ap.parse_args()
+
+    # Nothing outside the command line may change what is timed: the library reads no environment variable, and a variable
+    # that LOOKS like one of its former tuning knobs (or a library override used by tools/) is refused rather than ignored.
+    overrides = sorted(k for k in os.environ if k.startswith("DEODR_HIP_"))
+    assert not overrides, f"unset {overrides}: bench.py times the library as built, without overrides"
 
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
@@ -182,8 +286,8 @@ def main():
         torch.cuda.synchronize()
 
     # per-kernel hipEvents on every 4th step of the timed region (an event pair takes ~3 us of stream time: timing all
-    # five launches of every step would add ~10 % to the step being measured)
-    hr.lib().deodr_hip_profile_enable(0 if os.environ.get("DEODR_BENCH_NO_EVENTS") else args.time_every)
+    # launches of every step would add ~10 % to the step being measured)
+    hr.lib().deodr_hip_profile_enable(args.time_every)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -199,11 +303,9 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
-    # spill pool never overflowed during the run (deferred check, outside the timed region)
-    sc = ds.c_struct()
-    over, need = C.c_int(0), C.c_ulonglong(0)
-    hr.lib().deodr_hip_workspace_status(C.byref(sc), C.c_void_p(r.workspace.data_ptr()), r.nbytes, None, C.byref(over), C.byref(need))
-    assert not over.value, "spill pool overflowed during the benchmark"
+    # spill pool never overflowed and the scene was valid during the run (deferred check, outside the timed region)
+    over, need, errs = r.status(ds)
+    assert not over and not errs, "spill pool overflowed (or invalid scene) during the benchmark"
 
     if rank == 0:
         px = world * B * S * S * args.steps
@@ -220,22 +322,38 @@ def main():
         if os.path.exists(tpath):  # HBM bytes per launch from the last PMC run (tools/profile_round.sh), gfx950 correction applied
             traffic = (json.load(open(tpath)).get(dom) or {}).get("bytes_per_launch")
         kernel_ms = sum(v["avg_ms"] for v in per_kernel.values())
+        # what the forward raster itself has to move: image + z of every pixel, the observation of the non-empty tiles (fused
+        # step), owner ids of the tiles that hold edges (counted from the workspace of the run: tile bitmap, saved edge counts)
+        necessary = None
+        try:
+            nonempty, edge_tiles = hr.tile_census(r, ds)
+            necessary = 4 * (Cc + 1) * B * S * S + (0 if args.two_pass else 4 * Cc * 64 * nonempty) + 4 * 64 * (edge_tiles if not args.two_pass else B * S * S // 64)
+        except Exception as e:
+            print(f"bench: tile census unavailable ({e!r})", file=sys.stderr)
+        step_s = dt / args.steps
+        dom_ms = per_kernel[dom]["avg_ms"]
         out = {
             "metric": "Mpixels/s forward+backward, 1024^2 20k-tri scene", "value": px / dt / 1e6, "unit": "Mpixels/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": step_s * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"BASELINE configs[2]: {S}x{S}, {T}-triangle bumpy sphere, C={Cc} (RGB+depth), sigma=1, "
                                    f"{B} views per GPU per step, float32 pixel buffers / float64 vertex arrays, all-double arithmetic",
                        "step": "renderScene + renderScene_B (two calls)" if args.two_pass else "deodr_hip_render_scene_fit (forward + adjoint of sum (image - obs)^2, one call)",
-                       "views_per_gpu": B, "global_views": B * world,
+                       "views_per_gpu": B, "global_views": B * world, "env_overrides": overrides,
                        "parallelism": f"views sharded {B}/GPU" + (", 1 RCCL all-reduce of the shared gradient per step" if world > 1 else "")},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": per_kernel[dom]["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": (per_kernel[dom]["GBps"] or 0) / HBM_PEAK_GBS, "traffic": traffic,
-                         "whole_step_alg_GBps": sum(alg.values()) / (dt / args.steps) / 1e9,
-                         "kernel_time_fraction_of_step": kernel_ms / (dt / args.steps * 1e3), "per_kernel": per_kernel},
+                         "necessary_bytes": necessary if dom == "raster_fwd_kernel" else None,
+                         "frac_necessary": (necessary / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if (necessary and dom == "raster_fwd_kernel" and dom_ms > 0) else None,
+                         "whole_step": {"alg_bytes": sum(alg.values()), "GBps": sum(alg.values()) / step_s / 1e9,
+                                        "frac": sum(alg.values()) / step_s / 1e9 / HBM_PEAK_GBS},
+                         "whole_step_alg_GBps": sum(alg.values()) / step_s / 1e9,
+                         "kernel_time_fraction_of_step": kernel_ms / (step_s * 1e3), "per_kernel": per_kernel},
         }  # fmt: skip
+        if world == 1 and not args.no_single_view:
+            out["single_view"] = single_view_latency(scenes, DeviceScene, HipRasterizer, dev, S, args.sigma, obs)
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(views[0], 2 * (image[0] - obs).cpu().numpy().astype(np.float64))
+            out["cpu_baseline"] = cpu_baseline(views[0], 2 * (image[0] - obs).cpu().numpy().astype(np.float64), poses, S)
         result_line = json.dumps(out)
     else:
         result_line = None

@@ -6,14 +6,16 @@
 //                           Cull, depth sum, stencil + attribute planes in double and in registers (dr_prims.h), edge records,
 //                           binning into 8 x 8 tiles (all slot requests of a 3 x 3 block of tiles in flight; large boxes by
 //                           the whole wavefront), lists of edge tiles / many-primitive tiles, optional gradient clearing
-//   raster_fwd_fast_kernel  1 wavefront / tile, lane = pixel.  Pass 1 (z-buffered triangles staged 16 at a time through LDS,
-//                           exact scanline spans, winner = min (Z, index)), shading, pass 2 (ordered edge overdraw) fused in
-//                           registers, ONE write of image / z / owner per pixel.  FUSED: also the adjoint of pass 1 for the
-//                           sum-of-squares residual in tiles without edges (deodr_hip_render_scene_fit)
+//   raster_fwd_fast_kernel  1 wavefront / NON-EMPTY tile, lane = pixel (a wave whose tile received no primitive -- two out of
+//                           three -- learns it from one scalar load of the set-up kernel's tile bitmap and retires; the
+//                           background of those tiles is streamed by a few fill waves, 32 tiles each).  Pass 1 (z-buffered
+//                           triangles staged 16 at a time through LDS, exact scanline spans, winner = min (Z, index)),
+//                           shading of the winner, pass 2 (ordered edge overdraw) fused in registers, ONE write of image / z
+//                           (/ owner) per pixel.  FUSED: also the adjoint of pass 1 for the sum-of-squares residual in
+//                           tiles without edges (deodr_hip_render_scene_fit)
 //   raster_bwd_fast_kernel  (two-call path) adjoint of pass 1 in every tile without edges
 //   raster_bwd_edge_kernel  persistent waves over the listed edge tiles: adjoint of pass 2 (un-blend in reverse order, moments
 //                           by a transposing butterfly, one 15-lane atomic per edge and tile), then of pass 1
-//   raster_bwd_heavy_kernel the rare tiles with more than EMAX edges, generic code
 //   finalize_kernel         per primitive: moments -> plane adjoints -> 3x3-inverse adjoint -> vertex gradients
 //   raster_fwd_kernel / raster_bwd_kernel   the same algorithm without LDS staging: nb_colors > 4, antialiase_error
 //
@@ -23,11 +25,14 @@
 #include <hip/hip_runtime.h>
 
 #include <math.h>
+#include <stddef.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
+#include <mutex>
+#include <unordered_set>
 #include <utility>
 #include <vector>
 
@@ -66,6 +71,7 @@ constexpr size_t SWEEP_BYTES = SWEEP_SNAP + 64;						   // 3.6 KB per tile: cur[
 // arithmetic).  For up to SNAP_CAP such tiles per view the forward also saves the colour after every batch, so that every
 // batch of the reverse sweep can be given to a wavefront of its own (it starts from the colour before its batch, and from the
 // gradient scaled by the transparencies of the nearer edges drawn over the pixel).
+constexpr int ROW_GROUP = 2; // tile rows per strip dealt to an XCD by the raster kernels (xcd_strip_row)
 constexpr int SNAP_CAP = 256;
 constexpr int CHUNKS = 128 / 16; // batches of a tile = wavefronts that may share its reverse sweep
 constexpr size_t SNAP_BYTES = (CHUNKS - 1) * CH * 64 * sizeof(double);
@@ -79,18 +85,26 @@ struct WsHeader // 64 bytes per view at the start of the view's workspace
 	uint32_t epoch;			// number of forwards run on this workspace (advanced by one thread of the forward raster)
 	uint32_t cur;			// parity used by the forward whose state the workspace holds (written by its set-up kernel)
 	uint32_t needed_max;	// sticky: largest spill count ever seen (the host compares it with the pool capacity)
-	uint32_t heavy_count[2]; // tiles the fast adjoint kernel deferred to raster_bwd_heavy_kernel (parity of the adjoint's forward)
+	uint32_t scene_errors;	// sticky: DEODR_HIP_ERR_* bits raised by the set-up kernel (checkSceneValid's index checks, H.h:2700-2712)
+	uint32_t owners_partial; // 1: the last forward was the fused one (owner ids only written for the tiles that hold edges)
 	uint32_t snap_count[2];	 // tiles whose forward sweep is also saved batch by batch (edge_snap), by forward parity
-	uint32_t pad[5];
+	// view 0 only: maximum / union of needed_max / scene_errors over the views, so that the host polls ONE 64-byte block
+	uint32_t all_needed_max, all_scene_errors;
+	uint32_t pad[3];
 };
 static_assert(sizeof(WsHeader) == 64, "");
+static_assert(offsetof(WsHeader, all_needed_max) == 4 * DEODR_HIP_STATUS_WORD_NEEDED_PAIRS &&
+				  offsetof(WsHeader, all_scene_errors) == 4 * DEODR_HIP_STATUS_WORD_SCENE_ERRORS &&
+				  (int)dr::SCENE_ERR_FACES == DEODR_HIP_ERR_FACES && (int)dr::SCENE_ERR_FACES_UV == DEODR_HIP_ERR_FACES_UV &&
+				  (int)dr::SCENE_ERR_NO_TEXTURE == DEODR_HIP_ERR_NO_TEXTURE,
+			  "status block layout published in include/deodr_hip.h");
 
 struct Layout
 {
 	size_t hdr, tri_rec, tri_planes, tri_acc, edge_rec, edge_planes, edge_acc, tri_cnt, edge_cnt, edge_saved, tri_list, edge_list, tri_pool,
-		edge_pool, face_id, heavy_list, edge_tile_cnt, edge_tiles, first_flag, edge_slot, edge_sweep, edge_snap, view_bytes;
+		edge_pool, face_id, tile_bits, tri_flag, edge_tile_cnt, edge_tiles, first_flag, edge_slot, edge_sweep, edge_snap, view_bytes;
 	uint32_t tri_pool_cap, edge_pool_cap;
-	int tiles_x, tiles_y, ntiles, P, sub_cap, save_sub;
+	int tiles_x, tiles_y, ntiles, nwords, P, sub_cap, save_sub;
 };
 
 size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -127,7 +141,14 @@ Layout make_layout(int T, int H, int W, int C, size_t pool_pairs)
 	L.tri_pool = take(sizeof(uint2) * (size_t)L.tri_pool_cap);
 	L.edge_pool = take(sizeof(uint2) * (size_t)L.edge_pool_cap);
 	L.face_id = take(sizeof(int32_t) * (size_t)H * W);
-	L.heavy_list = take(sizeof(uint32_t) * L.ntiles);
+	// one bit per tile, set by whoever bins the first primitive into the tile; double-buffered by forward parity like the spill
+	// counters (the set-up kernel of a forward fills [cur] and clears [1 - cur]), so nobody ever clears a bit another wave reads
+	L.nwords = (L.ntiles + 31) / 32;
+	L.tile_bits = take(sizeof(uint32_t) * 2 * L.nwords);
+	// kind | front << 2 of every triangle of the last forward: what finalize_kernel needs to know about a triangle before it
+	// touches anything else (one coalesced byte per thread instead of a 128-byte record line per triangle, two out of three
+	// of which are culled)
+	L.tri_flag = take((size_t)T);
 	L.sub_cap = (L.ntiles + NSUB - 1) / NSUB;
 	L.edge_tile_cnt = take(sizeof(uint32_t) * 2 * LIST_KINDS * NSUB * CNT_STRIDE); // [epoch parity][kind][sub-list]
 	L.edge_tiles = take(sizeof(uint32_t) * LIST_KINDS * NSUB * (size_t)L.sub_cap);	// [kind][sub-list][sub_cap]
@@ -159,7 +180,6 @@ struct KParams
 	int first_tiles; // the staged forward with one tile per workgroup follows: flag and list the many-primitive tiles (FWD_FIRST)
 	int row_group;	 // tile rows per strip dealt to an XCD by the raster kernels (xcd_strip_row); 0: one band per XCD
 	int clear_grads; // the set-up kernel zeroes the per-view gradient arrays (a fit step that wants fresh gradients: no separate fills)
-	int debug; // ablation switches for profiling (DEODR_HIP_DEBUG), 0 in production
 	// workspace
 	char *ws;
 	Layout L;
@@ -175,7 +195,8 @@ struct ViewPtrs
 	uint32_t *tri_cnt, *edge_cnt, *edge_saved, *tri_list, *edge_list;
 	uint2 *tri_pool, *edge_pool;
 	int32_t *face_id;
-	uint32_t *heavy_list;
+	uint32_t *tile_bits;
+	uint8_t *tri_flag;
 	uint32_t *edge_slot;
 	char *edge_sweep, *edge_snap;
 	uint32_t *first_flag;				  // 1: the tile is on the list of tiles the forward rasterizes first
@@ -201,7 +222,8 @@ __device__ __forceinline__ ViewPtrs view_ptrs(const KParams &p, int view)
 	v.tri_pool = (uint2 *)(b + p.L.tri_pool);
 	v.edge_pool = (uint2 *)(b + p.L.edge_pool);
 	v.face_id = (int32_t *)(b + p.L.face_id);
-	v.heavy_list = (uint32_t *)(b + p.L.heavy_list);
+	v.tile_bits = (uint32_t *)(b + p.L.tile_bits);
+	v.tri_flag = (uint8_t *)(b + p.L.tri_flag);
 	v.edge_tile_cnt = (uint32_t *)(b + p.L.edge_tile_cnt);
 	v.edge_tiles = (uint32_t *)(b + p.L.edge_tiles);
 	v.first_flag = (uint32_t *)(b + p.L.first_flag);
@@ -239,6 +261,7 @@ __device__ __forceinline__ SceneView scene_view(const KParams &p, int view)
 	s.strict = p.strict;
 	s.persp = p.persp;
 	s.vtx_f64 = p.vtx_f64;
+	s.has_texture = p.texture != nullptr;
 	s.offset = p.offset;
 	s.sigma = p.sigma;
 	return s;
@@ -522,11 +545,15 @@ __global__ __launch_bounds__(PRIM_BLOCK) void setup_bin_kernel(KParams p)
 		w.hdr->cur = cur;
 		w.hdr->tri_spill[1 - cur] = 0;
 		w.hdr->edge_spill[1 - cur] = 0;
-		w.hdr->heavy_count[1 - cur] = 0;
 		w.hdr->snap_count[1 - cur] = 0;
 	}
 	if (item < LIST_KINDS * NSUB)
 		w.edge_tile_cnt[((1 - cur) * LIST_KINDS * NSUB + item) * CNT_STRIDE] = 0;
+	for (int i = item; i < p.L.nwords; i += gridDim.x * blockDim.x)
+		w.tile_bits[(1 - cur) * p.L.nwords + i] = 0; // the bitmap of the next forward
+	uint32_t *const bits = w.tile_bits + cur * p.L.nwords;
+	// whoever bins the first triangle or the first edge into a tile marks it non-empty
+	auto mark = [&](int tile) { atomicOr(&bits[tile >> 5], 1u << (tile & 31)); };
 	if (p.clear_grads && view == 0 && p.uv_b)
 		for (int v = item; v < 2 * p.Vuv; v += gridDim.x * blockDim.x)
 		{ // shared by the views: zeroed once
@@ -571,8 +598,11 @@ __global__ __launch_bounds__(PRIM_BLOCK) void setup_bin_kernel(KParams p)
 		const int sub = (got == 0 ? 0 : (got == 16u ? 3 * NSUB : NSUB)) + tile % NSUB;
 		const uint32_t at = atomicAdd(&w.edge_tile_cnt[(cur * LIST_KINDS * NSUB + sub) * CNT_STRIDE], 1u);
 		w.edge_tiles[(size_t)sub * p.L.sub_cap + at] = (uint32_t)tile;
-		if (got == 0) // a place for the forward sweep of the tile (always written: a stale value must never be read)
+		if (got == 0)
+		{ // a place for the forward sweep of the tile (always written: a stale value must never be read)
 			w.edge_slot[tile] = at < (uint32_t)p.L.save_sub ? (uint32_t)sub * p.L.save_sub + at + 1u : 0u;
+			mark(tile);
+		}
 		static_assert(PRIO_EDGES == FIRST_PRIMS && PRIO_EDGES != 16, "one threshold for both lists; 16 = TB, one batch of edges");
 		if (got == (uint32_t)PRIO_EDGES && p.first_tiles)
 			claim_first_tile(p, w, cur, tile);
@@ -592,16 +622,19 @@ __global__ __launch_bounds__(PRIM_BLOCK) void setup_bin_kernel(KParams p)
 			if (k >= p.T)
 				break;
 			TriInputs t;
-			load_triangle(s, k, t, true);
 			TriRec rec;
-			setup_tri_only(s, t, rec, w.tri_planes + (size_t)k * 3 * s.P);
 			TriRec &out = w.tri_rec[k];
-			if (rec.kind == KIND_NONE)
-			{
-				out.kind = KIND_NONE;
-				out.front = rec.front;
+			if (const uint32_t bad = load_triangle(s, k, t, true))
+			{ // checkSceneValid (H.h:2700-2712): the triangle is dropped and the sticky error word tells the host
+				atomicOr(&w.hdr->scene_errors, bad);
+				w.tri_flag[k] = 0;
 				break;
 			}
+			setup_tri_only(s, t, rec, w.tri_planes + (size_t)k * 3 * s.P);
+			w.tri_flag[k] = (uint8_t)(rec.kind | (rec.front ? 4 : 0));
+			if (rec.kind == KIND_NONE)
+				break; // culled (or textured without shading): its record is never read -- the raster kernels reach records
+					   // through the tile lists, the finalize kernel looks at tri_flag first
 			rec.pad0[0] = rec.pad0[1] = 0;
 			rec.pad1[0] = rec.pad1[1] = rec.pad1[2] = 0;
 			out = rec;
@@ -643,6 +676,8 @@ __global__ __launch_bounds__(PRIM_BLOCK) void setup_bin_kernel(KParams p)
 						{
 							const int tile = (ty0 + by + q / 3) * p.L.tiles_x + tx0 + bx + q % 3;
 							place_in_tile(w.tri_list, K_TRI, w.tri_pool, p.L.tri_pool_cap, &w.hdr->tri_spill[cur], tile, (uint32_t)k, slot[q]);
+							if (slot[q] == 0)
+								mark(tile);
 							if (p.first_tiles && slot[q] == (uint32_t)FIRST_PRIMS)
 								claim_first_tile(p, w, cur, tile);
 						}
@@ -660,10 +695,14 @@ __global__ __launch_bounds__(PRIM_BLOCK) void setup_bin_kernel(KParams p)
 				break;
 			const int k = slot / 3, n = slot - 3 * k;
 			TriInputs t;
-			load_triangle(s, k, t, true);
 			EdgeRec e;
-			setup_edge_only(s, t, k, n, e, w.edge_planes + (size_t)slot * 3 * s.P);
 			EdgeRec &eout = w.edge_rec[slot];
+			if (load_triangle(s, k, t, true))
+			{ // invalid indices (reported by the triangle's own thread)
+				eout.kind = KIND_NONE;
+				break;
+			}
+			setup_edge_only(s, t, k, n, e, w.edge_planes + (size_t)slot * 3 * s.P);
 			if (e.kind == KIND_NONE)
 			{
 				eout.kind = KIND_NONE;
@@ -730,10 +769,14 @@ __global__ __launch_bounds__(PRIM_BLOCK) void setup_bin_kernel(KParams p)
 			const int tx = tx0 + t % ntx, ty = ty0 + t / ntx, tile = ty * p.L.tiles_x + tx;
 			if (tri_block)
 			{
-				if (!tile_outside_halfplanes<3>(q, tx, ty) &&
-					push_tile(w.tri_cnt, w.tri_list, K_TRI, w.tri_pool, p.L.tri_pool_cap, &w.hdr->tri_spill[cur], tile, prim) == (uint32_t)FIRST_PRIMS &&
-					p.first_tiles)
-					claim_first_tile(p, w, cur, tile);
+				if (!tile_outside_halfplanes<3>(q, tx, ty))
+				{
+					const uint32_t got = push_tile(w.tri_cnt, w.tri_list, K_TRI, w.tri_pool, p.L.tri_pool_cap, &w.hdr->tri_spill[cur], tile, prim);
+					if (got == 0)
+						mark(tile);
+					if (got == (uint32_t)FIRST_PRIMS && p.first_tiles)
+						claim_first_tile(p, w, cur, tile);
+				}
 			}
 			else if (!tile_outside_halfplanes<4>(q, tx, ty))
 				listed(tile, push_tile(w.edge_cnt, w.edge_list, K_EDGE, w.edge_pool, p.L.edge_pool_cap, &w.hdr->edge_spill[cur], tile, prim));
@@ -828,6 +871,28 @@ __device__ __forceinline__ double background_channel(const KParams &p, int view,
 }
 
 // ------------------------------------------------------------------------------------------------- forward raster
+
+// One thread per view closes the epoch of a forward (nobody else reads `epoch` or `needed_max` during the forward raster): the
+// sticky spill high-water mark, and -- in the header of view 0 -- the maximum / union over the views that the host polls with
+// ONE 64-byte copy (deodr_hip_workspace_status, HipRasterizer's deferred check).
+__device__ __forceinline__ void close_epoch(const KParams &p, const ViewPtrs &w, bool fused)
+{
+	const uint32_t cur = w.hdr->cur;
+	const uint32_t a = w.hdr->tri_spill[cur], bq = w.hdr->edge_spill[cur];
+	uint32_t m = a > bq ? a : bq;
+	if (m > w.hdr->needed_max)
+		w.hdr->needed_max = m;
+	else
+		m = w.hdr->needed_max;
+	w.hdr->owners_partial = fused ? 1u : 0u;
+	WsHeader *all = (WsHeader *)(p.ws + p.L.hdr);
+	if (m > all->all_needed_max) // monotone: a stale read only costs a redundant atomic
+		atomicMax(&all->all_needed_max, m);
+	const uint32_t errs = w.hdr->scene_errors;
+	if (errs)
+		atomicOr(&all->all_scene_errors, errs);
+	w.hdr->epoch = w.hdr->epoch + 1;
+}
 
 template <class PixT>
 __global__ __launch_bounds__(256) void raster_fwd_kernel(KParams p)
@@ -1066,14 +1131,7 @@ __global__ __launch_bounds__(256) void raster_fwd_kernel(KParams p)
 		}
 	}
 	if (blockIdx.x == 0 && threadIdx.x == 0)
-	{ // one thread per view closes the epoch; nobody else reads `epoch` or `needed_max` during this kernel
-		const uint32_t cur = w.hdr->cur;
-		const uint32_t a = w.hdr->tri_spill[cur], bq = w.hdr->edge_spill[cur];
-		const uint32_t m = a > bq ? a : bq;
-		if (m > w.hdr->needed_max)
-			w.hdr->needed_max = m;
-		w.hdr->epoch = w.hdr->epoch + 1;
-	}
+		close_epoch(p, w, false);
 }
 
 // ---------------------------------------------------------------------------------- forward raster, LDS-staged fast path
@@ -1201,13 +1259,15 @@ __device__ __forceinline__ void tri_batch(const KParams &p, WaveLds &S, int nb, 
 	if (!inb)
 		mine = 0;
 	const double x = x0 + lx, y = y0 + row;
+	// Depth test only: the winner of the batch is remembered by its slot and shaded ONCE after the loop (interpolating the
+	// C attribute planes at every change of winner was most of the arithmetic of this loop).
+	int jbest = -1;
 	for (int j = 0; j < nb; j++)
 	{
 		const bool c = (mine >> j) & 1u;
 		if (__ballot(c) == 0)
 			continue;
-		const TriRec &rec = S.rec[j];
-		double Z = plane_at(rec.xZ, x, y);
+		double Z = plane_at(S.rec[j].xZ, x, y);
 		if (persp)
 			Z = 1 / Z;
 		const int k = (int)S.ids[j];
@@ -1215,27 +1275,33 @@ __device__ __forceinline__ void tri_batch(const KParams &p, WaveLds &S, int nb, 
 		{
 			st.zbest = Z;
 			st.kbest = k;
-			st.kind = rec.kind;
-			const double *pl = &S.planes[j * 12];
-			if (rec.kind == KIND_TEXTURED)
+			jbest = j;
+		}
+	}
+	if (jbest >= 0)
+	{ // per-lane reads of the winner's record and planes (LDS, a few distinct slots per tile)
+		const int kind = S.rec[jbest].kind;
+		const double *pl = &S.planes[jbest * 12];
+		const double Z = st.zbest;
+		st.kind = kind;
+		if (kind == KIND_TEXTURED)
+		{
+			st.v[0] = plane_at(pl, x, y);
+			st.v[1] = plane_at(pl + 3, x, y);
+			st.v[2] = plane_at(pl + 6, x, y);
+			if (persp)
 			{
-				st.v[0] = plane_at(pl, x, y);
-				st.v[1] = plane_at(pl + 3, x, y);
-				st.v[2] = plane_at(pl + 6, x, y);
-				if (persp)
-				{
-					st.v[2] = st.v[2] * Z;
-					st.v[0] = st.v[0] * Z;
-					st.v[1] = st.v[1] * Z;
-				}
+				st.v[2] = st.v[2] * Z;
+				st.v[0] = st.v[0] * Z;
+				st.v[1] = st.v[1] * Z;
 			}
-			else
-			{
+		}
+		else
+		{
 #pragma unroll
-				for (int cc = 0; cc < CH; cc++)
-					if (cc < C)
-						st.v[cc] = interp_channel(pl, cc, x, y, persp, Z);
-			}
+			for (int cc = 0; cc < CH; cc++)
+				if (cc < C)
+					st.v[cc] = interp_channel(pl, cc, x, y, persp, Z);
 		}
 	}
 	lds_sync(); // the next batch overwrites the staging area
@@ -1335,19 +1401,77 @@ template <class PixT>
 __device__ __forceinline__ void owner_adjoint(const KParams &p, const ViewPtrs &w, int lane, double x, double y, int owner, int kind, const double *g,
 											  const Tap &tap, double L, double *tab, uint32_t *own);
 
+// Background of one tile that received no primitive: colour, depth = +inf, no owner (H.h:2728-2744).
+template <class PixT>
+__device__ __forceinline__ void fill_background_tile(const KParams &p, int view, int32_t *face_id, int tx, int ty, int lane, const double *bgc,
+													 bool owners)
+{
+	const int W = p.W, H = p.H, C = p.C;
+	const int px = tx * TILE + (lane & 7), py = ty * TILE + (lane >> 3);
+	if (px >= W || py >= H)
+		return;
+	const size_t pix = (size_t)py * W + px;
+	const size_t vpix = (size_t)view * H * W + pix;
+	if (p.image)
+	{
+		PixT *out = (PixT *)p.image + vpix * C;
+		double col[CH];
+#pragma unroll
+		for (int cc = 0; cc < CH; cc++)
+			col[cc] = (cc < C && p.bg_image) ? (double)((const PixT *)p.bg_image)[vpix * C + cc] : bgc[cc];
+		if (C == 4)
+		{
+			typedef PixT V4 __attribute__((ext_vector_type(4)));
+			const V4 v = {(PixT)col[0], (PixT)col[1], (PixT)col[2], (PixT)col[3]};
+			__builtin_nontemporal_store(v, (V4 *)out);
+		}
+		else
+		{
+#pragma unroll
+			for (int cc = 0; cc < CH; cc++)
+				if (cc < C)
+					__builtin_nontemporal_store((PixT)col[cc], out + cc);
+		}
+	}
+	if (p.zbuf)
+		__builtin_nontemporal_store((PixT)INFINITY, (PixT *)p.zbuf + vpix);
+	if (owners)
+		__builtin_nontemporal_store((int32_t)-1, face_id + pix);
+}
+
+// Grid of the staged forward (1-D, one wavefront per workgroup):
+//   [0, n_views * FWD_FIRST)   with p.first_tiles: one entry of a view's list of many-primitive tiles each (views fastest, so
+//                              that every view's long tiles start at once)
+//   then periods of FILL_GROUP + FILL_BLOCKS blocks: FILL_GROUP blocks that map to one (view, tile) each and FILL_BLOCKS
+//   "fill" blocks that stream the background of the empty tiles of one bitmap word (32 tiles) each.
+// Two tiles out of three receive no primitive.  Their waves used to cost a third of the kernel's slot-time (launch + a vector
+// memory round trip + the stores); now a tile wave reads its bit of the set-up kernel's bitmap with one scalar load (constant
+// cache: 64 bytes cover 512 tiles) and retires, and the stores of 32 empty tiles share one fill wave.  Both periods are
+// multiples of 8, so a tile block keeps the XCD (block index % 8) that xcd_band assumes.
+constexpr int FILL_GROUP = 256, FILL_BLOCKS = FILL_GROUP / 32, FILL_PERIOD = FILL_GROUP + FILL_BLOCKS;
+
+__host__ __device__ inline unsigned fwd_fast_grid(int n_views, int ntiles, int nwords, bool first_tiles)
+{
+	const long long tiles = (long long)n_views * ntiles, words = (long long)n_views * nwords;
+	const long long by_tiles = (tiles + FILL_GROUP - 1) / FILL_GROUP, by_words = (words + FILL_BLOCKS - 1) / FILL_BLOCKS;
+	return (unsigned)((first_tiles ? n_views * FWD_FIRST : 0) + (by_tiles > by_words ? by_tiles : by_words) * FILL_PERIOD);
+}
+
 // FUSED: the forward of a fit step.  The loss is L = sum (image - obs)^2, so dL/dimage is known the moment a pixel is
 // resolved: tiles without silhouette edges back-propagate into their owners' accumulators right here (no second pass over the
-// frame, no owner buffer round trip); tiles with edges are left to raster_bwd_edge_kernel.
-// Five waves per SIMD (96 VGPRs, a few spills): the wave timeline shows the kernel slot-bound -- ~3 800 of the 4 096 slots that
-// the natural 111 VGPRs allow are occupied throughout -- and more resident waves hide more of the dependent loads than the
-// spills cost (measured: 4 -> 156 us, 5 -> 151, 6 -> 149, 7 -> 154; at 6 the spill traffic nearly doubles the HBM bytes of
-// the kernel for those last 2 us, so 5).
-template <class PixT, int WPB, bool FUSED> // WPB wavefronts (= tiles) per workgroup
-__global__ __launch_bounds__(64 * WPB, 5) void raster_fwd_fast_kernel(KParams p)
+// frame, no owner buffer round trip -- the owner ids of those tiles are not even written); tiles with edges are left to
+// raster_bwd_edge_kernel.
+// Five waves per SIMD (96 VGPRs): more resident waves hide more of the dependent loads than the few spills cost
+// (measured in round 1: 4 -> 156 us, 5 -> 151, 6 -> 149, 7 -> 154; at 6 the spill traffic nearly doubles the HBM bytes).
+#ifndef DR_FWD_WAVES
+#define DR_FWD_WAVES 5 // waves per SIMD the staged forward is compiled for (tools/build_variants.sh builds the neighbours)
+#endif
+template <class PixT, bool FUSED>
+__global__ __launch_bounds__(64, DR_FWD_WAVES) void raster_fwd_fast_kernel(KParams p)
 {
 	DR_WAVE_TRACE_SCOPE(2);
-	__shared__ WaveLds s_lds[WPB];
-	__shared__ EdgeSort s_es[WPB];
+	__shared__ WaveLds s_lds[1];
+	__shared__ EdgeSort s_es[1];
 #ifdef DR_FWD_TRACE
 	// per-tile phase timing (tools/fwd_trace.py): eight counters over the first row of the tile in the z buffer
 	uint32_t ftr[8] = {0x7fc0f00du, 0, 0, 0, 0, 0, 0, 0};
@@ -1356,13 +1480,10 @@ __global__ __launch_bounds__(64 * WPB, 5) void raster_fwd_fast_kernel(KParams p)
 #else
 #define DR_FTRACE(i)
 #endif
-	// Block roles.  WPB == 1 (the default): 1-D grid; with p.first_tiles its first n_views * FWD_FIRST blocks each take one
-	// entry of a view's list of many-primitive tiles (views fastest, so that every view's long tiles start at once), the
-	// others map to (view, tile) and leave the flagged tiles alone.  WPB == 4: grid (strips, views), no list.
-	const int wave = uniform(threadIdx.x >> 6), lane = threadIdx.x & 63;
+	constexpr int wave = 0;
+	const int lane = threadIdx.x & 63;
 	int view, tx, ty;
-	bool listed_tile = false, closes_epoch;
-	if (WPB == 1)
+	bool listed_tile = false, closes_epoch = false;
 	{
 		const int per_view = p.L.ntiles, nfirst = p.first_tiles ? p.n_views * FWD_FIRST : 0;
 		int bid = blockIdx.x;
@@ -1379,27 +1500,52 @@ __global__ __launch_bounds__(64 * WPB, 5) void raster_fwd_fast_kernel(KParams p)
 			tx = t % p.L.tiles_x;
 			ty = t / p.L.tiles_x;
 			listed_tile = true;
-			closes_epoch = false;
 		}
 		else
 		{
 			bid -= nfirst;
-			view = bid / per_view;
-			const int bx = bid - view * per_view;
+			const int period = bid / FILL_PERIOD, r = bid - period * FILL_PERIOD;
+			if (r >= FILL_GROUP)
+			{ // ---- fill block: the empty tiles of one word of a view's bitmap
+				const int gw = period * FILL_BLOCKS + (r - FILL_GROUP);
+				if (gw >= p.n_views * p.L.nwords)
+					return;
+				view = gw / p.L.nwords;
+				const int wi = gw - view * p.L.nwords;
+				const ViewPtrs wf = view_ptrs(p, view);
+				const uint32_t cur = wf.hdr->cur, b0 = wf.tile_bits[wi], b1 = wf.tile_bits[p.L.nwords + wi];
+				const int base = wi * 32, valid = p.L.ntiles - base < 32 ? p.L.ntiles - base : 32;
+				uint32_t empty = ~(cur ? b1 : b0) & (valid == 32 ? 0xffffffffu : (1u << valid) - 1u);
+				empty = (uint32_t)uniform((int)empty);
+				// the adjoint finds the edge count of every tile in edge_saved: none here
+				if (lane < 32 && ((empty >> lane) & 1u))
+					wf.edge_saved[base + lane] = 0;
+				double bgc[CH] = {0, 0, 0, 0};
+				if (!p.bg_image)
+				{
+#pragma unroll
+					for (int cc = 0; cc < CH; cc++)
+						if (cc < p.C)
+							bgc[cc] = (double)((const PixT *)p.bg_color)[cc];
+				}
+				while (empty)
+				{
+					const int tile = base + __ffs((int)empty) - 1;
+					empty &= empty - 1;
+					fill_background_tile<PixT>(p, view, wf.face_id, tile % p.L.tiles_x, tile / p.L.tiles_x, lane, bgc, !FUSED);
+				}
+				return;
+			}
+			const long long t = (long long)period * FILL_GROUP + r;
+			if (t >= (long long)p.n_views * per_view)
+				return;
+			view = (int)(t / per_view);
+			const int bx = (int)(t - (long long)view * per_view);
 			const int b = xcd_band(bx, per_view);
 			ty = xcd_strip_row(b / p.L.tiles_x, p.L.tiles_y, p.row_group);
 			tx = b % p.L.tiles_x;
 			closes_epoch = bx == 0;
 		}
-	}
-	else
-	{
-		view = blockIdx.y;
-		const int strips_x = (p.L.tiles_x + WPB - 1) / WPB;
-		const int b = xcd_band(blockIdx.x, gridDim.x);
-		ty = xcd_strip_row(b / strips_x, p.L.tiles_y, p.row_group);
-		tx = (b % strips_x) * WPB + wave;
-		closes_epoch = blockIdx.x == 0;
 	}
 	const ViewPtrs w = view_ptrs(p, view);
 	const int W = p.W, H = p.H, C = p.C, P = p.L.P;
@@ -1407,9 +1553,16 @@ __global__ __launch_bounds__(64 * WPB, 5) void raster_fwd_fast_kernel(KParams p)
 	const PixT *texture = (const PixT *)p.texture;
 	WaveLds &S = s_lds[wave];
 
-	if (tx < p.L.tiles_x)
+	const int tile = ty * p.L.tiles_x + tx;
+	// ---- is there anything in this tile?  One scalar load (both parities of the word requested with the parity)
+	bool nonempty = true;
+	if (!listed_tile)
 	{
-		const int tile = ty * p.L.tiles_x + tx;
+		const uint32_t cur = w.hdr->cur, b0 = w.tile_bits[tile >> 5], b1 = w.tile_bits[p.L.nwords + (tile >> 5)];
+		nonempty = (((cur ? b1 : b0) >> (tile & 31)) & 1u) != 0;
+	}
+	if (nonempty)
+	{
 		const int x0 = tx * TILE, y0 = ty * TILE;
 		const int px = x0 + (lane & 7), py = y0 + (lane >> 3);
 		const bool inb = px < W && py < H;
@@ -1418,18 +1571,14 @@ __global__ __launch_bounds__(64 * WPB, 5) void raster_fwd_fast_kernel(KParams p)
 		const double x = px, y = py;
 		// the inline triangle list is fetched together with the counters (one memory round trip instead of two)
 		const uint32_t list_entry = w.tri_list[(size_t)tile * K_TRI + (lane & (K_TRI - 1))];
-		int ntri = uniform((int)w.tri_cnt[tile]);
-		int nedge = uniform((int)w.edge_cnt[tile]);
+		const int ntri = uniform((int)w.tri_cnt[tile]);
+		const int nedge = uniform((int)w.edge_cnt[tile]);
 		const uint32_t slot_word = (uint32_t)uniform((int)w.edge_slot[tile]); // fresh whenever the tile has edges (set-up)
-		const bool taken = WPB == 1 && p.first_tiles && !listed_tile && uniform((int)w.first_flag[tile]) != 0;
+		const bool taken = p.first_tiles && !listed_tile && uniform((int)w.first_flag[tile]) != 0;
 		if (taken && lane == 0)
 			w.first_flag[tile] = 0; // a block at the head of the grid rasterizes this tile; the flag has served
 		if (!taken)
 		{
-		if (p.debug & 1)
-			ntri = 0;
-		if (p.debug & 2)
-			nedge = 0;
 		if (lane == 0 && (ntri | nedge))
 		{
 			w.tri_cnt[tile] = 0;
@@ -1440,31 +1589,16 @@ __global__ __launch_bounds__(64 * WPB, 5) void raster_fwd_fast_kernel(KParams p)
 		if (lane == 0)
 			w.edge_saved[tile] = (uint32_t)nedge | (sweep_slot ? SWEEP_SAVED : 0u);
 		if ((ntri | nedge) == 0)
-		{ // two tiles out of three hold no primitive: background, no depth, no owner -- and nothing else to run through
-			if (inb && !(p.debug & 4))
+		{ // cannot happen (the bit of a tile is set with its first primitive); kept so that a frame is complete whatever happens
+			double bgc[CH] = {0, 0, 0, 0};
+			if (!p.bg_image)
 			{
-				if (p.image)
-				{
-					PixT *out = (PixT *)p.image + vpix * C;
-					if (C == 4)
-					{
-						typedef PixT V4 __attribute__((ext_vector_type(4)));
-						const V4 v = {(PixT)background_channel<PixT>(p, view, pix, 0), (PixT)background_channel<PixT>(p, view, pix, 1),
-									  (PixT)background_channel<PixT>(p, view, pix, 2), (PixT)background_channel<PixT>(p, view, pix, 3)};
-						__builtin_nontemporal_store(v, (V4 *)out);
-					}
-					else
-					{
 #pragma unroll
-						for (int cc = 0; cc < CH; cc++)
-							if (cc < C)
-								__builtin_nontemporal_store((PixT)background_channel<PixT>(p, view, pix, cc), out + cc);
-					}
-				}
-				if (p.zbuf)
-					__builtin_nontemporal_store((PixT)INFINITY, (PixT *)p.zbuf + vpix);
-				__builtin_nontemporal_store((int32_t)-1, w.face_id + pix);
+				for (int cc = 0; cc < CH; cc++)
+					if (cc < C)
+						bgc[cc] = (double)((const PixT *)p.bg_color)[cc];
 			}
+			fill_background_tile<PixT>(p, view, w.face_id, tx, ty, lane, bgc, !FUSED);
 		}
 		else
 		{
@@ -1679,7 +1813,7 @@ __global__ __launch_bounds__(64 * WPB, 5) void raster_fwd_fast_kernel(KParams p)
 		}
 		DR_FTRACE(4); // colour resolved, edges blended
 		// ---- one write per pixel
-		if (inb && !(p.debug & 4))
+		if (inb)
 		{
 			if (p.image)
 			{
@@ -1701,7 +1835,9 @@ __global__ __launch_bounds__(64 * WPB, 5) void raster_fwd_fast_kernel(KParams p)
 			}
 			if (p.zbuf)
 				__builtin_nontemporal_store((PixT)st.zbest, (PixT *)p.zbuf + vpix);
-			__builtin_nontemporal_store(pack_owner(st.kbest, st.kind), w.face_id + pix);
+			// a fused forward back-propagates through a tile without edges right below: nobody reads its owner ids again
+			if (!FUSED || nedge > 0)
+				__builtin_nontemporal_store(pack_owner(st.kbest, st.kind), w.face_id + pix);
 		}
 		DR_FTRACE(5); // frame stores issued
 		if (FUSED && nedge == 0 && __ballot(st.kbest >= 0) != 0)
@@ -1732,14 +1868,7 @@ __global__ __launch_bounds__(64 * WPB, 5) void raster_fwd_fast_kernel(KParams p)
 		} // not left to a block at the head of the grid
 	}
 	if (closes_epoch && threadIdx.x == 0)
-	{ // one thread per view closes the epoch; nobody else reads `epoch` or `needed_max` during this kernel
-		const uint32_t cur = w.hdr->cur;
-		const uint32_t a = w.hdr->tri_spill[cur], bq = w.hdr->edge_spill[cur];
-		const uint32_t m = a > bq ? a : bq;
-		if (m > w.hdr->needed_max)
-			w.hdr->needed_max = m;
-		w.hdr->epoch = w.hdr->epoch + 1;
-	}
+		close_epoch(p, w, FUSED);
 }
 
 // ------------------------------------------------------------------------------------------------ backward raster
@@ -1768,12 +1897,15 @@ __device__ __forceinline__ void texture_scatter(PixT *texture_b, const Tap &tap,
 			unsafeAtomicAdd(texture_b + tap.idx[q] + c, (PixT)wgt[q]);
 }
 
-// adjoint of one tile, any channel count / edge count / mode; `order` is a per-wave LDS array of MAX_SORTED entries
-template <class PixT>
-__device__ __noinline__ void bwd_tile_generic(const KParams &p, int view, int tx, int ty, int lane, volatile uint32_t *order)
+// adjoint of one tile, any channel count / edge count / mode; `order` is a per-wave LDS array of MAX_SORTED entries.
+// LEAN: the instance inlined into raster_bwd_edge_kernel for the (pathological) tiles with more than EMAX edges: at most CH
+// channels and no antialiase_error, which the compiler can then drop.
+template <class PixT, bool LEAN>
+__device__ __forceinline__ void bwd_tile_generic_impl(const KParams &p, int view, int tx, int ty, int lane, volatile uint32_t *order)
 {
 	const ViewPtrs w = view_ptrs(p, view);
 	const int W = p.W, H = p.H, C = p.C, P = p.L.P;
+	const bool aa_err = !LEAN && p.aa_err;
 	const PixT *texture = (const PixT *)p.texture;
 	PixT *texture_b = (PixT *)p.texture_b;
 	const int tile = ty * p.L.tiles_x + tx;
@@ -1782,14 +1914,10 @@ __device__ __noinline__ void bwd_tile_generic(const KParams &p, int view, int tx
 	const size_t pix = (size_t)py * W + px;
 	const size_t vpix = (size_t)view * H * W + pix;
 	const double x = px, y = py;
-	int nedge = uniform((int)(w.edge_saved[tile] & ~SWEEP_SAVED));
-	if (p.debug & 32)
-		nedge = 0;
+	const int nedge = uniform((int)(w.edge_saved[tile] & ~SWEEP_SAVED));
 	int owner = -1, kind = KIND_NONE;
 	if (inb)
 		unpack_owner(w.face_id[pix], owner, kind);
-	if (p.debug & 16)
-		owner = -1;
 	if (__ballot(owner >= 0) == 0 && nedge == 0)
 		return;
 
@@ -1870,7 +1998,7 @@ __device__ __noinline__ void bwd_tile_generic(const KParams &p, int view, int tx
 
 	// ---- antialiase_error mode: the edges blended the squared residual err_buffer, not the image (H.h:2200-2368, 2481-2618)
 	double eb = 0; // running adjoint of err_buffer at this pixel
-	if (p.aa_err)
+	if (aa_err)
 	{
 		const PixT *obs = (const PixT *)p.obs + vpix * C;
 		eb = inb ? (double)((const PixT *)p.err_b)[vpix] : 0.0;
@@ -1967,7 +2095,7 @@ __device__ __noinline__ void bwd_tile_generic(const KParams &p, int view, int tx
 		}
 	}
 	{
-		for (int c0 = 0; c0 < C; c0 += CH)
+		for (int c0 = 0; c0 < (LEAN ? 1 : C); c0 += CH)
 		{
 			double g[CH], base[CH];
 #pragma unroll
@@ -1977,14 +2105,14 @@ __device__ __noinline__ void bwd_tile_generic(const KParams &p, int view, int tx
 				base[j] = 0;
 				if (c0 + j < C && inb)
 				{
-					if (p.aa_err) // image_b = -2 (obs - image) err_buffer_b, H.h:3054-3060
+					if (aa_err) // image_b = -2 (obs - image) err_buffer_b, H.h:3054-3060
 						g[j] = -2 * ((double)((const PixT *)p.obs)[vpix * C + c0 + j] - base_channel(c0 + j)) * eb;
 					else
 						g[j] = p.image_b ? (double)((const PixT *)p.image_b)[vpix * C + c0 + j]
 										 : 2 * ((double)((const PixT *)p.image_in)[vpix * C + c0 + j] - (double)((const PixT *)p.obs)[vpix * C + c0 + j]);
 				}
 			}
-			if (nedge > 0 && !p.aa_err)
+			if (nedge > 0 && !aa_err)
 			{
 #pragma unroll
 				for (int j = 0; j < CH; j++)
@@ -2172,6 +2300,12 @@ __device__ __noinline__ void bwd_tile_generic(const KParams &p, int view, int tx
 		add_moments(acc + 3, (mine && !tap.out[1]) ? own_e_B[1] : 0.0, x, y, lane);
 		add_moments(acc + 6, mine ? own_L_B : 0.0, x, y, lane);
 	}
+}
+
+template <class PixT>
+__device__ __noinline__ void bwd_tile_generic(const KParams &p, int view, int tx, int ty, int lane, volatile uint32_t *order)
+{
+	bwd_tile_generic_impl<PixT, false>(p, view, tx, ty, lane, order);
 }
 
 template <class PixT>
@@ -2403,7 +2537,7 @@ __device__ __forceinline__ void owner_adjoint(const KParams &p, const ViewPtrs &
 				mask &= mask - 1;
 				acc += tab[r * NMOM + m];
 			}
-			if (m < nm && acc != 0 && !(p.debug & 128))
+			if (m < nm && acc != 0)
 				atomic_add_f64(w.tri_acc + (size_t)o * nm + m, acc);
 		}
 		emask &= ~__ballot(sel);
@@ -2430,10 +2564,8 @@ __device__ __forceinline__ void bwd_fast_tile(const KParams &p, const ViewPtrs &
 	const int32_t raw_owner = inb ? w.face_id[pix] : -1;
 	const uint32_t raw_nedge = (uint32_t)uniform((int)w.edge_saved[tile]);
 	const uint32_t sweep_slot = EDGES ? (uint32_t)uniform((int)w.edge_slot[tile]) : 0u;
-	int nedge = (int)(raw_nedge & ~SWEEP_SAVED);
-	const bool sweep_saved = EDGES && (raw_nedge & SWEEP_SAVED) && sweep_slot && !(p.debug & 64);
-	if (p.debug & 32)
-		nedge = 0;
+	const int nedge = (int)(raw_nedge & ~SWEEP_SAVED);
+	const bool sweep_saved = EDGES && (raw_nedge & SWEEP_SAVED) && sweep_slot;
 	if ((nedge > 0) != EDGES || nedge > skip_above)
 		return; // the other kernel's tile (or one this kernel has already taken from its list of long tiles)
 	// batches of the reverse sweep this wavefront runs: all of them, or -- when the forward saved the colour after every batch
@@ -2467,15 +2599,15 @@ __device__ __forceinline__ void bwd_fast_tile(const KParams &p, const ViewPtrs &
 		n_edges = gather_sorted_edges(*es, w, p, tile, nedge, lane);
 	DR_TRACE(2);
 	if (EDGES && n_edges < 0)
-	{ // more than EMAX edges in one tile (or pool overflow) -> queued for raster_bwd_heavy_kernel
-		if (lane == 0)
-			w.heavy_list[atomicAdd(&w.hdr->heavy_count[w.hdr->cur], 1u)] = (uint32_t)tile;
+	{ // more than EMAX edges in one tile (or pool overflow): the un-staged code, right here (pathological and slow, but no
+	  // queue and no extra launch for the tiles that never exist in a real scene)
+		lds_sync();
+		bwd_tile_generic_impl<PixT, true>(p, view, tx, ty, lane, (volatile uint32_t *)es->sorted);
+		lds_sync();
 		return;
 	}
 	int owner = -1, kind = KIND_NONE;
 	unpack_owner(raw_owner, owner, kind);
-	if (p.debug & 16)
-		owner = -1;
 	if (__ballot(owner >= 0) == 0 && nedge == 0)
 		return;
 
@@ -2781,19 +2913,21 @@ __device__ __forceinline__ void bwd_fast_tile(const KParams &p, const ViewPtrs &
 #undef DR_TRACE
 }
 
-template <class PixT, int WPB>
-__global__ __launch_bounds__(64 * WPB, 6) void raster_bwd_fast_kernel(KParams p)
-{ // every tile of the frame; those with silhouette edges are left to raster_bwd_edge_kernel
-	__shared__ BwdLds s_lds[WPB];
+template <class PixT>
+__global__ __launch_bounds__(64, 6) void raster_bwd_fast_kernel(KParams p)
+{ // every tile of the frame (one wavefront each); those with silhouette edges are left to raster_bwd_edge_kernel, those without
+  // any primitive are recognised in the forward's tile bitmap (one scalar load) before anything is read
+	__shared__ BwdLds s_lds;
 	const int view = blockIdx.y;
-	const int wave = uniform(threadIdx.x >> 6), lane = threadIdx.x & 63;
+	const int lane = threadIdx.x & 63;
 	const ViewPtrs w = view_ptrs(p, view);
-	const int strips_x = (p.L.tiles_x + WPB - 1) / WPB;
 	const int b = xcd_band(blockIdx.x, gridDim.x);
-	const int ty = xcd_strip_row(b / strips_x, p.L.tiles_y, p.row_group), tx = (b % strips_x) * WPB + wave;
-	if (tx >= p.L.tiles_x)
+	const int ty = xcd_strip_row(b / p.L.tiles_x, p.L.tiles_y, p.row_group), tx = b % p.L.tiles_x;
+	const int tile = ty * p.L.tiles_x + tx;
+	const uint32_t cur = w.hdr->cur, b0 = w.tile_bits[tile >> 5], b1 = w.tile_bits[p.L.nwords + (tile >> 5)];
+	if (!(((cur ? b1 : b0) >> (tile & 31)) & 1u))
 		return;
-	bwd_fast_tile<PixT, false>(p, w, view, tx, ty, lane, s_lds[wave], nullptr);
+	bwd_fast_tile<PixT, false>(p, w, view, tx, ty, lane, s_lds, nullptr);
 }
 
 template <class PixT>
@@ -2836,23 +2970,6 @@ __global__ __launch_bounds__(64, 2) void raster_bwd_edge_kernel(KParams p)
 	}
 }
 
-template <class PixT>
-__global__ __launch_bounds__(256) void raster_bwd_heavy_kernel(KParams p)
-{ // the few tiles raster_bwd_fast_kernel deferred (more than K_EDGE silhouette edges); normally the queue is empty
-	__shared__ volatile uint32_t s_order[4][MAX_SORTED];
-	const int view = blockIdx.y;
-	const int wave = uniform(threadIdx.x >> 6), lane = threadIdx.x & 63;
-	const ViewPtrs w = view_ptrs(p, view);
-	// normally an empty launch: the three words are requested together so that it costs one memory round trip, not two
-	const uint32_t cur = w.hdr->cur, n0 = w.hdr->heavy_count[0], n1 = w.hdr->heavy_count[1];
-	const uint32_t n = cur ? n1 : n0;
-	for (uint32_t i = blockIdx.x * 4 + wave; i < n; i += gridDim.x * 4)
-	{
-		const int tile = (int)w.heavy_list[i];
-		bwd_tile_generic<PixT>(p, view, tile % p.L.tiles_x, tile / p.L.tiles_x, lane, s_order[wave]);
-	}
-}
-
 // ------------------------------------------------------------------------------------------------------- finalize
 
 __global__ __launch_bounds__(PRIM_BLOCK) void finalize_kernel(KParams p)
@@ -2869,18 +2986,16 @@ __global__ __launch_bounds__(PRIM_BLOCK) void finalize_kernel(KParams p)
 	g.shade_b = (char *)p.shade_b + (size_t)view * p.V * es;
 	g.uv_b = p.uv_b;
 	const int P = s.P;
-	if (blockIdx.x == 0 && threadIdx.x == 0)
-		w.hdr->heavy_count[w.hdr->cur] = 0; // the deferred-tile queue of this adjoint has been drained
 	if (tri_block)
 	{
 		const int k = blockIdx.x * PRIM_BLOCK + threadIdx.x;
 		if (k >= p.T)
 			return;
-		const TriRec &rec = w.tri_rec[k];
+		const uint32_t flag = w.tri_flag[k];
 		double *acc = w.tri_acc + (size_t)k * 3 * P;
-		if (!rec.front || rec.kind == KIND_NONE)
+		if (!(flag & 4u) || (flag & 3u) == KIND_NONE)
 			return; // culled triangles own no accumulators
-		finalize_triangle(s, g, k, rec, acc, DeviceAdd());
+		finalize_triangle(s, g, k, (int)(flag & 3u), acc, DeviceAdd());
 		for (int i = 0; i < 3 * P; i++)
 			acc[i] = 0; // self-cleaning accumulators
 		return;
@@ -2889,7 +3004,7 @@ __global__ __launch_bounds__(PRIM_BLOCK) void finalize_kernel(KParams p)
 	if (slot < 0)
 		return;
 	const int k = slot / 3, n = slot - 3 * k;
-	if (!w.tri_rec[k].front)
+	if (!(w.tri_flag[k] & 4u))
 		return; // not a silhouette edge of a front-facing triangle in this forward (its slot may hold a stale record)
 	const EdgeRec &e = w.edge_rec[slot];
 	if (e.kind == KIND_NONE)
@@ -2948,6 +3063,8 @@ int fill_params(const DeodrHipScene *sc, double sigma, void *workspace, size_t w
 			return fail("backward gradient propagation not supported yet with perspective_correct=True"); // H.h:810
 		if (!sc->uv_b || !sc->ij_b || !sc->shade_b || !sc->colors_b)
 			return fail("scene gradient array == NULL");
+		if (sc->texture && !sc->texture_b)
+			return fail("scene.texture_b == NULL although scene.texture is given"); // H.h:2694
 	}
 	if (!workspace)
 		return fail("workspace == NULL");
@@ -3001,12 +3118,7 @@ int fill_params(const DeodrHipScene *sc, double sigma, void *workspace, size_t w
 	p.offset = sc->integer_pixel_centers ? 0.0 : 0.5;
 	p.sigma = sigma;
 	p.ws = (char *)workspace;
-	{
-		static const int dbg = getenv("DEODR_HIP_DEBUG") ? atoi(getenv("DEODR_HIP_DEBUG")) : 0;
-		p.debug = dbg;
-		static const int row_group = getenv("DEODR_HIP_ROWGROUP") ? atoi(getenv("DEODR_HIP_ROWGROUP")) : 2;
-		p.row_group = row_group;
-	}
+	p.row_group = ROW_GROUP;
 	return 0;
 }
 
@@ -3027,27 +3139,23 @@ struct ProfEvent
 bool g_profile = false;	  // the launches of the current call are bracketed by events
 int g_profile_every = 0;	  // deodr_hip_profile_enable(n): 0 off, n > 0: every n-th forward (and the adjoint that follows it)
 unsigned g_profile_calls = 0; // forwards seen since profiling was enabled
-bool g_force_generic = false; // DEODR_HIP_FORCE_GENERIC=1: run the un-staged kernels (tests cover both)
-const int g_edge_waves = getenv("DEODR_HIP_EDGE_WAVES") ? atoi(getenv("DEODR_HIP_EDGE_WAVES")) : 1024; // persistent waves per view of the adjoint's edge kernel
-const int g_first_tiles = getenv("DEODR_HIP_FIRST_TILES") ? atoi(getenv("DEODR_HIP_FIRST_TILES")) : 1; // 0: no many-primitive-tiles-first order
-const int g_wpb = getenv("DEODR_HIP_WPB") ? atoi(getenv("DEODR_HIP_WPB")) : 1; // wavefronts per workgroup of the staged kernels: 1 or 4
+bool g_force_generic = false; // deodr_hip_force_generic(1): run the un-staged kernels (the parity suite covers both families)
+// Tuning constants (measured in round 1, profiles/README.md); deliberately NOT read from the environment: nothing outside the
+// arguments of a call may change what the call launches.
+constexpr int EDGE_WAVES = 1024; // persistent waves per view of the adjoint's edge kernel
 
 template <class PixT>
-void launch_adjoint_raster(const KParams &p, bool fast, bool owner_tiles, int wpb, dim3 grid, dim3 edge_grid, hipStream_t st)
+void launch_adjoint_raster(const KParams &p, bool fast, bool owner_tiles, dim3 grid4, dim3 edge_grid, hipStream_t st)
 {
 	if (!fast)
 	{
-		hipLaunchKernelGGL(raster_bwd_kernel<PixT>, grid, dim3(256), 0, st, p);
+		hipLaunchKernelGGL(raster_bwd_kernel<PixT>, grid4, dim3(256), 0, st, p);
 		return;
 	}
-	if (!owner_tiles)
-		; // a fused forward has already back-propagated through the tiles without edges
-	else if (wpb == 1)
-		hipLaunchKernelGGL((raster_bwd_fast_kernel<PixT, 1>), grid, dim3(64), 0, st, p);
-	else
-		hipLaunchKernelGGL((raster_bwd_fast_kernel<PixT, 4>), grid, dim3(256), 0, st, p);
+	if (owner_tiles) // (after a fused forward the tiles without edges have already been back-propagated)
+		hipLaunchKernelGGL(raster_bwd_fast_kernel<PixT>, dim3(p.L.ntiles, p.n_views), dim3(64), 0, st, p);
 	// (running the two kernels side by side on a forked stream was measured: no gain, the edge kernel just stretches)
-	if (p.sigma > 0 && !(p.debug & 32))
+	if (p.sigma > 0)
 		hipLaunchKernelGGL(raster_bwd_edge_kernel<PixT>, edge_grid, dim3(64), 0, st, p);
 }
 
@@ -3087,78 +3195,64 @@ struct ScopedKernelTimer
 };
 
 template <class PixT>
-void launch_forward_raster(const KParams &p, bool fast, bool fused, int wpb, dim3 grid, hipStream_t stream)
+void launch_forward_raster(const KParams &p, bool fast, bool fused, dim3 grid4, hipStream_t stream)
 {
-	// one tile per workgroup: 1-D grid, the listed many-primitive tiles of every view first (see the kernel)
-	const dim3 flat((unsigned)p.n_views * (unsigned)((p.first_tiles ? FWD_FIRST : 0) + p.L.ntiles));
 	if (!fast)
-		hipLaunchKernelGGL(raster_fwd_kernel<PixT>, grid, dim3(256), 0, stream, p);
-	else if (wpb == 1 && fused)
-		hipLaunchKernelGGL((raster_fwd_fast_kernel<PixT, 1, true>), flat, dim3(64), 0, stream, p);
-	else if (wpb == 1)
-		hipLaunchKernelGGL((raster_fwd_fast_kernel<PixT, 1, false>), flat, dim3(64), 0, stream, p);
-	else if (fused)
-		hipLaunchKernelGGL((raster_fwd_fast_kernel<PixT, 4, true>), grid, dim3(256), 0, stream, p);
+	{
+		hipLaunchKernelGGL(raster_fwd_kernel<PixT>, grid4, dim3(256), 0, stream, p);
+		return;
+	}
+	const dim3 flat(fwd_fast_grid(p.n_views, p.L.ntiles, p.L.nwords, p.first_tiles != 0));
+	if (fused)
+		hipLaunchKernelGGL((raster_fwd_fast_kernel<PixT, true>), flat, dim3(64), 0, stream, p);
 	else
-		hipLaunchKernelGGL((raster_fwd_fast_kernel<PixT, 4, false>), grid, dim3(256), 0, stream, p);
+		hipLaunchKernelGGL((raster_fwd_fast_kernel<PixT, false>), flat, dim3(64), 0, stream, p);
 }
 
+// grid of the un-staged kernels: four tiles (wavefronts) per workgroup
+dim3 generic_grid(const KParams &p, int n_views) { return dim3((unsigned)(((p.L.tiles_x + 3) / 4) * p.L.tiles_y), (unsigned)n_views); }
+
 // fused: the forward also back-propagates L = sum (image - obs)^2 through the tiles that have no silhouette edge (staged
-// kernels only; the caller checks `staged_path`)
+// kernels only; the caller checks)
 int launch_forward(const DeodrHipScene *sc, KParams &p, hipStream_t stream, bool fused = false)
 {
 	const int n_views = sc->n_views;
 	g_profile = g_profile_every > 0 && (g_profile_calls++ % (unsigned)g_profile_every) == 0;
 	p.n_views = n_views;
-	p.first_tiles = !p.aa_err && p.C <= CH && !g_force_generic && g_wpb == 1 && g_first_tiles;
+	const bool fast = !p.aa_err && p.C <= CH && !g_force_generic;
+	p.first_tiles = fast;
 	if (p.T > 0)
 	{
 		dim3 grid(prim_blocks(p.T), n_views);
 		ScopedKernelTimer t(KID_SETUP, stream);
 		hipLaunchKernelGGL(setup_bin_kernel, grid, dim3(PRIM_BLOCK), 0, stream, p);
 	}
-	const bool fast = !p.aa_err && p.C <= CH && !g_force_generic;
-	const int wpb = fast ? g_wpb : 4; // wavefronts (tiles) per workgroup of the staged kernels (tuning knob DEODR_HIP_WPB)
-	const int strips_x = (p.L.tiles_x + wpb - 1) / wpb;
-	dim3 grid(strips_x * p.L.tiles_y, n_views);
 	{
 		ScopedKernelTimer t(KID_RASTER_FWD, stream);
 		if (sc->pixel_dtype == DEODR_HIP_F64)
-			launch_forward_raster<double>(p, fast, fused && fast, wpb, grid, stream);
+			launch_forward_raster<double>(p, fast, fused && fast, generic_grid(p, n_views), stream);
 		else
-			launch_forward_raster<float>(p, fast, fused && fast, wpb, grid, stream);
+			launch_forward_raster<float>(p, fast, fused && fast, generic_grid(p, n_views), stream);
 	}
 	return check_hip(hipGetLastError(), "forward launch");
 }
 
-} // namespace
-
-// adjoint raster (+ deferred tiles) and the per-primitive finalize; owner_tiles = false after a fused forward
+// adjoint raster and the per-primitive finalize; owner_tiles = false after a fused forward
 int launch_adjoint(const DeodrHipScene *sc, KParams &p, hipStream_t st, bool owner_tiles)
 {
 	const bool fast = !p.aa_err && p.C <= CH && !g_force_generic;
-	const int wpb = fast ? g_wpb : 4;
-	const int strips_x = (p.L.tiles_x + wpb - 1) / wpb;
-	dim3 grid(strips_x * p.L.tiles_y, sc->n_views);
+	p.n_views = sc->n_views;
 	// persistent waves of the edge kernel: enough to cover a silhouette-heavy single view, few enough that with many views
 	// the waves that find their sub-list exhausted cost nothing
-	int edge_waves = p.L.ntiles < g_edge_waves ? p.L.ntiles : g_edge_waves;
+	int edge_waves = p.L.ntiles < EDGE_WAVES ? p.L.ntiles : EDGE_WAVES;
 	edge_waves = (edge_waves + NSUB - 1) / NSUB * NSUB;
 	dim3 edge_grid(sc->n_views, edge_waves);
 	{
 		ScopedKernelTimer t(KID_RASTER_BWD, st);
 		if (sc->pixel_dtype == DEODR_HIP_F64)
-			launch_adjoint_raster<double>(p, fast, owner_tiles, wpb, grid, edge_grid, st);
+			launch_adjoint_raster<double>(p, fast, owner_tiles, generic_grid(p, sc->n_views), edge_grid, st);
 		else
-			launch_adjoint_raster<float>(p, fast, owner_tiles, wpb, grid, edge_grid, st);
-		if (fast)
-		{ // a few blocks per view drain the deferred-tile queue (usually empty); finalize_kernel resets it
-			dim3 gh(16, sc->n_views);
-			if (sc->pixel_dtype == DEODR_HIP_F64)
-				hipLaunchKernelGGL(raster_bwd_heavy_kernel<double>, gh, dim3(256), 0, st, p);
-			else
-				hipLaunchKernelGGL(raster_bwd_heavy_kernel<float>, gh, dim3(256), 0, st, p);
-		}
+			launch_adjoint_raster<float>(p, fast, owner_tiles, generic_grid(p, sc->n_views), edge_grid, st);
 	}
 	if (p.T > 0)
 	{
@@ -3168,6 +3262,26 @@ int launch_adjoint(const DeodrHipScene *sc, KParams &p, hipStream_t st, bool own
 	}
 	return check_hip(hipGetLastError(), "backward launch");
 }
+
+// Workspaces whose last forward was the fused one: their owner buffer is incomplete (tiles without edges are not written), so a
+// later deodr_hip_render_scene_b that claims to have the forward state must rebuild it.
+std::mutex g_fused_mutex;
+std::unordered_set<const void *> g_fused_ws;
+void note_forward(const void *workspace, bool fused)
+{
+	std::lock_guard<std::mutex> lock(g_fused_mutex);
+	if (fused)
+		g_fused_ws.insert(workspace);
+	else
+		g_fused_ws.erase(workspace);
+}
+bool last_forward_was_fused(const void *workspace)
+{
+	std::lock_guard<std::mutex> lock(g_fused_mutex);
+	return g_fused_ws.count(workspace) != 0;
+}
+
+} // namespace
 
 extern "C" {
 
@@ -3231,6 +3345,7 @@ int deodr_hip_render_scene(const DeodrHipScene *sc, void *image, void *z_buffer,
 	p.aa_err = antialiase_error != 0;
 	p.obs = obs;
 	p.err = err_buffer;
+	note_forward(workspace, false);
 	return launch_forward(sc, p, (hipStream_t)stream);
 }
 
@@ -3251,8 +3366,10 @@ int deodr_hip_render_scene_b(const DeodrHipScene *sc, const void *image, const v
 	else if (!image_b && !(image && obs))
 		return fail("image_b == NULL (or, for the residual mode, image and obs)");
 	hipStream_t st = (hipStream_t)stream;
-	if (!have_forward_state)
-	{ // stateless use: rebuild records, tile lists and the owner buffer (no image / z written)
+	if (!have_forward_state || last_forward_was_fused(workspace))
+	{ // stateless use (or a fused forward, which leaves no complete owner buffer): rebuild records, tile lists and the owner
+	  // buffer (no image / z written)
+		note_forward(workspace, false);
 		KParams f = p;
 		f.image = nullptr;
 		f.zbuf = nullptr;
@@ -3288,7 +3405,8 @@ int deodr_hip_render_scene_fit(const DeodrHipScene *sc, void *image, void *z_buf
 		if (p.texture_b && check_hip(hipMemsetAsync(p.texture_b, 0, (size_t)p.tex_h * p.tex_w * p.C * ps, st), "clear texture_b"))
 			return 1;
 	}
-	const bool fused = p.C <= CH && !g_force_generic && !(p.debug & 256);
+	const bool fused = p.C <= CH && !g_force_generic;
+	note_forward(workspace, fused);
 	if (launch_forward(sc, p, st, fused))
 		return 1;
 	return launch_adjoint(sc, p, st, !fused);
@@ -3302,7 +3420,7 @@ int deodr_hip_debug_wave_trace(void *dst, size_t bytes) // tools/wave_trace.py
 #endif
 
 int deodr_hip_workspace_status(const DeodrHipScene *sc, void *workspace, size_t workspace_bytes, void *stream, int *overflowed,
-							   unsigned long long *needed_pairs)
+							   unsigned long long *needed_pairs, int *scene_errors)
 {
 	KParams p;
 	if (fill_params(sc, 1.0, workspace, workspace_bytes, p, false))
@@ -3310,6 +3428,7 @@ int deodr_hip_workspace_status(const DeodrHipScene *sc, void *workspace, size_t 
 	if (check_hip(hipStreamSynchronize((hipStream_t)stream), "status sync"))
 		return 1;
 	unsigned long long worst = 0;
+	unsigned errors = 0;
 	for (int v = 0; v < sc->n_views; v++)
 	{
 		WsHeader h;
@@ -3317,11 +3436,61 @@ int deodr_hip_workspace_status(const DeodrHipScene *sc, void *workspace, size_t 
 			return 1;
 		if (h.needed_max > worst)
 			worst = h.needed_max;
+		errors |= h.scene_errors;
 	}
 	if (needed_pairs)
 		*needed_pairs = worst;
 	if (overflowed)
-		*overflowed = worst > p.L.tri_pool_cap;
+		*overflowed = worst > (p.L.tri_pool_cap < p.L.edge_pool_cap ? p.L.tri_pool_cap : p.L.edge_pool_cap);
+	if (scene_errors)
+		*scene_errors = (int)errors;
+	return 0;
+}
+
+int deodr_hip_workspace_census(const DeodrHipScene *sc, void *workspace, size_t workspace_bytes, void *stream,
+								unsigned long long *nonempty_tiles, unsigned long long *edge_tiles)
+{ // measurement hook: how many tiles of the last forward held a primitive / a silhouette edge (all views)
+	KParams p;
+	if (fill_params(sc, 1.0, workspace, workspace_bytes, p, false))
+		return 1;
+	if (check_hip(hipStreamSynchronize((hipStream_t)stream), "census sync"))
+		return 1;
+	unsigned long long filled = 0, edged = 0;
+	std::vector<uint32_t> bits(p.L.nwords), saved(p.L.ntiles);
+	for (int v = 0; v < sc->n_views; v++)
+	{
+		const char *base = (const char *)workspace + (size_t)v * p.L.view_bytes;
+		WsHeader h;
+		if (check_hip(hipMemcpy(&h, base + p.L.hdr, sizeof h, hipMemcpyDeviceToHost), "census copy") ||
+			check_hip(hipMemcpy(bits.data(), base + p.L.tile_bits + sizeof(uint32_t) * (size_t)(h.cur & 1u) * p.L.nwords, sizeof(uint32_t) * p.L.nwords,
+								hipMemcpyDeviceToHost),
+					  "census copy") ||
+			check_hip(hipMemcpy(saved.data(), base + p.L.edge_saved, sizeof(uint32_t) * p.L.ntiles, hipMemcpyDeviceToHost), "census copy"))
+			return 1;
+		for (int t = 0; t < p.L.ntiles; t++)
+			if ((bits[t >> 5] >> (t & 31)) & 1u)
+			{
+				filled++;
+				edged += (saved[t] & ~SWEEP_SAVED) != 0;
+			}
+	}
+	if (nonempty_tiles)
+		*nonempty_tiles = filled;
+	if (edge_tiles)
+		*edge_tiles = edged;
+	return 0;
+}
+
+int deodr_hip_workspace_pool_pairs(const DeodrHipScene *sc, size_t workspace_bytes, unsigned long long *pool_pairs)
+{ // capacity (in pairs) of the spill pools of a workspace of this size: what the polled `all_needed_max` is compared with
+	if (!sc || sc->n_views <= 0)
+		return fail("scene == NULL");
+	char dummy;
+	KParams p;
+	if (fill_params(sc, 1.0, &dummy, workspace_bytes, p, false))
+		return 1;
+	if (pool_pairs)
+		*pool_pairs = p.L.tri_pool_cap < p.L.edge_pool_cap ? p.L.tri_pool_cap : p.L.edge_pool_cap;
 	return 0;
 }
 

@@ -24,6 +24,7 @@ struct SceneView // one view of the scene: plain device (or host, in the simulat
 	int tex_h, tex_w;
 	bool clockwise, culling, strict, persp;
 	bool vtx_f64;
+	bool has_texture; // scene.texture != NULL
 	double offset; // 0 (integer pixel centres) or 0.5, H.h:2783
 	double sigma;
 };
@@ -144,16 +145,36 @@ struct TriInputs
 	double sum_depth, area;
 };
 
-DR_HD void load_triangle(const SceneView &s, int k, TriInputs &t, bool with_attributes)
+// The index checks of checkSceneValid (H.h:2700-2712), made where the indices are read: an out-of-range entry of faces /
+// faces_uv (or a textured triangle in a scene without texture) must never be dereferenced.
+enum SceneError : uint32_t
+{
+	SCENE_ERR_FACES = 1,	  // faces[k][i] >= nb_vertices
+	SCENE_ERR_FACES_UV = 2,	  // faces_uv[k][i] >= nb_uv
+	SCENE_ERR_NO_TEXTURE = 4, // textured[k] && shaded[k] but scene.texture == NULL
+};
+
+// -> 0, or the SceneError bits of triangle k (then nothing was gathered through its indices and the caller must drop it)
+DR_HD uint32_t load_triangle(const SceneView &s, int k, TriInputs &t, bool with_attributes)
 {
 	const uint32_t *face = s.faces + 3 * (size_t)k, *face_uv = s.faces_uv + 3 * (size_t)k;
+	uint32_t bad = 0;
 	for (int i = 0; i < 3; i++)
 	{
 		t.f[i] = face[i];
 		t.fuv[i] = face_uv[i];
+		bad |= t.f[i] >= (uint32_t)s.V ? (uint32_t)SCENE_ERR_FACES : 0u;
+		bad |= t.fuv[i] >= (uint32_t)s.Vuv ? (uint32_t)SCENE_ERR_FACES_UV : 0u;
 	}
 	t.tex = s.textured[k] != 0;
 	t.both = t.tex && s.shaded[k] != 0;
+	bad |= (t.both && !s.has_texture) ? (uint32_t)SCENE_ERR_NO_TEXTURE : 0u;
+	if (bad)
+	{
+		t.sum_depth = 0;
+		t.area = 0;
+		return bad;
+	}
 	for (int i = 0; i < 3; i++)
 	{
 		t.Vraw[i][0] = ldv(s.ij, 2 * (size_t)t.f[i], s.vtx_f64);
@@ -188,6 +209,7 @@ DR_HD void load_triangle(const SceneView &s, int k, TriInputs &t, bool with_attr
 		t.sum_depth += t.Zv[i];
 	}
 	t.area = front ? signed_area(t.Vraw, s.clockwise) : 0.0;
+	return 0;
 }
 
 // Triangle part of the set-up: record + attribute planes.  Pass-1 kind follows H.h:2785-2819.
@@ -279,7 +301,14 @@ DR_HD void setup_triangle(const SceneView &s, int k, TriRec &rec, double *tri_pl
 						  double *edge_planes /*[3][3P]*/)
 {
 	TriInputs t;
-	load_triangle(s, k, t, true);
+	if (load_triangle(s, k, t, true))
+	{ // invalid indices: dropped (the device kernel also raises the scene's sticky error word)
+		rec.kind = KIND_NONE;
+		rec.front = 0;
+		for (int n = 0; n < 3; n++)
+			erec[n].kind = KIND_NONE;
+		return;
+	}
 	setup_tri_only(s, t, rec, tri_planes);
 	for (int n = 0; n < 3; n++)
 		setup_edge_only(s, t, k, n, erec[n], edge_planes + (size_t)n * 3 * s.P);
@@ -294,10 +323,8 @@ struct GradView // adjoint arrays of one view (vertex dtype), accumulated into
 
 // `Add` is a functor  add(void* array, size_t index, bool f64, double value)  (atomicAdd on the device)
 template <class Add>
-DR_HD void finalize_triangle(const SceneView &s, const GradView &g, int k, const TriRec &rec, const double *acc /*[3P]*/, Add add)
-{
-	if (!rec.front || rec.kind == KIND_NONE)
-		return; // the adjoint only visits front-facing triangles (H.h:3063) of a drawable kind
+DR_HD void finalize_triangle(const SceneView &s, const GradView &g, int k, int kind, const double *acc /*[3P]*/, Add add)
+{ // the caller has checked that the triangle is front-facing (the adjoint only visits those, H.h:3063) and of a drawable kind
 	const uint32_t *face = s.faces + 3 * (size_t)k, *face_uv = s.faces_uv + 3 * (size_t)k;
 	double V[3][2];
 	for (int i = 0; i < 3; i++)
@@ -310,7 +337,7 @@ DR_HD void finalize_triangle(const SceneView &s, const GradView &g, int k, const
 	inv3(b2x, x2b);
 	for (int i = 0; i < 9; i++)
 		x2b_B[i] = b2x_B[i] = 0;
-	if (rec.kind == KIND_TEXTURED)
+	if (kind == KIND_TEXTURED)
 	{ // H.h:1138-1148
 		for (int c = 0; c < 2; c++)
 		{

@@ -20,7 +20,9 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libdeodr_hip.so")
-ABI_VERSION = 2
+ABI_VERSION = 3
+ERR_FACES, ERR_FACES_UV, ERR_NO_TEXTURE = 1, 2, 4  # include/deodr_hip.h DEODR_HIP_ERR_*
+_STATUS_NEEDED, _STATUS_ERRORS = 11, 12  # words of the 64-byte status block at the start of the workspace
 
 
 class _SceneC(C.Structure):
@@ -64,11 +66,40 @@ def lib():
                                                  C.c_size_t, C.c_void_p]  # fmt: skip
         L.deodr_hip_workspace_status.restype = C.c_int
         L.deodr_hip_workspace_status.argtypes = [C.POINTER(_SceneC), C.c_void_p, C.c_size_t, C.c_void_p, C.POINTER(C.c_int),
+                                                 C.POINTER(C.c_ulonglong), C.POINTER(C.c_int)]  # fmt: skip
+        L.deodr_hip_workspace_census.restype = C.c_int
+        L.deodr_hip_workspace_census.argtypes = [C.POINTER(_SceneC), C.c_void_p, C.c_size_t, C.c_void_p, C.POINTER(C.c_ulonglong),
                                                  C.POINTER(C.c_ulonglong)]  # fmt: skip
-        if os.environ.get("DEODR_HIP_FORCE_GENERIC") == "1":  # test hook: exercise the un-staged kernels too
-            L.deodr_hip_force_generic(1)
+        L.deodr_hip_workspace_pool_pairs.restype = C.c_int
+        L.deodr_hip_workspace_pool_pairs.argtypes = [C.POINTER(_SceneC), C.c_size_t, C.POINTER(C.c_ulonglong)]
         _lib = L
     return _lib
+
+
+def force_generic(on):
+    """Test hook (``deodr_hip_force_generic``): route every call through the un-staged kernels.  Process-wide."""
+    lib().deodr_hip_force_generic(int(bool(on)))
+
+
+def tile_census(rasterizer, ds):
+    """(tiles with a primitive, tiles with silhouette edges) of the last forward on `rasterizer`, over all views (synchronises)."""
+    sc = ds.c_struct()
+    a, b = C.c_ulonglong(0), C.c_ulonglong(0)
+    with torch.cuda.device(rasterizer.device):
+        _check(lib().deodr_hip_workspace_census(C.byref(sc), _ptr(rasterizer.workspace), rasterizer.nbytes, _stream(rasterizer.device),
+                                                C.byref(a), C.byref(b)))  # fmt: skip
+    return int(a.value), int(b.value)
+
+
+def scene_error_message(bits):
+    what = []
+    if bits & ERR_FACES:
+        what.append("an entry of scene.faces is >= the number of vertices")
+    if bits & ERR_FACES_UV:
+        what.append("an entry of scene.faces_uv is >= the number of uv vertices")
+    if bits & ERR_NO_TEXTURE:
+        what.append("a triangle is textured and shaded but the scene has no texture")
+    return "invalid scene (checkSceneValid): " + "; ".join(what)
 
 
 def _check(rc):
@@ -80,8 +111,20 @@ def _ptr(t):
     return None if t is None else C.c_void_p(t.data_ptr())
 
 
-def _stream():
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+def _stream(device=None):
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def _on(t, device, dtype, shape, what):
+    """`t` as a contiguous tensor of `dtype` on `device` with `shape` (no copy when it already is one)."""
+    if not torch.is_tensor(t):
+        t = torch.as_tensor(np.asarray(t))
+    t = t.to(device=device, dtype=dtype)
+    if tuple(t.shape) != tuple(shape):
+        if t.numel() != int(np.prod(shape)):
+            raise ValueError(f"{what}: expected shape {tuple(shape)}, got {tuple(t.shape)}")
+        t = t.reshape(shape)
+    return t.contiguous()
 
 
 class DeviceScene:
@@ -95,10 +138,12 @@ class DeviceScene:
     def __init__(self, faces, faces_uv, textured, shaded, uv, ij, depths, colors, shade, edgeflags, height, width, texture=None,
                  background_color=None, background_image=None, clockwise=False, backface_culling=True, strict_edge=True,
                  perspective_correct=False, integer_pixel_centers=True, vertex_dtype=torch.float64, pixel_dtype=torch.float32,
-                 device="cuda"):  # fmt: skip
+                 device="cuda", validate=True):  # fmt: skip
         dev = torch.device(device)
         if dev.type != "cuda":
             raise RuntimeError("deodr_amd needs a ROCm device; there is no CPU path")
+        if dev.index is None:
+            dev = torch.device("cuda", torch.cuda.current_device())
         self.device, self.vertex_dtype, self.pixel_dtype = dev, vertex_dtype, pixel_dtype
         as_t = lambda a, dt: torch.as_tensor(np.asarray(a) if not torch.is_tensor(a) else a).to(device=dev, dtype=dt).contiguous()
         self.faces = as_t(np.asarray(faces).astype(np.int64) if not torch.is_tensor(faces) else faces, torch.int32)
@@ -117,6 +162,21 @@ class DeviceScene:
         self.set_views(ij, depths, colors, shade, edgeflags)
         if self.background_image is not None:
             self.background_image = self.background_image.reshape(self.n_views, self.height, self.width, self.nb_colors).contiguous()
+        if validate:
+            self.validate()
+
+    def validate(self):
+        """checkSceneValid's index checks (reference H.h:2700-2712), once per topology (synchronises).  The set-up kernel
+        makes the same checks on every forward and raises the workspace's sticky error word; this one fails early."""
+        V, Vuv = int(self.depths.shape[1]), int(self.uv.shape[0])
+        if self.nb_triangles:
+            # int32 storage of uint32 indices: a negative value is an index >= 2^31
+            if int(self.faces.min()) < 0 or int(self.faces.max()) >= V:
+                raise ValueError(scene_error_message(ERR_FACES))
+            if int(self.faces_uv.min()) < 0 or int(self.faces_uv.max()) >= Vuv:
+                raise ValueError(scene_error_message(ERR_FACES_UV))
+            if self.texture is None and bool((self.textured.bool() & self.shaded.bool()).any()):
+                raise ValueError(scene_error_message(ERR_NO_TEXTURE))
 
     def set_views(self, ij=None, depths=None, colors=None, shade=None, edgeflags=None):
         """Replace per-view arrays (tensors are used as they are when already contiguous on the device)."""
@@ -173,58 +233,153 @@ class HipRasterizer:
     """Owns the device workspace of one scene shape and runs renderScene / renderScene_B on it.
 
     The workspace keeps the forward state (per-primitive records, tile lists, per-pixel owner ids) between
-    :meth:`render` and :meth:`render_backward`, like ``Scene2D.store_backward`` does in the reference (dr.py:618-627)."""
+    :meth:`render` and :meth:`render_backward`, like ``Scene2D.store_backward`` does in the reference (dr.py:618-627).
+    Every forward is stamped with a generation number (``self.generation``); :meth:`render_backward` reuses the state only
+    when the caller's stamp is still the current one and recomputes it otherwise.
 
-    def __init__(self, nb_triangles, height, width, nb_colors, n_views=1, device="cuda", pool_pairs=0):
+    Spill-pool overflow and invalid scene indices are detected WITHOUT synchronising: after a forward the 64-byte status block
+    of the workspace is copied asynchronously to pinned memory (every ``poll_every`` forwards, and after each of the first
+    two) and inspected at the next call.  An overflow found that way means that frames rendered since the poll were
+    incomplete: the workspace is regrown and a RuntimeError says so.  ``check_overflow=True`` on a call checks synchronously
+    (and regrows / repeats transparently)."""
+
+    def __init__(self, nb_triangles, height, width, nb_colors, n_views=1, device="cuda", pool_pairs=0, poll_every=8):
         self.dims = (int(nb_triangles), int(height), int(width), int(nb_colors), int(n_views))
         self.device = torch.device(device)
+        if self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
+        self.poll_every = int(poll_every)
+        self.generation = 0
         self._alloc(pool_pairs)
-        self._checked = False
 
     def _alloc(self, pool_pairs):
         self.pool_pairs = int(pool_pairs)
         nbytes = lib().deodr_hip_workspace_bytes(*self.dims, self.pool_pairs)
         if nbytes == 0:
             raise ValueError("invalid scene dimensions")
-        self.workspace = torch.zeros(nbytes, dtype=torch.uint8, device=self.device)  # must start zero-filled
+        with torch.cuda.device(self.device):
+            self.workspace = torch.zeros(nbytes, dtype=torch.uint8, device=self.device)  # must start zero-filled
         self.nbytes = nbytes
+        self._status_words = self.workspace[:64].view(torch.int32)
+        self._status_host = torch.zeros(16, dtype=torch.int32).pin_memory()
+        self._status_event = None  # recorded after the last asynchronous copy of the status block
+        self._forwards = 0
+        self._checked = False
+        self._pool_cap = None
+        self._last = None
 
     @classmethod
     def for_scene(cls, ds, pool_pairs=0):
         return cls(ds.nb_triangles, ds.height, ds.width, ds.nb_colors, ds.n_views, ds.device, pool_pairs)
 
+    # ---- status ------------------------------------------------------------------------------------------------------
+
+    def _capacity(self, sc):
+        if self._pool_cap is None:
+            cap = C.c_ulonglong(0)
+            _check(lib().deodr_hip_workspace_pool_pairs(C.byref(sc), self.nbytes, C.byref(cap)))
+            self._pool_cap = int(cap.value)
+        return self._pool_cap
+
+    def _inspect_poll(self, sc):
+        """Look at the last completed asynchronous copy of the status block (never waits)."""
+        ev = self._status_event
+        if ev is None or torch.cuda.is_current_stream_capturing() or not ev.query():
+            return
+        self._status_event = None
+        needed, errors = int(self._status_host[_STATUS_NEEDED]) & 0xFFFFFFFF, int(self._status_host[_STATUS_ERRORS])
+        if errors:
+            raise RuntimeError("deodr_hip: " + scene_error_message(errors))
+        if needed > self._capacity(sc):
+            self._alloc(max(2 * needed, 1024))
+            raise RuntimeError(
+                f"deodr_hip: the spill pool of the workspace overflowed ({needed} pairs needed): frames rendered since the last "
+                "check were incomplete; the workspace has been regrown, render again"
+            )
+
+    def _poll(self):
+        """Queue an asynchronous copy of the status block behind the forward that was just launched."""
+        self._forwards += 1
+        if torch.cuda.is_current_stream_capturing():
+            return
+        if self._status_event is None and (self._forwards <= 2 or self._forwards % self.poll_every == 0):
+            self._status_host.copy_(self._status_words, non_blocking=True)
+            self._status_event = torch.cuda.Event()
+            self._status_event.record()
+
+    def status(self, ds):
+        """Synchronous check: -> (overflowed, needed_pairs, scene_error_bits)."""
+        sc = ds.c_struct()
+        over, need, errs = C.c_int(0), C.c_ulonglong(0), C.c_int(0)
+        with torch.cuda.device(self.device):
+            _check(lib().deodr_hip_workspace_status(C.byref(sc), _ptr(self.workspace), self.nbytes, _stream(self.device), C.byref(over),
+                                                    C.byref(need), C.byref(errs)))  # fmt: skip
+        return bool(over.value), int(need.value), int(errs.value)
+
+    def _check_scene(self, ds):
+        n, H, W, Cc = ds.n_views, ds.height, ds.width, ds.nb_colors
+        if (ds.nb_triangles, H, W, Cc, n) != self.dims:
+            raise ValueError("scene shape differs from the workspace shape")
+        if ds.device != self.device:
+            raise ValueError(f"scene lives on {ds.device}, the workspace on {self.device}")
+
+    def _frame(self, ds, out):
+        n, H, W, Cc = ds.n_views, ds.height, ds.width, ds.nb_colors
+        pd = ds.pixel_dtype
+        if out is None:
+            return torch.empty((n, H, W, Cc), dtype=pd, device=ds.device), torch.empty((n, H, W), dtype=pd, device=ds.device)
+        image, z = out
+        for t, shape in ((image, (n, H, W, Cc)), (z, (n, H, W))):
+            if t.device != ds.device or t.dtype != pd or tuple(t.shape) != shape or not t.is_contiguous():
+                raise ValueError("out= buffers must be contiguous pixel-dtype tensors [n,H,W,C] / [n,H,W] on the scene's device")
+        return image, z
+
+    def _run_checked(self, ds, launch, check_overflow):
+        """Launch a forward; with a synchronous check, regrow the workspace and repeat until nothing spills."""
+        sync = check_overflow is True or (check_overflow is None and not self._checked)
+        for _attempt in range(16):
+            launch()
+            if not sync:
+                self._poll()
+                return
+            over, need, errs = self.status(ds)
+            self._checked = True
+            if errs:
+                raise RuntimeError("deodr_hip: " + scene_error_message(errs))
+            if not over:
+                self._forwards += 1
+                return
+            self._alloc(max(2 * need, 1024))  # regrow (zero-filled) and render again
+            self._checked = True
+        # the pool doubles every time: this is not a scene that needs more room, something is wrong
+        raise RuntimeError("deodr_hip: the spill pool still overflows after 16 regrows")
+
+    # ---- calls -------------------------------------------------------------------------------------------------------
+
     def render(self, ds, sigma=1.0, antialiase_error=False, obs=None, out=None, check_overflow=None):
         """-> (image [n,H,W,C], z_buffer [n,H,W][, err_buffer [n,H,W]]) as pixel-dtype device tensors.
 
-        ``check_overflow`` (default: only on the first call) synchronises once to make sure no tile list spilled past the
-        pool; if one did the workspace is regrown and the render repeated."""
+        ``check_overflow``: True = synchronise and make sure no tile list spilled past the pool (regrow + repeat if one did);
+        None (default) = do that on the first call only, afterwards poll asynchronously; False = only poll."""
+        self._check_scene(ds)
         n, H, W, Cc = ds.n_views, ds.height, ds.width, ds.nb_colors
-        assert (ds.nb_triangles, H, W, Cc, n) == self.dims, "scene shape differs from the workspace shape"
         pd = ds.pixel_dtype
-        if out is None:
-            image = torch.empty((n, H, W, Cc), dtype=pd, device=ds.device)
-            z = torch.empty((n, H, W), dtype=pd, device=ds.device)
-        else:
-            image, z = out
-        err = obs_t = None
-        if antialiase_error:
-            obs_t = obs.to(device=ds.device, dtype=pd).reshape(n, H, W, Cc).contiguous()
-            err = torch.empty((n, H, W), dtype=pd, device=ds.device)
-        sc = ds.c_struct()
-        for _attempt in range(16):
-            _check(lib().deodr_hip_render_scene(C.byref(sc), _ptr(image), _ptr(z), float(sigma), int(antialiase_error), _ptr(obs_t),
-                                                _ptr(err), _ptr(self.workspace), self.nbytes, _stream()))  # fmt: skip
-            if check_overflow is False or (check_overflow is None and self._checked):
-                break
-            over, need = C.c_int(0), C.c_ulonglong(0)
-            _check(lib().deodr_hip_workspace_status(C.byref(sc), _ptr(self.workspace), self.nbytes, _stream(), C.byref(over), C.byref(need)))
-            self._checked = True
-            if not over.value:
-                break
-            self._alloc(max(2 * int(need.value), 1024))  # regrow (zero-filled) and render again
-        else:  # the pool doubles every time: this is not a scene that needs more room, something is wrong
-            raise RuntimeError("deodr_hip: the spill pool still overflows after 16 regrows")
-        self._last = (ds, float(sigma), bool(antialiase_error), obs_t, image, err)
+        with torch.cuda.device(self.device):
+            sc = ds.c_struct()
+            self._inspect_poll(sc)
+            image, z = self._frame(ds, out)
+            err = obs_t = None
+            if antialiase_error:
+                obs_t = _on(obs, ds.device, pd, (n, H, W, Cc), "obs")
+                err = torch.empty((n, H, W), dtype=pd, device=ds.device)
+
+            def launch():
+                _check(lib().deodr_hip_render_scene(C.byref(sc), _ptr(image), _ptr(z), float(sigma), int(antialiase_error), _ptr(obs_t),
+                                                    _ptr(err), _ptr(self.workspace), self.nbytes, _stream(self.device)))  # fmt: skip
+
+            self._run_checked(ds, launch, check_overflow)
+        self.generation += 1
+        self._last = (ds, float(sigma), bool(antialiase_error), obs_t, image, err, self.generation, False)
         return (image, z, err) if antialiase_error else (image, z)
 
     def render_fit(self, ds, obs, sigma=1.0, grads=None, out=None, check_overflow=None, clear_grads=False):
@@ -234,50 +389,66 @@ class HipRasterizer:
         ``Scene2D.render_compare_and_backward`` does with ``antialiase_error=False``), but the forward raster already
         back-propagates through every tile without silhouette edges, so the frame is traversed once.  ``clear_grads``: zero
         ``grads`` first, inside the same kernel launches (otherwise they are accumulated into)."""
+        self._check_scene(ds)
         n, H, W, Cc = ds.n_views, ds.height, ds.width, ds.nb_colors
-        assert (ds.nb_triangles, H, W, Cc, n) == self.dims, "scene shape differs from the workspace shape"
         pd = ds.pixel_dtype
-        if out is None:
-            image = torch.empty((n, H, W, Cc), dtype=pd, device=ds.device)
-            z = torch.empty((n, H, W), dtype=pd, device=ds.device)
-        else:
-            image, z = out
-        obs_t = obs.to(device=ds.device, dtype=pd)
-        if tuple(obs_t.shape) != (n, H, W, Cc) or not obs_t.is_contiguous():  # pass [n,H,W,C] to avoid this copy
-            obs_t = obs_t.expand(n, H, W, Cc).contiguous()
-        if check_overflow or (check_overflow is None and not self._checked):
-            self.render(ds, sigma, out=(image, z), check_overflow=True)  # sizes the spill pool once (synchronises)
-        if grads is None:
-            grads = ds.zero_grads()
-        sc = ds.c_struct(grads)
-        _check(lib().deodr_hip_render_scene_fit(C.byref(sc), _ptr(image), _ptr(z), float(sigma), _ptr(obs_t), int(bool(clear_grads)),
-                                                _ptr(self.workspace), self.nbytes, _stream()))  # fmt: skip
-        self._last = (ds, float(sigma), False, obs_t, image, None)
+        with torch.cuda.device(self.device):
+            image, z = self._frame(ds, out)
+            obs_t = obs if torch.is_tensor(obs) else torch.as_tensor(np.asarray(obs))
+            obs_t = obs_t.to(device=ds.device, dtype=pd)
+            if tuple(obs_t.shape) != (n, H, W, Cc) or not obs_t.is_contiguous():  # pass [n,H,W,C] to avoid this copy
+                obs_t = obs_t.expand(n, H, W, Cc).contiguous()
+            if check_overflow or (check_overflow is None and not self._checked):
+                self.render(ds, sigma, out=(image, z), check_overflow=True)  # sizes the spill pool once (synchronises)
+            if grads is None:
+                grads = ds.zero_grads()
+            sc = ds.c_struct(grads)
+            self._inspect_poll(sc)
+            _check(lib().deodr_hip_render_scene_fit(C.byref(sc), _ptr(image), _ptr(z), float(sigma), _ptr(obs_t), int(bool(clear_grads)),
+                                                    _ptr(self.workspace), self.nbytes, _stream(self.device)))  # fmt: skip
+            self._poll()
+        self.generation += 1
+        self._last = (ds, float(sigma), False, obs_t, image, None, self.generation, True)
         return image, z, grads
 
-    def render_backward(self, ds, image_b=None, err_buffer_b=None, grads=None, have_forward_state=True, residual_obs=None):
+    def render_backward(self, ds, image_b=None, err_buffer_b=None, grads=None, have_forward_state=True, residual_obs=None,
+                        generation=None, sigma=None):  # fmt: skip
         """Adjoint of the last :meth:`render` of ``ds``; returns the dict of gradient tensors (accumulated into ``grads``
         when given, fresh zeros otherwise).  Nothing passed in is mutated.
 
         ``residual_obs`` (instead of ``image_b``): propagate the gradient of ``sum((image - residual_obs)**2)`` where
-        ``image`` is the output of the last render; ``2 (image - obs)`` is formed inside the kernel."""
-        last_ds, sigma, aa, obs_t, image, _ = self._last
+        ``image`` is the output of the last render; ``2 (image - obs)`` is formed inside the kernel.
+        ``generation``: the value of ``self.generation`` right after the forward this adjoint belongs to; when another forward
+        has run on the workspace since (two renders in one autograd graph), the forward state is recomputed from ``ds``
+        instead of being trusted (pass that forward's ``sigma`` too)."""
+        self._check_scene(ds)
+        last_ds, last_sigma, aa, obs_t, image, _err, gen, fused = self._last
+        sigma = last_sigma if sigma is None else float(sigma)
         n, H, W, Cc = ds.n_views, ds.height, ds.width, ds.nb_colors
         pd = ds.pixel_dtype
-        if grads is None:
-            grads = ds.zero_grads()
-        sc = ds.c_struct(grads)
-        ib = eb = None
-        if aa:
-            eb = err_buffer_b.to(device=ds.device, dtype=pd).reshape(n, H, W).contiguous()
-        elif residual_obs is not None:
-            obs_t = residual_obs.to(device=ds.device, dtype=pd)
-            if tuple(obs_t.shape) != (n, H, W, Cc) or not obs_t.is_contiguous():  # pass [n,H,W,C] to avoid this copy
-                obs_t = obs_t.expand(n, H, W, Cc).contiguous()
-        else:
-            ib = image_b.to(device=ds.device, dtype=pd).reshape(n, H, W, Cc).contiguous()
-        _check(lib().deodr_hip_render_scene_b(C.byref(sc), _ptr(image), None, _ptr(ib), sigma, int(aa), _ptr(obs_t), None, _ptr(eb),
-                                              _ptr(self.workspace), self.nbytes, int(have_forward_state and last_ds is ds), _stream()))  # fmt: skip
+        with torch.cuda.device(self.device):
+            if grads is None:
+                grads = ds.zero_grads()
+            sc = ds.c_struct(grads)
+            ib = eb = None
+            if aa:
+                eb = _on(err_buffer_b, ds.device, pd, (n, H, W), "err_buffer_b")
+            elif residual_obs is not None:
+                obs_t = residual_obs if torch.is_tensor(residual_obs) else torch.as_tensor(np.asarray(residual_obs))
+                obs_t = obs_t.to(device=ds.device, dtype=pd)
+                if tuple(obs_t.shape) != (n, H, W, Cc) or not obs_t.is_contiguous():  # pass [n,H,W,C] to avoid this copy
+                    obs_t = obs_t.expand(n, H, W, Cc).contiguous()
+            else:
+                ib = _on(image_b, ds.device, pd, (n, H, W, Cc), "image_b")
+            state = have_forward_state and last_ds is ds and not fused and (generation is None or generation == gen)
+            _check(lib().deodr_hip_render_scene_b(C.byref(sc), _ptr(image), None, _ptr(ib), sigma, int(aa), _ptr(obs_t), None, _ptr(eb),
+                                                  _ptr(self.workspace), self.nbytes, int(state), _stream(self.device)))  # fmt: skip
+            if not state:
+                # a forward ran inside the call: the workspace now holds the state of THIS (ds, sigma), stamped anew so that
+                # any other pending adjoint sees that its own forward state is gone
+                self._poll()
+                self.generation += 1
+                self._last = (ds, sigma, aa, obs_t, image, _err, self.generation, False)
         return grads
 
 
@@ -351,11 +522,21 @@ def renderSceneBCpp(scene, sigma, image, z_buffer, image_b=None, antialiase_erro
     dev = ds.device
     img_t = torch.as_tensor(_np(image, np.float64)).to(dev)[None]
     obs_t = None if obs is None else torch.as_tensor(_np(obs, np.float64)).to(dev)[None].contiguous()
-    r._last = (ds, float(sigma), bool(antialiase_error), obs_t, img_t, None)
-    if antialiase_error:
-        g = r.render_backward(ds, err_buffer_b=torch.as_tensor(_np(err_buffer_b, np.float64)), have_forward_state=False)
+    for _attempt in range(16):
+        r.generation += 1
+        r._last = (ds, float(sigma), bool(antialiase_error), obs_t, img_t, None, r.generation, False)
+        if antialiase_error:
+            g = r.render_backward(ds, err_buffer_b=torch.as_tensor(_np(err_buffer_b, np.float64)), have_forward_state=False)
+        else:
+            g = r.render_backward(ds, image_b=torch.as_tensor(_np(image_b, np.float64)), have_forward_state=False)
+        over, need, errs = r.status(ds)  # the call is synchronous anyway: the stateless forward must not have spilled
+        if errs:
+            raise RuntimeError("deodr_hip: " + scene_error_message(errs))
+        if not over:
+            break
+        r._alloc(max(2 * need, 1024))
     else:
-        g = r.render_backward(ds, image_b=torch.as_tensor(_np(image_b, np.float64)), have_forward_state=False)
+        raise RuntimeError("deodr_hip: the spill pool still overflows after 16 regrows")
     for name in ("uv_b", "ij_b", "shade_b", "colors_b", "texture_b"):
         new = g[name]
         old = getattr(scene, name, None)

@@ -95,7 +95,9 @@ int deodr_hip_render_scene(const DeodrHipScene *scene, void *image, void *z_buff
  * from the rendered image (what Scene2D.render_compare_and_backward does on the host, dr.py:728-732) instead of being
  * written to and read back from HBM.
  * have_forward_state != 0: the workspace still holds the state of the matching deodr_hip_render_scene call (same scene
- * arrays, same sigma) and is reused; 0: the forward state is recomputed first (stateless use, as the reference). */
+ * arrays, same sigma) and is reused; 0: the forward state is recomputed first (stateless use, as the reference).  After a
+ * deodr_hip_render_scene_fit on the same workspace the state is always recomputed (the fused forward does not keep the
+ * owner ids of the tiles it has already back-propagated through). */
 int deodr_hip_render_scene_b(const DeodrHipScene *scene, const void *image, const void *z_buffer, const void *image_b,
 							 double sigma, int antialiase_error, const void *obs, const void *err_buffer,
 							 const void *err_buffer_b, void *workspace, size_t workspace_bytes, int have_forward_state,
@@ -112,12 +114,29 @@ int deodr_hip_render_scene_b(const DeodrHipScene *scene, const void *image, cons
 int deodr_hip_render_scene_fit(const DeodrHipScene *scene, void *image, void *z_buffer, double sigma, const void *obs,
 							   int clear_gradients, void *workspace, size_t workspace_bytes, void *stream);
 
-/* Synchronises `stream` and reports whether any forward since the workspace was zero-filled overflowed the spill pool
+/* Bits of the sticky scene-error word: the index checks of the reference's checkSceneValid
+ * (DifferentiableRenderer.h:2700-2712: `faces` entries < nb_vertices, `faces_uv` entries < nb_uv; plus the null-texture
+ * check of H.h:2687-2694 that needs per-triangle data) are made by the set-up kernel where it reads the indices -- a
+ * device-resident scene is never copied to the host to be validated.  An offending triangle is dropped (never
+ * dereferenced) and the word is raised; the reference throws instead. */
+#define DEODR_HIP_ERR_FACES 1	   /* an entry of faces is >= nb_vertices */
+#define DEODR_HIP_ERR_FACES_UV 2   /* an entry of faces_uv is >= nb_uv */
+#define DEODR_HIP_ERR_NO_TEXTURE 4 /* textured[k] && shaded[k] for some k although scene.texture == NULL */
+
+/* Synchronises `stream` and reports (1) whether any forward since the workspace was zero-filled overflowed the spill pool
  * (then that result was incomplete and the call must be repeated with a workspace sized for a larger `pool_pairs`):
- * *needed_pairs receives the largest number of spilled pairs seen in any view.  Costs a device synchronisation: call it
- * once after the first render of a scene (or after a batch of renders), not per frame. */
+ * *needed_pairs receives the largest number of spilled pairs seen in any view; (2) the union of the DEODR_HIP_ERR_* bits
+ * raised by any forward (*scene_errors; 0 = the scene passed checkSceneValid's index checks).  Costs a device
+ * synchronisation: call it after the first render of a scene, or poll instead: the first 64 bytes of the workspace are a
+ * status block of sixteen uint32 whose words [11] and [12] hold the same two values for all views (max of needed pairs, union
+ * of error bits) after every forward -- an asynchronous 64-byte copy to pinned memory, inspected later, costs no
+ * synchronisation (deodr_amd.hip_renderer.HipRasterizer does that).  deodr_hip_workspace_pool_pairs gives the capacity the
+ * first value has to be compared with. */
 int deodr_hip_workspace_status(const DeodrHipScene *scene, void *workspace, size_t workspace_bytes, void *stream, int *overflowed,
-							   unsigned long long *needed_pairs);
+							   unsigned long long *needed_pairs, int *scene_errors);
+int deodr_hip_workspace_pool_pairs(const DeodrHipScene *scene, size_t workspace_bytes, unsigned long long *pool_pairs);
+#define DEODR_HIP_STATUS_WORD_NEEDED_PAIRS 11
+#define DEODR_HIP_STATUS_WORD_SCENE_ERRORS 12
 
 /* Measurement hooks (bench.py): deodr_hip_profile_enable(n), n > 0: the kernel launches of every n-th forward (and of the
  * adjoint that follows it) are bracketed by hipEvents recorded on the launch stream; 0: off.  An event pair costs ~3 us of
@@ -128,8 +147,14 @@ int deodr_hip_workspace_status(const DeodrHipScene *scene, void *workspace, size
 int deodr_hip_profile_enable(int every);
 int deodr_hip_profile_read(double ms_sum[4], unsigned long long launches[4]);
 
+/* Measurement hook (bench.py's "necessary bytes"): synchronises `stream` and counts, over all views of the last forward, the
+ * 8 x 8-pixel tiles that received at least one primitive and those that hold silhouette edges. */
+int deodr_hip_workspace_census(const DeodrHipScene *scene, void *workspace, size_t workspace_bytes, void *stream,
+							   unsigned long long *nonempty_tiles, unsigned long long *edge_tiles);
+
 /* Test hook: non-zero makes every call use the generic (un-staged) kernels that otherwise only serve nb_colors > 4 and
- * antialiase_error, so that the parity suite can exercise both code paths on the same scenes. */
+ * antialiase_error, so that the parity suite can exercise both code paths on the same scenes.  This (and the profiling
+ * hook above) is the only process-wide state; the library reads NO environment variable. */
 int deodr_hip_force_generic(int on);
 
 /* Message of the last error returned on this host thread. */
@@ -137,7 +162,7 @@ const char *deodr_hip_last_error(void);
 
 /* ABI version of this header; bumped on any incompatible change. */
 int deodr_hip_abi_version(void);
-#define DEODR_HIP_ABI_VERSION 2
+#define DEODR_HIP_ABI_VERSION 3
 
 #ifdef __cplusplus
 }

@@ -2,6 +2,10 @@
 import sys, os, time
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+if "--lib" in sys.argv:  # a variant of the library (tools/build_variants.sh): trace builds, other occupancies
+    import deodr_amd.hip_renderer as _hr
+
+    _hr.LIB_PATH = os.path.abspath(sys.argv[sys.argv.index("--lib") + 1])
 from deodr_amd import scenes
 from deodr_amd.hip_renderer import DeviceScene, HipRasterizer
 

@@ -3,6 +3,10 @@ over the first row of each non-empty tile in the z buffer).  Run on the GPU box.
 import sys, os
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+if "--lib" in sys.argv:  # a variant of the library (tools/build_variants.sh): trace builds, other occupancies
+    import deodr_amd.hip_renderer as _hr
+
+    _hr.LIB_PATH = os.path.abspath(sys.argv[sys.argv.index("--lib") + 1])
 from deodr_amd import scenes
 from deodr_amd.hip_renderer import DeviceScene, HipRasterizer
 

@@ -2,7 +2,7 @@
 cd /tmp && export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc
 mkdir -p $OUT
-run() { rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $OUT/$NAME -o p -- python $GRAFT_REPO_ROOT/bench.py --steps 4 --warmup 1 --no-cpu-baseline $BENCH_ARGS > $OUT/$NAME.log 2>&1; }
+run() { rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $OUT/$NAME -o p -- python $GRAFT_REPO_ROOT/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-single-view $BENCH_ARGS > $OUT/$NAME.log 2>&1; }
 NAME=sq1; run SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY
 NAME=sq2; run SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_ACTIVE_INST_SCA
 NAME=fetch; run FETCH_SIZE

@@ -2,7 +2,7 @@
 cd /tmp && export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc1
 rm -rf $OUT; mkdir -p $OUT
-rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $OUT/c -o p -- python $GRAFT_REPO_ROOT/bench.py --steps 4 --warmup 1 --no-cpu-baseline $BENCH_ARGS > $OUT/log 2>&1
+rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $OUT/c -o p -- python $GRAFT_REPO_ROOT/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-single-view $BENCH_ARGS > $OUT/log 2>&1
 python - <<'PY'
 import csv, glob, os, collections, re
 out = os.environ['GRAFT_REPO_ROOT'] + '/gpurun_out/pmc1'
