@@ -143,7 +143,9 @@ def mesh_scene(
         u, v = tri[:, 1] - tri[:, 0], tri[:, 2] - tri[:, 0]
         cr = u[:, 0] * v[:, 1] - u[:, 1] * v[:, 0]
         zf = depths[faces.astype(np.int64)].mean(axis=1)
-        clockwise = bool(np.sum((cr > 0) * (zf.max() - zf)) > np.sum((cr < 0) * (zf.max() - zf)))
+        # the faces of one winding sign are on average nearer than those of the other: that sign is "front" (a count of
+        # faces weighted by nearness -- round 1's rule -- is nearly balanced on a sphere in perspective and flipped with the pose)
+        clockwise = bool(zf[cr > 0].mean() < zf[cr < 0].mean()) if (cr > 0).any() and (cr < 0).any() else bool((cr > 0).any())
     normals = vertex_normals(vertices, faces.astype(np.int64), clockwise)
     luminosity = np.maximum(0, -normals @ np.asarray(light, dtype=np.float64)) + ambient
     nv, nt = vertices.shape[0], faces.shape[0]
