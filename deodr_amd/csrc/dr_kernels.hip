@@ -44,6 +44,10 @@ using namespace dr;
 namespace
 {
 
+#ifndef DR_ABLATE
+#define DR_ABLATE 0 // measurement builds only (tools/build_variants.sh): 4 no frame stores of non-empty tiles, 8 no fill waves'
+					// stores, 128 no accumulator atomics of the owner adjoint.  The product is always built with 0.
+#endif
 constexpr int TILE = 8;		// 8 x 8 pixels = one wavefront, lane = (y & 7) * 8 + (x & 7)
 constexpr int K_TRI = 32;	// inline triangle slots per tile; more spill to the pool
 constexpr int K_EDGE = 32;	// inline edge slots per tile (== TB: one staged batch)
@@ -52,13 +56,11 @@ constexpr int MAX_SORTED = 64; // edges of a tile whose blending order is cached
 constexpr int NSUB = 8;		// sub-lists of the per-view list of tiles that hold silhouette edges (tile % NSUB: bounded, 8 append counters)
 constexpr int CNT_STRIDE = 32; // uint32 between two append counters (one 128-byte line each)
 constexpr int PRIO_EDGES = 8; // tiles with more edges than this are also listed apart: the adjoint's edge kernel starts with them
-// Tiles that receive more than FIRST_PRIMS triangles (or edges) are the long poles of the forward raster: the first
-// FWD_FIRST of them per view are flagged (`first_flag`) and listed, and the staged forward kernel dispatches them before
-// anything else -- otherwise the many-primitive tiles of the last view end 30 us after every other wave of the kernel.
-// The block that finds its own tile flagged leaves it alone and clears the flag (nobody else reads it).
+// Tiles that receive more than FIRST_PRIMS triangles (or edges) are the long poles of the forward raster: the scan kernel
+// puts them at the head of the work list, so that the 25-50 us waves start at time 0 instead of ending 30 us after every
+// other wave of the kernel.
 constexpr int FIRST_PRIMS = 8;
-constexpr int FWD_FIRST = 512; // listed tiles per view (NSUB sub-lists of FWD_FIRST / NSUB)
-constexpr int LIST_KINDS = 4; // edge tiles, tiles with > PRIO_EDGES edges, first tiles of the forward, tiles with > TB edges
+constexpr int LIST_KINDS = 4; // edge tiles, tiles with > PRIO_EDGES edges, (unused), tiles with > TB edges
 // The forward sweep over a tile's edges (pass 2) leaves, per pixel, the antialiased colour in double and the mask of the
 // edges drawn: the forward raster saves both for the first SAVE_SUB edge tiles of every sub-list, so that the adjoint's edge
 // kernel starts with the reverse sweep instead of repeating the forward one (half of its time per tile).
@@ -90,7 +92,8 @@ struct WsHeader // 64 bytes per view at the start of the view's workspace
 	uint32_t snap_count[2];	 // tiles whose forward sweep is also saved batch by batch (edge_snap), by forward parity
 	// view 0 only: maximum / union of needed_max / scene_errors over the views, so that the host polls ONE 64-byte block
 	uint32_t all_needed_max, all_scene_errors;
-	uint32_t pad[3];
+	uint32_t work_count[2]; // entries of the forward's work list: [0] many-primitive tiles (from the front), [1] the others (from the back)
+	uint32_t pad[1];
 };
 static_assert(sizeof(WsHeader) == 64, "");
 static_assert(offsetof(WsHeader, all_needed_max) == 4 * DEODR_HIP_STATUS_WORD_NEEDED_PAIRS &&
@@ -102,7 +105,7 @@ static_assert(offsetof(WsHeader, all_needed_max) == 4 * DEODR_HIP_STATUS_WORD_NE
 struct Layout
 {
 	size_t hdr, tri_rec, tri_planes, tri_acc, edge_rec, edge_planes, edge_acc, tri_cnt, edge_cnt, edge_saved, tri_list, edge_list, tri_pool,
-		edge_pool, face_id, tile_bits, tri_flag, edge_tile_cnt, edge_tiles, first_flag, edge_slot, edge_sweep, edge_snap, view_bytes;
+		edge_pool, face_id, tile_bits, tri_flag, work_list, edge_tile_cnt, edge_tiles, edge_slot, edge_sweep, edge_snap, view_bytes;
 	uint32_t tri_pool_cap, edge_pool_cap;
 	int tiles_x, tiles_y, ntiles, nwords, P, sub_cap, save_sub;
 };
@@ -141,10 +144,11 @@ Layout make_layout(int T, int H, int W, int C, size_t pool_pairs)
 	L.tri_pool = take(sizeof(uint2) * (size_t)L.tri_pool_cap);
 	L.edge_pool = take(sizeof(uint2) * (size_t)L.edge_pool_cap);
 	L.face_id = take(sizeof(int32_t) * (size_t)H * W);
-	// one bit per tile, set by whoever bins the first primitive into the tile; double-buffered by forward parity like the spill
-	// counters (the set-up kernel of a forward fills [cur] and clears [1 - cur]), so nobody ever clears a bit another wave reads
+	// one bit per tile (the tile received a primitive) and the work list of the staged forward: one uint4 {tile, triangles,
+	// edges, sweep slot} per non-empty tile, both written by tile_scan_kernel between set-up and forward raster
 	L.nwords = (L.ntiles + 31) / 32;
-	L.tile_bits = take(sizeof(uint32_t) * 2 * L.nwords);
+	L.tile_bits = take(sizeof(uint32_t) * L.nwords);
+	L.work_list = take(sizeof(uint4) * (size_t)L.ntiles);
 	// kind | front << 2 of every triangle of the last forward: what finalize_kernel needs to know about a triangle before it
 	// touches anything else (one coalesced byte per thread instead of a 128-byte record line per triangle, two out of three
 	// of which are culled)
@@ -152,7 +156,6 @@ Layout make_layout(int T, int H, int W, int C, size_t pool_pairs)
 	L.sub_cap = (L.ntiles + NSUB - 1) / NSUB;
 	L.edge_tile_cnt = take(sizeof(uint32_t) * 2 * LIST_KINDS * NSUB * CNT_STRIDE); // [epoch parity][kind][sub-list]
 	L.edge_tiles = take(sizeof(uint32_t) * LIST_KINDS * NSUB * (size_t)L.sub_cap);	// [kind][sub-list][sub_cap]
-	L.first_flag = take(sizeof(uint32_t) * L.ntiles);
 	L.edge_slot = take(sizeof(uint32_t) * L.ntiles); // 1 + index of the tile's slot in edge_sweep, 0: none
 	L.save_sub = SAVE_SUB < L.sub_cap ? SAVE_SUB : L.sub_cap; // saved sweeps per sub-list
 	L.edge_sweep = take(SWEEP_BYTES * NSUB * (size_t)L.save_sub);
@@ -177,7 +180,7 @@ struct KParams
 	const void *image_b, *obs, *err_b, *image_in;
 	int aa_err;
 	int n_views;
-	int first_tiles; // the staged forward with one tile per workgroup follows: flag and list the many-primitive tiles (FWD_FIRST)
+	int tile_blocks; // staged forward: workgroups per view that walk the work list (multiple of 512, or tiny frames: <= ntiles)
 	int row_group;	 // tile rows per strip dealt to an XCD by the raster kernels (xcd_strip_row); 0: one band per XCD
 	int clear_grads; // the set-up kernel zeroes the per-view gradient arrays (a fit step that wants fresh gradients: no separate fills)
 	// workspace
@@ -199,7 +202,7 @@ struct ViewPtrs
 	uint8_t *tri_flag;
 	uint32_t *edge_slot;
 	char *edge_sweep, *edge_snap;
-	uint32_t *first_flag;				  // 1: the tile is on the list of tiles the forward rasterizes first
+	uint4 *work_list;
 	uint32_t *edge_tile_cnt, *edge_tiles; // tiles with silhouette edges: NSUB counters per epoch parity, NSUB sub-lists of sub_cap tiles
 };
 
@@ -226,7 +229,7 @@ __device__ __forceinline__ ViewPtrs view_ptrs(const KParams &p, int view)
 	v.tri_flag = (uint8_t *)(b + p.L.tri_flag);
 	v.edge_tile_cnt = (uint32_t *)(b + p.L.edge_tile_cnt);
 	v.edge_tiles = (uint32_t *)(b + p.L.edge_tiles);
-	v.first_flag = (uint32_t *)(b + p.L.first_flag);
+	v.work_list = (uint4 *)(b + p.L.work_list);
 	v.edge_slot = (uint32_t *)(b + p.L.edge_slot);
 	v.edge_sweep = b + p.L.edge_sweep;
 	v.edge_snap = b + p.L.edge_snap;
@@ -385,20 +388,6 @@ __device__ __forceinline__ int xcd_strip_row(int pr, int tiles_y, int group)
 
 // ----------------------------------------------------------------------------------------------------- set-up + bin
 
-// The (FIRST_PRIMS + 1)-th triangle or edge of a tile claims the tile for the head of the forward's dispatch order: whoever
-// sets the flag first lists the tile; if the view's list is full the flag is withdrawn (the tile is rasterized in place).
-__device__ __forceinline__ void claim_first_tile(const KParams &p, const ViewPtrs &w, uint32_t cur, int tile)
-{
-	if (atomicOr(&w.first_flag[tile], 1u))
-		return;
-	const int sub = 2 * NSUB + tile % NSUB;
-	const uint32_t at = atomicAdd(&w.edge_tile_cnt[(cur * LIST_KINDS * NSUB + sub) * CNT_STRIDE], 1u);
-	if (at < (uint32_t)(FWD_FIRST / NSUB))
-		w.edge_tiles[(size_t)sub * p.L.sub_cap + at] = (uint32_t)tile;
-	else
-		atomicAnd(&w.first_flag[tile], 0u);
-}
-
 __device__ __forceinline__ void place_in_tile(uint32_t *list, int cap_inline, uint2 *pool, uint32_t pool_cap, uint32_t *spill, int tile,
 											  uint32_t prim, uint32_t slot)
 {
@@ -546,14 +535,10 @@ __global__ __launch_bounds__(PRIM_BLOCK) void setup_bin_kernel(KParams p)
 		w.hdr->tri_spill[1 - cur] = 0;
 		w.hdr->edge_spill[1 - cur] = 0;
 		w.hdr->snap_count[1 - cur] = 0;
+		w.hdr->work_count[0] = w.hdr->work_count[1] = 0; // filled by tile_scan_kernel, read by the forward raster
 	}
 	if (item < LIST_KINDS * NSUB)
 		w.edge_tile_cnt[((1 - cur) * LIST_KINDS * NSUB + item) * CNT_STRIDE] = 0;
-	for (int i = item; i < p.L.nwords; i += gridDim.x * blockDim.x)
-		w.tile_bits[(1 - cur) * p.L.nwords + i] = 0; // the bitmap of the next forward
-	uint32_t *const bits = w.tile_bits + cur * p.L.nwords;
-	// whoever bins the first triangle or the first edge into a tile marks it non-empty
-	auto mark = [&](int tile) { atomicOr(&bits[tile >> 5], 1u << (tile & 31)); };
 	if (p.clear_grads && view == 0 && p.uv_b)
 		for (int v = item; v < 2 * p.Vuv; v += gridDim.x * blockDim.x)
 		{ // shared by the views: zeroed once
@@ -598,14 +583,9 @@ __global__ __launch_bounds__(PRIM_BLOCK) void setup_bin_kernel(KParams p)
 		const int sub = (got == 0 ? 0 : (got == 16u ? 3 * NSUB : NSUB)) + tile % NSUB;
 		const uint32_t at = atomicAdd(&w.edge_tile_cnt[(cur * LIST_KINDS * NSUB + sub) * CNT_STRIDE], 1u);
 		w.edge_tiles[(size_t)sub * p.L.sub_cap + at] = (uint32_t)tile;
-		if (got == 0)
-		{ // a place for the forward sweep of the tile (always written: a stale value must never be read)
+		if (got == 0) // a place for the forward sweep of the tile (always written: a stale value must never be read)
 			w.edge_slot[tile] = at < (uint32_t)p.L.save_sub ? (uint32_t)sub * p.L.save_sub + at + 1u : 0u;
-			mark(tile);
-		}
-		static_assert(PRIO_EDGES == FIRST_PRIMS && PRIO_EDGES != 16, "one threshold for both lists; 16 = TB, one batch of edges");
-		if (got == (uint32_t)PRIO_EDGES && p.first_tiles)
-			claim_first_tile(p, w, cur, tile);
+		static_assert(PRIO_EDGES != 16, "16 = TB, one batch of edges");
 	};
 	// A primitive whose bounding box needs more than COOP_BLOCKS blocks of 3 x 3 tiles is not binned by its own thread
 	// (hundreds of dependent atomic round trips in one lane: 0.3 ms of set-up for a 1 000-triangle mesh filling a 1024^2
@@ -676,10 +656,6 @@ __global__ __launch_bounds__(PRIM_BLOCK) void setup_bin_kernel(KParams p)
 						{
 							const int tile = (ty0 + by + q / 3) * p.L.tiles_x + tx0 + bx + q % 3;
 							place_in_tile(w.tri_list, K_TRI, w.tri_pool, p.L.tri_pool_cap, &w.hdr->tri_spill[cur], tile, (uint32_t)k, slot[q]);
-							if (slot[q] == 0)
-								mark(tile);
-							if (p.first_tiles && slot[q] == (uint32_t)FIRST_PRIMS)
-								claim_first_tile(p, w, cur, tile);
 						}
 				}
 		} while (false);
@@ -770,13 +746,7 @@ __global__ __launch_bounds__(PRIM_BLOCK) void setup_bin_kernel(KParams p)
 			if (tri_block)
 			{
 				if (!tile_outside_halfplanes<3>(q, tx, ty))
-				{
-					const uint32_t got = push_tile(w.tri_cnt, w.tri_list, K_TRI, w.tri_pool, p.L.tri_pool_cap, &w.hdr->tri_spill[cur], tile, prim);
-					if (got == 0)
-						mark(tile);
-					if (got == (uint32_t)FIRST_PRIMS && p.first_tiles)
-						claim_first_tile(p, w, cur, tile);
-				}
+					push_tile(w.tri_cnt, w.tri_list, K_TRI, w.tri_pool, p.L.tri_pool_cap, &w.hdr->tri_spill[cur], tile, prim);
 			}
 			else if (!tile_outside_halfplanes<4>(q, tx, ty))
 				listed(tile, push_tile(w.edge_cnt, w.edge_list, K_EDGE, w.edge_pool, p.L.edge_pool_cap, &w.hdr->edge_spill[cur], tile, prim));
@@ -853,11 +823,11 @@ __device__ __forceinline__ bool edge_touches(const EdgeRec &e, int x, int y, int
 	return Z < zbest;
 }
 
-template <class PixT>
+template <class PixT, bool TEX = true>
 __device__ __forceinline__ double edge_channel(const EdgeRec &e, const double *planes, const PixT *texture, const Tap &tap, double L, int c, double x,
 											   double y, bool persp, double Z)
 {
-	if (e.kind == KIND_TEXTURED)
+	if (TEX && e.kind == KIND_TEXTURED)
 		return textured_channel(texture, tap, c) * L;
 	return interp_channel(planes, c, x, y, persp, Z);
 }
@@ -1218,6 +1188,7 @@ __device__ __forceinline__ void stage_batch(WaveLds &S, const Rec *recs, const d
 	}
 }
 
+template <bool TEX>
 __device__ __forceinline__ void tri_batch(const KParams &p, WaveLds &S, int nb, int lane, int x0, int y0, bool inb, PixState &st)
 {
 	const int W = p.W, H = p.H, C = p.C;
@@ -1284,7 +1255,7 @@ __device__ __forceinline__ void tri_batch(const KParams &p, WaveLds &S, int nb, 
 		const double *pl = &S.planes[jbest * 12];
 		const double Z = st.zbest;
 		st.kind = kind;
-		if (kind == KIND_TEXTURED)
+		if (kind == KIND_TEXTURED && TEX)
 		{
 			st.v[0] = plane_at(pl, x, y);
 			st.v[1] = plane_at(pl + 3, x, y);
@@ -1397,15 +1368,15 @@ __device__ __forceinline__ uint32_t stage_edge_batch(WaveLds &S, const EdgeSort 
 	return inb ? gather_column_bits(&S.cover[lane >> 3][0], lane & 7) : 0u;
 }
 
-template <class PixT>
+template <class PixT, bool TEX>
 __device__ __forceinline__ void owner_adjoint(const KParams &p, const ViewPtrs &w, int lane, double x, double y, int owner, int kind, const double *g,
 											  const Tap &tap, double L, double *tab, uint32_t *own);
 
 // Background of one tile that received no primitive: colour, depth = +inf, no owner (H.h:2728-2744).
 template <class PixT>
 __device__ __forceinline__ void fill_background_tile(const KParams &p, int view, int32_t *face_id, int tx, int ty, int lane, const double *bgc,
-													 bool owners)
-{
+													 int owners)
+{ // owners: 1 = also the owner ids (none), 0 = not, -1 = colour only (the caller writes depth and owners of four tiles at once)
 	const int W = p.W, H = p.H, C = p.C;
 	const int px = tx * TILE + (lane & 7), py = ty * TILE + (lane >> 3);
 	if (px >= W || py >= H)
@@ -1433,40 +1404,175 @@ __device__ __forceinline__ void fill_background_tile(const KParams &p, int view,
 					__builtin_nontemporal_store((PixT)col[cc], out + cc);
 		}
 	}
+	if (owners < 0)
+		return;
 	if (p.zbuf)
 		__builtin_nontemporal_store((PixT)INFINITY, (PixT *)p.zbuf + vpix);
 	if (owners)
 		__builtin_nontemporal_store((int32_t)-1, face_id + pix);
 }
 
-// Grid of the staged forward (1-D, one wavefront per workgroup):
-//   [0, n_views * FWD_FIRST)   with p.first_tiles: one entry of a view's list of many-primitive tiles each (views fastest, so
-//                              that every view's long tiles start at once)
-//   then periods of FILL_GROUP + FILL_BLOCKS blocks: FILL_GROUP blocks that map to one (view, tile) each and FILL_BLOCKS
-//   "fill" blocks that stream the background of the empty tiles of one bitmap word (32 tiles) each.
-// Two tiles out of three receive no primitive.  Their waves used to cost a third of the kernel's slot-time (launch + a vector
-// memory round trip + the stores); now a tile wave reads its bit of the set-up kernel's bitmap with one scalar load (constant
-// cache: 64 bytes cover 512 tiles) and retires, and the stores of 32 empty tiles share one fill wave.  Both periods are
-// multiples of 8, so a tile block keeps the XCD (block index % 8) that xcd_band assumes.
-constexpr int FILL_GROUP = 256, FILL_BLOCKS = FILL_GROUP / 32, FILL_PERIOD = FILL_GROUP + FILL_BLOCKS;
+// ------------------------------------------------------------------------------------------------ tile scan
+//
+// Between set-up and the staged forward raster: one thread per tile turns the per-tile counters that binning left into
+//   * the work list of the forward: one uint4 {tile, triangles, edges, sweep slot} per NON-EMPTY tile -- the tiles with more
+//     than FIRST_PRIMS triangles or edges from the front of the array (the long poles start first), the others from the back;
+//   * the tile bitmap (bit = the tile received a primitive) that the fill waves of the forward and the adjoint's owner-tile
+//     kernel read;
+//   * edge_saved[tile] (edge count + whether the forward will save its sweep), and the counters zeroed for the next forward.
+// Two tiles out of three receive nothing: this is what lets the forward launch one wavefront per tile that HAS work instead of
+// one per tile of the frame (the waves of the empty tiles used to take a third of its slot-time), and it takes the
+// many-primitive-tile flags and lists (two more dependent atomics per lane) out of the set-up kernel.
+constexpr int SCAN_BLOCK = 256;
 
-__host__ __device__ inline unsigned fwd_fast_grid(int n_views, int ntiles, int nwords, bool first_tiles)
+__global__ __launch_bounds__(SCAN_BLOCK) void tile_scan_kernel(KParams p)
 {
-	const long long tiles = (long long)n_views * ntiles, words = (long long)n_views * nwords;
-	const long long by_tiles = (tiles + FILL_GROUP - 1) / FILL_GROUP, by_words = (words + FILL_BLOCKS - 1) / FILL_BLOCKS;
-	return (unsigned)((first_tiles ? n_views * FWD_FIRST : 0) + (by_tiles > by_words ? by_tiles : by_words) * FILL_PERIOD);
+	__shared__ uint32_t s_cnt[2][SCAN_BLOCK / 64];
+	__shared__ uint32_t s_base[2];
+	const int view = blockIdx.y;
+	const ViewPtrs w = view_ptrs(p, view);
+	const int tile = blockIdx.x * SCAN_BLOCK + threadIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	const bool valid = tile < p.L.ntiles;
+	uint32_t ntri = 0, nedge = 0, slot_word = 0;
+	if (valid)
+	{
+		ntri = w.tri_cnt[tile];
+		nedge = w.edge_cnt[tile];
+		slot_word = w.edge_slot[tile]; // fresh whenever the tile has edges (set-up)
+	}
+	const bool work = (ntri | nedge) != 0;
+	if (work)
+	{ // self-cleaning counters
+		w.tri_cnt[tile] = 0;
+		w.edge_cnt[tile] = 0;
+	}
+	// the adjoint finds the edge count, and whether the forward sweep over the edges is saved, in edge_saved
+	const uint32_t sweep_slot = (nedge > 0 && nedge <= (uint32_t)EMAX && !p.persp) ? slot_word : 0u;
+	if (valid)
+		w.edge_saved[tile] = nedge | (sweep_slot ? SWEEP_SAVED : 0u);
+	const unsigned long long wm = __ballot(work);
+	if (lane == 0 && valid)
+		w.tile_bits[tile >> 5] = (uint32_t)wm;
+	if (lane == 32 && valid)
+		w.tile_bits[tile >> 5] = (uint32_t)(wm >> 32);
+	// ---- compaction: rank inside the wavefront, wavefront totals through LDS, ONE atomic per class and block
+	const bool heavy = work && (ntri > (uint32_t)FIRST_PRIMS || nedge > (uint32_t)FIRST_PRIMS);
+	const unsigned long long hm = __ballot(heavy), lm = wm & ~hm, below = (1ull << lane) - 1ull;
+	if (lane == 0)
+	{
+		s_cnt[0][wave] = (uint32_t)__popcll(hm);
+		s_cnt[1][wave] = (uint32_t)__popcll(lm);
+	}
+	__syncthreads();
+	uint32_t before[2] = {0, 0}, total[2] = {0, 0};
+#pragma unroll
+	for (int i = 0; i < SCAN_BLOCK / 64; i++)
+#pragma unroll
+		for (int c = 0; c < 2; c++)
+		{
+			const uint32_t n = s_cnt[c][i];
+			before[c] += i < wave ? n : 0u;
+			total[c] += n;
+		}
+	if (threadIdx.x < 2 && total[threadIdx.x])
+		s_base[threadIdx.x] = atomicAdd(&w.hdr->work_count[threadIdx.x], total[threadIdx.x]);
+	__syncthreads();
+	if (work)
+	{
+		const uint4 entry = make_uint4((uint32_t)tile, ntri, nedge, sweep_slot);
+		if (heavy)
+			w.work_list[s_base[0] + before[0] + (uint32_t)__popcll(hm & below)] = entry;
+		else
+			w.work_list[(uint32_t)p.L.ntiles - 1u - (s_base[1] + before[1] + (uint32_t)__popcll(lm & below))] = entry;
+	}
+}
+
+// ------------------------------------------------------------------------------------------------ background fill
+//
+// The background of the tiles that received no primitive (two out of three): 110 MB of plain stores per 8-view step that
+// depend on nothing but the tile bitmap.  As workgroups of the forward raster they cost it 22 us: a fill wave lives as long as
+// the store queue lets it, and it holds one of the forward's (register-fat) wave slots while it does.  As a kernel of its own,
+// with 24 registers per lane, launched on a side stream right after the scan, its waves fit into the registers and wave
+// slots the forward / edge / finalize kernels leave unused, and the stores drain while those kernels compute.
+// One wavefront per bitmap word (32 tiles).  Four consecutive empty tiles of a tile row share one 16-byte-per-lane store of
+// depth (and of owner ids): 128 contiguous bytes per pixel row instead of 4 x 32.
+constexpr int FILL_WAVES = 4; // wavefronts (bitmap words) per workgroup
+
+template <class PixT>
+__global__ __launch_bounds__(64 * FILL_WAVES) void fill_kernel(KParams p, int owners)
+{
+	const int lane = threadIdx.x & 63;
+	const int gw = blockIdx.x * FILL_WAVES + (threadIdx.x >> 6);
+	if (gw >= p.n_views * p.L.nwords)
+		return;
+	const int view = gw / p.L.nwords, wi = gw - view * p.L.nwords;
+	const ViewPtrs w = view_ptrs(p, view);
+	const int base = wi * 32, valid = p.L.ntiles - base < 32 ? p.L.ntiles - base : 32;
+	uint32_t empty = ~w.tile_bits[wi] & (valid == 32 ? 0xffffffffu : (1u << valid) - 1u);
+	empty = (uint32_t)uniform((int)empty);
+	if (!empty)
+		return;
+	const int W = p.W, H = p.H, C = p.C;
+	double bgc[CH] = {0, 0, 0, 0};
+	if (!p.bg_image)
+	{
+#pragma unroll
+		for (int cc = 0; cc < CH; cc++)
+			if (cc < C)
+				bgc[cc] = (double)((const PixT *)p.bg_color)[cc];
+	}
+	// groups of four tiles side by side in one tile row, every pixel of them inside the frame
+	const bool quads = (p.L.tiles_x & 3) == 0 && (W & 7) == 0 && (H & 7) == 0 && sizeof(PixT) == 4;
+	typedef PixT P4 __attribute__((ext_vector_type(4)));
+	typedef int32_t I4 __attribute__((ext_vector_type(4)));
+	for (int g = 0; g < 8; g++)
+	{
+		const uint32_t nib = (empty >> (4 * g)) & 0xfu;
+		if (!nib)
+			continue;
+		const int tile0 = base + 4 * g, tx0 = tile0 % p.L.tiles_x, ty = tile0 / p.L.tiles_x;
+		const bool quad = quads && nib == 0xfu;
+		for (int i = 0; i < 4; i++)
+			if ((nib >> i) & 1u) // (tiles of an incomplete group can lie in two tile rows: each finds its own)
+				fill_background_tile<PixT>(p, view, w.face_id, (tile0 + i) % p.L.tiles_x, (tile0 + i) / p.L.tiles_x, lane, bgc, quad ? -1 : owners);
+		if (quad)
+		{ // depth (and owners) of the four tiles: lane = (pixel row, 16-byte piece of the row's 32 pixels)
+			const size_t pix = (size_t)(ty * TILE + (lane >> 3)) * W + tx0 * TILE + 4 * (lane & 7);
+			if (p.zbuf)
+			{
+				const P4 inf4 = {(PixT)INFINITY, (PixT)INFINITY, (PixT)INFINITY, (PixT)INFINITY};
+				__builtin_nontemporal_store(inf4, (P4 *)((PixT *)p.zbuf + (size_t)view * H * W + pix));
+			}
+			if (owners)
+			{
+				const I4 none = {-1, -1, -1, -1};
+				__builtin_nontemporal_store(none, (I4 *)(w.face_id + pix));
+			}
+		}
+	}
+}
+
+// Grid of the staged forward (1-D, one wavefront per workgroup).  Workgroup b: view (b / 8) % n_views,
+// q = (b / 8 / n_views) * 8 + b % 8 in [0, p.tile_blocks); it walks the entries rank(q), rank(q) + tile_blocks, ... of the
+// view's work list (usually one or two).  rank() deals the list to the XCDs in chunks of 64 consecutive entries (workgroup b
+// runs on XCD b % 8; consecutive entries are neighbouring tiles, which share triangle records and should share an L2).
+constexpr int WORK_CHUNK = 64;
+
+__host__ __device__ inline int fwd_tile_blocks(int ntiles)
+{ // workgroups per view that walk the work list: a quarter of the tiles (about a third of a frame's tiles hold primitives)
+	const int unit = 8 * WORK_CHUNK;
+	const int g = ((ntiles / 4 + unit - 1) / unit) * unit;
+	return g > 0 && g <= ntiles ? g : ntiles; // tiny frames: one workgroup per tile, plain order
 }
 
 // FUSED: the forward of a fit step.  The loss is L = sum (image - obs)^2, so dL/dimage is known the moment a pixel is
 // resolved: tiles without silhouette edges back-propagate into their owners' accumulators right here (no second pass over the
 // frame, no owner buffer round trip -- the owner ids of those tiles are not even written); tiles with edges are left to
 // raster_bwd_edge_kernel.
-// Five waves per SIMD (96 VGPRs): more resident waves hide more of the dependent loads than the few spills cost
-// (measured in round 1: 4 -> 156 us, 5 -> 151, 6 -> 149, 7 -> 154; at 6 the spill traffic nearly doubles the HBM bytes).
 #ifndef DR_FWD_WAVES
-#define DR_FWD_WAVES 5 // waves per SIMD the staged forward is compiled for (tools/build_variants.sh builds the neighbours)
+#define DR_FWD_WAVES 4 // waves per SIMD the staged forward is compiled for (tools/build_variants.sh builds the neighbours)
 #endif
-template <class PixT, bool FUSED>
+template <class PixT, bool FUSED, bool TEX>
 __global__ __launch_bounds__(64, DR_FWD_WAVES) void raster_fwd_fast_kernel(KParams p)
 {
 	DR_WAVE_TRACE_SCOPE(2);
@@ -1475,132 +1581,55 @@ __global__ __launch_bounds__(64, DR_FWD_WAVES) void raster_fwd_fast_kernel(KPara
 #ifdef DR_FWD_TRACE
 	// per-tile phase timing (tools/fwd_trace.py): eight counters over the first row of the tile in the z buffer
 	uint32_t ftr[8] = {0x7fc0f00du, 0, 0, 0, 0, 0, 0, 0};
-	const uint64_t ftr0 = __builtin_readcyclecounter();
 #define DR_FTRACE(i) ftr[i] = (uint32_t)(__builtin_readcyclecounter() - ftr0)
 #else
 #define DR_FTRACE(i)
 #endif
 	constexpr int wave = 0;
-	const int lane = threadIdx.x & 63;
-	int view, tx, ty;
-	bool listed_tile = false, closes_epoch = false;
+	const int lane0 = threadIdx.x & 63;
+	const int G = p.tile_blocks;
+	const long long b = blockIdx.x;
+	int view, q;
+	const bool chunked = G % (8 * WORK_CHUNK) == 0;
+	if (chunked)
 	{
-		const int per_view = p.L.ntiles, nfirst = p.first_tiles ? p.n_views * FWD_FIRST : 0;
-		int bid = blockIdx.x;
-		if (bid < nfirst)
-		{
-			view = bid % p.n_views;
-			const int slot = bid / p.n_views, sub = 2 * NSUB + slot % NSUB, idx = slot / NSUB;
-			const ViewPtrs wl = view_ptrs(p, view);
-			const uint32_t n0 = wl.edge_tile_cnt[sub * CNT_STRIDE], n1 = wl.edge_tile_cnt[(LIST_KINDS * NSUB + sub) * CNT_STRIDE];
-			const uint32_t n = wl.hdr->cur ? n1 : n0; // both parities requested with the parity: one round trip
-			if ((uint32_t)idx >= (n < (uint32_t)(FWD_FIRST / NSUB) ? n : (uint32_t)(FWD_FIRST / NSUB)))
-				return;
-			const int t = uniform((int)wl.edge_tiles[(size_t)sub * p.L.sub_cap + idx]);
-			tx = t % p.L.tiles_x;
-			ty = t / p.L.tiles_x;
-			listed_tile = true;
-		}
-		else
-		{
-			bid -= nfirst;
-			const int period = bid / FILL_PERIOD, r = bid - period * FILL_PERIOD;
-			if (r >= FILL_GROUP)
-			{ // ---- fill block: the empty tiles of one word of a view's bitmap
-				const int gw = period * FILL_BLOCKS + (r - FILL_GROUP);
-				if (gw >= p.n_views * p.L.nwords)
-					return;
-				view = gw / p.L.nwords;
-				const int wi = gw - view * p.L.nwords;
-				const ViewPtrs wf = view_ptrs(p, view);
-				const uint32_t cur = wf.hdr->cur, b0 = wf.tile_bits[wi], b1 = wf.tile_bits[p.L.nwords + wi];
-				const int base = wi * 32, valid = p.L.ntiles - base < 32 ? p.L.ntiles - base : 32;
-				uint32_t empty = ~(cur ? b1 : b0) & (valid == 32 ? 0xffffffffu : (1u << valid) - 1u);
-				empty = (uint32_t)uniform((int)empty);
-				// the adjoint finds the edge count of every tile in edge_saved: none here
-				if (lane < 32 && ((empty >> lane) & 1u))
-					wf.edge_saved[base + lane] = 0;
-				double bgc[CH] = {0, 0, 0, 0};
-				if (!p.bg_image)
-				{
-#pragma unroll
-					for (int cc = 0; cc < CH; cc++)
-						if (cc < p.C)
-							bgc[cc] = (double)((const PixT *)p.bg_color)[cc];
-				}
-				while (empty)
-				{
-					const int tile = base + __ffs((int)empty) - 1;
-					empty &= empty - 1;
-					fill_background_tile<PixT>(p, view, wf.face_id, tile % p.L.tiles_x, tile / p.L.tiles_x, lane, bgc, !FUSED);
-				}
-				return;
-			}
-			const long long t = (long long)period * FILL_GROUP + r;
-			if (t >= (long long)p.n_views * per_view)
-				return;
-			view = (int)(t / per_view);
-			const int bx = (int)(t - (long long)view * per_view);
-			const int b = xcd_band(bx, per_view);
-			ty = xcd_strip_row(b / p.L.tiles_x, p.L.tiles_y, p.row_group);
-			tx = b % p.L.tiles_x;
-			closes_epoch = bx == 0;
-		}
+		view = (int)((b >> 3) % p.n_views);
+		q = (int)((b >> 3) / p.n_views) * 8 + (int)(b & 7);
+	}
+	else
+	{
+		view = (int)(b % p.n_views);
+		q = (int)(b / p.n_views);
 	}
 	const ViewPtrs w = view_ptrs(p, view);
 	const int W = p.W, H = p.H, C = p.C, P = p.L.P;
 	const bool persp = p.persp;
 	const PixT *texture = (const PixT *)p.texture;
 	WaveLds &S = s_lds[wave];
-
-	const int tile = ty * p.L.tiles_x + tx;
-	// ---- is there anything in this tile?  One scalar load (both parities of the word requested with the parity)
-	bool nonempty = true;
-	if (!listed_tile)
+	const uint32_t n_heavy = w.hdr->work_count[0], n_work = n_heavy + w.hdr->work_count[1];
+	uint32_t rank = chunked ? (uint32_t)((((q >> 3) / WORK_CHUNK) * 8 + (q & 7)) * WORK_CHUNK + (q >> 3) % WORK_CHUNK) : (uint32_t)q;
+	for (; rank < n_work; rank += (uint32_t)G)
 	{
-		const uint32_t cur = w.hdr->cur, b0 = w.tile_bits[tile >> 5], b1 = w.tile_bits[p.L.nwords + (tile >> 5)];
-		nonempty = (((cur ? b1 : b0) >> (tile & 31)) & 1u) != 0;
-	}
-	if (nonempty)
-	{
+#ifdef DR_FWD_TRACE
+		const uint64_t ftr0 = __builtin_readcyclecounter();
+#endif
+		// (the lane index is made opaque per iteration: otherwise every lane-dependent address of the body is hoisted out of the
+		// loop and kept -- spilled -- in registers across it: + 150 VGPRs for a loop that usually runs once or twice)
+		int lane = lane0;
+		asm volatile("" : "+v"(lane));
+		// entry of the work list: tile, counters and sweep slot in ONE 16-byte scalar load
+		const uint4 entry = w.work_list[rank < n_heavy ? rank : (uint32_t)p.L.ntiles - 1u - (rank - n_heavy)];
+		const int tile = uniform((int)entry.x), ntri = uniform((int)entry.y), nedge = uniform((int)entry.z);
+		const uint32_t sweep_slot = (uint32_t)uniform((int)entry.w);
+		const int tx = tile % p.L.tiles_x, ty = tile / p.L.tiles_x;
 		const int x0 = tx * TILE, y0 = ty * TILE;
 		const int px = x0 + (lane & 7), py = y0 + (lane >> 3);
 		const bool inb = px < W && py < H;
 		const size_t pix = (size_t)py * W + px;
 		const size_t vpix = (size_t)view * H * W + pix;
 		const double x = px, y = py;
-		// the inline triangle list is fetched together with the counters (one memory round trip instead of two)
 		const uint32_t list_entry = w.tri_list[(size_t)tile * K_TRI + (lane & (K_TRI - 1))];
-		const int ntri = uniform((int)w.tri_cnt[tile]);
-		const int nedge = uniform((int)w.edge_cnt[tile]);
-		const uint32_t slot_word = (uint32_t)uniform((int)w.edge_slot[tile]); // fresh whenever the tile has edges (set-up)
-		const bool taken = p.first_tiles && !listed_tile && uniform((int)w.first_flag[tile]) != 0;
-		if (taken && lane == 0)
-			w.first_flag[tile] = 0; // a block at the head of the grid rasterizes this tile; the flag has served
-		if (!taken)
 		{
-		if (lane == 0 && (ntri | nedge))
-		{
-			w.tri_cnt[tile] = 0;
-			w.edge_cnt[tile] = 0;
-		}
-		// the adjoint finds the edge count, and whether the forward sweep over the edges is saved (below), in edge_saved
-		const uint32_t sweep_slot = (nedge > 0 && nedge <= EMAX && !persp) ? slot_word : 0u;
-		if (lane == 0)
-			w.edge_saved[tile] = (uint32_t)nedge | (sweep_slot ? SWEEP_SAVED : 0u);
-		if ((ntri | nedge) == 0)
-		{ // cannot happen (the bit of a tile is set with its first primitive); kept so that a frame is complete whatever happens
-			double bgc[CH] = {0, 0, 0, 0};
-			if (!p.bg_image)
-			{
-#pragma unroll
-				for (int cc = 0; cc < CH; cc++)
-					if (cc < C)
-						bgc[cc] = (double)((const PixT *)p.bg_color)[cc];
-			}
-			fill_background_tile<PixT>(p, view, w.face_id, tx, ty, lane, bgc, !FUSED);
-		}
-		else
 		{
 		PixT ob[CH] = {0, 0, 0, 0};
 		if (FUSED && ntri > 0 && nedge == 0 && inb)
@@ -1634,7 +1663,7 @@ __global__ __launch_bounds__(64, DR_FWD_WAVES) void raster_fwd_fast_kernel(KPara
 				lds_sync();
 				stage_batch(S, w.tri_rec, w.tri_planes, P, nb, lane);
 				lds_sync();
-				tri_batch(p, S, nb, lane, x0, y0, inb, st);
+				tri_batch<TEX>(p, S, nb, lane, x0, y0, inb, st);
 			}
 			if (ntri > K_TRI)
 			{ // spilled pairs of this tile: compact them out of the pool, TB at a time
@@ -1663,7 +1692,7 @@ __global__ __launch_bounds__(64, DR_FWD_WAVES) void raster_fwd_fast_kernel(KPara
 							lds_sync();
 							stage_batch(S, w.tri_rec, w.tri_planes, P, TB, lane);
 							lds_sync();
-							tri_batch(p, S, TB, lane, x0, y0, inb, st);
+							tri_batch<TEX>(p, S, TB, lane, x0, y0, inb, st);
 							fill = 0;
 						}
 					}
@@ -1673,7 +1702,7 @@ __global__ __launch_bounds__(64, DR_FWD_WAVES) void raster_fwd_fast_kernel(KPara
 					lds_sync();
 					stage_batch(S, w.tri_rec, w.tri_planes, P, fill, lane);
 					lds_sync();
-					tri_batch(p, S, fill, lane, x0, y0, inb, st);
+					tri_batch<TEX>(p, S, fill, lane, x0, y0, inb, st);
 				}
 			}
 		}
@@ -1691,7 +1720,7 @@ __global__ __launch_bounds__(64, DR_FWD_WAVES) void raster_fwd_fast_kernel(KPara
 		}
 		Tap tap;
 		double L = 0;
-		if (st.kbest >= 0 && st.kind == KIND_TEXTURED)
+		if (st.kbest >= 0 && st.kind == KIND_TEXTURED && TEX)
 		{
 			bilinear_tap(p.tex_w, p.tex_h, st.v[0], st.v[1], C, tap);
 			L = st.v[2];
@@ -1744,13 +1773,13 @@ __global__ __launch_bounds__(64, DR_FWD_WAVES) void raster_fwd_fast_kernel(KPara
 						const double Tr = plane_at(e.x2t, x, y);
 						Tap etap;
 						double eL = 0, eUV[2];
-						if (e.kind == KIND_TEXTURED)
+						if (e.kind == KIND_TEXTURED && TEX)
 							textured_tap(ep, x, y, persp, Ze, p.tex_w, p.tex_h, C, etap, eL, eUV);
 #pragma unroll
 						for (int cc = 0; cc < CH; cc++)
 							if (cc < C)
 							{
-								const double A = edge_channel(e, ep, texture, etap, eL, cc, x, y, persp, Ze);
+								const double A = edge_channel<PixT, TEX>(e, ep, texture, etap, eL, cc, x, y, persp, Ze);
 								col[cc] *= Tr;
 								col[cc] += (1 - Tr) * A;
 							}
@@ -1798,13 +1827,13 @@ __global__ __launch_bounds__(64, DR_FWD_WAVES) void raster_fwd_fast_kernel(KPara
 					const double Tr = plane_at(e.x2t, x, y);
 					Tap etap;
 					double eL = 0, eUV[2];
-					if (e.kind == KIND_TEXTURED)
+					if (e.kind == KIND_TEXTURED && TEX)
 						textured_tap(ep, x, y, persp, Ze, p.tex_w, p.tex_h, C, etap, eL, eUV);
 #pragma unroll
 					for (int cc = 0; cc < CH; cc++)
 						if (cc < C)
 						{
-							const double A = edge_channel(e, ep, texture, etap, eL, cc, x, y, persp, Ze);
+							const double A = edge_channel<PixT, TEX>(e, ep, texture, etap, eL, cc, x, y, persp, Ze);
 							col[cc] *= Tr;
 							col[cc] += (1 - Tr) * A;
 						}
@@ -1813,7 +1842,7 @@ __global__ __launch_bounds__(64, DR_FWD_WAVES) void raster_fwd_fast_kernel(KPara
 		}
 		DR_FTRACE(4); // colour resolved, edges blended
 		// ---- one write per pixel
-		if (inb)
+		if (inb && !(DR_ABLATE & 4))
 		{
 			if (p.image)
 			{
@@ -1851,7 +1880,7 @@ __global__ __launch_bounds__(64, DR_FWD_WAVES) void raster_fwd_fast_kernel(KPara
 			for (int cc = 0; cc < CH; cc++)
 				g[cc] = (cc < C && inb) ? 2 * ((double)(PixT)col[cc] - (double)ob[cc]) : 0.0;
 			lds_sync();
-			owner_adjoint<PixT>(p, w, lane, x, y, st.kbest, st.kbest >= 0 ? st.kind : (int)KIND_NONE, g, tap, L, (double *)&S.rec[0],
+			owner_adjoint<PixT, TEX>(p, w, lane, x, y, st.kbest, st.kbest >= 0 ? st.kind : (int)KIND_NONE, g, tap, L, (double *)&S.rec[0],
 								(uint32_t *)&S.cover[0][0]);
 		}
 #ifdef DR_FWD_TRACE
@@ -1864,10 +1893,11 @@ __global__ __launch_bounds__(64, DR_FWD_WAVES) void raster_fwd_fast_kernel(KPara
 			((uint32_t *)p.zbuf)[(size_t)view * H * W + (size_t)y0 * W + x0 + lane] = v;
 		}
 #endif
-			}
-		} // not left to a block at the head of the grid
+		}
+		}
+		lds_sync(); // the next tile of this wavefront reuses the staging area
 	}
-	if (closes_epoch && threadIdx.x == 0)
+	if (q == 0 && threadIdx.x == 0)
 		close_epoch(p, w, FUSED);
 }
 
@@ -1900,7 +1930,7 @@ __device__ __forceinline__ void texture_scatter(PixT *texture_b, const Tap &tap,
 // adjoint of one tile, any channel count / edge count / mode; `order` is a per-wave LDS array of MAX_SORTED entries.
 // LEAN: the instance inlined into raster_bwd_edge_kernel for the (pathological) tiles with more than EMAX edges: at most CH
 // channels and no antialiase_error, which the compiler can then drop.
-template <class PixT, bool LEAN>
+template <class PixT, bool LEAN, bool TEX = true>
 __device__ __forceinline__ void bwd_tile_generic_impl(const KParams &p, int view, int tx, int ty, int lane, volatile uint32_t *order)
 {
 	const ViewPtrs w = view_ptrs(p, view);
@@ -1931,13 +1961,13 @@ __device__ __forceinline__ void bwd_tile_generic_impl(const KParams &p, int view
 		const TriRec &r = w.tri_rec[owner];
 		planes = w.tri_planes + (size_t)owner * 3 * P;
 		zown = plane_at(r.xZ, x, y);
-		if (kind == KIND_TEXTURED)
+		if (kind == KIND_TEXTURED && TEX)
 			textured_tap(planes, x, y, false, zown, p.tex_w, p.tex_h, C, tap, L, UV);
 	}
 	auto base_channel = [&](int c) -> double { // un-antialiased colour of the pixel
 		if (owner < 0)
 			return inb ? background_channel<PixT>(p, view, pix, c) : 0.0;
-		if (kind == KIND_TEXTURED)
+		if (kind == KIND_TEXTURED && TEX)
 			return textured_channel(texture, tap, c) * L;
 		return interp_channel(planes, c, x, y, false, zown);
 	};
@@ -2016,7 +2046,7 @@ __device__ __forceinline__ void bwd_tile_generic_impl(const KParams &p, int view
 				double Err = 0;
 				for (int c = 0; c < C; c++)
 				{
-					double d = edge_channel(e, ep, texture, etap, eL, c, x, y, false, 0.0) - (double)obs[c];
+					double d = edge_channel<PixT, TEX>(e, ep, texture, etap, eL, c, x, y, false, 0.0) - (double)obs[c];
 					Err += d * d;
 				}
 				return Err;
@@ -2043,7 +2073,7 @@ __device__ __forceinline__ void bwd_tile_generic_impl(const KParams &p, int view
 					const double Tq = plane_at(eq.x2t, x, y);
 					Tap qtap;
 					double qL = 0, qUV[2];
-					if (eq.kind == KIND_TEXTURED)
+					if (eq.kind == KIND_TEXTURED && TEX)
 						textured_tap(qp, x, y, false, 0.0, p.tex_w, p.tex_h, C, qtap, qL, qUV);
 					prev *= Tq;
 					prev += (1 - Tq) * edge_err(eq, qp, qtap, qL);
@@ -2051,7 +2081,7 @@ __device__ __forceinline__ void bwd_tile_generic_impl(const KParams &p, int view
 				const double Tr = plane_at(e.x2t, x, y);
 				Tap etap;
 				double eL = 0, eUV[2] = {0, 0};
-				if (e.kind == KIND_TEXTURED && hit)
+				if (e.kind == KIND_TEXTURED && TEX && hit)
 					textured_tap(ep, x, y, false, 0.0, p.tex_w, p.tex_h, C, etap, eL, eUV);
 				double T_B = 0, L_B = 0, e_B[2] = {0, 0}, Err_B = 0;
 				if (hit)
@@ -2066,7 +2096,7 @@ __device__ __forceinline__ void bwd_tile_generic_impl(const KParams &p, int view
 					double A_B = 0;
 					if (hit)
 					{
-						if (e.kind == KIND_TEXTURED)
+						if (e.kind == KIND_TEXTURED && TEX)
 						{ // H.h:2315-2326
 							const double i00 = ldp(texture, etap.idx[0] + c), i10 = ldp(texture, etap.idx[1] + c);
 							const double i01 = ldp(texture, etap.idx[2] + c), i11 = ldp(texture, etap.idx[3] + c);
@@ -2081,10 +2111,10 @@ __device__ __forceinline__ void bwd_tile_generic_impl(const KParams &p, int view
 						else // H.h:2579-2588, with the row fold the reference forgot (defect D2) restored
 							A_B = 2 * (interp_channel(ep, c, x, y, false, 0.0) - (double)obs[c]) * Err_B;
 					}
-					if (e.kind != KIND_TEXTURED)
+					if (e.kind != KIND_TEXTURED || !TEX)
 						add_moments(eacc + 3 * c, A_B, x, y, lane);
 				}
-				if (e.kind == KIND_TEXTURED)
+				if (e.kind == KIND_TEXTURED && TEX)
 				{
 					add_moments(eacc + 0, (hit && !etap.out[0]) ? e_B[0] : 0.0, x, y, lane);
 					add_moments(eacc + 3, (hit && !etap.out[1]) ? e_B[1] : 0.0, x, y, lane);
@@ -2133,14 +2163,14 @@ __device__ __forceinline__ void bwd_tile_generic_impl(const KParams &p, int view
 					const double Tq = plane_at(eq.x2t, x, y);
 					Tap qtap;
 					double qL = 0, qUV[2];
-					if (eq.kind == KIND_TEXTURED)
+					if (eq.kind == KIND_TEXTURED && TEX)
 						textured_tap(qp, x, y, false, 0.0, p.tex_w, p.tex_h, C, qtap, qL, qUV);
 #pragma unroll
 					for (int j = 0; j < CH; j++)
 						if (c0 + j < C)
 						{
 							aa[j] *= Tq;
-							aa[j] += (1 - Tq) * edge_channel(eq, qp, texture, qtap, qL, c0 + j, x, y, false, 0.0);
+							aa[j] += (1 - Tq) * edge_channel<PixT, TEX>(eq, qp, texture, qtap, qL, c0 + j, x, y, false, 0.0);
 						}
 				}
 				// adjoint of pass 2: near -> far (H.h:2961-3052)
@@ -2167,13 +2197,13 @@ __device__ __forceinline__ void bwd_tile_generic_impl(const KParams &p, int view
 					{
 						Tap utap;
 						double uL = 0, uUV[2];
-						if (e.kind == KIND_TEXTURED)
+						if (e.kind == KIND_TEXTURED && TEX)
 							textured_tap(ep, x, y, false, 0.0, p.tex_w, p.tex_h, C, utap, uL, uUV);
 #pragma unroll
 						for (int j = 0; j < CH; j++)
 							if (c0 + j < C)
 							{
-								prev[j] = (aa[j] - (1 - Tr_here) * edge_channel(e, ep, texture, utap, uL, c0 + j, x, y, false, 0.0)) / Tr_here;
+								prev[j] = (aa[j] - (1 - Tr_here) * edge_channel<PixT, TEX>(e, ep, texture, utap, uL, c0 + j, x, y, false, 0.0)) / Tr_here;
 								aa[j] = prev[j];
 							}
 					}
@@ -2188,14 +2218,14 @@ __device__ __forceinline__ void bwd_tile_generic_impl(const KParams &p, int view
 						const double Tq = plane_at(eq.x2t, x, y);
 						Tap qtap;
 						double qL = 0, qUV[2];
-						if (eq.kind == KIND_TEXTURED)
+						if (eq.kind == KIND_TEXTURED && TEX)
 							textured_tap(qp, x, y, false, 0.0, p.tex_w, p.tex_h, C, qtap, qL, qUV);
 #pragma unroll
 						for (int j = 0; j < CH; j++)
 							if (c0 + j < C)
 							{
 								prev[j] *= Tq;
-								prev[j] += (1 - Tq) * edge_channel(eq, qp, texture, qtap, qL, c0 + j, x, y, false, 0.0);
+								prev[j] += (1 - Tq) * edge_channel<PixT, TEX>(eq, qp, texture, qtap, qL, c0 + j, x, y, false, 0.0);
 							}
 					}
 					if (need_replay)
@@ -2207,7 +2237,7 @@ __device__ __forceinline__ void bwd_tile_generic_impl(const KParams &p, int view
 					const double Tr = plane_at(e.x2t, x, y);
 					Tap etap;
 					double eL = 0, eUV[2] = {0, 0};
-					if (e.kind == KIND_TEXTURED && hit)
+					if (e.kind == KIND_TEXTURED && TEX && hit)
 						textured_tap(ep, x, y, false, 0.0, p.tex_w, p.tex_h, C, etap, eL, eUV);
 					double T_B = 0, L_B = 0, e_B[2] = {0, 0};
 #pragma unroll
@@ -2219,7 +2249,7 @@ __device__ __forceinline__ void bwd_tile_generic_impl(const KParams &p, int view
 						double A_B = 0;
 						if (hit)
 						{
-							if (e.kind == KIND_TEXTURED)
+							if (e.kind == KIND_TEXTURED && TEX)
 							{ // H.h:2006-2021
 								const double i00 = ldp(texture, etap.idx[0] + c), i10 = ldp(texture, etap.idx[1] + c);
 								const double i01 = ldp(texture, etap.idx[2] + c), i11 = ldp(texture, etap.idx[3] + c);
@@ -2240,10 +2270,10 @@ __device__ __forceinline__ void bwd_tile_generic_impl(const KParams &p, int view
 							}
 							g[j] *= Tr;
 						}
-						if (e.kind != KIND_TEXTURED)
+						if (e.kind != KIND_TEXTURED || !TEX)
 							add_moments(eacc + 3 * c, A_B, x, y, lane);
 					}
-					if (e.kind == KIND_TEXTURED)
+					if (e.kind == KIND_TEXTURED && TEX)
 					{
 						add_moments(eacc + 0, (hit && !etap.out[0]) ? e_B[0] : 0.0, x, y, lane);
 						add_moments(eacc + 3, (hit && !etap.out[1]) ? e_B[1] : 0.0, x, y, lane);
@@ -2253,7 +2283,7 @@ __device__ __forceinline__ void bwd_tile_generic_impl(const KParams &p, int view
 				}
 			}
 			// adjoint of pass 1: what is left of g belongs to the triangle that owns the pixel (H.h:1024-1037, 1320-1353)
-			if (kind == KIND_TEXTURED)
+			if (kind == KIND_TEXTURED && TEX)
 			{
 #pragma unroll
 				for (int j = 0; j < CH; j++)
@@ -2288,12 +2318,12 @@ __device__ __forceinline__ void bwd_tile_generic_impl(const KParams &p, int view
 		}
 	}
 	// textured owners: the channel sums are complete, reduce the UV and shade plane adjoints
-	unsigned long long rem = __ballot(owner >= 0 && kind == KIND_TEXTURED);
+	unsigned long long rem = __ballot(owner >= 0 && kind == KIND_TEXTURED && TEX);
 	while (rem)
 	{
 		const int l = __ffsll((long long)rem) - 1;
 		const int cur = __shfl(owner, l, 64);
-		const bool mine = owner == cur && kind == KIND_TEXTURED;
+		const bool mine = owner == cur && kind == KIND_TEXTURED && TEX;
 		rem &= ~__ballot(owner == cur);
 		double *acc = w.tri_acc + (size_t)cur * 3 * P;
 		add_moments(acc + 0, (mine && !tap.out[0]) ? own_e_B[0] : 0.0, x, y, lane);
@@ -2350,7 +2380,7 @@ static_assert(RUNS * NMOM * sizeof(double) <= sizeof(WaveLds::rec) + sizeof(Wave
 
 // Adjoint of pass 1 for one tile: g = dL/d(colour written by pass 1) of this lane's pixel, owned by triangle `owner`.
 // tab (RUNS * NMOM doubles) and own (RUNS words) are LDS scratch of this wave.  All 64 lanes must call it.
-template <class PixT>
+template <class PixT, bool TEX>
 __device__ __forceinline__ void owner_adjoint(const KParams &p, const ViewPtrs &w, int lane, double x, double y, int owner, int kind, const double *g,
 											  const Tap &tap, double L, double *tab, uint32_t *own)
 {
@@ -2364,7 +2394,7 @@ __device__ __forceinline__ void owner_adjoint(const KParams &p, const ViewPtrs &
 	// dozen texels for 768 contributions), and atomics to one address serialise in the L2 at ~80 ns each: when the window
 	// fits the LDS scratch, the contributions are summed there (ds_add_f64) and each touched texel leaves with ONE global
 	// atomic -- "per-tile LDS partials before a single atomicAdd".
-	const bool textured = kind == KIND_TEXTURED;
+	const bool textured = kind == KIND_TEXTURED && TEX;
 	int fu = 0, fv = 0, win_u0 = 0, win_v0 = 0, win_w = 0, win_h = 0;
 	bool windowed = false;
 	if (texture_b && __ballot(textured))
@@ -2537,8 +2567,10 @@ __device__ __forceinline__ void owner_adjoint(const KParams &p, const ViewPtrs &
 				mask &= mask - 1;
 				acc += tab[r * NMOM + m];
 			}
+#if !(DR_ABLATE & 128)
 			if (m < nm && acc != 0)
 				atomic_add_f64(w.tri_acc + (size_t)o * nm + m, acc);
+#endif
 		}
 		emask &= ~__ballot(sel);
 	}
@@ -2546,7 +2578,7 @@ __device__ __forceinline__ void owner_adjoint(const KParams &p, const ViewPtrs &
 
 // One tile of the adjoint.  EDGES = false: tiles without silhouette edges (the edge code is compiled out: half the
 // registers, twice the resident waves to hide the memory latency); EDGES = true: the tiles that have some.
-template <class PixT, bool EDGES>
+template <class PixT, bool EDGES, bool TEX>
 __device__ __forceinline__ void bwd_fast_tile(const KParams &p, const ViewPtrs &w, int view, int tx, int ty, int lane, BwdLds &S, EdgeSort *es, // es: only for EDGES
 											  int skip_above = 0x7fffffff, int chunk = -1)
 { // chunk >= 0: this wavefront is one of CHUNKS that may share the reverse sweep of a many-edged tile (batch `chunk` of it)
@@ -2602,7 +2634,7 @@ __device__ __forceinline__ void bwd_fast_tile(const KParams &p, const ViewPtrs &
 	{ // more than EMAX edges in one tile (or pool overflow): the un-staged code, right here (pathological and slow, but no
 	  // queue and no extra launch for the tiles that never exist in a real scene)
 		lds_sync();
-		bwd_tile_generic_impl<PixT, true>(p, view, tx, ty, lane, (volatile uint32_t *)es->sorted);
+		bwd_tile_generic_impl<PixT, true, TEX>(p, view, tx, ty, lane, (volatile uint32_t *)es->sorted);
 		lds_sync();
 		return;
 	}
@@ -2636,7 +2668,7 @@ __device__ __forceinline__ void bwd_fast_tile(const KParams &p, const ViewPtrs &
 	if (owner >= 0)
 	{
 		planes = w.tri_planes + (size_t)owner * 3 * P;
-		if (kind == KIND_TEXTURED)
+		if (kind == KIND_TEXTURED && TEX)
 			textured_tap(planes, x, y, false, 0.0, p.tex_w, p.tex_h, C, tap, L, UV);
 	}
 
@@ -2652,7 +2684,7 @@ __device__ __forceinline__ void bwd_fast_tile(const KParams &p, const ViewPtrs &
 #pragma unroll
 				for (int cc = 0; cc < CH; cc++)
 					if (cc < C)
-						base[cc] = kind == KIND_TEXTURED ? textured_channel(texture, tap, cc) * L : interp_channel(planes, cc, x, y, false, 0.0);
+						base[cc] = kind == KIND_TEXTURED && TEX ? textured_channel(texture, tap, cc) * L : interp_channel(planes, cc, x, y, false, 0.0);
 			}
 			else if (inb)
 			{
@@ -2708,14 +2740,14 @@ __device__ __forceinline__ void bwd_fast_tile(const KParams &p, const ViewPtrs &
 					const double Tq = plane_at(eq.x2t, x, y);
 					Tap qtap;
 					double qL = 0, qUV[2];
-					if (eq.kind == KIND_TEXTURED)
+					if (eq.kind == KIND_TEXTURED && TEX)
 						textured_tap(qp, x, y, false, 0.0, p.tex_w, p.tex_h, C, qtap, qL, qUV);
 #pragma unroll
 					for (int cc = 0; cc < CH; cc++)
 						if (cc < C)
 						{
 							cur[cc] *= Tq;
-							cur[cc] += (1 - Tq) * edge_channel(eq, qp, texture, qtap, qL, cc, x, y, false, 0.0);
+							cur[cc] += (1 - Tq) * edge_channel<PixT, TEX>(eq, qp, texture, qtap, qL, cc, x, y, false, 0.0);
 						}
 				}
 			}
@@ -2777,14 +2809,14 @@ __device__ __forceinline__ void bwd_fast_tile(const KParams &p, const ViewPtrs &
 				{
 					Tap utap;
 					double uL = 0, uUV[2];
-					if (e.kind == KIND_TEXTURED)
+					if (e.kind == KIND_TEXTURED && TEX)
 						textured_tap(ep, x, y, false, 0.0, p.tex_w, p.tex_h, C, utap, uL, uUV);
 					const double inv_T = 1 / Tr_here; // one division for the C channels (the reference divides each: 1 ulp apart)
 #pragma unroll
 					for (int cc = 0; cc < CH; cc++)
 						if (cc < C)
 						{
-							prev[cc] = (cur[cc] - (1 - Tr_here) * edge_channel(e, ep, texture, utap, uL, cc, x, y, false, 0.0)) * inv_T;
+							prev[cc] = (cur[cc] - (1 - Tr_here) * edge_channel<PixT, TEX>(e, ep, texture, utap, uL, cc, x, y, false, 0.0)) * inv_T;
 							cur[cc] = prev[cc];
 						}
 				}
@@ -2813,14 +2845,14 @@ __device__ __forceinline__ void bwd_fast_tile(const KParams &p, const ViewPtrs &
 						const double Tq = plane_at(eq.x2t, x, y);
 						Tap qtap;
 						double qL = 0, qUV[2];
-						if (eq.kind == KIND_TEXTURED)
+						if (eq.kind == KIND_TEXTURED && TEX)
 							textured_tap(qp, x, y, false, 0.0, p.tex_w, p.tex_h, C, qtap, qL, qUV);
 #pragma unroll
 						for (int cc = 0; cc < CH; cc++)
 							if (cc < C)
 							{
 								prev[cc] *= Tq;
-								prev[cc] += (1 - Tq) * edge_channel(eq, qp, texture, qtap, qL, cc, x, y, false, 0.0);
+								prev[cc] += (1 - Tq) * edge_channel<PixT, TEX>(eq, qp, texture, qtap, qL, cc, x, y, false, 0.0);
 							}
 					}
 					if (need_replay)
@@ -2836,7 +2868,7 @@ __device__ __forceinline__ void bwd_fast_tile(const KParams &p, const ViewPtrs &
 				{
 					const double Tr = Tr_here;
 					double T_B = 0;
-					if (e.kind == KIND_TEXTURED)
+					if (e.kind == KIND_TEXTURED && TEX)
 					{ // H.h:2006-2021
 						Tap etap;
 						double eL, eUV[2], L_B = 0, e_B[2] = {0, 0};
@@ -2899,7 +2931,7 @@ __device__ __forceinline__ void bwd_fast_tile(const KParams &p, const ViewPtrs &
 	if (EDGES && b_lo > 0)
 		return; // the wavefront that ran batch 0 (the farthest edges) holds the gradient that reaches pass 1
 	// ---- adjoint of pass 1: g now belongs to the triangle that owns the pixel
-	owner_adjoint<PixT>(p, w, lane, x, y, owner, kind, g, tap, L, (double *)&S.rec[0], (uint32_t *)&S.cover[0][0]);
+	owner_adjoint<PixT, TEX>(p, w, lane, x, y, owner, kind, g, tap, L, (double *)&S.rec[0], (uint32_t *)&S.cover[0][0]);
 #ifdef DR_TILE_TRACE
 	DR_TRACE(5);
 	if (EDGES && lane < 8)
@@ -2913,7 +2945,7 @@ __device__ __forceinline__ void bwd_fast_tile(const KParams &p, const ViewPtrs &
 #undef DR_TRACE
 }
 
-template <class PixT>
+template <class PixT, bool TEX>
 __global__ __launch_bounds__(64, 6) void raster_bwd_fast_kernel(KParams p)
 { // every tile of the frame (one wavefront each); those with silhouette edges are left to raster_bwd_edge_kernel, those without
   // any primitive are recognised in the forward's tile bitmap (one scalar load) before anything is read
@@ -2924,13 +2956,12 @@ __global__ __launch_bounds__(64, 6) void raster_bwd_fast_kernel(KParams p)
 	const int b = xcd_band(blockIdx.x, gridDim.x);
 	const int ty = xcd_strip_row(b / p.L.tiles_x, p.L.tiles_y, p.row_group), tx = b % p.L.tiles_x;
 	const int tile = ty * p.L.tiles_x + tx;
-	const uint32_t cur = w.hdr->cur, b0 = w.tile_bits[tile >> 5], b1 = w.tile_bits[p.L.nwords + (tile >> 5)];
-	if (!(((cur ? b1 : b0) >> (tile & 31)) & 1u))
+	if (!((w.tile_bits[tile >> 5] >> (tile & 31)) & 1u))
 		return;
-	bwd_fast_tile<PixT, false>(p, w, view, tx, ty, lane, s_lds, nullptr);
+	bwd_fast_tile<PixT, false, TEX>(p, w, view, tx, ty, lane, s_lds, nullptr);
 }
 
-template <class PixT>
+template <class PixT, bool TEX>
 __global__ __launch_bounds__(64, 2) void raster_bwd_edge_kernel(KParams p)
 { // persistent waves over the lists of tiles that hold silhouette edges (built by setup_bin_kernel).  Grid (views, waves):
   // the first waves dispatched are wave 0 of every view, and every wave starts with the many-edged tiles -- the kernel
@@ -2964,7 +2995,7 @@ __global__ __launch_bounds__(64, 2) void raster_bwd_edge_kernel(KParams p)
 		else
 			tile = (int)all[i - n_multi - n_long], lo = 0, hi = PRIO_EDGES;
 		tile = uniform(tile);
-		bwd_fast_tile<PixT, true>(p, w, view, tile % p.L.tiles_x, tile / p.L.tiles_x, lane, s_lds, &s_es, hi, chunk);
+		bwd_fast_tile<PixT, true, TEX>(p, w, view, tile % p.L.tiles_x, tile / p.L.tiles_x, lane, s_lds, &s_es, hi, chunk);
 		(void)lo; // a listed tile always has more edges than the threshold of its list
 		lds_sync();
 	}
@@ -3152,11 +3183,24 @@ void launch_adjoint_raster(const KParams &p, bool fast, bool owner_tiles, dim3 g
 		hipLaunchKernelGGL(raster_bwd_kernel<PixT>, grid4, dim3(256), 0, st, p);
 		return;
 	}
+	// the kernels are compiled twice: a scene without texture (no KIND_TEXTURED primitive can exist: the set-up kernel drops
+	// textured triangles of such a scene and raises DEODR_HIP_ERR_NO_TEXTURE) runs the instances without any texture code
+	const bool tex = p.texture != nullptr;
 	if (owner_tiles) // (after a fused forward the tiles without edges have already been back-propagated)
-		hipLaunchKernelGGL(raster_bwd_fast_kernel<PixT>, dim3(p.L.ntiles, p.n_views), dim3(64), 0, st, p);
+	{
+		if (tex)
+			hipLaunchKernelGGL((raster_bwd_fast_kernel<PixT, true>), dim3(p.L.ntiles, p.n_views), dim3(64), 0, st, p);
+		else
+			hipLaunchKernelGGL((raster_bwd_fast_kernel<PixT, false>), dim3(p.L.ntiles, p.n_views), dim3(64), 0, st, p);
+	}
 	// (running the two kernels side by side on a forked stream was measured: no gain, the edge kernel just stretches)
 	if (p.sigma > 0)
-		hipLaunchKernelGGL(raster_bwd_edge_kernel<PixT>, edge_grid, dim3(64), 0, st, p);
+	{
+		if (tex)
+			hipLaunchKernelGGL((raster_bwd_edge_kernel<PixT, true>), edge_grid, dim3(64), 0, st, p);
+		else
+			hipLaunchKernelGGL((raster_bwd_edge_kernel<PixT, false>), edge_grid, dim3(64), 0, st, p);
+	}
 }
 
 std::vector<ProfEvent> g_prof_events;
@@ -3194,33 +3238,82 @@ struct ScopedKernelTimer
 	}
 };
 
-template <class PixT>
-void launch_forward_raster(const KParams &p, bool fast, bool fused, dim3 grid4, hipStream_t stream)
+// The side stream the background fill runs on (one per device, created at first use), with the two events that fork it from
+// and join it back to the caller's stream.  Re-recording an event does not disturb a wait already enqueued on its previous
+// record, so one pair serves every call; the mutex keeps the record / wait pairs of concurrent host threads together.  Under
+// stream capture the fork / join become edges of the captured graph.
+struct SideStream
 {
-	if (!fast)
+	hipStream_t stream = nullptr;
+	hipEvent_t fork = nullptr, join = nullptr;
+};
+std::mutex g_side_mutex;
+std::vector<SideStream> g_side;
+
+int side_stream(SideStream &out)
+{
+	int dev = 0;
+	if (check_hip(hipGetDevice(&dev), "hipGetDevice"))
+		return 1;
+	if ((size_t)dev >= g_side.size())
+		g_side.resize(dev + 1);
+	SideStream &ss = g_side[dev];
+	if (!ss.stream)
 	{
-		hipLaunchKernelGGL(raster_fwd_kernel<PixT>, grid4, dim3(256), 0, stream, p);
-		return;
+		if (check_hip(hipStreamCreateWithFlags(&ss.stream, hipStreamNonBlocking), "side stream") ||
+			check_hip(hipEventCreateWithFlags(&ss.fork, hipEventDisableTiming), "side event") ||
+			check_hip(hipEventCreateWithFlags(&ss.join, hipEventDisableTiming), "side event"))
+			return 1;
 	}
-	const dim3 flat(fwd_fast_grid(p.n_views, p.L.ntiles, p.L.nwords, p.first_tiles != 0));
-	if (fused)
-		hipLaunchKernelGGL((raster_fwd_fast_kernel<PixT, true>), flat, dim3(64), 0, stream, p);
+	out = ss;
+	return 0;
+}
+
+// Staged forward: counters -> work list + tile bitmap (scan), then the raster on the caller's stream and, forked from it, the
+// background fill on the side stream.  *join receives the event the caller's stream has to wait for before the call returns
+// control to it (the fill overlaps whatever the call launches in between).
+template <class PixT>
+int launch_forward_staged(const KParams &p, bool fused, hipStream_t stream, hipEvent_t *join)
+{
+	KParams q = p;
+	q.tile_blocks = fwd_tile_blocks(p.L.ntiles);
+	hipLaunchKernelGGL(tile_scan_kernel, dim3((p.L.ntiles + SCAN_BLOCK - 1) / SCAN_BLOCK, p.n_views), dim3(SCAN_BLOCK), 0, stream, q);
+	{
+		std::lock_guard<std::mutex> lock(g_side_mutex);
+		SideStream ss;
+		if (side_stream(ss) || check_hip(hipEventRecord(ss.fork, stream), "fork") || check_hip(hipStreamWaitEvent(ss.stream, ss.fork, 0), "fork"))
+			return 1;
+		const unsigned words = (unsigned)(p.n_views * p.L.nwords);
+		hipLaunchKernelGGL(fill_kernel<PixT>, dim3((words + FILL_WAVES - 1) / FILL_WAVES), dim3(64 * FILL_WAVES), 0, ss.stream, q, fused ? 0 : 1);
+		if (check_hip(hipEventRecord(ss.join, ss.stream), "join"))
+			return 1;
+		*join = ss.join;
+	}
+	const dim3 grid((unsigned)p.n_views * (unsigned)q.tile_blocks);
+	const bool tex = p.texture != nullptr; // (see launch_adjoint_raster)
+	if (fused && tex)
+		hipLaunchKernelGGL((raster_fwd_fast_kernel<PixT, true, true>), grid, dim3(64), 0, stream, q);
+	else if (fused)
+		hipLaunchKernelGGL((raster_fwd_fast_kernel<PixT, true, false>), grid, dim3(64), 0, stream, q);
+	else if (tex)
+		hipLaunchKernelGGL((raster_fwd_fast_kernel<PixT, false, true>), grid, dim3(64), 0, stream, q);
 	else
-		hipLaunchKernelGGL((raster_fwd_fast_kernel<PixT, false>), flat, dim3(64), 0, stream, p);
+		hipLaunchKernelGGL((raster_fwd_fast_kernel<PixT, false, false>), grid, dim3(64), 0, stream, q);
+	return 0;
 }
 
 // grid of the un-staged kernels: four tiles (wavefronts) per workgroup
 dim3 generic_grid(const KParams &p, int n_views) { return dim3((unsigned)(((p.L.tiles_x + 3) / 4) * p.L.tiles_y), (unsigned)n_views); }
 
 // fused: the forward also back-propagates L = sum (image - obs)^2 through the tiles that have no silhouette edge (staged
-// kernels only; the caller checks)
-int launch_forward(const DeodrHipScene *sc, KParams &p, hipStream_t stream, bool fused = false)
+// kernels only; the caller checks).  *join: see launch_forward_staged (nullptr when nothing was forked).
+int launch_forward(const DeodrHipScene *sc, KParams &p, hipStream_t stream, hipEvent_t *join, bool fused = false)
 {
 	const int n_views = sc->n_views;
+	*join = nullptr;
 	g_profile = g_profile_every > 0 && (g_profile_calls++ % (unsigned)g_profile_every) == 0;
 	p.n_views = n_views;
 	const bool fast = !p.aa_err && p.C <= CH && !g_force_generic;
-	p.first_tiles = fast;
 	if (p.T > 0)
 	{
 		dim3 grid(prim_blocks(p.T), n_views);
@@ -3229,13 +3322,22 @@ int launch_forward(const DeodrHipScene *sc, KParams &p, hipStream_t stream, bool
 	}
 	{
 		ScopedKernelTimer t(KID_RASTER_FWD, stream);
-		if (sc->pixel_dtype == DEODR_HIP_F64)
-			launch_forward_raster<double>(p, fast, fused && fast, generic_grid(p, n_views), stream);
+		const bool f64 = sc->pixel_dtype == DEODR_HIP_F64;
+		if (fast)
+		{
+			if (f64 ? launch_forward_staged<double>(p, fused, stream, join) : launch_forward_staged<float>(p, fused, stream, join))
+				return 1;
+		}
+		else if (f64)
+			hipLaunchKernelGGL(raster_fwd_kernel<double>, generic_grid(p, n_views), dim3(256), 0, stream, p);
 		else
-			launch_forward_raster<float>(p, fast, fused && fast, generic_grid(p, n_views), stream);
+			hipLaunchKernelGGL(raster_fwd_kernel<float>, generic_grid(p, n_views), dim3(256), 0, stream, p);
 	}
 	return check_hip(hipGetLastError(), "forward launch");
 }
+
+// the caller's stream waits for the side stream's work of this call
+int join_side(hipStream_t stream, hipEvent_t join) { return join ? check_hip(hipStreamWaitEvent(stream, join, 0), "join") : 0; }
 
 // adjoint raster and the per-primitive finalize; owner_tiles = false after a fused forward
 int launch_adjoint(const DeodrHipScene *sc, KParams &p, hipStream_t st, bool owner_tiles)
@@ -3346,7 +3448,10 @@ int deodr_hip_render_scene(const DeodrHipScene *sc, void *image, void *z_buffer,
 	p.obs = obs;
 	p.err = err_buffer;
 	note_forward(workspace, false);
-	return launch_forward(sc, p, (hipStream_t)stream);
+	hipEvent_t join = nullptr;
+	if (launch_forward(sc, p, (hipStream_t)stream, &join))
+		return 1;
+	return join_side((hipStream_t)stream, join);
 }
 
 int deodr_hip_render_scene_b(const DeodrHipScene *sc, const void *image, const void *z_buffer, const void *image_b, double sigma,
@@ -3366,6 +3471,7 @@ int deodr_hip_render_scene_b(const DeodrHipScene *sc, const void *image, const v
 	else if (!image_b && !(image && obs))
 		return fail("image_b == NULL (or, for the residual mode, image and obs)");
 	hipStream_t st = (hipStream_t)stream;
+	hipEvent_t join = nullptr;
 	if (!have_forward_state || last_forward_was_fused(workspace))
 	{ // stateless use (or a fused forward, which leaves no complete owner buffer): rebuild records, tile lists and the owner
 	  // buffer (no image / z written)
@@ -3374,7 +3480,7 @@ int deodr_hip_render_scene_b(const DeodrHipScene *sc, const void *image, const v
 		f.image = nullptr;
 		f.zbuf = nullptr;
 		f.aa_err = 0;
-		if (launch_forward(sc, f, st))
+		if (launch_forward(sc, f, st, &join) || join_side(st, join)) // (the generic adjoint reads the owner ids of every tile)
 			return 1;
 	}
 	p.image_b = image_b;
@@ -3407,9 +3513,12 @@ int deodr_hip_render_scene_fit(const DeodrHipScene *sc, void *image, void *z_buf
 	}
 	const bool fused = p.C <= CH && !g_force_generic;
 	note_forward(workspace, fused);
-	if (launch_forward(sc, p, st, fused))
+	hipEvent_t join = nullptr;
+	if (launch_forward(sc, p, st, &join, fused))
 		return 1;
-	return launch_adjoint(sc, p, st, !fused);
+	if (launch_adjoint(sc, p, st, !fused))
+		return 1;
+	return join_side(st, join); // the background fill has been overlapping the adjoint
 }
 
 #ifdef DR_WAVE_TRACE
@@ -3462,9 +3571,7 @@ int deodr_hip_workspace_census(const DeodrHipScene *sc, void *workspace, size_t 
 		const char *base = (const char *)workspace + (size_t)v * p.L.view_bytes;
 		WsHeader h;
 		if (check_hip(hipMemcpy(&h, base + p.L.hdr, sizeof h, hipMemcpyDeviceToHost), "census copy") ||
-			check_hip(hipMemcpy(bits.data(), base + p.L.tile_bits + sizeof(uint32_t) * (size_t)(h.cur & 1u) * p.L.nwords, sizeof(uint32_t) * p.L.nwords,
-								hipMemcpyDeviceToHost),
-					  "census copy") ||
+			check_hip(hipMemcpy(bits.data(), base + p.L.tile_bits, sizeof(uint32_t) * p.L.nwords, hipMemcpyDeviceToHost), "census copy") ||
 			check_hip(hipMemcpy(saved.data(), base + p.L.edge_saved, sizeof(uint32_t) * p.L.ntiles, hipMemcpyDeviceToHost), "census copy"))
 			return 1;
 		for (int t = 0; t < p.L.ntiles; t++)

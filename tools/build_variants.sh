@@ -4,7 +4,8 @@
 #   fwdtrace   -DDR_FWD_TRACE   per-tile phase counters of the fused forward   (tools/fwd_trace.py)
 #   wavetrace  -DDR_WAVE_TRACE  start / end of every wave                       (tools/wave_trace.py)
 #   tiletrace  -DDR_TILE_TRACE  per-tile counters of the adjoint's edge kernel  (tools/tile_trace.py)
-#   fwdN       -DDR_FWD_WAVES=N the staged forward compiled for N waves / SIMD  (bench through tools/bench_variant.py)
+#   fwdN       -DDR_FWD_WAVES=N the staged forward compiled for N waves / SIMD  (tools/step_time.py --lib)
+#   ablM       -DDR_ABLATE=M    ablation masks of the fused forward (4 no frame stores, 8 no fill stores, 128 no accumulator atomics)
 cd "$(dirname "$0")/../deodr_amd/csrc" || exit 1
 OUT=../../tools/variants
 mkdir -p $OUT
@@ -16,6 +17,7 @@ for v in ${@:-fwdtrace wavetrace tiletrace fwd4 fwd6}; do
     wavetrace) build $v -DDR_WAVE_TRACE ;;
     tiletrace) build $v -DDR_TILE_TRACE ;;
     fwd*) build $v -DDR_FWD_WAVES=${v#fwd} ;;
+    abl*) build $v "-DDR_ABLATE=${v#abl} -DDR_FWD_WAVES=4" ;;
     *) build $v "$EXTRA" ;;
   esac
 done
