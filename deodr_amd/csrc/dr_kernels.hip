@@ -78,7 +78,18 @@ constexpr int SNAP_CAP = 256;
 constexpr int CHUNKS = 128 / 16; // batches of a tile = wavefronts that may share its reverse sweep
 constexpr size_t SNAP_BYTES = (CHUNKS - 1) * CH * 64 * sizeof(double);
 
-struct WsHeader // 64 bytes per view at the start of the view's workspace
+// Entry of the staged forward's work list (one per non-empty tile, written by tile_scan_kernel): everything a wavefront needs to
+// start on the tile comes with ONE memory round trip -- the header with a scalar load, the first triangle ids with a vector
+// load issued at the same time (a tile with more triangles reads its inline list / the spill pool as well).
+constexpr int ENTRY_IDS = 12;
+struct alignas(64) WorkEntry
+{
+	uint32_t tile, ntri, nedge, sweep_slot;
+	uint32_t ids[ENTRY_IDS];
+};
+static_assert(sizeof(WorkEntry) == 64, "");
+
+struct WsHeader // 64 bytes per view at the start of the view's workspace (also the status block the host may poll)
 {
 	// Spill counters are double-buffered by the parity of `epoch` (one forward = one epoch): the set-up kernel of a forward
 	// counts into [cur] and clears [1 - cur] for the next forward, so no memset node and no last-block ticket is needed.
@@ -148,7 +159,7 @@ Layout make_layout(int T, int H, int W, int C, size_t pool_pairs)
 	// edges, sweep slot} per non-empty tile, both written by tile_scan_kernel between set-up and forward raster
 	L.nwords = (L.ntiles + 31) / 32;
 	L.tile_bits = take(sizeof(uint32_t) * L.nwords);
-	L.work_list = take(sizeof(uint4) * (size_t)L.ntiles);
+	L.work_list = take(sizeof(WorkEntry) * (size_t)L.ntiles);
 	// kind | front << 2 of every triangle of the last forward: what finalize_kernel needs to know about a triangle before it
 	// touches anything else (one coalesced byte per thread instead of a 128-byte record line per triangle, two out of three
 	// of which are culled)
@@ -202,7 +213,7 @@ struct ViewPtrs
 	uint8_t *tri_flag;
 	uint32_t *edge_slot;
 	char *edge_sweep, *edge_snap;
-	uint4 *work_list;
+	WorkEntry *work_list;
 	uint32_t *edge_tile_cnt, *edge_tiles; // tiles with silhouette edges: NSUB counters per epoch parity, NSUB sub-lists of sub_cap tiles
 };
 
@@ -229,7 +240,7 @@ __device__ __forceinline__ ViewPtrs view_ptrs(const KParams &p, int view)
 	v.tri_flag = (uint8_t *)(b + p.L.tri_flag);
 	v.edge_tile_cnt = (uint32_t *)(b + p.L.edge_tile_cnt);
 	v.edge_tiles = (uint32_t *)(b + p.L.edge_tiles);
-	v.work_list = (uint4 *)(b + p.L.work_list);
+	v.work_list = (WorkEntry *)(b + p.L.work_list);
 	v.edge_slot = (uint32_t *)(b + p.L.edge_slot);
 	v.edge_sweep = b + p.L.edge_sweep;
 	v.edge_snap = b + p.L.edge_snap;
@@ -727,8 +738,8 @@ __global__ __launch_bounds__(PRIM_BLOCK) void setup_bin_kernel(KParams p)
 				}
 		} while (false);
 	}
-	// ---- the large primitives of this wavefront, one after the other, 64 tiles of the bounding box at a time
 	const int lane = threadIdx.x & 63;
+	// ---- the large primitives of this wavefront, one after the other, 64 tiles of the bounding box at a time
 	unsigned long long todo = __ballot(big);
 	while (todo)
 	{
@@ -1168,24 +1179,41 @@ __device__ __forceinline__ uint32_t gather_column_bits(const uint8_t *row_bytes,
 	return m;
 }
 
-// stage `nb` primitives whose ids are in S.ids: records (128 B each, 8 lanes x 16 B) and planes (3P doubles each)
+// stage `nb` primitives whose ids are in S.ids: records (128 B each, 8 lanes x 16 B) and planes (3P doubles each).
+// Every global load is issued before the first LDS store: ONE memory round trip per batch (a rolled loop over the planes
+// paid one per 64 doubles, i.e. two or three for a batch of more than five primitives).
 template <class Rec>
 __device__ __forceinline__ void stage_batch(WaveLds &S, const Rec *recs, const double *planes, int P, int nb, int lane)
 {
+	static_assert(TB == 16, "two record pieces and three plane doubles per lane");
 	const int piece = lane & 7;
-#pragma unroll
-	for (int q = 0; q < TB / 8; q++)
-	{
-		const int j = q * 8 + (lane >> 3);
-		if (j < nb)
-			((uint4 *)&S.rec[j])[piece] = ((const uint4 *)(recs + S.ids[j]))[piece];
-	}
-	const int np = 3 * P;
-	for (int i = lane; i < nb * np; i += 64)
-	{
-		const int j = i / np, c = i - j * np;
-		S.planes[j * 12 + c] = planes[(size_t)S.ids[j] * np + c];
-	}
+	const int np = 3 * P, total = nb * np; // np = 9 or 12
+	const int j0 = lane >> 3, j1 = 8 + (lane >> 3);
+	const int i0 = lane, i1 = lane + 64, i2 = lane + 128;
+	const int a0 = np == 12 ? i0 / 12 : i0 / 9, a1 = np == 12 ? i1 / 12 : i1 / 9, a2 = np == 12 ? i2 / 12 : i2 / 9;
+	const int c0 = i0 - a0 * np, c1 = i1 - a1 * np, c2 = i2 - a2 * np;
+	uint4 r0 = make_uint4(0, 0, 0, 0), r1 = r0;
+	double v0 = 0, v1 = 0, v2 = 0;
+	if (j0 < nb)
+		r0 = ((const uint4 *)(recs + S.ids[j0]))[piece];
+	if (j1 < nb)
+		r1 = ((const uint4 *)(recs + S.ids[j1]))[piece];
+	if (i0 < total)
+		v0 = planes[(size_t)S.ids[a0] * np + c0];
+	if (i1 < total)
+		v1 = planes[(size_t)S.ids[a1] * np + c1];
+	if (i2 < total)
+		v2 = planes[(size_t)S.ids[a2] * np + c2];
+	if (j0 < nb)
+		((uint4 *)&S.rec[j0])[piece] = r0;
+	if (j1 < nb)
+		((uint4 *)&S.rec[j1])[piece] = r1;
+	if (i0 < total)
+		S.planes[a0 * 12 + c0] = v0;
+	if (i1 < total)
+		S.planes[a1 * 12 + c1] = v1;
+	if (i2 < total)
+		S.planes[a2 * 12 + c2] = v2;
 }
 
 template <bool TEX>
@@ -1230,19 +1258,22 @@ __device__ __forceinline__ void tri_batch(const KParams &p, WaveLds &S, int nb, 
 	if (!inb)
 		mine = 0;
 	const double x = x0 + lx, y = y0 + row;
-	// Depth test only: the winner of the batch is remembered by its slot and shaded ONCE after the loop (interpolating the
-	// C attribute planes at every change of winner was most of the arithmetic of this loop).
+	// Depth test: every lane walks the triangles that cover ITS pixel (bits of `mine`), not the triangles of the batch -- with
+	// back-face culling a pixel is covered by one triangle, rarely two, so the wavefront makes one or two passes instead of one
+	// per triangle of the batch (the 93-triangle tile at the limb of the sphere: 96 -> ~12).  The winner is remembered by its slot
+	// and shaded ONCE after the loop.  Lane-varying LDS addresses: a few distinct records per pass.
 	int jbest = -1;
-	for (int j = 0; j < nb; j++)
+	uint32_t todo = mine;
+	while (__ballot(todo != 0))
 	{
-		const bool c = (mine >> j) & 1u;
-		if (__ballot(c) == 0)
-			continue;
+		const bool act = todo != 0;
+		const int j = act ? __ffs((int)todo) - 1 : 0;
+		todo &= todo - 1;
 		double Z = plane_at(S.rec[j].xZ, x, y);
 		if (persp)
 			Z = 1 / Z;
 		const int k = (int)S.ids[j];
-		if (c && (Z < st.zbest || (Z == st.zbest && k < st.kbest)))
+		if (act && (Z < st.zbest || (Z == st.zbest && k < st.kbest)))
 		{
 			st.zbest = Z;
 			st.kbest = k;
@@ -1423,7 +1454,8 @@ __device__ __forceinline__ void fill_background_tile(const KParams &p, int view,
 // Two tiles out of three receive nothing: this is what lets the forward launch one wavefront per tile that HAS work instead of
 // one per tile of the frame (the waves of the empty tiles used to take a third of its slot-time), and it takes the
 // many-primitive-tile flags and lists (two more dependent atomics per lane) out of the set-up kernel.
-constexpr int SCAN_BLOCK = 256;
+constexpr int SCAN_BLOCK = 256, WORK_CHUNK = 64;
+constexpr int HEAVY_SHARE = 8; // one tile workgroup in HEAVY_SHARE walks the list of the many-primitive tiles
 
 __global__ __launch_bounds__(SCAN_BLOCK) void tile_scan_kernel(KParams p)
 {
@@ -1456,7 +1488,7 @@ __global__ __launch_bounds__(SCAN_BLOCK) void tile_scan_kernel(KParams p)
 	if (lane == 32 && valid)
 		w.tile_bits[tile >> 5] = (uint32_t)(wm >> 32);
 	// ---- compaction: rank inside the wavefront, wavefront totals through LDS, ONE atomic per class and block
-	const bool heavy = work && (ntri > (uint32_t)FIRST_PRIMS || nedge > (uint32_t)FIRST_PRIMS);
+	const bool heavy = work && p.tile_blocks % (8 * WORK_CHUNK) == 0 && (ntri > (uint32_t)FIRST_PRIMS || nedge > (uint32_t)FIRST_PRIMS);
 	const unsigned long long hm = __ballot(heavy), lm = wm & ~hm, below = (1ull << lane) - 1ull;
 	if (lane == 0)
 	{
@@ -1479,11 +1511,16 @@ __global__ __launch_bounds__(SCAN_BLOCK) void tile_scan_kernel(KParams p)
 	__syncthreads();
 	if (work)
 	{
-		const uint4 entry = make_uint4((uint32_t)tile, ntri, nedge, sweep_slot);
-		if (heavy)
-			w.work_list[s_base[0] + before[0] + (uint32_t)__popcll(hm & below)] = entry;
-		else
-			w.work_list[(uint32_t)p.L.ntiles - 1u - (s_base[1] + before[1] + (uint32_t)__popcll(lm & below))] = entry;
+		WorkEntry &e = heavy ? w.work_list[s_base[0] + before[0] + (uint32_t)__popcll(hm & below)]
+							 : w.work_list[(uint32_t)p.L.ntiles - 1u - (s_base[1] + before[1] + (uint32_t)__popcll(lm & below))];
+		uint4 *out = (uint4 *)&e;
+		out[0] = make_uint4((uint32_t)tile, ntri, nedge, sweep_slot);
+		static_assert(ENTRY_IDS == 12 && K_TRI >= ENTRY_IDS, "three 16-byte pieces of the tile's inline list");
+		const uint4 *ids = (const uint4 *)(w.tri_list + (size_t)tile * K_TRI);
+		const uint4 a = ids[0], b = ntri > 4 ? ids[1] : a, c = ntri > 8 ? ids[2] : a;
+		out[1] = a;
+		out[2] = b;
+		out[3] = c;
 	}
 }
 
@@ -1556,7 +1593,6 @@ __global__ __launch_bounds__(64 * FILL_WAVES) void fill_kernel(KParams p, int ow
 // q = (b / 8 / n_views) * 8 + b % 8 in [0, p.tile_blocks); it walks the entries rank(q), rank(q) + tile_blocks, ... of the
 // view's work list (usually one or two).  rank() deals the list to the XCDs in chunks of 64 consecutive entries (workgroup b
 // runs on XCD b % 8; consecutive entries are neighbouring tiles, which share triangle records and should share an L2).
-constexpr int WORK_CHUNK = 64;
 
 __host__ __device__ inline int fwd_tile_blocks(int ntiles)
 { // workgroups per view that walk the work list: a quarter of the tiles (about a third of a frame's tiles hold primitives)
@@ -1569,8 +1605,10 @@ __host__ __device__ inline int fwd_tile_blocks(int ntiles)
 // resolved: tiles without silhouette edges back-propagate into their owners' accumulators right here (no second pass over the
 // frame, no owner buffer round trip -- the owner ids of those tiles are not even written); tiles with edges are left to
 // raster_bwd_edge_kernel.
+// Waves per SIMD the staged forward is compiled for: without texture code it fits five (96 registers), with it four
+// (tools/build_variants.sh builds the neighbours: -DDR_FWD_WAVES=n forces n for both).
 #ifndef DR_FWD_WAVES
-#define DR_FWD_WAVES 4 // waves per SIMD the staged forward is compiled for (tools/build_variants.sh builds the neighbours)
+#define DR_FWD_WAVES (TEX ? 4 : 5)
 #endif
 template <class PixT, bool FUSED, bool TEX>
 __global__ __launch_bounds__(64, DR_FWD_WAVES) void raster_fwd_fast_kernel(KParams p)
@@ -1606,9 +1644,17 @@ __global__ __launch_bounds__(64, DR_FWD_WAVES) void raster_fwd_fast_kernel(KPara
 	const bool persp = p.persp;
 	const PixT *texture = (const PixT *)p.texture;
 	WaveLds &S = s_lds[wave];
-	const uint32_t n_heavy = w.hdr->work_count[0], n_work = n_heavy + w.hdr->work_count[1];
-	uint32_t rank = chunked ? (uint32_t)((((q >> 3) / WORK_CHUNK) * 8 + (q & 7)) * WORK_CHUNK + (q >> 3) % WORK_CHUNK) : (uint32_t)q;
-	for (; rank < n_work; rank += (uint32_t)G)
+	// The first G / HEAVY_SHARE workgroups of a view walk the many-primitive tiles (front of the list), the others the rest (from
+	// the back): the index of a workgroup's entry does not depend on the counts, so the counts, the entry header and the
+	// entry's triangle ids are all requested at once.
+	// (tiny frames -- G not a multiple of 512 -- have one class only: the scan kernel lists every tile as "other")
+	const int Gh = chunked ? G / HEAVY_SHARE : 0;
+	const bool heavy_list = q < Gh;
+	const int qq = heavy_list ? q : q - Gh, stride = heavy_list ? Gh : G - Gh;
+	const bool chunk_here = chunked && stride % (8 * WORK_CHUNK) == 0;
+	uint32_t rank = chunk_here ? (uint32_t)((((qq >> 3) / WORK_CHUNK) * 8 + (qq & 7)) * WORK_CHUNK + (qq >> 3) % WORK_CHUNK) : (uint32_t)qq;
+	const uint32_t n_work = w.hdr->work_count[heavy_list ? 0 : 1];
+	for (; rank < n_work; rank += (uint32_t)stride)
 	{
 #ifdef DR_FWD_TRACE
 		const uint64_t ftr0 = __builtin_readcyclecounter();
@@ -1617,10 +1663,10 @@ __global__ __launch_bounds__(64, DR_FWD_WAVES) void raster_fwd_fast_kernel(KPara
 		// loop and kept -- spilled -- in registers across it: + 150 VGPRs for a loop that usually runs once or twice)
 		int lane = lane0;
 		asm volatile("" : "+v"(lane));
-		// entry of the work list: tile, counters and sweep slot in ONE 16-byte scalar load
-		const uint4 entry = w.work_list[rank < n_heavy ? rank : (uint32_t)p.L.ntiles - 1u - (rank - n_heavy)];
-		const int tile = uniform((int)entry.x), ntri = uniform((int)entry.y), nedge = uniform((int)entry.z);
-		const uint32_t sweep_slot = (uint32_t)uniform((int)entry.w);
+		const WorkEntry &entry = w.work_list[heavy_list ? rank : (uint32_t)p.L.ntiles - 1u - rank];
+		const uint32_t ids12 = entry.ids[lane < ENTRY_IDS ? lane : 0];
+		const int tile = uniform((int)entry.tile), ntri = uniform((int)entry.ntri), nedge = uniform((int)entry.nedge);
+		const uint32_t sweep_slot = (uint32_t)uniform((int)entry.sweep_slot);
 		const int tx = tile % p.L.tiles_x, ty = tile / p.L.tiles_x;
 		const int x0 = tx * TILE, y0 = ty * TILE;
 		const int px = x0 + (lane & 7), py = y0 + (lane >> 3);
@@ -1628,7 +1674,8 @@ __global__ __launch_bounds__(64, DR_FWD_WAVES) void raster_fwd_fast_kernel(KPara
 		const size_t pix = (size_t)py * W + px;
 		const size_t vpix = (size_t)view * H * W + pix;
 		const double x = px, y = py;
-		const uint32_t list_entry = w.tri_list[(size_t)tile * K_TRI + (lane & (K_TRI - 1))];
+		// more than ENTRY_IDS triangles: the rest of the inline list (one more round trip, one tile in ten)
+		const uint32_t list_entry = ntri <= ENTRY_IDS ? ids12 : w.tri_list[(size_t)tile * K_TRI + (lane & (K_TRI - 1))];
 		{
 		{
 		PixT ob[CH] = {0, 0, 0, 0};
@@ -2962,7 +3009,7 @@ __global__ __launch_bounds__(64, 6) void raster_bwd_fast_kernel(KParams p)
 }
 
 template <class PixT, bool TEX>
-__global__ __launch_bounds__(64, 2) void raster_bwd_edge_kernel(KParams p)
+__global__ __launch_bounds__(64, TEX ? 2 : 4) void raster_bwd_edge_kernel(KParams p)
 { // persistent waves over the lists of tiles that hold silhouette edges (built by setup_bin_kernel).  Grid (views, waves):
   // the first waves dispatched are wave 0 of every view, and every wave starts with the many-edged tiles -- the kernel
   // lasts as long as its slowest tile, so those must not start late.  Wave g walks sub-list g % NSUB from entry g / NSUB
@@ -3004,7 +3051,9 @@ __global__ __launch_bounds__(64, 2) void raster_bwd_edge_kernel(KParams p)
 // ------------------------------------------------------------------------------------------------------- finalize
 
 __global__ __launch_bounds__(PRIM_BLOCK) void finalize_kernel(KParams p)
-{ // same split as setup_bin_kernel: triangle blocks, then edge-slot blocks compacted to the flagged slots
+{ // same split as setup_bin_kernel: triangle blocks, then edge-slot blocks compacted to the flagged slots.
+  // (Lists of the front-facing triangles / drawn edges compacted by the set-up kernel were tried: a quarter as many wavefronts,
+  // all lanes busy -- and 32 -> 41 us: the kernel is a chain of dependent round trips, fewer wavefronts overlap fewer of them.)
 	DR_WAVE_TRACE_SCOPE(1);
 	const int view = blockIdx.y;
 	const bool tri_block = (int)blockIdx.x < prim_tri_blocks(p.T);
