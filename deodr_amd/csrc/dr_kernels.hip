@@ -1216,9 +1216,21 @@ __device__ __forceinline__ void stage_batch(WaveLds &S, const Rec *recs, const d
 		S.planes[a2 * 12 + c2] = v2;
 }
 
+#ifdef DR_FWD_TRACE
+#define DR_TRACE_ARGS , uint32_t *ftr, uint64_t ftr0
+#define DR_TRACE_PASS , ftr, ftr0
+#define DR_BTRACE(i)                                                                                                         \
+	if (ftr[i] == 0)                                                                                                         \
+	ftr[i] = (uint32_t)(__builtin_readcyclecounter() - ftr0)
+#else
+#define DR_TRACE_ARGS
+#define DR_TRACE_PASS
+#define DR_BTRACE(i)
+#endif
 template <bool TEX>
-__device__ __forceinline__ void tri_batch(const KParams &p, WaveLds &S, int nb, int lane, int x0, int y0, bool inb, PixState &st)
+__device__ __forceinline__ void tri_batch(const KParams &p, WaveLds &S, int nb, int lane, int x0, int y0, bool inb, PixState &st DR_TRACE_ARGS)
 {
+	DR_BTRACE(8); // records staged (first batch)
 	const int W = p.W, H = p.H, C = p.C;
 	const bool persp = p.persp, strict = p.strict;
 	// spans: lane = slot * 8 + row
@@ -1252,6 +1264,7 @@ __device__ __forceinline__ void tri_batch(const KParams &p, WaveLds &S, int nb, 
 		if (j < TB)
 			S.cover[r][j] = (uint8_t)m;
 	}
+	DR_BTRACE(9); // spans computed
 	lds_sync();
 	const int lx = lane & 7, row = lane >> 3;
 	uint32_t mine = gather_column_bits(&S.cover[row][0], lx);
@@ -1280,6 +1293,7 @@ __device__ __forceinline__ void tri_batch(const KParams &p, WaveLds &S, int nb, 
 			jbest = j;
 		}
 	}
+	DR_BTRACE(10); // depth test done
 	if (jbest >= 0)
 	{ // per-lane reads of the winner's record and planes (LDS, a few distinct slots per tile)
 		const int kind = S.rec[jbest].kind;
@@ -1618,7 +1632,7 @@ __global__ __launch_bounds__(64, DR_FWD_WAVES) void raster_fwd_fast_kernel(KPara
 	__shared__ EdgeSort s_es[1];
 #ifdef DR_FWD_TRACE
 	// per-tile phase timing (tools/fwd_trace.py): eight counters over the first row of the tile in the z buffer
-	uint32_t ftr[8] = {0x7fc0f00du, 0, 0, 0, 0, 0, 0, 0};
+	uint32_t ftr[16] = {0x7fc0f00du, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #define DR_FTRACE(i) ftr[i] = (uint32_t)(__builtin_readcyclecounter() - ftr0)
 #else
 #define DR_FTRACE(i)
@@ -1658,6 +1672,7 @@ __global__ __launch_bounds__(64, DR_FWD_WAVES) void raster_fwd_fast_kernel(KPara
 	{
 #ifdef DR_FWD_TRACE
 		const uint64_t ftr0 = __builtin_readcyclecounter();
+		ftr[8] = ftr[9] = ftr[10] = ftr[11] = ftr[12] = 0;
 #endif
 		// (the lane index is made opaque per iteration: otherwise every lane-dependent address of the body is hoisted out of the
 		// loop and kept -- spilled -- in registers across it: + 150 VGPRs for a loop that usually runs once or twice)
@@ -1710,7 +1725,7 @@ __global__ __launch_bounds__(64, DR_FWD_WAVES) void raster_fwd_fast_kernel(KPara
 				lds_sync();
 				stage_batch(S, w.tri_rec, w.tri_planes, P, nb, lane);
 				lds_sync();
-				tri_batch<TEX>(p, S, nb, lane, x0, y0, inb, st);
+				tri_batch<TEX>(p, S, nb, lane, x0, y0, inb, st DR_TRACE_PASS);
 			}
 			if (ntri > K_TRI)
 			{ // spilled pairs of this tile: compact them out of the pool, TB at a time
@@ -1739,7 +1754,7 @@ __global__ __launch_bounds__(64, DR_FWD_WAVES) void raster_fwd_fast_kernel(KPara
 							lds_sync();
 							stage_batch(S, w.tri_rec, w.tri_planes, P, TB, lane);
 							lds_sync();
-							tri_batch<TEX>(p, S, TB, lane, x0, y0, inb, st);
+							tri_batch<TEX>(p, S, TB, lane, x0, y0, inb, st DR_TRACE_PASS);
 							fill = 0;
 						}
 					}
@@ -1749,7 +1764,7 @@ __global__ __launch_bounds__(64, DR_FWD_WAVES) void raster_fwd_fast_kernel(KPara
 					lds_sync();
 					stage_batch(S, w.tri_rec, w.tri_planes, P, fill, lane);
 					lds_sync();
-					tri_batch<TEX>(p, S, fill, lane, x0, y0, inb, st);
+					tri_batch<TEX>(p, S, fill, lane, x0, y0, inb, st DR_TRACE_PASS);
 				}
 			}
 		}
@@ -1932,12 +1947,12 @@ __global__ __launch_bounds__(64, DR_FWD_WAVES) void raster_fwd_fast_kernel(KPara
 		}
 #ifdef DR_FWD_TRACE
 		DR_FTRACE(6); // adjoint of pass 1 issued
-		if (lane < 8 && p.zbuf)
+		if (lane < 16 && p.zbuf)
 		{
 			uint32_t v = 0;
-			for (int i = 0; i < 8; i++)
+			for (int i = 0; i < 16; i++)
 				v = lane == i ? ftr[i] : v;
-			((uint32_t *)p.zbuf)[(size_t)view * H * W + (size_t)y0 * W + x0 + lane] = v;
+			((uint32_t *)p.zbuf)[(size_t)view * H * W + (size_t)(y0 + (lane >> 3)) * W + x0 + (lane & 7)] = v;
 		}
 #endif
 		}

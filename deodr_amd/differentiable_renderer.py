@@ -220,3 +220,14 @@ class Scene2D(Scene2DBase):
             err = float(np.sum(err_buffer))
             self.render_backward(2 * diff_image, make_copies=make_copies)
         return image, z_buffer, err_buffer, err
+
+
+# the 3-D level of the reference's module (Camera, Scene3D: dr.py:250-522, 735-1174) lives in scene3d_compat (adapters over the
+# device-resident pipeline of deodr_amd.scene3d); re-exported here so that `from deodr_amd.differentiable_renderer import ...`
+# reads like the reference's import
+def __getattr__(name):
+    if name in ("Camera", "PerspectiveCamera", "default_camera", "Scene3D"):
+        from . import scene3d_compat
+
+        return getattr(scene3d_compat, name)
+    raise AttributeError(name)

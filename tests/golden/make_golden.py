@@ -18,6 +18,14 @@ Fixtures
                        the goldens of tests/test_triangle_soup_fitting.py:29-108.
   hand_mesh.npz        vertices / faces of deodr/data/hand.obj read with deodr/obj.py (input data for
                        BASELINE configs 2 and 4).
+  depth_hand_fit.npz   deodr/examples/depth_image_hand_fitting.py `run(dl_library="none")`: the cropped depth image (float32 as
+                       in deodr/data/depth.bin), the 50 energies of MeshDepthFitter.step (last one = the golden of the
+                       reference's tests/test_depth_image_hand_fitting.py:36-42) and, for iteration 0, every intermediate of
+                       the Scene3D front half: projected points (distortion camera), depths, silhouette edge flags, the
+                       rendered depth image, the vertex / quaternion / translation gradients, the rigid energy and its gradient.
+  rgb_hand_fit.npz     deodr/examples/rgb_image_hand_fitting.py `run(dl_library="none")`: the image (uint8), background colour,
+                       50 energies of MeshRGBFitterWithPose.step and the iteration-0 intermediates (vertex normals,
+                       luminosity, rendered image, gradients of vertices, lights and colour).
 """
 
 import hashlib
@@ -130,9 +138,105 @@ def hand():
     print("hand mesh", np.shape(vertices), np.shape(faces))
 
 
+def depth_hand_fit():
+    """deodr/examples/depth_image_hand_fitting.py:24-66 with dl_library="none", instrumented at iteration 0."""
+    import deodr
+    from deodr import ColoredTriMesh
+    from deodr.mesh_fitter import MeshDepthFitter
+
+    raw = np.fliplr(np.fromfile(os.path.join(deodr.data_path, "depth.bin"), dtype=np.float32).reshape(240, 320))[20:-20, 60:-60]
+    depth_image = raw.astype(np.float64)
+    max_depth = 450
+    depth_image[depth_image == 0] = max_depth
+    depth_image = depth_image / max_depth
+    faces, vertices = deodr.read_obj(os.path.join(deodr.data_path, "hand.obj"))
+    mesh = ColoredTriMesh(faces.copy(), vertices=vertices, nb_colors=0)
+    euler_init, translation_init = np.array([0.1, 0.1, 0.1]), np.zeros(3)
+    fitter = MeshDepthFitter(mesh.vertices, mesh.faces, euler_init, translation_init, cregu=1000)
+    distortion = np.array([1, 0, 0, 0, 0])
+    fitter.set_image(depth_image, focal=241, distortion=distortion)
+    fitter.set_max_depth(1)
+    fitter.set_depth_scale(110 / max_depth)
+    out = dict(depth_raw_f32=np.ascontiguousarray(raw), max_depth=max_depth, focal=241.0, distortion=distortion.astype(np.float64),
+               euler_init=euler_init, translation_init=translation_init, cregu=1000.0, depth_scale=110 / max_depth,
+               quaternion_init=fitter.transform_quaternion_init, camera_extrinsic=fitter.camera.extrinsic,
+               camera_intrinsic=fitter.camera.intrinsic)
+    energies = []
+    for it in range(50):
+        energy, synthetic_depth, diff_image = fitter.step()
+        energies.append(energy)
+        if it == 0:
+            s2 = fitter.scene.scene_2d
+            out.update(it0_ij=np.array(s2.ij), it0_depths=np.array(s2.depths), it0_edgeflags=np.array(s2.edgeflags),
+                       it0_depth_image=np.array(fitter.depth_not_clipped), it0_vertices_transformed_b=np.array(fitter.scene.mesh._vertices_b),
+                       it0_vertices_b=np.array(fitter._vertices_b), it0_quaternion_b=np.array(fitter.transform_quaternion_b),
+                       it0_translation_b=np.array(fitter.transform_translation_b), it0_ij_b=np.array(s2.ij_b),
+                       it0_colors_b=np.array(s2.colors_b), it0_vertices_transformed=np.array(fitter.mesh.vertices))
+            e_rigid, g_rigid, _ = fitter.rigid_energy.evaluate(fitter.vertices - fitter.speed_vertices)  # the vertices of iteration 0
+            out.update(it0_energy_rigid=e_rigid, it0_grad_rigid=np.array(g_rigid))
+    out["energies"] = np.array(energies)
+    out["final_vertices"], out["final_quaternion"], out["final_translation"] = fitter.vertices, fitter.transform_quaternion, fitter.transform_translation
+    np.savez_compressed(os.path.join(OUT, "depth_hand_fit.npz"), **out)
+    print("depth hand fit: energies[0], [49] =", energies[0], energies[49])
+
+
+def rgb_hand_fit():
+    """deodr/examples/rgb_image_hand_fitting.py:27-100 with dl_library="none", instrumented at iteration 0."""
+    import deodr
+    from deodr import ColoredTriMesh, read_obj
+    from deodr.mesh_fitter import MeshRGBFitterWithPose
+    from PIL import Image
+
+    img_u8 = np.asarray(Image.open(os.path.join(deodr.data_path, "hand.png")))
+    hand_image = img_u8.astype(np.double) / 255
+    faces, vertices = read_obj(os.path.join(deodr.data_path, "hand.obj"))
+    mesh = ColoredTriMesh(faces.copy(), vertices=vertices, nb_colors=3)
+    default_color = np.array([0.4, 0.3, 0.25])
+    default_light_directional = -np.array([0.1, 0.5, 0.4])
+    default_light_ambient = 0.6
+    euler_init = np.array([0, 0, 0])
+    translation_init = np.mean(mesh.vertices, axis=0)
+    mesh.set_vertices(mesh.vertices - translation_init[None, :])
+    fitter = MeshRGBFitterWithPose(mesh.vertices, mesh.faces, default_color=default_color, default_light_directional=default_light_directional,
+                                   default_light_ambient=default_light_ambient, update_lights=True, update_color=True, euler_init=euler_init,
+                                   translation_init=translation_init, cregu=1000)
+    fitter.reset()
+    background_color = np.median(np.vstack((hand_image[:10, :10, :].reshape(-1, 3), hand_image[-10:, :10, :].reshape(-1, 3),
+                                            hand_image[-10:, -10:, :].reshape(-1, 3), hand_image[:10, -10:, :].reshape(-1, 3))), axis=0)
+    background_color = np.asarray(background_color, dtype=np.float64)
+    fitter.set_image(hand_image)
+    fitter.set_background_color(background_color)
+    out = dict(image_u8=img_u8, background_color=background_color, default_color=default_color,
+               default_light_directional=default_light_directional, default_light_ambient=default_light_ambient,
+               translation_init=translation_init, vertices_centered=np.array(mesh.vertices), cregu=1000.0,
+               camera_extrinsic=fitter.camera.extrinsic, camera_intrinsic=fitter.camera.intrinsic)
+    energies = []
+    for it in range(50):
+        energy, image, diff_image = fitter.step()
+        energies.append(energy)
+        if it == 0:
+            s2 = fitter.scene.scene_2d
+            out.update(it0_ij=np.array(s2.ij), it0_depths=np.array(s2.depths), it0_edgeflags=np.array(s2.edgeflags), it0_colors=np.array(s2.colors),
+                       it0_image=np.array(image), it0_vertex_normals=np.array(fitter.mesh.vertex_normals),
+                       it0_vertices_transformed_b=np.array(fitter.scene.mesh._vertices_b), it0_vertices_b=np.array(fitter._vertices_b),
+                       it0_quaternion_b=np.array(fitter.transform_quaternion_b), it0_translation_b=np.array(fitter.transform_translation_b),
+                       it0_light_directional_b=np.array(fitter.light_directional_b), it0_light_ambient_b=float(fitter.light_ambient_b),
+                       it0_mesh_color_b=np.array(fitter.mesh_color_b), it0_ij_b=np.array(s2.ij_b), it0_colors_b=np.array(s2.colors_b),
+                       it0_vertices_transformed=np.array(fitter.mesh.vertices))
+    out["energies"] = np.array(energies)
+    np.savez_compressed(os.path.join(OUT, "rgb_hand_fit.npz"), **out)
+    print("rgb hand fit: energies[0], [49] =", energies[0], energies[49])
+
+
 if __name__ == "__main__":
+    only = sys.argv[1:]
     with tempfile.TemporaryDirectory() as tmp:
         build_reference(tmp)
-        soup(False)
-        soup(True)
-        hand()
+        if not only or "soup" in only:
+            soup(False)
+            soup(True)
+        if not only or "hand" in only:
+            hand()
+        if not only or "fits" in only:
+            depth_hand_fit()
+            rgb_hand_fit()

@@ -26,7 +26,7 @@ for _ in range(3):
 torch.cuda.synchronize()
 zi = z.cpu().numpy().view(np.uint32)
 v, yy, xx = np.nonzero(zi == 0x7FC0F00D)
-rows = np.stack([zi[v, yy, xx + i] for i in range(8)], 1).astype(np.int64)
+rows = np.stack([zi[v, yy + i // 8, xx + i % 8] for i in range(16)], 1).astype(np.int64)
 ntri, nedge = rows[:, 1] & 0xFFFF, rows[:, 1] >> 16
 print("non-empty tiles:", len(rows), " with edges:", int((nedge > 0).sum()), " triangles/tile mean %.1f p50 %d p90 %d max %d" % (ntri.mean(), *np.percentile(ntri, [50, 90]), ntri.max()))
 names = ["prologue + counters", "pass 1 (stage, spans, z)", "resolve + edges", "frame stores", "adjoint of pass 1"]
@@ -36,6 +36,10 @@ sel = nedge == 0
 for i, n in enumerate(names):
     print("%-26s cycles (tiles without edges): mean %7.0f  p50 %7.0f  p90 %7.0f" % (n, d[sel, i].mean(), *np.percentile(d[sel, i], [50, 90])))
 print("%-26s cycles: mean %7.0f  p50 %7.0f  p90 %7.0f  max %7.0f" % ("whole tile", t[sel, 4].mean(), *np.percentile(t[sel, 4], [50, 90]), t[sel, 4].max()))
+sub = rows[:, 8:11]
+for nm, a, b in (("  entry -> records staged", t[:, 0], sub[:, 0]), ("  spans", sub[:, 0], sub[:, 1]), ("  depth test", sub[:, 1], sub[:, 2]), ("  shading of the winner", sub[:, 2], t[:, 1])):
+    dd = (b - a)[sel & (ntri <= 16)]
+    print("%-26s cycles (first batch, tiles without edges): mean %7.0f  p50 %7.0f  p90 %7.0f" % (nm, dd.mean(), *np.percentile(dd, [50, 90])))
 for lo, hi in [(1, 4), (5, 8), (9, 16), (17, 32), (33, 1000)]:
     m = sel & (ntri >= lo) & (ntri <= hi)
     if m.any():
