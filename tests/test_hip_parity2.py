@@ -277,8 +277,8 @@ def test_soup_fit_50_iterations_lockstep(oracle_api, clockwise, aa):
     if not aa:
         golden = d["aa0_losses50"]
         assert np.array_equal(np.array(losses_ref), golden)  # the checker reproduces the reference's curve bit for bit
-        assert np.abs(np.array(losses_free) - golden).max() <= 1e-7 * golden.max(), "free-running fit leaves the reference's loss curve"
-    assert abs(losses_free[-1] - losses_ref[-1]) <= 1e-7 * losses_ref[-1]
+        assert np.abs(np.array(losses_free) - golden).max() <= 1e-6 * golden.max(), "free-running fit leaves the reference's loss curve"
+    assert abs(losses_free[-1] - losses_ref[-1]) <= 1e-6 * losses_ref[-1]
 
 
 def test_run_to_run_determinism_bound(oracle_api):
