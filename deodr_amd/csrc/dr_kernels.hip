@@ -46,25 +46,27 @@ namespace
 
 #ifndef DR_ABLATE
 #define DR_ABLATE 0 // measurement builds only (tools/build_variants.sh): 4 no frame stores of non-empty tiles, 8 no fill waves'
-					// stores, 128 no accumulator atomics of the owner adjoint.  The product is always built with 0.
+					// stores, 128 no accumulator atomics of the owner adjoint, 256 no owner adjoint in the fused forward, 512 no span
+					// arithmetic (every staged triangle covers its whole tile).  The product is always built with 0.
 #endif
 constexpr int TILE = 8;		// 8 x 8 pixels = one wavefront, lane = (y & 7) * 8 + (x & 7)
 constexpr int K_TRI = 32;	// inline triangle slots per tile; more spill to the pool
 constexpr int K_EDGE = 32;	// inline edge slots per tile (== TB: one staged batch)
 constexpr int CH = 4;		// colour channels kept in registers at a time
 constexpr int MAX_SORTED = 64; // edges of a tile whose blending order is cached in LDS
-constexpr int NSUB = 8;		// sub-lists of the per-view list of tiles that hold silhouette edges (tile % NSUB: bounded, 8 append counters)
 constexpr int CNT_STRIDE = 32; // uint32 between two append counters (one 128-byte line each)
-constexpr int PRIO_EDGES = 8; // tiles with more edges than this are also listed apart: the adjoint's edge kernel starts with them
+constexpr int PRIO_EDGES = 8; // tiles with more edges than this are listed apart: the adjoint's edge kernel starts with them
 // Tiles that receive more than FIRST_PRIMS triangles (or edges) are the long poles of the forward raster: the scan kernel
 // puts them at the head of the work list, so that the 25-50 us waves start at time 0 instead of ending 30 us after every
 // other wave of the kernel.
 constexpr int FIRST_PRIMS = 8;
-constexpr int LIST_KINDS = 4; // edge tiles, tiles with > PRIO_EDGES edges, (unused), tiles with > TB edges
+// Lists of the tiles that hold silhouette edges, by edge count (disjoint; written by tile_scan_kernel, walked by
+// raster_bwd_edge_kernel): 0 = 1 .. PRIO_EDGES edges, 1 = PRIO_EDGES + 1 .. TB (one batch), 2 = more than one batch.
+constexpr int EDGE_LISTS = 3;
 // The forward sweep over a tile's edges (pass 2) leaves, per pixel, the antialiased colour in double and the mask of the
 // edges drawn: the forward raster saves both for the first SAVE_SUB edge tiles of every sub-list, so that the adjoint's edge
 // kernel starts with the reverse sweep instead of repeating the forward one (half of its time per tile).
-constexpr int SAVE_SUB = 512;
+constexpr int SWEEP_CAP = 4096; // saved sweeps per view
 constexpr uint32_t SWEEP_SAVED = 0x80000000u; // flag in edge_saved[tile]
 constexpr size_t SWEEP_ORDER = 64 * (CH * sizeof(double) + (128 / 16) * sizeof(uint16_t)); // offset of the saved blending order
 constexpr size_t SWEEP_SNAP = SWEEP_ORDER + 128 * sizeof(uint32_t);   // offset of the word: 1 + index of the tile's snapshots, 0: none
@@ -118,7 +120,8 @@ struct Layout
 	size_t hdr, tri_rec, tri_planes, tri_acc, edge_rec, edge_planes, edge_acc, tri_cnt, edge_cnt, edge_saved, tri_list, edge_list, tri_pool,
 		edge_pool, face_id, tile_bits, tri_flag, work_list, edge_tile_cnt, edge_tiles, edge_slot, edge_sweep, edge_snap, view_bytes;
 	uint32_t tri_pool_cap, edge_pool_cap;
-	int tiles_x, tiles_y, ntiles, nwords, P, sub_cap, save_sub;
+	size_t edge_fin;
+	int tiles_x, tiles_y, ntiles, nwords, P, sweep_cap;
 };
 
 size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -164,12 +167,15 @@ Layout make_layout(int T, int H, int W, int C, size_t pool_pairs)
 	// touches anything else (one coalesced byte per thread instead of a 128-byte record line per triangle, two out of three
 	// of which are culled)
 	L.tri_flag = take((size_t)T);
-	L.sub_cap = (L.ntiles + NSUB - 1) / NSUB;
-	L.edge_tile_cnt = take(sizeof(uint32_t) * 2 * LIST_KINDS * NSUB * CNT_STRIDE); // [epoch parity][kind][sub-list]
-	L.edge_tiles = take(sizeof(uint32_t) * LIST_KINDS * NSUB * (size_t)L.sub_cap);	// [kind][sub-list][sub_cap]
+	L.edge_tile_cnt = take(sizeof(uint32_t) * (EDGE_LISTS + 1) * CNT_STRIDE); // append counters of the lists + the sweep-slot counter
+	L.edge_tiles = take(sizeof(uint32_t) * EDGE_LISTS * (size_t)L.ntiles);	   // [list][ntiles]
 	L.edge_slot = take(sizeof(uint32_t) * L.ntiles); // 1 + index of the tile's slot in edge_sweep, 0: none
-	L.save_sub = SAVE_SUB < L.sub_cap ? SAVE_SUB : L.sub_cap; // saved sweeps per sub-list
-	L.edge_sweep = take(SWEEP_BYTES * NSUB * (size_t)L.save_sub);
+	L.sweep_cap = SWEEP_CAP < L.ntiles ? SWEEP_CAP : L.ntiles;
+	L.edge_sweep = take(SWEEP_BYTES * (size_t)L.sweep_cap);
+	// what finalize_kernel needs of a drawn silhouette edge besides its record: vertex ids, positions, attributes (written by the
+	// set-up kernel, which has them in registers: the finalize thread of an edge then has ONE memory round trip before its arithmetic
+	// instead of three -- indices, vertices, record)
+	L.edge_fin = take(sizeof(EdgeFin) * 3 * (size_t)T);
 	L.edge_snap = take(SNAP_BYTES * SNAP_CAP);
 	L.view_bytes = o;
 	return L;
@@ -214,7 +220,8 @@ struct ViewPtrs
 	uint32_t *edge_slot;
 	char *edge_sweep, *edge_snap;
 	WorkEntry *work_list;
-	uint32_t *edge_tile_cnt, *edge_tiles; // tiles with silhouette edges: NSUB counters per epoch parity, NSUB sub-lists of sub_cap tiles
+	uint32_t *edge_tile_cnt, *edge_tiles; // tiles with silhouette edges: EDGE_LISTS (+ 1) counters, EDGE_LISTS lists of ntiles entries
+	EdgeFin *edge_fin;
 };
 
 __device__ __forceinline__ ViewPtrs view_ptrs(const KParams &p, int view)
@@ -242,6 +249,7 @@ __device__ __forceinline__ ViewPtrs view_ptrs(const KParams &p, int view)
 	v.edge_tiles = (uint32_t *)(b + p.L.edge_tiles);
 	v.work_list = (WorkEntry *)(b + p.L.work_list);
 	v.edge_slot = (uint32_t *)(b + p.L.edge_slot);
+	v.edge_fin = (EdgeFin *)(b + p.L.edge_fin);
 	v.edge_sweep = b + p.L.edge_sweep;
 	v.edge_snap = b + p.L.edge_snap;
 	return v;
@@ -368,7 +376,7 @@ struct DeviceAdd // accumulate a vertex gradient (the reference's `+=` into scen
 {
 	__device__ __forceinline__ void operator()(void *arr, size_t i, bool f64, double v) const
 	{
-		if (v == 0)
+		if (v == 0 || (DR_ABLATE & 1024))
 			return;
 		if (f64)
 			unsafeAtomicAdd((double *)arr + i, v);
@@ -377,6 +385,17 @@ struct DeviceAdd // accumulate a vertex gradient (the reference's `+=` into scen
 	}
 };
 
+// finalize_triangle's sinks (dr_prims.h).  AtomicSink: every contribution goes straight to the gradient arrays.
+struct AtomicSink
+{
+	const SceneView &s;
+	const GradView &g;
+	uint32_t f[3], fuv[3];
+	__device__ __forceinline__ void color(int i, int c, double v) { DeviceAdd()(g.colors_b, (size_t)f[i] * s.C + c, s.vtx_f64, v); }
+	__device__ __forceinline__ void shade(int i, double v) { DeviceAdd()(g.shade_b, f[i], s.vtx_f64, v); }
+	__device__ __forceinline__ void uv(int i, int c, double v) { DeviceAdd()(g.uv_b, 2 * (size_t)fuv[i] + c, s.vtx_f64, v); }
+	__device__ __forceinline__ void ij(int i, int d, double v) { DeviceAdd()(g.ij_b, 2 * (size_t)f[i] + d, s.vtx_f64, v); }
+};
 // XCD-aware block order: the dispatcher sends block b to XCD b % 8; give every XCD one contiguous band of the
 // screen so that neighbouring tiles (which share triangle records) share an L2.  Bijective for any block count.
 __device__ __forceinline__ int xcd_band(int b, int n)
@@ -469,23 +488,58 @@ __device__ __forceinline__ bool tile_outside_halfplanes(const double *eq, int tx
 	return false;
 }
 
-// Work split of the per-primitive kernels (set-up, finalize).  Blocks [0, tri_blocks) take PRIM_BLOCK triangles each.  The
+// Work split of the per-primitive kernels (set-up, finalize).  Triangle blocks take PRIM_BLOCK triangles each.  The
 // other blocks take PRIM_BLOCK edge slots (3 k + n) each, of which only the few per cent flagged as silhouette edges need
 // work: the block compacts them through LDS so that they fill the lanes of its first wavefront(s) and the others retire at
 // once (one thread per slot left ~2 busy lanes in almost every wavefront of the long edge path).
+// (Workgroups of one wavefront -- 64 triangles, or a span of 256 edge slots compacted by each of four single-wave blocks -- were
+// measured: every wave starts within 10 us instead of 23, and the kernels take 38 / 35 us instead of 35 / 33: they are bound by
+// the memory-side atomics and the arithmetic of the long waves, not by wave slots.)
 constexpr int PRIM_BLOCK = 256;
+#ifndef DR_PRIM_WAVES
+#define DR_PRIM_WAVES 3 // waves per SIMD the per-primitive kernels are compiled for (4: spills, same time)
+#endif
 constexpr int COOP_BLOCKS = 8; // 3 x 3-tile blocks of a bounding box one thread bins by itself
 
 __host__ __device__ inline int prim_tri_blocks(int T) { return (T + PRIM_BLOCK - 1) / PRIM_BLOCK; }
 __host__ __device__ inline int prim_blocks(int T) { return prim_tri_blocks(T) + (3 * T + PRIM_BLOCK - 1) / PRIM_BLOCK; }
 
+// Grid of the per-primitive kernels: 1-D, n_views * prim_blocks(T) workgroups.  The edge-slot blocks of every view come first,
+// then the triangle blocks (views fastest inside each class): the wavefront that works on flagged edges is the longest
+// dependent chain of both kernels (13 - 20 us against 3 us for a triangle wavefront, tools/wave_trace.py), and dispatched after
+// the triangle blocks it was the 15 us tail of the kernel.
+#ifndef DR_EDGE_FIRST
+#define DR_EDGE_FIRST 1
+#endif
+struct PrimWork
+{
+	int view, index; // index of the block inside its class
+	bool tri;
+	int view_block; // a block id in [0, prim_blocks(T)) inside the view (housekeeping loops)
+};
+__device__ __forceinline__ PrimWork prim_work(const KParams &p)
+{
+	const int TBk = prim_tri_blocks(p.T), EB = prim_blocks(p.T) - TBk, nv = p.n_views;
+	int b = (int)blockIdx.x;
+	PrimWork w;
+	const int first = (DR_EDGE_FIRST ? EB : TBk) * nv;
+	const bool in_first = b < first;
+	if (!in_first)
+		b -= first;
+	w.view = b % nv;
+	w.index = b / nv;
+	w.tri = DR_EDGE_FIRST ? !in_first : in_first;
+	w.view_block = w.tri ? w.index : TBk + w.index;
+	return w;
+}
+
 // -> the slot this thread works on, or -1.  Called by every thread of an edge block.
-__device__ __forceinline__ int compact_flagged_slots(const KParams &p, const uint8_t *edgeflags)
+__device__ __forceinline__ int compact_flagged_slots(const KParams &p, const uint8_t *edgeflags, int edge_block)
 {
 	__shared__ uint32_t s_slots[PRIM_BLOCK];
 	__shared__ uint32_t s_count[PRIM_BLOCK / 64];
 	const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-	const int slot = (blockIdx.x - prim_tri_blocks(p.T)) * PRIM_BLOCK + tid;
+	const int slot = edge_block * PRIM_BLOCK + tid;
 	const bool flagged = p.sigma > 0 && slot < 3 * p.T && edgeflags[slot] != 0;
 	const unsigned long long m = __ballot(flagged);
 	if (lane == 0)
@@ -508,11 +562,25 @@ __device__ __forceinline__ int compact_flagged_slots(const KParams &p, const uin
 #ifdef DR_WAVE_TRACE
 // timeline of the per-primitive kernels: [wave slot] = (start, end) in 10 ns ticks of the constant 100 MHz counter
 __device__ unsigned long long g_wave_trace[3][1 << 18][2]; // 0 set-up, 1 finalize, 2 forward raster
+__device__ unsigned long long g_wave_phase[4][1 << 16][8];  // 0 set-up, 1 finalize: time stamps inside the wavefronts that work on edges
 struct WaveTrace
 {
 	int which;
 	unsigned long long t0;
-	__device__ WaveTrace(int w) : which(w), t0(__builtin_amdgcn_s_memrealtime()) {}
+	__device__ void phase(int i, int tri = 0) const
+	{
+		if ((threadIdx.x & 63) == 0 && which < 2)
+		{
+			const unsigned id = (blockIdx.y * gridDim.x + blockIdx.x) * (blockDim.x >> 6) + (threadIdx.x >> 6);
+			if (id < (1u << 16))
+			{
+				if (i == 1)
+					g_wave_phase[which + 2 * tri][id][0] = t0;
+				g_wave_phase[which + 2 * tri][id][i] = __builtin_amdgcn_s_memrealtime();
+			}
+		}
+	}
+	__device__ WaveTrace(int w) : which(w), t0(__builtin_amdgcn_s_memrealtime()) { phase(0); }
 	__device__ ~WaveTrace()
 	{
 		if ((threadIdx.x & 63) == 0)
@@ -527,16 +595,22 @@ struct WaveTrace
 	}
 };
 #define DR_WAVE_TRACE_SCOPE(w) WaveTrace wave_trace_scope(w)
+#define DR_WAVE_PHASE(i) wave_trace_scope.phase(i)
+#define DR_WAVE_PHASE_T(i) wave_trace_scope.phase(i, 1)
 #else
 #define DR_WAVE_TRACE_SCOPE(w)
+#define DR_WAVE_PHASE(i)
+#define DR_WAVE_PHASE_T(i)
 #endif
 
-__global__ __launch_bounds__(PRIM_BLOCK) void setup_bin_kernel(KParams p)
+__global__ __launch_bounds__(PRIM_BLOCK, DR_PRIM_WAVES) void setup_bin_kernel(KParams p)
 {
 	DR_WAVE_TRACE_SCOPE(0);
-	const int view = blockIdx.y;
-	const int item = blockIdx.x * PRIM_BLOCK + threadIdx.x; // only an id for the housekeeping below
-	const bool tri_block = (int)blockIdx.x < prim_tri_blocks(p.T);
+	const PrimWork pw = prim_work(p);
+	const int view = pw.view;
+	const int item = pw.view_block * PRIM_BLOCK + threadIdx.x; // only an id for the housekeeping below
+	const int n_items = prim_blocks(p.T) * PRIM_BLOCK;
+	const bool tri_block = pw.tri;
 	const SceneView s = scene_view(p, view);
 	const ViewPtrs w = view_ptrs(p, view);
 	const uint32_t cur = w.hdr->epoch & 1u; // stable during this kernel: only the forward raster advances the epoch
@@ -548,10 +622,10 @@ __global__ __launch_bounds__(PRIM_BLOCK) void setup_bin_kernel(KParams p)
 		w.hdr->snap_count[1 - cur] = 0;
 		w.hdr->work_count[0] = w.hdr->work_count[1] = 0; // filled by tile_scan_kernel, read by the forward raster
 	}
-	if (item < LIST_KINDS * NSUB)
-		w.edge_tile_cnt[((1 - cur) * LIST_KINDS * NSUB + item) * CNT_STRIDE] = 0;
+	if (item <= EDGE_LISTS) // appended to by tile_scan_kernel, the next kernel on the stream
+		w.edge_tile_cnt[item * CNT_STRIDE] = 0;
 	if (p.clear_grads && view == 0 && p.uv_b)
-		for (int v = item; v < 2 * p.Vuv; v += gridDim.x * blockDim.x)
+		for (int v = item; v < 2 * p.Vuv; v += n_items)
 		{ // shared by the views: zeroed once
 			if (p.vtx_f64)
 				((double *)p.uv_b)[v] = 0;
@@ -559,7 +633,7 @@ __global__ __launch_bounds__(PRIM_BLOCK) void setup_bin_kernel(KParams p)
 				((float *)p.uv_b)[v] = 0;
 		}
 	if (p.clear_grads)
-		for (int v = item; v < p.V; v += gridDim.x * blockDim.x)
+		for (int v = item; v < p.V; v += n_items)
 		{ // nothing accumulates into them before finalize_kernel, two kernels later
 			const size_t at = (size_t)view * p.V + v;
 			if (p.vtx_f64)
@@ -586,30 +660,45 @@ __global__ __launch_bounds__(PRIM_BLOCK) void setup_bin_kernel(KParams p)
 	// Records are built in registers and leave with one 128-byte store: the binning below reads the local copy (reading a
 	// record back from HBM right after writing it costs a full memory round trip per field), a culled triangle only gets its two
 	// flags written, an edge slot that is not a silhouette edge nothing at all.
-	// on its first edge a tile joins the list the adjoint's edge kernel walks; on its (PRIO_EDGES + 1)-th also the list of
-	// the long tiles that kernel starts with (the kernel lasts as long as its slowest tile)
-	auto listed = [&](int tile, uint32_t got) {
-		if (got != 0 && got != (uint32_t)PRIO_EDGES && got != 16u)
-			return;
-		const int sub = (got == 0 ? 0 : (got == 16u ? 3 * NSUB : NSUB)) + tile % NSUB;
-		const uint32_t at = atomicAdd(&w.edge_tile_cnt[(cur * LIST_KINDS * NSUB + sub) * CNT_STRIDE], 1u);
-		w.edge_tiles[(size_t)sub * p.L.sub_cap + at] = (uint32_t)tile;
-		if (got == 0) // a place for the forward sweep of the tile (always written: a stale value must never be read)
-			w.edge_slot[tile] = at < (uint32_t)p.L.save_sub ? (uint32_t)sub * p.L.save_sub + at + 1u : 0u;
-		static_assert(PRIO_EDGES != 16, "16 = TB, one batch of edges");
-	};
 	// A primitive whose bounding box needs more than COOP_BLOCKS blocks of 3 x 3 tiles is not binned by its own thread
 	// (hundreds of dependent atomic round trips in one lane: 0.3 ms of set-up for a 1 000-triangle mesh filling a 1024^2
 	// frame) but handed to the whole wavefront below: its half-planes and box are kept here.  Smaller ones stay with their
 	// thread (all threads at once beat the wavefront working through its large primitives one after the other).
-	bool big = false;
-	double hp[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-	int btx0 = 0, bty0 = 0, bntx = 0, bnty = 0, bprim = 0;
+	const int lane = threadIdx.x & 63;
+	// ---- the large primitives of this wavefront, one after the other, 64 tiles of the bounding box at a time
+	auto bin_large = [&](bool big, const double *hp, int btx0, int bty0, int bntx, int bnty, int bprim) {
+		unsigned long long todo = __ballot(big);
+		while (todo)
+		{
+			const int src = __ffsll((long long)todo) - 1;
+			todo &= todo - 1;
+			double q[12];
+#pragma unroll
+			for (int i = 0; i < 12; i++)
+				q[i] = __shfl(hp[i], src, 64);
+			const int tx0 = __shfl(btx0, src, 64), ty0 = __shfl(bty0, src, 64), ntx = __shfl(bntx, src, 64), nty = __shfl(bnty, src, 64);
+			const uint32_t prim = (uint32_t)__shfl(bprim, src, 64);
+			for (int t = lane; t < ntx * nty; t += 64)
+			{
+				const int tx = tx0 + t % ntx, ty = ty0 + t / ntx, tile = ty * p.L.tiles_x + tx;
+				if (tri_block)
+				{
+					if (!tile_outside_halfplanes<3>(q, tx, ty))
+						push_tile(w.tri_cnt, w.tri_list, K_TRI, w.tri_pool, p.L.tri_pool_cap, &w.hdr->tri_spill[cur], tile, prim);
+				}
+				else if (!tile_outside_halfplanes<4>(q, tx, ty))
+					push_tile(w.edge_cnt, w.edge_list, K_EDGE, w.edge_pool, p.L.edge_pool_cap, &w.hdr->edge_spill[cur], tile, prim);
+			}
+		}
+	};
 	if (tri_block)
 	{
+		bool big = false;
+		double hp[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+		int btx0 = 0, bty0 = 0, bntx = 0, bnty = 0, bprim = 0;
 		do
 		{
-			const int k = item;
+			const int k = pw.index * PRIM_BLOCK + threadIdx.x;
 			if (k >= p.T)
 				break;
 			TriInputs t;
@@ -621,17 +710,20 @@ __global__ __launch_bounds__(PRIM_BLOCK) void setup_bin_kernel(KParams p)
 				w.tri_flag[k] = 0;
 				break;
 			}
+			DR_WAVE_PHASE_T(1); // inputs (?)
 			setup_tri_only(s, t, rec, w.tri_planes + (size_t)k * 3 * s.P);
+			DR_WAVE_PHASE_T(2); // record computed
 			w.tri_flag[k] = (uint8_t)(rec.kind | (rec.front ? 4 : 0));
 			if (rec.kind == KIND_NONE)
 				break; // culled (or textured without shading): its record is never read -- the raster kernels reach records
 					   // through the tile lists, the finalize kernel looks at tri_flag first
 			rec.pad0[0] = rec.pad0[1] = 0;
 			rec.pad1[0] = rec.pad1[1] = rec.pad1[2] = 0;
-			out = rec;
+			if (!(DR_ABLATE & 4096))
+				out = rec;
 			const int x0 = rec.x_min < 0 ? 0 : rec.x_min, x1 = rec.x_max > s.W - 1 ? s.W - 1 : rec.x_max;
 			const int y0 = rec.y_begin[0] < 0 ? 0 : rec.y_begin[0], y1 = rec.y_end[1] > s.H - 1 ? s.H - 1 : rec.y_end[1];
-			if (x0 > x1 || y0 > y1)
+			if (x0 > x1 || y0 > y1 || (DR_ABLATE & 2048))
 				break;
 			const double eq[9] = {rec.eq[0][0], rec.eq[0][1], rec.eq[0][2], rec.eq[1][0], rec.eq[1][1], rec.eq[1][2], rec.eq[2][0], rec.eq[2][1], rec.eq[2][2]};
 			const int tx0 = x0 / TILE, ty0 = y0 / TILE, ntx = x1 / TILE - tx0 + 1, nty = y1 / TILE - ty0 + 1;
@@ -644,6 +736,7 @@ __global__ __launch_bounds__(PRIM_BLOCK) void setup_bin_kernel(KParams p)
 				btx0 = tx0, bty0 = ty0, bntx = ntx, bnty = nty, bprim = k;
 				break;
 			}
+			DR_WAVE_PHASE_T(3); // record stored
 			// 3 x 3 tiles at a time (the usual small triangle: once), the slot requests of a block all in flight together: one
 			// memory round trip per block, not one per tile
 			for (int by = 0; by < nty; by += 3)
@@ -670,14 +763,20 @@ __global__ __launch_bounds__(PRIM_BLOCK) void setup_bin_kernel(KParams p)
 						}
 				}
 		} while (false);
+		DR_WAVE_PHASE_T(4);
+		bin_large(big, hp, btx0, bty0, bntx, bnty, bprim);
+		return;
 	}
-	else
+	// nothing is written for the ~97 % of slots that are not silhouette edges: records are only reached through the
+	// tile lists, and finalize_kernel works from the same flags
+	const int slot = compact_flagged_slots(p, s.edgeflags, pw.index);
+	DR_WAVE_PHASE(1); // flags compacted
 	{
+		bool big = false;
+		double hp[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+		int btx0 = 0, bty0 = 0, bntx = 0, bnty = 0, bprim = 0;
 		do
 		{
-			// nothing is written for the ~97 % of slots that are not silhouette edges: records are only reached through the
-			// tile lists, and finalize_kernel works from the same flags
-			const int slot = compact_flagged_slots(p, s.edgeflags);
 			if (slot < 0)
 				break;
 			const int k = slot / 3, n = slot - 3 * k;
@@ -689,7 +788,11 @@ __global__ __launch_bounds__(PRIM_BLOCK) void setup_bin_kernel(KParams p)
 				eout.kind = KIND_NONE;
 				break;
 			}
-			setup_edge_only(s, t, k, n, e, w.edge_planes + (size_t)slot * 3 * s.P);
+			DR_WAVE_PHASE(2); // inputs arrived (?)
+			// (the finalize inputs go straight to memory: kept in registers until the record is complete they cost the kernel a
+			// wave per SIMD; those of an edge that turns out not to be drawn are never read)
+			setup_edge_only(s, t, k, n, e, w.edge_planes + (size_t)slot * 3 * s.P, &w.edge_fin[slot]);
+			DR_WAVE_PHASE(3); // record computed
 			if (e.kind == KIND_NONE)
 			{
 				eout.kind = KIND_NONE;
@@ -698,6 +801,7 @@ __global__ __launch_bounds__(PRIM_BLOCK) void setup_bin_kernel(KParams p)
 			for (int i = 0; i < 7; i++)
 				e.pad0[i] = 0;
 			eout = e;
+			DR_WAVE_PHASE(4); // record stored
 			if (e.x_begin > e.x_end || e.y_begin > e.y_end)
 				break;
 			const double band[12] = {e.x2b[0], e.x2b[1], e.x2b[2], e.x2b[3], e.x2b[4], e.x2b[5], e.x2t[0], e.x2t[1], e.x2t[2],
@@ -733,35 +837,11 @@ __global__ __launch_bounds__(PRIM_BLOCK) void setup_bin_kernel(KParams p)
 						{
 							const int tile = (ty0 + by + q / 3) * p.L.tiles_x + tx0 + bx + q % 3;
 							place_in_tile(w.edge_list, K_EDGE, w.edge_pool, p.L.edge_pool_cap, &w.hdr->edge_spill[cur], tile, (uint32_t)slot, got[q]);
-							listed(tile, got[q]);
 						}
 				}
 		} while (false);
-	}
-	const int lane = threadIdx.x & 63;
-	// ---- the large primitives of this wavefront, one after the other, 64 tiles of the bounding box at a time
-	unsigned long long todo = __ballot(big);
-	while (todo)
-	{
-		const int src = __ffsll((long long)todo) - 1;
-		todo &= todo - 1;
-		double q[12];
-#pragma unroll
-		for (int i = 0; i < 12; i++)
-			q[i] = __shfl(hp[i], src, 64);
-		const int tx0 = __shfl(btx0, src, 64), ty0 = __shfl(bty0, src, 64), ntx = __shfl(bntx, src, 64), nty = __shfl(bnty, src, 64);
-		const uint32_t prim = (uint32_t)__shfl(bprim, src, 64);
-		for (int t = lane; t < ntx * nty; t += 64)
-		{
-			const int tx = tx0 + t % ntx, ty = ty0 + t / ntx, tile = ty * p.L.tiles_x + tx;
-			if (tri_block)
-			{
-				if (!tile_outside_halfplanes<3>(q, tx, ty))
-					push_tile(w.tri_cnt, w.tri_list, K_TRI, w.tri_pool, p.L.tri_pool_cap, &w.hdr->tri_spill[cur], tile, prim);
-			}
-			else if (!tile_outside_halfplanes<4>(q, tx, ty))
-				listed(tile, push_tile(w.edge_cnt, w.edge_list, K_EDGE, w.edge_pool, p.L.edge_pool_cap, &w.hdr->edge_spill[cur], tile, prim));
-		}
+		DR_WAVE_PHASE(5); // own binning done
+		bin_large(big, hp, btx0, bty0, bntx, bnty, bprim);
 	}
 }
 
@@ -1242,7 +1322,9 @@ __device__ __forceinline__ void tri_batch(const KParams &p, WaveLds &S, int nb, 
 		if (j < nb)
 		{
 			const TriRec &rec = S.rec[j];
-			if (rec.kind != KIND_NONE)
+			if (DR_ABLATE & 512)
+				m = 0xffu;
+			else if (rec.kind != KIND_NONE)
 			{
 				// A row lies in one half of the triangle (above or below its middle vertex), so one span (two divisions, not
 				// four) per (triangle, row); only the non-strict fill rule puts the middle-vertex row in both halves.
@@ -1473,18 +1555,27 @@ constexpr int HEAVY_SHARE = 8; // one tile workgroup in HEAVY_SHARE walks the li
 
 __global__ __launch_bounds__(SCAN_BLOCK) void tile_scan_kernel(KParams p)
 {
-	__shared__ uint32_t s_cnt[2][SCAN_BLOCK / 64];
-	__shared__ uint32_t s_base[2];
+	// classes compacted by this kernel: 0 many-primitive tiles (front of the work list), 1 the other non-empty tiles (back of it),
+	// 2 .. 4 the three lists of edge tiles, 5 every edge tile (its rank is the tile's slot in edge_sweep)
+	constexpr int NCLS = 3 + EDGE_LISTS;
+	__shared__ uint32_t s_cnt[NCLS][SCAN_BLOCK / 64];
+	__shared__ uint32_t s_base[NCLS];
 	const int view = blockIdx.y;
 	const ViewPtrs w = view_ptrs(p, view);
 	const int tile = blockIdx.x * SCAN_BLOCK + threadIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 	const bool valid = tile < p.L.ntiles;
-	uint32_t ntri = 0, nedge = 0, slot_word = 0;
+	uint32_t ntri = 0, nedge = 0;
+	uint4 ida = make_uint4(0, 0, 0, 0), idb = ida, idc = ida;
 	if (valid)
-	{
+	{ // (the head of the tile's inline list is requested with the counters: one round trip, not two; stale ids of a tile that
+	  // received nothing this time are simply not used)
 		ntri = w.tri_cnt[tile];
 		nedge = w.edge_cnt[tile];
-		slot_word = w.edge_slot[tile]; // fresh whenever the tile has edges (set-up)
+		static_assert(ENTRY_IDS == 12 && K_TRI >= ENTRY_IDS, "three 16-byte pieces of the tile's inline list");
+		const uint4 *ids = (const uint4 *)(w.tri_list + (size_t)tile * K_TRI);
+		ida = ids[0];
+		idb = ids[1];
+		idc = ids[2];
 	}
 	const bool work = (ntri | nedge) != 0;
 	if (work)
@@ -1492,10 +1583,6 @@ __global__ __launch_bounds__(SCAN_BLOCK) void tile_scan_kernel(KParams p)
 		w.tri_cnt[tile] = 0;
 		w.edge_cnt[tile] = 0;
 	}
-	// the adjoint finds the edge count, and whether the forward sweep over the edges is saved, in edge_saved
-	const uint32_t sweep_slot = (nedge > 0 && nedge <= (uint32_t)EMAX && !p.persp) ? slot_word : 0u;
-	if (valid)
-		w.edge_saved[tile] = nedge | (sweep_slot ? SWEEP_SAVED : 0u);
 	const unsigned long long wm = __ballot(work);
 	if (lane == 0 && valid)
 		w.tile_bits[tile >> 5] = (uint32_t)wm;
@@ -1503,38 +1590,61 @@ __global__ __launch_bounds__(SCAN_BLOCK) void tile_scan_kernel(KParams p)
 		w.tile_bits[tile >> 5] = (uint32_t)(wm >> 32);
 	// ---- compaction: rank inside the wavefront, wavefront totals through LDS, ONE atomic per class and block
 	const bool heavy = work && p.tile_blocks % (8 * WORK_CHUNK) == 0 && (ntri > (uint32_t)FIRST_PRIMS || nedge > (uint32_t)FIRST_PRIMS);
-	const unsigned long long hm = __ballot(heavy), lm = wm & ~hm, below = (1ull << lane) - 1ull;
-	if (lane == 0)
+	const int elist = nedge == 0 ? -1 : (nedge <= (uint32_t)PRIO_EDGES ? 0 : (nedge <= (uint32_t)TB ? 1 : 2));
+	unsigned long long m[NCLS];
+	m[0] = __ballot(heavy);
+	m[1] = wm & ~m[0];
+#pragma unroll
+	for (int c = 0; c < EDGE_LISTS; c++)
+		m[2 + c] = __ballot(elist == c);
+	m[2 + EDGE_LISTS] = __ballot(nedge > 0);
+	const unsigned long long below = (1ull << lane) - 1ull;
+	if (lane < NCLS)
 	{
-		s_cnt[0][wave] = (uint32_t)__popcll(hm);
-		s_cnt[1][wave] = (uint32_t)__popcll(lm);
+		unsigned long long mine = 0;
+#pragma unroll
+		for (int c = 0; c < NCLS; c++)
+			mine = lane == c ? m[c] : mine;
+		s_cnt[lane][wave] = (uint32_t)__popcll(mine);
 	}
 	__syncthreads();
-	uint32_t before[2] = {0, 0}, total[2] = {0, 0};
+	if (threadIdx.x < NCLS)
+	{
+		uint32_t total = 0;
 #pragma unroll
-	for (int i = 0; i < SCAN_BLOCK / 64; i++)
-#pragma unroll
-		for (int c = 0; c < 2; c++)
-		{
-			const uint32_t n = s_cnt[c][i];
-			before[c] += i < wave ? n : 0u;
-			total[c] += n;
-		}
-	if (threadIdx.x < 2 && total[threadIdx.x])
-		s_base[threadIdx.x] = atomicAdd(&w.hdr->work_count[threadIdx.x], total[threadIdx.x]);
+		for (int i = 0; i < SCAN_BLOCK / 64; i++)
+			total += s_cnt[threadIdx.x][i];
+		uint32_t *counter = threadIdx.x < 2 ? &w.hdr->work_count[threadIdx.x] : &w.edge_tile_cnt[(threadIdx.x - 2) * CNT_STRIDE];
+		s_base[threadIdx.x] = total ? atomicAdd(counter, total) : 0u;
+	}
 	__syncthreads();
+	auto position = [&](int c, unsigned long long members) { // of this thread in class c (the thread must belong to it)
+		uint32_t at = s_base[c];
+		for (int i = 0; i < wave; i++)
+			at += s_cnt[c][i];
+		return at + (uint32_t)__popcll(members & below);
+	};
+	// the adjoint finds the edge count, and whether the forward sweep over the edges is saved, in edge_saved
+	uint32_t sweep_slot = 0;
+	if (nedge > 0)
+	{
+		const uint32_t at = position(2 + EDGE_LISTS, m[2 + EDGE_LISTS]);
+		const uint32_t slot_word = at < (uint32_t)p.L.sweep_cap ? at + 1u : 0u;
+		w.edge_slot[tile] = slot_word; // always written: a stale value must never be read
+		sweep_slot = (nedge <= (uint32_t)EMAX && !p.persp) ? slot_word : 0u;
+		static_assert(EDGE_LISTS == 3, "select below");
+		w.edge_tiles[(size_t)elist * p.L.ntiles + position(2 + elist, elist == 0 ? m[2] : (elist == 1 ? m[3] : m[4]))] = (uint32_t)tile;
+	}
+	if (valid)
+		w.edge_saved[tile] = nedge | (sweep_slot ? SWEEP_SAVED : 0u);
 	if (work)
 	{
-		WorkEntry &e = heavy ? w.work_list[s_base[0] + before[0] + (uint32_t)__popcll(hm & below)]
-							 : w.work_list[(uint32_t)p.L.ntiles - 1u - (s_base[1] + before[1] + (uint32_t)__popcll(lm & below))];
+		WorkEntry &e = heavy ? w.work_list[position(0, m[0])] : w.work_list[(uint32_t)p.L.ntiles - 1u - position(1, m[1])];
 		uint4 *out = (uint4 *)&e;
 		out[0] = make_uint4((uint32_t)tile, ntri, nedge, sweep_slot);
-		static_assert(ENTRY_IDS == 12 && K_TRI >= ENTRY_IDS, "three 16-byte pieces of the tile's inline list");
-		const uint4 *ids = (const uint4 *)(w.tri_list + (size_t)tile * K_TRI);
-		const uint4 a = ids[0], b = ntri > 4 ? ids[1] : a, c = ntri > 8 ? ids[2] : a;
-		out[1] = a;
-		out[2] = b;
-		out[3] = c;
+		out[1] = ida;
+		out[2] = idb;
+		out[3] = idc;
 	}
 }
 
@@ -1942,8 +2052,9 @@ __global__ __launch_bounds__(64, DR_FWD_WAVES) void raster_fwd_fast_kernel(KPara
 			for (int cc = 0; cc < CH; cc++)
 				g[cc] = (cc < C && inb) ? 2 * ((double)(PixT)col[cc] - (double)ob[cc]) : 0.0;
 			lds_sync();
-			owner_adjoint<PixT, TEX>(p, w, lane, x, y, st.kbest, st.kbest >= 0 ? st.kind : (int)KIND_NONE, g, tap, L, (double *)&S.rec[0],
-								(uint32_t *)&S.cover[0][0]);
+			if (!(DR_ABLATE & 256))
+				owner_adjoint<PixT, TEX>(p, w, lane, x, y, st.kbest, st.kbest >= 0 ? st.kind : (int)KIND_NONE, g, tap, L, (double *)&S.rec[0],
+									(uint32_t *)&S.cover[0][0]);
 		}
 #ifdef DR_FWD_TRACE
 		DR_FTRACE(6); // adjoint of pass 1 issued
@@ -2642,7 +2753,7 @@ __device__ __forceinline__ void owner_adjoint(const KParams &p, const ViewPtrs &
 // registers, twice the resident waves to hide the memory latency); EDGES = true: the tiles that have some.
 template <class PixT, bool EDGES, bool TEX>
 __device__ __forceinline__ void bwd_fast_tile(const KParams &p, const ViewPtrs &w, int view, int tx, int ty, int lane, BwdLds &S, EdgeSort *es, // es: only for EDGES
-											  int skip_above = 0x7fffffff, int chunk = -1)
+											  int chunk = -1)
 { // chunk >= 0: this wavefront is one of CHUNKS that may share the reverse sweep of a many-edged tile (batch `chunk` of it)
 	const int W = p.W, H = p.H, C = p.C, P = p.L.P;
 	const PixT *texture = (const PixT *)p.texture;
@@ -2660,8 +2771,8 @@ __device__ __forceinline__ void bwd_fast_tile(const KParams &p, const ViewPtrs &
 	const uint32_t sweep_slot = EDGES ? (uint32_t)uniform((int)w.edge_slot[tile]) : 0u;
 	const int nedge = (int)(raw_nedge & ~SWEEP_SAVED);
 	const bool sweep_saved = EDGES && (raw_nedge & SWEEP_SAVED) && sweep_slot;
-	if ((nedge > 0) != EDGES || nedge > skip_above)
-		return; // the other kernel's tile (or one this kernel has already taken from its list of long tiles)
+	if ((nedge > 0) != EDGES)
+		return; // the other kernel's tile
 	// batches of the reverse sweep this wavefront runs: all of them, or -- when the forward saved the colour after every batch
 	// -- only batch `chunk`
 	const int nbatch_all = (nedge + TB - 1) / TB;
@@ -3025,53 +3136,45 @@ __global__ __launch_bounds__(64, 6) void raster_bwd_fast_kernel(KParams p)
 
 template <class PixT, bool TEX>
 __global__ __launch_bounds__(64, TEX ? 2 : 4) void raster_bwd_edge_kernel(KParams p)
-{ // persistent waves over the lists of tiles that hold silhouette edges (built by setup_bin_kernel).  Grid (views, waves):
+{ // persistent waves over the lists of tiles that hold silhouette edges (built by tile_scan_kernel).  Grid (views, waves):
   // the first waves dispatched are wave 0 of every view, and every wave starts with the many-edged tiles -- the kernel
-  // lasts as long as its slowest tile, so those must not start late.  Wave g walks sub-list g % NSUB from entry g / NSUB
-  // in steps of gridDim.y / NSUB.
+  // lasts as long as its slowest tile, so those must not start late.  Wave g takes the work items g, g + gridDim.y, ...
 	__shared__ BwdLds s_lds;
 	__shared__ EdgeSort s_es;
 	const int view = blockIdx.x;
 	const int lane = threadIdx.x;
 	const ViewPtrs w = view_ptrs(p, view);
-	const int sub = blockIdx.y % NSUB, stride = gridDim.y / NSUB;
-	// the counters of both parities are requested together with the parity itself: one memory round trip, not two
-	const uint32_t *cnt0 = w.edge_tile_cnt, *cnt1 = w.edge_tile_cnt + (size_t)LIST_KINDS * NSUB * CNT_STRIDE;
-	const uint32_t cur = w.hdr->cur;
-	const uint32_t a0 = cnt0[sub * CNT_STRIDE], l0 = cnt0[(NSUB + sub) * CNT_STRIDE], a1 = cnt1[sub * CNT_STRIDE], l1 = cnt1[(NSUB + sub) * CNT_STRIDE];
-	const uint32_t v0 = cnt0[(3 * NSUB + sub) * CNT_STRIDE], v1 = cnt1[(3 * NSUB + sub) * CNT_STRIDE];
-	const uint32_t n_all = cur ? a1 : a0, n_long = cur ? l1 : l0, n_multi = (cur ? v1 : v0) * CHUNKS;
-	const uint32_t *all = w.edge_tiles + (size_t)sub * p.L.sub_cap, *longs = w.edge_tiles + (size_t)(NSUB + sub) * p.L.sub_cap;
-	const uint32_t *multi = w.edge_tiles + (size_t)(3 * NSUB + sub) * p.L.sub_cap;
-	// Work items of a sub-list: first the tiles with more than one batch of edges, each offered to CHUNKS wavefronts (one per
-	// batch of its reverse sweep; those the tile has no use for return at once), then the other tiles with more than
-	// PRIO_EDGES edges, then the rest.
+	const uint32_t n_short = w.edge_tile_cnt[0], n_long = w.edge_tile_cnt[CNT_STRIDE], n_multi = w.edge_tile_cnt[2 * CNT_STRIDE] * CHUNKS;
+	const uint32_t *shorts = w.edge_tiles, *longs = w.edge_tiles + p.L.ntiles, *multi = w.edge_tiles + 2 * (size_t)p.L.ntiles;
+	// Work items: first the tiles with more than one batch of edges, each offered to CHUNKS wavefronts (one per batch of its
+	// reverse sweep; those the tile has no use for return at once), then the other tiles with more than PRIO_EDGES edges, then
+	// the rest.
 #pragma nounroll
-	for (uint32_t i = blockIdx.y / NSUB; i < n_multi + n_long + n_all; i += stride)
+	for (uint32_t i = blockIdx.y; i < n_multi + n_long + n_short; i += gridDim.y)
 	{
-		int tile, lo, hi, chunk = -1; // the tile is processed when lo < its edge count <= hi
+		int tile, chunk = -1;
 		if (i < n_multi)
-			tile = (int)multi[i / CHUNKS], chunk = (int)(i % CHUNKS), lo = TB, hi = 0x7fffffff;
+			tile = (int)multi[i / CHUNKS], chunk = (int)(i % CHUNKS);
 		else if (i < n_multi + n_long)
-			tile = (int)longs[i - n_multi], lo = 0, hi = TB;
+			tile = (int)longs[i - n_multi];
 		else
-			tile = (int)all[i - n_multi - n_long], lo = 0, hi = PRIO_EDGES;
+			tile = (int)shorts[i - n_multi - n_long];
 		tile = uniform(tile);
-		bwd_fast_tile<PixT, true, TEX>(p, w, view, tile % p.L.tiles_x, tile / p.L.tiles_x, lane, s_lds, &s_es, hi, chunk);
-		(void)lo; // a listed tile always has more edges than the threshold of its list
+		bwd_fast_tile<PixT, true, TEX>(p, w, view, tile % p.L.tiles_x, tile / p.L.tiles_x, lane, s_lds, &s_es, chunk);
 		lds_sync();
 	}
 }
 
 // ------------------------------------------------------------------------------------------------------- finalize
 
-__global__ __launch_bounds__(PRIM_BLOCK) void finalize_kernel(KParams p)
+__global__ __launch_bounds__(PRIM_BLOCK, DR_PRIM_WAVES) void finalize_kernel(KParams p)
 { // same split as setup_bin_kernel: triangle blocks, then edge-slot blocks compacted to the flagged slots.
   // (Lists of the front-facing triangles / drawn edges compacted by the set-up kernel were tried: a quarter as many wavefronts,
   // all lanes busy -- and 32 -> 41 us: the kernel is a chain of dependent round trips, fewer wavefronts overlap fewer of them.)
 	DR_WAVE_TRACE_SCOPE(1);
-	const int view = blockIdx.y;
-	const bool tri_block = (int)blockIdx.x < prim_tri_blocks(p.T);
+	const PrimWork pw = prim_work(p);
+	const int view = pw.view;
+	const bool tri_block = pw.tri;
 	const SceneView s = scene_view(p, view);
 	const ViewPtrs w = view_ptrs(p, view);
 	const size_t es = p.vtx_f64 ? 8 : 4;
@@ -3083,31 +3186,82 @@ __global__ __launch_bounds__(PRIM_BLOCK) void finalize_kernel(KParams p)
 	const int P = s.P;
 	if (tri_block)
 	{
-		const int k = blockIdx.x * PRIM_BLOCK + threadIdx.x;
+		const int k = pw.index * PRIM_BLOCK + threadIdx.x;
 		if (k >= p.T)
 			return;
+		// the vertex indices are requested together with the flag (one memory round trip, not two): using them in the branch
+		// condition keeps the compiler from sinking the loads below it (an index never has its top bit set: V < 2^31)
 		const uint32_t flag = w.tri_flag[k];
+		const uint32_t f0 = p.faces[3 * (size_t)k], f1 = p.faces[3 * (size_t)k + 1], f2 = p.faces[3 * (size_t)k + 2];
 		double *acc = w.tri_acc + (size_t)k * 3 * P;
-		if (!(flag & 4u) || (flag & 3u) == KIND_NONE)
+		if (!(flag & 4u) || (flag & 3u) == KIND_NONE || (int32_t)(f0 | f1 | f2) < 0)
 			return; // culled triangles own no accumulators
-		finalize_triangle(s, g, k, (int)(flag & 3u), acc, DeviceAdd());
+		DR_WAVE_PHASE_T(1); // flags + indices arrived
+		AtomicSink sink = {s, g, {f0, f1, f2}, {p.faces_uv[3 * (size_t)k], p.faces_uv[3 * (size_t)k + 1], p.faces_uv[3 * (size_t)k + 2]}};
+		if (P <= 4)
+		{ // a register copy of the accumulators: all twelve loads in flight together (read through the pointer, each plane's
+		  // loads would wait behind the atomics of the plane before: they might alias)
+			double la[12];
+#pragma unroll
+			for (int i = 0; i < 12; i++)
+				la[i] = i < 3 * P ? acc[i] : 0.0;
+			finalize_triangle<true>(s, k, (int)(flag & 3u), la, sink);
+		}
+		else
+			finalize_triangle<false>(s, k, (int)(flag & 3u), acc, sink);
+		// (merging the adjoints of the triangles of a wavefront that share a vertex in an LDS table before they leave -- a third
+		// fewer atomic requests at the memory side -- was measured: 34 -> 35 us)
+		DR_WAVE_PHASE_T(2); // arithmetic done, atomics issued
 		for (int i = 0; i < 3 * P; i++)
 			acc[i] = 0; // self-cleaning accumulators
+		DR_WAVE_PHASE_T(3);
 		return;
 	}
-	const int slot = compact_flagged_slots(p, s.edgeflags);
-	if (slot < 0)
-		return;
-	const int k = slot / 3, n = slot - 3 * k;
-	if (!(w.tri_flag[k] & 4u))
-		return; // not a silhouette edge of a front-facing triangle in this forward (its slot may hold a stale record)
-	const EdgeRec &e = w.edge_rec[slot];
-	if (e.kind == KIND_NONE)
-		return;
-	double *acc = w.edge_acc + (size_t)slot * (3 * P + 3);
-	finalize_edge(s, g, k, n, e, acc, DeviceAdd());
-	for (int i = 0; i < 3 * P + 3; i++)
-		acc[i] = 0;
+	const int slot = compact_flagged_slots(p, s.edgeflags, pw.index);
+	DR_WAVE_PHASE(1); // flags compacted
+	if (slot >= 0)
+	{
+		// Record, finalize inputs and accumulators of the slot are all requested at once: ONE memory round trip before the
+		// arithmetic.  The set-up kernel of this forward wrote the record's kind for EVERY flagged slot (KIND_NONE for an edge of
+		// a back-facing triangle), so nothing read here is stale.
+		const EdgeRec &er = w.edge_rec[slot];
+		const int kind = er.kind;
+		double *acc = w.edge_acc + (size_t)slot * (3 * P + 3);
+		if (P <= 4)
+		{
+			double x2b[6], la[12], lt[3];
+#pragma unroll
+			for (int i = 0; i < 6; i++)
+				x2b[i] = er.x2b[i];
+			EdgeFin fin = w.edge_fin[slot];
+#pragma unroll
+			for (int i = 0; i < 12; i++)
+				la[i] = i < 3 * P ? acc[i] : 0.0;
+#pragma unroll
+			for (int i = 0; i < 3; i++)
+				lt[i] = acc[3 * P + i];
+			// (empty statement that "uses" one value of every group: the loads are issued -- and waited for together -- before
+			// the branch instead of being sunk below it, where each group would cost a round trip of its own)
+			asm volatile("" : "+v"(x2b[0]), "+v"(la[0]), "+v"(lt[0]), "+v"(fin.V[0][0]));
+			DR_WAVE_PHASE(2); // inputs arrived
+			if (kind == KIND_NONE)
+				return;
+			if (fin.has_att)
+				finalize_edge_fin(s, g, kind, x2b, fin, la, lt, DeviceAdd());
+			else
+				finalize_edge(s, g, slot / 3, slot % 3, er, acc, DeviceAdd());
+		}
+		else
+		{
+			if (kind == KIND_NONE)
+				return;
+			finalize_edge(s, g, slot / 3, slot % 3, er, acc, DeviceAdd());
+		}
+		DR_WAVE_PHASE(3); // arithmetic done, atomics issued
+		for (int i = 0; i < 3 * P + 3; i++)
+			acc[i] = 0;
+		DR_WAVE_PHASE(4);
+	}
 }
 
 // ------------------------------------------------------------------------------------------------------ host side
@@ -3380,7 +3534,7 @@ int launch_forward(const DeodrHipScene *sc, KParams &p, hipStream_t stream, hipE
 	const bool fast = !p.aa_err && p.C <= CH && !g_force_generic;
 	if (p.T > 0)
 	{
-		dim3 grid(prim_blocks(p.T), n_views);
+		dim3 grid((unsigned)prim_blocks(p.T) * (unsigned)n_views);
 		ScopedKernelTimer t(KID_SETUP, stream);
 		hipLaunchKernelGGL(setup_bin_kernel, grid, dim3(PRIM_BLOCK), 0, stream, p);
 	}
@@ -3410,8 +3564,7 @@ int launch_adjoint(const DeodrHipScene *sc, KParams &p, hipStream_t st, bool own
 	p.n_views = sc->n_views;
 	// persistent waves of the edge kernel: enough to cover a silhouette-heavy single view, few enough that with many views
 	// the waves that find their sub-list exhausted cost nothing
-	int edge_waves = p.L.ntiles < EDGE_WAVES ? p.L.ntiles : EDGE_WAVES;
-	edge_waves = (edge_waves + NSUB - 1) / NSUB * NSUB;
+	const int edge_waves = p.L.ntiles < EDGE_WAVES ? p.L.ntiles : EDGE_WAVES;
 	dim3 edge_grid(sc->n_views, edge_waves);
 	{
 		ScopedKernelTimer t(KID_RASTER_BWD, st);
@@ -3422,7 +3575,7 @@ int launch_adjoint(const DeodrHipScene *sc, KParams &p, hipStream_t st, bool own
 	}
 	if (p.T > 0)
 	{
-		dim3 g2(prim_blocks(p.T), sc->n_views);
+		dim3 g2((unsigned)prim_blocks(p.T) * (unsigned)sc->n_views);
 		ScopedKernelTimer t(KID_FINALIZE, st);
 		hipLaunchKernelGGL(finalize_kernel, g2, dim3(PRIM_BLOCK), 0, st, p);
 	}
@@ -3586,6 +3739,10 @@ int deodr_hip_render_scene_fit(const DeodrHipScene *sc, void *image, void *z_buf
 }
 
 #ifdef DR_WAVE_TRACE
+int deodr_hip_debug_wave_phase(void *dst, size_t bytes) // tools/wave_trace.py
+{
+	return check_hip(hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_wave_phase), bytes < sizeof(g_wave_phase) ? bytes : sizeof(g_wave_phase)), "wave phase");
+}
 int deodr_hip_debug_wave_trace(void *dst, size_t bytes) // tools/wave_trace.py
 {
 	return check_hip(hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_wave_trace), bytes < sizeof(g_wave_trace) ? bytes : sizeof(g_wave_trace)), "wave trace");

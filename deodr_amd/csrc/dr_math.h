@@ -61,6 +61,18 @@ struct alignas(16) EdgeRec // 128 bytes, slot 3*triangle + n
 };
 static_assert(sizeof(EdgeRec) == 128, "EdgeRec must stay 128 bytes");
 
+// What the finalize step of a drawn silhouette edge reads besides its EdgeRec (slot 3*triangle + n): the two vertices of the
+// edge as the set-up step saw them, so that the adjoint algebra starts after ONE memory round trip.
+struct alignas(16) EdgeFin // 128 bytes
+{
+	double V[2][2];	  // vertex positions, pixel-centre offset removed
+	double att[2][4]; // per vertex: colour channels (nb_colors <= 4), or u, v, shade of a textured edge
+	uint32_t vid[2], uvid[2];
+	uint32_t has_att; // 0: attributes not stored (nb_colors > 4, or a textured-but-unshaded triangle): finalize gathers them
+	uint32_t pad[3];
+};
+static_assert(sizeof(EdgeFin) == 128, "EdgeFin must stay 128 bytes");
+
 // ----------------------------------------------------------------------------------------------------- 3x3 algebra
 
 // cofactor m = s (S[a] S[b] - S[c] S[d]); row order = order of the reference's adjoint sweep (H.h:172-231)

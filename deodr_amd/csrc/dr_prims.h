@@ -254,7 +254,7 @@ DR_HD T pick3(T v0, T v1, T v2, int i)
 }
 
 // Edge n of triangle k: eligibility H.h:2847-2853, kind H.h:2868-2895, stencil H.h:1366-1460.
-DR_HD void setup_edge_only(const SceneView &s, const TriInputs &t, int k, int n, EdgeRec &e, double *ep /*[3P]*/)
+DR_HD void setup_edge_only(const SceneView &s, const TriInputs &t, int k, int n, EdgeRec &e, double *ep /*[3P]*/, EdgeFin *fin = nullptr)
 {
 	e.kind = KIND_NONE;
 	if (!(s.sigma > 0) || !(t.area > 0) || !s.edgeflags[3 * (size_t)k + n])
@@ -276,6 +276,23 @@ DR_HD void setup_edge_only(const SceneView &s, const TriInputs &t, int k, int n,
 	double zz[2] = {s.persp ? 1 / EZ[0] : EZ[0], s.persp ? 1 / EZ[1] : EZ[1]};
 	for (int j = 0; j < 3; j++)
 		e.xZ[j] = plane_coef(2, zz, e.x2b, j);
+	if (fin)
+	{ // inputs of the edge's finalize step (finalize_edge_fin)
+		for (int i = 0; i < 2; i++)
+			for (int d = 0; d < 2; d++)
+				fin->V[i][d] = EV[i][d];
+		fin->vid[0] = DR_PICK(t.f, a);
+		fin->vid[1] = DR_PICK(t.f, b);
+		fin->uvid[0] = DR_PICK(t.fuv, a);
+		fin->uvid[1] = DR_PICK(t.fuv, b);
+		fin->has_att = (t.both || (s.C <= 4 && !t.tex)) ? 1u : 0u;
+		fin->pad[0] = fin->pad[1] = fin->pad[2] = 0;
+		for (int c = 0; c < 4; c++)
+		{
+			fin->att[0][c] = DR_PICK2(t.att, a, c);
+			fin->att[1][c] = DR_PICK2(t.att, b, c);
+		}
+	}
 	if (t.both || (s.C <= 4 && !t.tex))
 	{
 		double eatt[3][4];
@@ -322,8 +339,16 @@ struct GradView // adjoint arrays of one view (vertex dtype), accumulated into
 };
 
 // `Add` is a functor  add(void* array, size_t index, bool f64, double value)  (atomicAdd on the device)
-template <class Add>
-DR_HD void finalize_triangle(const SceneView &s, const GradView &g, int k, int kind, const double *acc /*[3P]*/, Add add)
+// Where finalize_triangle sends the adjoint of corner i of the triangle (i and the channel / coordinate index are compile-time
+// constants at every call): the device kernel either adds them straight to the gradient arrays (atomics) or collects them in
+// registers to merge the contributions of the triangles of a wavefront that share a vertex first.
+//   sink.color(i, c, v)   d/d colors[face[i]][c]        sink.shade(i, v)   d/d shade[face[i]]
+//   sink.uv(i, c, v)      d/d uv[face_uv[i]][c]          sink.ij(i, d, v)   d/d ij[face[i]][d]
+//
+// SMALL: the caller knows that nb_colors <= 4 (the loop over a run-time channel count is compiled out, so that `acc` may be a
+// register-resident copy of the accumulators: no dynamic indexing)
+template <bool SMALL = false, class Sink>
+DR_HD void finalize_triangle(const SceneView &s, int k, int kind, const double *acc /*[3P]*/, Sink &sink)
 { // the caller has checked that the triangle is front-facing (the adjoint only visits those, H.h:3063) and of a drawable kind
 	const uint32_t *face = s.faces + 3 * (size_t)k, *face_uv = s.faces_uv + 3 * (size_t)k;
 	double V[3][2];
@@ -339,23 +364,26 @@ DR_HD void finalize_triangle(const SceneView &s, const GradView &g, int k, int k
 		x2b_B[i] = b2x_B[i] = 0;
 	if (kind == KIND_TEXTURED)
 	{ // H.h:1138-1148
+#pragma unroll
 		for (int c = 0; c < 2; c++)
 		{
 			double a[3], a_B[3] = {0, 0, 0};
 			for (int i = 0; i < 3; i++)
 				a[i] = ldv(s.uv, 2 * (size_t)face_uv[i] + c, s.vtx_f64);
 			plane_adjoint(3, acc + 3 * c, a, a_B, x2b, x2b_B);
+#pragma unroll
 			for (int i = 0; i < 3; i++)
-				add(g.uv_b, 2 * (size_t)face_uv[i] + c, s.vtx_f64, a_B[i]);
+				sink.uv(i, c, a_B[i]);
 		}
 		double a[3], a_B[3] = {0, 0, 0};
 		for (int i = 0; i < 3; i++)
 			a[i] = ldv(s.shade, face[i], s.vtx_f64);
 		plane_adjoint(3, acc + 6, a, a_B, x2b, x2b_B);
+#pragma unroll
 		for (int i = 0; i < 3; i++)
-			add(g.shade_b, face[i], s.vtx_f64, a_B[i]);
+			sink.shade(i, a_B[i]);
 	}
-	else if (s.C <= 4)
+	else if (SMALL || s.C <= 4)
 	{ // same as below, unrolled under a guard: every colour load is in flight before the first one is used (a rolled loop
 	  // pays one memory round trip per channel)
 		double a[4][3];
@@ -369,24 +397,28 @@ DR_HD void finalize_triangle(const SceneView &s, const GradView &g, int k, int k
 			{
 				double a_B[3] = {0, 0, 0};
 				plane_adjoint(3, acc + 3 * c, a[c], a_B, x2b, x2b_B);
+#pragma unroll
 				for (int i = 0; i < 3; i++)
-					add(g.colors_b, (size_t)face[i] * s.C + c, s.vtx_f64, a_B[i]);
+					sink.color(i, c, a_B[i]);
 			}
 	}
-	else
+	else if (!SMALL)
 		for (int c = 0; c < s.C; c++)
 		{ // H.h:841-851
 			double a[3], a_B[3] = {0, 0, 0};
 			for (int i = 0; i < 3; i++)
 				a[i] = ldv(s.colors, (size_t)face[i] * s.C + c, s.vtx_f64);
 			plane_adjoint(3, acc + 3 * c, a, a_B, x2b, x2b_B);
+#pragma unroll
 			for (int i = 0; i < 3; i++)
-				add(g.colors_b, (size_t)face[i] * s.C + c, s.vtx_f64, a_B[i]);
+				sink.color(i, c, a_B[i]);
 		}
 	inv3_adjoint(b2x, b2x_B, x2b_B); // H.h:854-858
+#pragma unroll
 	for (int v = 0; v < 3; v++)
+#pragma unroll
 		for (int d = 0; d < 2; d++)
-			add(g.ij_b, 2 * (size_t)face[v] + d, s.vtx_f64, b2x_B[3 * d + v]);
+			sink.ij(v, d, b2x_B[3 * d + v]);
 }
 
 template <class Add>
@@ -459,6 +491,49 @@ DR_HD void finalize_edge(const SceneView &s, const GradView &g, int k, int n, co
 	for (int i = 0; i < 2; i++)
 		for (int d = 0; d < 2; d++)
 			add(g.ij_b, 2 * (size_t)vid[i] + d, s.vtx_f64, V_B[i][d]);
+}
+
+// The same with the edge's inputs as the set-up step left them in an EdgeFin (no gather through faces / vertex arrays).  The
+// caller checks fin.has_att (otherwise: finalize_edge).
+template <class Add>
+DR_HD void finalize_edge_fin(const SceneView &s, const GradView &g, int kind, const double x2b[6], const EdgeFin &fin, const double *acc /*[12]*/,
+							 const double x2t_B[3], Add add)
+{
+	if (kind == KIND_NONE)
+		return;
+	double x2b_B[6] = {0, 0, 0, 0, 0, 0};
+	if (kind == KIND_TEXTURED)
+	{ // H.h:2045-2056
+#pragma unroll
+		for (int c = 0; c < 2; c++)
+		{
+			double a[3] = {fin.att[0][c], fin.att[1][c], 0}, a_B[3] = {0, 0, 0};
+			plane_adjoint(2, acc + 3 * c, a, a_B, x2b, x2b_B);
+			for (int i = 0; i < 2; i++)
+				add(g.uv_b, 2 * (size_t)fin.uvid[i] + c, s.vtx_f64, a_B[i]);
+		}
+		double a[3] = {fin.att[0][2], fin.att[1][2], 0}, a_B[3] = {0, 0, 0};
+		plane_adjoint(2, acc + 6, a, a_B, x2b, x2b_B);
+		for (int i = 0; i < 2; i++)
+			add(g.shade_b, fin.vid[i], s.vtx_f64, a_B[i]);
+	}
+	else
+	{ // H.h:1758-1767
+#pragma unroll
+		for (int c = 0; c < 4; c++)
+			if (c < s.C)
+			{
+				double a[3] = {fin.att[0][c], fin.att[1][c], 0}, a_B[3] = {0, 0, 0};
+				plane_adjoint(2, acc + 3 * c, a, a_B, x2b, x2b_B);
+				for (int i = 0; i < 2; i++)
+					add(g.colors_b, (size_t)fin.vid[i] * s.C + c, s.vtx_f64, a_B[i]);
+			}
+	}
+	double V_B[2][2] = {{0, 0}, {0, 0}};
+	edge_stencil_adjoint(fin.V, V_B, s.sigma, x2b_B, x2t_B, s.clockwise);
+	for (int i = 0; i < 2; i++)
+		for (int d = 0; d < 2; d++)
+			add(g.ij_b, 2 * (size_t)fin.vid[i] + d, s.vtx_f64, V_B[i][d]);
 }
 
 // ------------------------------------------------------------------------------------------------- per-pixel helpers

@@ -17,7 +17,7 @@ for v in ${@:-fwdtrace wavetrace tiletrace fwd4 fwd6}; do
     wavetrace) build $v -DDR_WAVE_TRACE ;;
     tiletrace) build $v -DDR_TILE_TRACE ;;
     fwd*) build $v -DDR_FWD_WAVES=${v#fwd} ;;
-    abl*) build $v "-DDR_ABLATE=${v#abl} -DDR_FWD_WAVES=4" ;;
+    abl*) build $v "-DDR_ABLATE=${v#abl}" ;;
     *) build $v "$EXTRA" ;;
   esac
 done

@@ -1,8 +1,11 @@
 #!/bin/bash
-# counters (args) per kernel over the bench workload:  bash tools/pmc_one.sh COUNTER1 COUNTER2 ...
+# bash tools/pmc_lib1.sh <lib|-> COUNTER...   : counters per kernel for one library variant (bounded)
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/pmc1; rm -rf $OUT; mkdir -p $OUT
-timeout -k 5 120 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $OUT -o p -- python $R/tools/step_time.py --steps 2 > $OUT/log 2>&1
+R=$GRAFT_REPO_ROOT; lib=$1; shift
+LIBARG=""; [ "$lib" != "-" ] && LIBARG="--lib $R/$lib"
+OUT=$R/gpurun_out/pmc1/$(basename $lib .so); rm -rf $OUT; mkdir -p $OUT
+timeout -k 5 120 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $OUT -o p -- python $R/tools/step_time.py $LIBARG --steps 2 > $OUT/log 2>&1
+grep "Mpixel" $OUT/log
 python - $OUT <<'PY'
 import csv, glob, sys, collections, re
 out = sys.argv[1]
@@ -16,4 +19,3 @@ for f in glob.glob(f'{out}/*counter_collection.csv'):
 for k, d in agg.items():
     print(k, {c: round(v / cnt[(k,c)]) for c, v in d.items()})
 PY
-tail -3 $OUT/log | cut -c1-300

@@ -47,3 +47,18 @@ for which, name in enumerate(("setup_bin_kernel", "finalize_kernel", "raster_fwd
     print("   waves in flight at 39 instants:", [int(((start <= x) & (end > x)).sum()) for x in ts])
     late = np.argsort(-end)[:8]
     print("   last waves to end (start, life):", [(round(float(start[i]), 1), round(float(dur[i]), 1)) for i in late])
+
+# phases inside the wavefronts that work on flagged edges (set-up: 1 flags compacted, 2 inputs loaded, 3 record computed, 4 record
+# stored, 5 binning done; finalize: 1 flags compacted, 2 inputs arrived, 3 arithmetic done, 4 accumulators cleared)
+ph = np.zeros((4, 1 << 16, 8), dtype=np.uint64)
+L.deodr_hip_debug_wave_phase.argtypes = [C.c_void_p, C.c_size_t]
+if L.deodr_hip_debug_wave_phase(ph.ctypes.data, ph.nbytes) == 0:
+    for which, name, last in ((0, "setup_bin_kernel edge", 5), (1, "finalize_kernel edge", 4), (2, "setup_bin_kernel tri", 4), (3, "finalize_kernel tri", 3)):
+        t = ph[which].astype(np.int64)
+        ok = np.all(t[:, :last + 1] > 0, axis=1)
+        t = t[ok]
+        if len(t) == 0:
+            continue
+        d = np.diff(t[:, :last + 1], axis=1) * 0.01
+        print(f"{name}: {len(t)} wavefronts that went all the way; phase durations (us) mean / p90:",
+              [(round(float(d[:, i].mean()), 2), round(float(np.percentile(d[:, i], 90)), 2)) for i in range(last)], " whole mean %.2f" % ((t[:, last] - t[:, 0]).mean() * 0.01))
