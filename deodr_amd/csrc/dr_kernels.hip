@@ -199,6 +199,10 @@ struct KParams
 	int n_views;
 	int tile_blocks; // staged forward: workgroups per view that walk the work list (multiple of 512, or tiny frames: <= ntiles)
 	int row_group;	 // tile rows per strip dealt to an XCD by the raster kernels (xcd_strip_row); 0: one band per XCD
+	int pix_f64;	 // pixel buffers are double (for the kernels that are not templates on the pixel type)
+	// Background fill of a fit step (see fill_word): 0 = by fill_kernel on the side stream; otherwise by extra workgroups of the
+	// adjoint's kernels -- bit 0: raster_bwd_edge_kernel takes part, bit 1: finalize_kernel does (both: even / odd bitmap words)
+	int fill_mode;
 	int clear_grads; // the set-up kernel zeroes the per-view gradient arrays (a fit step that wants fresh gradients: no separate fills)
 	// workspace
 	char *ws;
@@ -1660,13 +1664,8 @@ __global__ __launch_bounds__(SCAN_BLOCK) void tile_scan_kernel(KParams p)
 constexpr int FILL_WAVES = 4; // wavefronts (bitmap words) per workgroup
 
 template <class PixT>
-__global__ __launch_bounds__(64 * FILL_WAVES) void fill_kernel(KParams p, int owners)
-{
-	const int lane = threadIdx.x & 63;
-	const int gw = blockIdx.x * FILL_WAVES + (threadIdx.x >> 6);
-	if (gw >= p.n_views * p.L.nwords)
-		return;
-	const int view = gw / p.L.nwords, wi = gw - view * p.L.nwords;
+__device__ __forceinline__ void fill_word(const KParams &p, int view, int wi, int lane, int owners)
+{ // background of the empty tiles of bitmap word wi of the view (one wavefront)
 	const ViewPtrs w = view_ptrs(p, view);
 	const int base = wi * 32, valid = p.L.ntiles - base < 32 ? p.L.ntiles - base : 32;
 	uint32_t empty = ~w.tile_bits[wi] & (valid == 32 ? 0xffffffffu : (1u << valid) - 1u);
@@ -1711,6 +1710,36 @@ __global__ __launch_bounds__(64 * FILL_WAVES) void fill_kernel(KParams p, int ow
 			}
 		}
 	}
+}
+
+template <class PixT>
+__global__ __launch_bounds__(64 * FILL_WAVES) void fill_kernel(KParams p, int owners)
+{
+	const int gw = blockIdx.x * FILL_WAVES + (threadIdx.x >> 6);
+	if (gw >= p.n_views * p.L.nwords)
+		return;
+	fill_word<PixT>(p, gw / p.L.nwords, gw % p.L.nwords, threadIdx.x & 63, owners);
+}
+
+// A fit step has two latency-bound kernels after the forward raster (edge tiles, finalize) whose wave slots and store bandwidth
+// are mostly idle: the background fill rides on them as extra workgroups instead of a kernel of its own on a forked stream --
+// the fork / join event packets cost the caller's stream two bubbles of ~7 us per step (rocprofv3 kernel trace: scan -> forward,
+// finalize -> next set-up).  Word wi of a view goes to the kernels that take part by parity.
+__host__ __device__ inline int fill_share(int fill_mode, int bit, int nwords)
+{ // bitmap words per view the kernel `bit` (0 edge tiles, 1 finalize) fills
+	if (!(fill_mode & (1 << bit)))
+		return 0;
+	return fill_mode == 3 ? (nwords + 1 - bit) / 2 : nwords;
+}
+__device__ __forceinline__ void fill_share_word(const KParams &p, int bit, int view, int i, int lane)
+{ // the i-th word of the share of kernel `bit`
+	const int wi = p.fill_mode == 3 ? 2 * i + bit : i;
+	if (wi >= p.L.nwords)
+		return;
+	if (p.pix_f64)
+		fill_word<double>(p, view, wi, lane, 0);
+	else
+		fill_word<float>(p, view, wi, lane, 0);
 }
 
 // Grid of the staged forward (1-D, one wavefront per workgroup).  Workgroup b: view (b / 8) % n_views,
@@ -3144,13 +3173,20 @@ __global__ __launch_bounds__(64, TEX ? 2 : 4) void raster_bwd_edge_kernel(KParam
 	const int view = blockIdx.x;
 	const int lane = threadIdx.x;
 	const ViewPtrs w = view_ptrs(p, view);
+	// the last workgroups of the grid stream the background of this kernel's share of the empty tiles (fill_share)
+	const int walkers = (int)gridDim.y - fill_share(p.fill_mode, 0, p.L.nwords);
+	if ((int)blockIdx.y >= walkers)
+	{
+		fill_share_word(p, 0, view, (int)blockIdx.y - walkers, lane);
+		return;
+	}
 	const uint32_t n_short = w.edge_tile_cnt[0], n_long = w.edge_tile_cnt[CNT_STRIDE], n_multi = w.edge_tile_cnt[2 * CNT_STRIDE] * CHUNKS;
 	const uint32_t *shorts = w.edge_tiles, *longs = w.edge_tiles + p.L.ntiles, *multi = w.edge_tiles + 2 * (size_t)p.L.ntiles;
 	// Work items: first the tiles with more than one batch of edges, each offered to CHUNKS wavefronts (one per batch of its
 	// reverse sweep; those the tile has no use for return at once), then the other tiles with more than PRIO_EDGES edges, then
 	// the rest.
 #pragma nounroll
-	for (uint32_t i = blockIdx.y; i < n_multi + n_long + n_short; i += gridDim.y)
+	for (uint32_t i = blockIdx.y; i < n_multi + n_long + n_short; i += (uint32_t)walkers)
 	{
 		int tile, chunk = -1;
 		if (i < n_multi)
@@ -3172,6 +3208,14 @@ __global__ __launch_bounds__(PRIM_BLOCK, DR_PRIM_WAVES) void finalize_kernel(KPa
   // (Lists of the front-facing triangles / drawn edges compacted by the set-up kernel were tried: a quarter as many wavefronts,
   // all lanes busy -- and 32 -> 41 us: the kernel is a chain of dependent round trips, fewer wavefronts overlap fewer of them.)
 	DR_WAVE_TRACE_SCOPE(1);
+	if ((int)blockIdx.x >= p.n_views * prim_blocks(p.T))
+	{ // the last workgroups of the grid stream the background of this kernel's share of the empty tiles (fill_share)
+		const int n = fill_share(p.fill_mode, 1, p.L.nwords);
+		const int gw = ((int)blockIdx.x - p.n_views * prim_blocks(p.T)) * (PRIM_BLOCK / 64) + (int)(threadIdx.x >> 6);
+		if (n > 0 && gw < p.n_views * n)
+			fill_share_word(p, 1, gw / n, gw % n, threadIdx.x & 63);
+		return;
+	}
 	const PrimWork pw = prim_work(p);
 	const int view = pw.view;
 	const bool tri_block = pw.tri;
@@ -3364,6 +3408,7 @@ int fill_params(const DeodrHipScene *sc, double sigma, void *workspace, size_t w
 	p.strict = sc->strict_edge != 0;
 	p.persp = sc->perspective_correct != 0;
 	p.vtx_f64 = sc->vertex_dtype == DEODR_HIP_F64;
+	p.pix_f64 = sc->pixel_dtype == DEODR_HIP_F64;
 	p.offset = sc->integer_pixel_centers ? 0.0 : 0.5;
 	p.sigma = sigma;
 	p.ws = (char *)workspace;
@@ -3496,6 +3541,7 @@ int launch_forward_staged(const KParams &p, bool fused, hipStream_t stream, hipE
 	KParams q = p;
 	q.tile_blocks = fwd_tile_blocks(p.L.ntiles);
 	hipLaunchKernelGGL(tile_scan_kernel, dim3((p.L.ntiles + SCAN_BLOCK - 1) / SCAN_BLOCK, p.n_views), dim3(SCAN_BLOCK), 0, stream, q);
+	if (p.fill_mode == 0)
 	{
 		std::lock_guard<std::mutex> lock(g_side_mutex);
 		SideStream ss;
@@ -3565,7 +3611,7 @@ int launch_adjoint(const DeodrHipScene *sc, KParams &p, hipStream_t st, bool own
 	// persistent waves of the edge kernel: enough to cover a silhouette-heavy single view, few enough that with many views
 	// the waves that find their sub-list exhausted cost nothing
 	const int edge_waves = p.L.ntiles < EDGE_WAVES ? p.L.ntiles : EDGE_WAVES;
-	dim3 edge_grid(sc->n_views, edge_waves);
+	dim3 edge_grid(sc->n_views, edge_waves + (fast ? fill_share(p.fill_mode, 0, p.L.nwords) : 0));
 	{
 		ScopedKernelTimer t(KID_RASTER_BWD, st);
 		if (sc->pixel_dtype == DEODR_HIP_F64)
@@ -3575,7 +3621,8 @@ int launch_adjoint(const DeodrHipScene *sc, KParams &p, hipStream_t st, bool own
 	}
 	if (p.T > 0)
 	{
-		dim3 g2((unsigned)prim_blocks(p.T) * (unsigned)sc->n_views);
+		const int fill_words = fast ? sc->n_views * fill_share(p.fill_mode, 1, p.L.nwords) : 0;
+		dim3 g2((unsigned)prim_blocks(p.T) * (unsigned)sc->n_views + (unsigned)((fill_words + PRIM_BLOCK / 64 - 1) / (PRIM_BLOCK / 64)));
 		ScopedKernelTimer t(KID_FINALIZE, st);
 		hipLaunchKernelGGL(finalize_kernel, g2, dim3(PRIM_BLOCK), 0, st, p);
 	}
@@ -3729,6 +3776,11 @@ int deodr_hip_render_scene_fit(const DeodrHipScene *sc, void *image, void *z_buf
 			return 1;
 	}
 	const bool fused = p.C <= CH && !g_force_generic;
+	// the background of the empty tiles rides on the adjoint's kernels (fill_share); without any of them: the side stream
+#ifndef DR_FILL_MASK
+#define DR_FILL_MASK 3 // measurement builds: 0 side stream, 1 edge kernel only, 2 finalize only
+#endif
+	p.fill_mode = fused ? (((sigma > 0 ? 1 : 0) | (p.T > 0 ? 2 : 0)) & DR_FILL_MASK) : 0;
 	note_forward(workspace, fused);
 	hipEvent_t join = nullptr;
 	if (launch_forward(sc, p, st, &join, fused))
