@@ -1337,6 +1337,14 @@ __device__ __forceinline__ void tri_batch(const KParams &p, WaveLds &S, int nb, 
 				int xb, xe;
 				tri_half_span(rec, in0 ? 0 : 1, yy, W, H, strict, xb, xe);
 				m = column_mask(xb, xe, x0);
+				if (DR_ABLATE & 16384)
+				{ // measurement: the span arithmetic a second time (its cost = the difference in instruction counts)
+					int yy2 = yy;
+					asm volatile("" : "+v"(yy2));
+					int xb2, xe2;
+					tri_half_span(rec, in0 ? 0 : 1, yy2, W, H, strict, xb2, xe2);
+					m &= column_mask(xb2, xe2, x0);
+				}
 				if (__ballot(in0 && in1))
 				{
 					if (in0 && in1)
@@ -2959,14 +2967,29 @@ __device__ __forceinline__ void bwd_fast_tile(const KParams &p, const ViewPtrs &
 		}
 		DR_TRACE(3);
 		if (chunked && b_hi < nbatch - 1)
-		{ // the gradient that reaches batch b_hi has been attenuated by every nearer edge drawn over the pixel
-			for (int r = (b_hi + 1) * TB; r < n_edges; r++)
+		{ // the gradient that reaches batch b_hi has been attenuated by every nearer edge drawn over the pixel.  The transparency
+		  // planes of those edges are gathered into the (still idle) staging area with ONE round of loads: read from memory inside
+		  // the loop they were a dependent round trip per edge -- 34 of them for the first batch of a 50-edge tile, the longest
+		  // wavefront of the kernel (tools/tile_trace.py: 41 k cycles)
+			const int r0 = (b_hi + 1) * TB;
+			double *xt = (double *)&S.rec[0];
+			static_assert(sizeof(S.rec) + sizeof(S.planes) >= 3 * sizeof(double) * EMAX, "room for the transparency planes of a tile's edges");
+			lds_sync();
+			for (int i = lane; i < n_edges - r0; i += 64)
+			{
+				const EdgeRec &eq = w.edge_rec[es->sorted[r0 + i]];
+				xt[3 * i] = eq.x2t[0];
+				xt[3 * i + 1] = eq.x2t[1];
+				xt[3 * i + 2] = eq.x2t[2];
+			}
+			lds_sync();
+			for (int r = r0; r < n_edges; r++)
 			{
 				uint32_t bits = 0;
 #pragma unroll
 				for (int bb = 0; bb < EMAX / TB; bb++)
 					bits = bb == (r / TB) ? tm[bb] : bits;
-				const double Tq = plane_at(w.edge_rec[es->sorted[r]].x2t, x, y);
+				const double Tq = plane_at(xt + 3 * (r - r0), x, y);
 				if ((bits >> (r % TB)) & 1u)
 				{
 #pragma unroll

@@ -15,7 +15,8 @@ python - <<PY
 import csv, glob, json, collections
 out = "$OUT"
 # bench.py's kernel groups (one hipEvent interval each) <- kernels of the library
-groups = {"setup_bin_kernel": ["setup_bin_kernel"], "raster_fwd_kernel": ["tile_scan_kernel", "raster_fwd_fast_kernel", "raster_fwd_kernel", "fill_kernel"],
+groups = {"setup_bin_kernel": ["setup_bin_kernel"], "raster_fwd_kernel": ["tile_scan_kernel", "raster_fwd_fast_kernel", "raster_fwd_kernel"],
+          "fill_kernel (forward-only calls: not part of the fit step)": ["fill_kernel"],
           "raster_bwd_kernel": ["raster_bwd_fast_kernel", "raster_bwd_edge_kernel", "raster_bwd_kernel"], "finalize_kernel": ["finalize_kernel"]}
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for c in ("fetch", "write"):
