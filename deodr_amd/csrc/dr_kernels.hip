@@ -1671,6 +1671,99 @@ __global__ __launch_bounds__(SCAN_BLOCK) void tile_scan_kernel(KParams p)
 // depth (and of owner ids): 128 contiguous bytes per pixel row instead of 4 x 32.
 constexpr int FILL_WAVES = 4; // wavefronts (bitmap words) per workgroup
 
+// Background of the run of empty tiles [txa, txb) of tile row ty.  Every pixel row of the run is ONE contiguous range of the
+// frame (image: (txb - txa) * 8 * C elements, depth / owner ids: (txb - txa) * 8), written in 16-byte pieces by consecutive
+// lanes whatever the channel count -- per tile and per channel (three strided 4-byte stores per lane for C = 3) the fill of a
+// 1024^2 x 8-view batch of the hand mesh ran at 1 TB/s.  Needs W % 8 == 0 (16-byte alignment of every piece).
+template <class PixT>
+__device__ __forceinline__ void fill_run(const KParams &p, int view, int32_t *face_id, int ty, int txa, int txb, int lane, const double *bgc, int owners)
+{
+	constexpr int E = 16 / (int)sizeof(PixT); // elements per piece
+	typedef PixT VE __attribute__((ext_vector_type(E)));
+	typedef int32_t I4 __attribute__((ext_vector_type(4)));
+	const int W = p.W, H = p.H, C = p.C;
+	const int x0 = txa * TILE, npx = (txb * TILE < W ? txb * TILE : W) - x0, y0 = ty * TILE, rows = H - y0 < TILE ? H - y0 : TILE;
+	// f(row, piece) for the `rows` x n pieces of a plane, consecutive lanes on consecutive pieces; no integer division in the loop
+	// (the fill waves live on store issue: every instruction between two stores counts)
+	auto for_pieces = [&](int n, auto f) {
+		if (n >= 64)
+		{
+			for (int row = 0; row < rows; row++)
+				for (int piece = lane; piece < n; piece += 64)
+					f(row, piece);
+			return;
+		}
+		const float rn = 1.0f / (float)n; // rows * n <= 8 * 63: exact after one correction step
+		for (int idx = lane; idx < rows * n; idx += 64)
+		{
+			int row = (int)((float)idx * rn), piece = idx - row * n;
+			if (piece < 0)
+				row--, piece += n;
+			if (piece >= n)
+				row++, piece -= n;
+			f(row, piece);
+		}
+	};
+	if (p.image)
+	{
+		PixT *img = (PixT *)p.image + ((size_t)view * H * W + (size_t)y0 * W + x0) * C;
+		const PixT *bgi = p.bg_image ? (const PixT *)p.bg_image + ((size_t)view * H * W + (size_t)y0 * W + x0) * C : nullptr;
+		const size_t row_stride = (size_t)W * C;
+		const int n = npx * C / E; // pieces per pixel row (npx is a multiple of 8: whole pieces)
+		auto pattern = [&](int piece) { // the background colour as it falls on piece `piece` of a row
+			VE v;
+			int ph = C == 3 ? (piece * E) % 3 : ((piece * E) & (C - 1)); // channel of the piece's first element
+#pragma unroll
+			for (int j = 0; j < E; j++)
+			{
+				v[j] = (PixT)(ph == 0 ? bgc[0] : (ph == 1 ? bgc[1] : (ph == 2 ? bgc[2] : bgc[3])));
+				ph = ph + 1 == C ? 0 : ph + 1;
+			}
+			return v;
+		};
+		if (n >= 64 && !bgi)
+		{ // the usual long run of a colour background: a lane's pieces lane, lane + 64, ... of a row see the pattern with period 3
+		  // (period 1 unless C = 3), so the three vectors are formed once and the loop is a store and a pointer increment
+			const VE v0 = pattern(lane), v1 = pattern(lane + 64), v2 = pattern(lane + 128);
+			for (int row = 0; row < rows; row++)
+			{
+				PixT *out = img + (size_t)row * row_stride + (size_t)lane * E;
+				int piece = lane;
+				for (; piece + 128 < n; piece += 192, out += 192 * E)
+				{
+					__builtin_nontemporal_store(v0, (VE *)out);
+					__builtin_nontemporal_store(v1, (VE *)(out + 64 * E));
+					__builtin_nontemporal_store(v2, (VE *)(out + 128 * E));
+				}
+				if (piece < n)
+					__builtin_nontemporal_store(v0, (VE *)out);
+				if (piece + 64 < n)
+					__builtin_nontemporal_store(v1, (VE *)(out + 64 * E));
+			}
+		}
+		else
+			for_pieces(n, [&](int row, int piece) {
+				const size_t at = (size_t)row * row_stride + (size_t)piece * E;
+				__builtin_nontemporal_store(bgi ? *(const VE *)(bgi + at) : pattern(piece), (VE *)(img + at));
+			});
+	}
+	if (p.zbuf)
+	{
+		VE inf;
+#pragma unroll
+		for (int j = 0; j < E; j++)
+			inf[j] = (PixT)INFINITY;
+		PixT *zb = (PixT *)p.zbuf + (size_t)view * H * W + (size_t)y0 * W + x0;
+		for_pieces(npx / E, [&](int row, int piece) { __builtin_nontemporal_store(inf, (VE *)(zb + (size_t)row * W + piece * E)); });
+	}
+	if (owners)
+	{
+		const I4 none = {-1, -1, -1, -1};
+		int32_t *own = face_id + (size_t)y0 * W + x0;
+		for_pieces(npx / 4, [&](int row, int piece) { __builtin_nontemporal_store(none, (I4 *)(own + (size_t)row * W + piece * 4)); });
+	}
+}
+
 template <class PixT>
 __device__ __forceinline__ void fill_word(const KParams &p, int view, int wi, int lane, int owners)
 { // background of the empty tiles of bitmap word wi of the view (one wavefront)
@@ -1680,7 +1773,7 @@ __device__ __forceinline__ void fill_word(const KParams &p, int view, int wi, in
 	empty = (uint32_t)uniform((int)empty);
 	if (!empty)
 		return;
-	const int W = p.W, H = p.H, C = p.C;
+	const int C = p.C;
 	double bgc[CH] = {0, 0, 0, 0};
 	if (!p.bg_image)
 	{
@@ -1689,35 +1782,24 @@ __device__ __forceinline__ void fill_word(const KParams &p, int view, int wi, in
 			if (cc < C)
 				bgc[cc] = (double)((const PixT *)p.bg_color)[cc];
 	}
-	// groups of four tiles side by side in one tile row, every pixel of them inside the frame
-	const bool quads = (p.L.tiles_x & 3) == 0 && (W & 7) == 0 && (H & 7) == 0 && sizeof(PixT) == 4;
-	typedef PixT P4 __attribute__((ext_vector_type(4)));
-	typedef int32_t I4 __attribute__((ext_vector_type(4)));
-	for (int g = 0; g < 8; g++)
-	{
-		const uint32_t nib = (empty >> (4 * g)) & 0xfu;
-		if (!nib)
-			continue;
-		const int tile0 = base + 4 * g, tx0 = tile0 % p.L.tiles_x, ty = tile0 / p.L.tiles_x;
-		const bool quad = quads && nib == 0xfu;
-		for (int i = 0; i < 4; i++)
-			if ((nib >> i) & 1u) // (tiles of an incomplete group can lie in two tile rows: each finds its own)
-				fill_background_tile<PixT>(p, view, w.face_id, (tile0 + i) % p.L.tiles_x, (tile0 + i) / p.L.tiles_x, lane, bgc, quad ? -1 : owners);
-		if (quad)
-		{ // depth (and owners) of the four tiles: lane = (pixel row, 16-byte piece of the row's 32 pixels)
-			const size_t pix = (size_t)(ty * TILE + (lane >> 3)) * W + tx0 * TILE + 4 * (lane & 7);
-			if (p.zbuf)
-			{
-				const P4 inf4 = {(PixT)INFINITY, (PixT)INFINITY, (PixT)INFINITY, (PixT)INFINITY};
-				__builtin_nontemporal_store(inf4, (P4 *)((PixT *)p.zbuf + (size_t)view * H * W + pix));
-			}
-			if (owners)
-			{
-				const I4 none = {-1, -1, -1, -1};
-				__builtin_nontemporal_store(none, (I4 *)(w.face_id + pix));
-			}
+	if ((p.W & 7) == 0)
+	{ // maximal runs of empty tiles inside one tile row
+		while (empty)
+		{
+			const int a = __ffs((int)empty) - 1;
+			const uint32_t rest = ~(empty >> a);			   // bit i clear: tile a + i is empty
+			int len = rest ? __ffs((int)rest) - 1 : 32 - a; // (all ones above a: the run goes to the end of the word)
+			const int t0 = base + a, ty = t0 / p.L.tiles_x, tx = t0 - ty * p.L.tiles_x;
+			if (tx + len > p.L.tiles_x)
+				len = p.L.tiles_x - tx; // the rest of the run lies in the next tile row
+			fill_run<PixT>(p, view, w.face_id, ty, tx, tx + len, lane, bgc, owners);
+			empty &= len >= 32 ? 0u : ~(((1u << len) - 1u) << a);
 		}
+		return;
 	}
+	for (int i = 0; i < 32; i++) // ragged frame width: tile by tile
+		if ((empty >> i) & 1u)
+			fill_background_tile<PixT>(p, view, w.face_id, (base + i) % p.L.tiles_x, (base + i) / p.L.tiles_x, lane, bgc, owners);
 }
 
 template <class PixT>

@@ -2,7 +2,7 @@
 # rocprofv3 kernel stats of tools/step_time.py (args passed through), summary printed
 cd /tmp && export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out/prof; rm -rf $OUT; mkdir -p $OUT
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o k -- python $GRAFT_REPO_ROOT/tools/step_time.py "$@" > $OUT/log 2>&1
+timeout -k 5 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o k -- python $GRAFT_REPO_ROOT/tools/step_time.py "$@" > $OUT/log 2>&1
 grep -v amdgpu.ids $OUT/log | tail -2
 cut -d, -f1-4 $OUT/k_kernel_stats.csv | grep -v "at::native\|rocclr" | sed 's/(anonymous namespace):://g; s/(KParams)//g; s/(KParams, int)//g' | head -12
 python3 - <<'PY'
