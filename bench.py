@@ -260,27 +260,62 @@ def main():
     image = torch.empty((B, S, S, Cc), dtype=torch.float32, device=dev)
     z = torch.empty((B, S, S), dtype=torch.float32, device=dev)
     grads = ds.zero_grads()
-    shared = torch.zeros(V * (2 + Cc), dtype=torch.float64, device=dev)  # packed shared-parameter gradient
+    # Multi-GPU: what the ranks share is the mesh -- 3-D vertex positions and vertex colours -- so the all-reduced buffer is
+    # [vertices_b (V x 3), colors_b summed over the views (V x C)].  vertices_b = sum over views of J^T ij_b with J = d ij / d X of
+    # the view's pinhole camera (the adjoint of deodr's Camera.project_points, dr.py:397-438, as one broadcast multiply + one
+    # reduction).  The views of this benchmark do not move, so J is formed once; a fitter recomputes it with the projection.
+    shared = torch.zeros(V * (3 + Cc), dtype=torch.float64, device=dev)  # packed shared-parameter gradient
+    jac = None
+    if world > 1 or args.force_dist:
+        verts, _faces = scenes.bumpy_sphere(100, 100)
+        J = np.empty((B, V, 2, 3))
+        for b, a in enumerate(poses):
+            cam = scenes.fit_camera(S, S, 60.0, verts, scenes.rotx(0.37) @ scenes.roty(0.23 + float(a)))
+            R, f = cam.extrinsic[:, :3], cam.intrinsic[0, 0]
+            pc = verts @ R.T + cam.extrinsic[:, 3]
+            for d in range(2):
+                J[b, :, d, :] = f / pc[:, 2:3] * (R[d][None, :] - (pc[:, d] / pc[:, 2])[:, None] * R[2][None, :])
+        assert np.abs(scenes.project(cam, verts)[0] - views[-1].ij).max() < 1e-9  # same cameras as the rendered views
+        jac = torch.as_tensor(J, device=dev)
 
     obs_views = obs.expand(B, S, S, Cc).contiguous()  # one observation per view (here the same synthetic image)
-    pending = [None]
+    # The reduction of step k (camera adjoint, packing, RCCL all-reduce) runs on a communication stream while step k + 1 renders:
+    # two sets of gradient buffers alternate, and a set is rendered into again only when the reduction that read it has finished.
+    comm = torch.cuda.Stream(device=dev) if dist is not None else None
+    grads_pp = [grads, ds.zero_grads()] if dist is not None else [grads]
+    shared_pp = [shared, torch.zeros_like(shared)]
+    reads_done, pending, it = [None, None], [None, None], [0]
 
     def step():
+        i = it[0] % len(grads_pp)
+        it[0] += 1
+        g = grads_pp[i]
+        if dist is not None and reads_done[i] is not None:
+            torch.cuda.current_stream().wait_event(reads_done[i])
         if args.two_pass:
-            grads["ij_b"].zero_()
-            grads["colors_b"].zero_()
+            g["ij_b"].zero_()
+            g["colors_b"].zero_()
             r.render(ds, args.sigma, out=(image, z), check_overflow=False)
             # adjoint of L = sum (image - obs)^2: dL/dimage = 2 (image - obs) is formed inside the adjoint kernel (residual mode)
-            r.render_backward(ds, residual_obs=obs_views, grads=grads)
+            r.render_backward(ds, residual_obs=obs_views, grads=g)
         else:
             # same outputs in one call: the forward raster back-propagates through the tiles without silhouette edges itself
             # (and zeroes the gradient arrays of the previous step on the way)
-            r.render_fit(ds, obs_views, args.sigma, grads=grads, out=(image, z), check_overflow=False, clear_grads=True)
+            r.render_fit(ds, obs_views, args.sigma, grads=g, out=(image, z), check_overflow=False, clear_grads=True)
         if dist is not None:
-            if pending[0] is not None:
-                pending[0].wait()  # the previous step's all-reduce overlapped this step's rendering
-            torch.cat((grads["ij_b"].sum(0).reshape(-1), grads["colors_b"].sum(0).reshape(-1)), out=shared)
-            pending[0] = dist.all_reduce(shared, async_op=True)
+            rendered = torch.cuda.Event()
+            rendered.record()
+            with torch.cuda.stream(comm):
+                comm.wait_event(rendered)
+                if pending[i] is not None:
+                    pending[i].wait()  # shared_pp[i] is free again
+                # three kernels: J^T ij_b as a broadcast multiply and a reduction over (views, image axes) written into the
+                # packed buffer, the colour gradients summed over the views next to it
+                torch.sum(g["ij_b"][..., None] * jac, dim=(0, 2), out=shared_pp[i][: 3 * V].view(V, 3))
+                torch.sum(g["colors_b"], dim=0, out=shared_pp[i][3 * V :].view(V, Cc))
+                reads_done[i] = torch.cuda.Event()
+                reads_done[i].record()
+                pending[i] = dist.all_reduce(shared_pp[i], async_op=True)
 
     # first call checks the spill pool once (synchronises), then nothing in the loop does
     r.render(ds, args.sigma, out=(image, z), check_overflow=True)
@@ -289,9 +324,11 @@ def main():
 
     def barrier():
         if dist is not None:
-            if pending[0] is not None:
-                pending[0].wait()
-                pending[0] = None
+            for k in range(2):
+                if pending[k] is not None:
+                    pending[k].wait()
+                    pending[k] = None
+            comm.synchronize()
             dist.barrier()
         torch.cuda.synchronize()
 
