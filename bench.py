@@ -291,7 +291,10 @@ def main():
         it[0] += 1
         g = grads_pp[i]
         if dist is not None and reads_done[i] is not None:
-            torch.cuda.current_stream().wait_event(reads_done[i])
+            # the reduction of two steps ago has read this set of gradient buffers: the HOST waits for it (it runs at most two
+            # steps ahead of the GPU, which is enough to keep it fed) -- a stream-side wait would put one more event packet, i.e.
+            # one more ~7 us bubble, between two steps
+            reads_done[i].synchronize()
         if args.two_pass:
             g["ij_b"].zero_()
             g["colors_b"].zero_()

@@ -3285,7 +3285,8 @@ __global__ __launch_bounds__(64, TEX ? 2 : 4) void raster_bwd_edge_kernel(KParam
 		fill_share_word(p, 0, view, (int)blockIdx.y - walkers, lane);
 		return;
 	}
-	const uint32_t n_short = w.edge_tile_cnt[0], n_long = w.edge_tile_cnt[CNT_STRIDE], n_multi = w.edge_tile_cnt[2 * CNT_STRIDE] * CHUNKS;
+	const uint32_t n_short = w.edge_tile_cnt[0], n_long = (DR_ABLATE & 65536) ? 0u : w.edge_tile_cnt[CNT_STRIDE],
+				   n_multi = (DR_ABLATE & 32768) ? 0u : w.edge_tile_cnt[2 * CNT_STRIDE] * CHUNKS; // (measurement builds: without the multi-batch / the 9-16-edge tiles)
 	const uint32_t *shorts = w.edge_tiles, *longs = w.edge_tiles + p.L.ntiles, *multi = w.edge_tiles + 2 * (size_t)p.L.ntiles;
 	// Work items: first the tiles with more than one batch of edges, each offered to CHUNKS wavefronts (one per batch of its
 	// reverse sweep; those the tile has no use for return at once), then the other tiles with more than PRIO_EDGES edges, then
