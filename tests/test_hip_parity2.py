@@ -525,3 +525,55 @@ def test_backward_after_fit_step_rebuilds_the_owner_buffer(oracle_api):
     for k in ("ij_b", "colors_b", "uv_b", "shade_b", "texture_b"):
         assert rel_err(g_two[k].cpu().numpy(), g_fit[k].cpu().numpy()) < 1e-9, k
         assert rel_err(grads[k].cpu().numpy(), g_fit[k].cpu().numpy()) < 1e-9, k
+
+
+@pytest.mark.parametrize("dt", [F32, F64])
+@pytest.mark.parametrize("sigma", [0.0, 1.0])
+@pytest.mark.parametrize("size,nb_colors,bg_image", [((64, 96), 3, False), ((37, 53), 3, True), ((40, 64), 1, False), ((72, 56), 4, True)])
+def test_fit_step_background_of_empty_tiles(oracle_api, size, nb_colors, bg_image, sigma, dt):
+    """The background fill of a fit step rides on the adjoint's kernels (edge tiles + finalize; finalize alone when sigma = 0) and
+    writes runs of empty tiles in 16-byte pieces: every channel count / pixel type / ragged width, against the frame of the
+    forward-only call (fill kernel on the forked stream) and against the checker."""
+    from hip_util import device_scene
+
+    H, W = size
+    s = scenes.soup_scene(n_tri=6, width=W, height=H, seed=3, flat=False, min_area=30.0)
+    rs = np.random.RandomState(5)
+    V = s.depths.shape[0]
+    s.colors = rs.rand(V, nb_colors)
+    s.colors_b = np.zeros_like(s.colors)
+    s.nb_colors = nb_colors
+    s.texture = np.zeros((0, 0, nb_colors))
+    s.texture_b = np.zeros((0, 0, nb_colors))
+    s.textured[:] = False
+    s.shaded[:] = False
+    if bg_image:
+        s.background_image, s.background_color = rs.rand(H, W, nb_colors), None
+    else:
+        s.background_image, s.background_color = None, rs.rand(nb_colors)
+    ds = device_scene([s], dt)
+    from deodr_amd.hip_renderer import HipRasterizer
+
+    r = HipRasterizer.for_scene(ds)
+    obs = torch.as_tensor(rs.rand(1, H, W, nb_colors), device=ds.device, dtype=dt)
+    image = torch.full((1, H, W, nb_colors), 777.0, dtype=dt, device=ds.device)
+    z = torch.full((1, H, W), 777.0, dtype=dt, device=ds.device)
+    r.render_fit(ds, obs, sigma, out=(image, z), check_overflow=True, clear_grads=True)
+    image2, z2 = r.render(ds, sigma)
+    torch.cuda.synchronize()
+    assert torch.equal(image, image2) and torch.equal(z, z2)
+    img_ref, z_ref = checker(oracle_api).render(s, sigma)
+    assert np.abs(image[0].cpu().numpy() - img_ref).max() < TOL[dt][0]
+    assert np.array_equal(np.isinf(z[0].cpu().numpy()), np.isinf(z_ref))
+
+
+def test_scene_without_triangles_is_rejected_like_the_reference(oracle_api):
+    """T = 0 means NULL face arrays: checkSceneValid (H.h:2667-2680) refuses them, and so does the C ABI -- with an error, not a crash"""
+    from deodr_amd.hip_renderer import DeviceScene, HipRasterizer
+
+    H, W, C = 48, 80, 3
+    ds = DeviceScene(np.zeros((0, 3), dtype=np.int64), np.zeros((0, 3), dtype=np.int64), np.zeros(0), np.zeros(0), np.zeros((1, 2)), np.zeros((1, 1, 2)),
+                     np.ones((1, 1)), np.zeros((1, 1, C)), np.zeros((1, 1)), np.zeros((1, 0, 3)), H, W, background_color=np.zeros(C), pixel_dtype=F32)  # fmt: skip
+    r = HipRasterizer.for_scene(ds)
+    with pytest.raises(RuntimeError, match="NULL"):
+        r.render(ds, 1.0)
