@@ -138,7 +138,9 @@ DR_HD void inv3_adjoint(const double S[9], double S_B[9], const double T_B[9]) /
 
 // value at column 0 of scanline y of the plane p = [px, py, p1]; summation order of the reference's row setup
 // (dot with t = {0, y, 1}: H.h:929-934, 1596-1598)
-DR_HD double row0(const double p[3], double y) { return ((0.0 + p[0] * 0.0) + p[1] * y) + p[2] * 1.0; }
+// (the reference's dot product also adds p[0] * 0 in front: for finite coefficients that term is +0 and changes nothing but
+// the sign of an exact zero, so it is not evaluated -- three double operations per plane evaluation)
+DR_HD double row0(const double p[3], double y) { return p[1] * y + p[2]; }
 DR_HD double plane_at(const double p[3], double x, double y) { return row0(p, y) + p[0] * x; }
 
 // plane coefficient j of an attribute given at nv vertices: sum_k a[k] x2b[3k + j]   (H.h:779-788, 1577-1585)
