@@ -2,26 +2,29 @@
 //
 // Kernels (n_views views per launch; DESIGN.md section 4 has the why of every choice below):
 //
-//   setup_bin_kernel        blocks of 256 threads: one triangle per thread, or 256 edge slots compacted to the flagged ones.
-//                           Cull, depth sum, stencil + attribute planes in double and in registers (dr_prims.h), edge records,
-//                           binning into 8 x 8 tiles (all slot requests of a 3 x 3 block of tiles in flight; large boxes by
-//                           the whole wavefront), lists of edge tiles / many-primitive tiles, optional gradient clearing
-//   raster_fwd_fast_kernel  1 wavefront / NON-EMPTY tile, lane = pixel (a wave whose tile received no primitive -- two out of
-//                           three -- learns it from one scalar load of the set-up kernel's tile bitmap and retires; the
-//                           background of those tiles is streamed by a few fill waves, 32 tiles each).  Pass 1 (z-buffered
-//                           triangles staged 16 at a time through LDS, exact scanline spans, winner = min (Z, index)),
-//                           shading of the winner, pass 2 (ordered edge overdraw) fused in registers, ONE write of image / z
-//                           (/ owner) per pixel.  FUSED: also the adjoint of pass 1 for the sum-of-squares residual in
-//                           tiles without edges (deodr_hip_render_scene_fit)
-//   raster_bwd_fast_kernel  (two-call path) adjoint of pass 1 in every tile without edges
+//   setup_bin_kernel        blocks of 256 threads on a 1-D grid, the edge blocks first: 256 edge slots compacted to the flagged
+//                           ones, or one triangle per thread.  Cull, depth sum, stencil + attribute planes in double and in
+//                           registers (dr_prims.h), edge records (+ the EdgeFin record finalize reads), the index checks of
+//                           checkSceneValid, binning into 8 x 8 tiles (all slot requests of a 3 x 3 block of tiles in flight;
+//                           large boxes by the whole wavefront), optional gradient clearing
+//   tile_scan_kernel        one thread per tile: counters -> work list of the NON-EMPTY tiles (entries carry the first triangle
+//                           ids; many-primitive tiles first), tile bitmap, three lists of edge tiles by edge count, sweep slots
+//   raster_fwd_fast_kernel  1 wavefront / work-list entry, lane = pixel.  Pass 1 (z-buffered triangles staged 16 at a time
+//                           through LDS, exact scanline spans, winner = min (Z, index)), shading of the winner, pass 2 (ordered
+//                           edge overdraw) fused in registers, ONE write of image / z (/ owner) per pixel.  FUSED: also the
+//                           adjoint of pass 1 for the sum-of-squares residual in tiles without edges (deodr_hip_render_scene_fit)
+//   fill_kernel / fill_word background + depth = inf of the empty tiles, runs of tiles written as contiguous 16-byte pieces:
+//                           a kernel on a forked stream (forward-only calls) or extra workgroups of the two kernels below (fit step)
+//   raster_bwd_fast_kernel  (two-call path) adjoint of pass 1 in every non-empty tile without edges
 //   raster_bwd_edge_kernel  persistent waves over the listed edge tiles: adjoint of pass 2 (un-blend in reverse order, moments
 //                           by a transposing butterfly, one 15-lane atomic per edge and tile), then of pass 1
 //   finalize_kernel         per primitive: moments -> plane adjoints -> 3x3-inverse adjoint -> vertex gradients
 //   raster_fwd_kernel / raster_bwd_kernel   the same algorithm without LDS staging: nb_colors > 4, antialiase_error
 //
 // No MFMA anywhere: the path is gather / scatter + streaming writes.  The workspace is self-cleaning (tile counters are
-// zeroed by the wave that consumed them, spill / list counters are double-buffered by the parity of the forward count,
-// the moment accumulators are zeroed by finalize) so a call never needs a memset node.
+// zeroed by the scan kernel, spill counters are double-buffered by the parity of the forward count, list counters are zeroed
+// by set-up, the moment accumulators by finalize) so a call never needs a memset node.  Every global atomic of the path is
+// executed at the memory side on this part (TCC_EA0_ATOMIC == TCC_ATOMIC): their number, not their addresses, is what counts.
 #include <hip/hip_runtime.h>
 
 #include <math.h>
@@ -395,7 +398,12 @@ struct AtomicSink
 	const SceneView &s;
 	const GradView &g;
 	uint32_t f[3], fuv[3];
-	__device__ __forceinline__ void color(int i, int c, double v) { DeviceAdd()(g.colors_b, (size_t)f[i] * s.C + c, s.vtx_f64, v); }
+	__device__ __forceinline__ void color(int i, int c, double v)
+	{
+		if ((DR_ABLATE & 131072) && c >= 2) // (measurement build: a third fewer atomic instructions per triangle)
+			return;
+		DeviceAdd()(g.colors_b, (size_t)f[i] * s.C + c, s.vtx_f64, v);
+	}
 	__device__ __forceinline__ void shade(int i, double v) { DeviceAdd()(g.shade_b, f[i], s.vtx_f64, v); }
 	__device__ __forceinline__ void uv(int i, int c, double v) { DeviceAdd()(g.uv_b, 2 * (size_t)fuv[i] + c, s.vtx_f64, v); }
 	__device__ __forceinline__ void ij(int i, int d, double v) { DeviceAdd()(g.ij_b, 2 * (size_t)f[i] + d, s.vtx_f64, v); }
