@@ -723,23 +723,47 @@ __global__ __launch_bounds__(PRIM_BLOCK, DR_PRIM_WAVES) void setup_bin_kernel(KP
 				break;
 			}
 			DR_WAVE_PHASE_T(1); // inputs (?)
-			setup_tri_only(s, t, rec, w.tri_planes + (size_t)k * 3 * s.P);
-			DR_WAVE_PHASE_T(2); // record computed
+			double x2b[9];
+			const bool drawn = setup_tri_geometry(s, t, rec, x2b) && rec.kind != KIND_NONE;
 			w.tri_flag[k] = (uint8_t)(rec.kind | (rec.front ? 4 : 0));
-			if (rec.kind == KIND_NONE)
+			if (!drawn)
 				break; // culled (or textured without shading): its record is never read -- the raster kernels reach records
 					   // through the tile lists, the finalize kernel looks at tri_flag first
+			const int x0 = rec.x_min < 0 ? 0 : rec.x_min, x1 = rec.x_max > s.W - 1 ? s.W - 1 : rec.x_max;
+			const int y0 = rec.y_begin[0] < 0 ? 0 : rec.y_begin[0], y1 = rec.y_end[1] > s.H - 1 ? s.H - 1 : rec.y_end[1];
+			const bool on_screen = !(x0 > x1 || y0 > y1 || (DR_ABLATE & 2048));
+			const double eq[9] = {rec.eq[0][0], rec.eq[0][1], rec.eq[0][2], rec.eq[1][0], rec.eq[1][1], rec.eq[1][2], rec.eq[2][0], rec.eq[2][1], rec.eq[2][2]};
+			const int tx0 = x0 / TILE, ty0 = y0 / TILE, ntx = x1 / TILE - tx0 + 1, nty = y1 / TILE - ty0 + 1;
+			const bool large = on_screen && ((ntx + 2) / 3) * ((nty + 2) / 3) > COOP_BLOCKS;
+			// The slot requests of the first 3 x 3 block of tiles (for the usual small triangle: all of them) leave NOW, before the
+			// attribute planes are formed and the record is stored: that arithmetic and those stores then overlap the round trip
+			// of the requests (5.5 of the 12.6 us of a triangle wavefront, tools/wave_trace.py) instead of preceding it.
+			uint32_t slot0[9];
+			bool use0[9];
+#pragma unroll
+			for (int q = 0; q < 9; q++)
+				use0[q] = false, slot0[q] = 0;
+			if (on_screen && !large)
+			{
+				const uint32_t outside = tiles3x3_outside_halfplanes<3>(eq, tx0, ty0);
+#pragma unroll
+				for (int q = 0; q < 9; q++)
+				{
+					const int dx = q % 3, dy = q / 3;
+					use0[q] = dx < ntx && dy < nty && !((outside >> q) & 1u);
+					if (use0[q])
+						slot0[q] = atomicAdd(&w.tri_cnt[(ty0 + dy) * p.L.tiles_x + tx0 + dx], 1u);
+				}
+			}
+			setup_tri_attributes(s, t, rec, x2b, w.tri_planes + (size_t)k * 3 * s.P);
+			DR_WAVE_PHASE_T(2); // record computed
 			rec.pad0[0] = rec.pad0[1] = 0;
 			rec.pad1[0] = rec.pad1[1] = rec.pad1[2] = 0;
 			if (!(DR_ABLATE & 4096))
 				out = rec;
-			const int x0 = rec.x_min < 0 ? 0 : rec.x_min, x1 = rec.x_max > s.W - 1 ? s.W - 1 : rec.x_max;
-			const int y0 = rec.y_begin[0] < 0 ? 0 : rec.y_begin[0], y1 = rec.y_end[1] > s.H - 1 ? s.H - 1 : rec.y_end[1];
-			if (x0 > x1 || y0 > y1 || (DR_ABLATE & 2048))
+			if (!on_screen)
 				break;
-			const double eq[9] = {rec.eq[0][0], rec.eq[0][1], rec.eq[0][2], rec.eq[1][0], rec.eq[1][1], rec.eq[1][2], rec.eq[2][0], rec.eq[2][1], rec.eq[2][2]};
-			const int tx0 = x0 / TILE, ty0 = y0 / TILE, ntx = x1 / TILE - tx0 + 1, nty = y1 / TILE - ty0 + 1;
-			if (((ntx + 2) / 3) * ((nty + 2) / 3) > COOP_BLOCKS)
+			if (large)
 			{
 				big = true;
 #pragma unroll
@@ -749,10 +773,16 @@ __global__ __launch_bounds__(PRIM_BLOCK, DR_PRIM_WAVES) void setup_bin_kernel(KP
 				break;
 			}
 			DR_WAVE_PHASE_T(3); // record stored
-			// 3 x 3 tiles at a time (the usual small triangle: once), the slot requests of a block all in flight together: one
-			// memory round trip per block, not one per tile
+#pragma unroll
+			for (int q = 0; q < 9; q++)
+				if (use0[q])
+				{
+					const int tile = (ty0 + q / 3) * p.L.tiles_x + tx0 + q % 3;
+					place_in_tile(w.tri_list, K_TRI, w.tri_pool, p.L.tri_pool_cap, &w.hdr->tri_spill[cur], tile, (uint32_t)k, slot0[q]);
+				}
+			// the other 3 x 3 blocks of a wider box, the slot requests of a block all in flight together
 			for (int by = 0; by < nty; by += 3)
-				for (int bx = 0; bx < ntx; bx += 3)
+				for (int bx = by == 0 ? 3 : 0; bx < ntx; bx += 3)
 				{
 					uint32_t slot[9];
 					bool use[9];

@@ -212,14 +212,17 @@ DR_HD uint32_t load_triangle(const SceneView &s, int k, TriInputs &t, bool with_
 	return 0;
 }
 
-// Triangle part of the set-up: record + attribute planes.  Pass-1 kind follows H.h:2785-2819.
-DR_HD void setup_tri_only(const SceneView &s, const TriInputs &t, TriRec &rec, double *tri_planes /*[3P]*/)
+// Triangle part of the set-up in two steps, so that the device kernel can request its tile slots between them (everything
+// binning needs -- edge equations and bounds -- comes out of the first step; the second one is independent arithmetic that
+// then overlaps the round trip of the slot requests).  Pass-1 kind follows H.h:2785-2819.
+// Step 1: stencil (edge equations, bounds, barycentric frame x2b) and kind.  -> false: culled, nothing else to do.
+DR_HD bool setup_tri_geometry(const SceneView &s, const TriInputs &t, TriRec &rec, double x2b[9])
 {
 	if (s.culling && !(t.area > 0))
 	{ // culled: neither pass 1 (H.h:2786) nor pass 2 (H.h:2847) nor the adjoint (H.h:3063) touches it -- no stencil needed
 		rec.kind = KIND_NONE;
 		rec.front = 0;
-		return;
+		return false;
 	}
 	double V[3][2];
 	for (int i = 0; i < 3; i++)
@@ -227,12 +230,17 @@ DR_HD void setup_tri_only(const SceneView &s, const TriInputs &t, TriRec &rec, d
 		V[i][0] = t.Vraw[i][0] - s.offset;
 		V[i][1] = t.Vraw[i][1] - s.offset;
 	}
-	double x2b[9];
 	tri_stencil(V, s.strict, rec, x2b);
 	rec.front = t.area > 0;
 	rec.kind = KIND_NONE;
 	if (t.area > 0 || !s.culling)
 		rec.kind = t.both ? KIND_TEXTURED : (t.tex ? KIND_NONE : KIND_INTERP);
+	return true;
+}
+
+// Step 2: the Z plane of the record and the attribute planes.
+DR_HD void setup_tri_attributes(const SceneView &s, const TriInputs &t, TriRec &rec, const double x2b[9], double *tri_planes /*[3P]*/)
+{
 	double zz[3];
 	for (int i = 0; i < 3; i++)
 		zz[i] = s.persp ? 1 / t.Zv[i] : t.Zv[i];
@@ -245,6 +253,13 @@ DR_HD void setup_tri_only(const SceneView &s, const TriInputs &t, TriRec &rec, d
 		else
 			attr_planes(s, rec.kind, 3, t.f, t.fuv, t.Zv, x2b, tri_planes);
 	}
+}
+
+DR_HD void setup_tri_only(const SceneView &s, const TriInputs &t, TriRec &rec, double *tri_planes /*[3P]*/)
+{
+	double x2b[9];
+	if (setup_tri_geometry(s, t, rec, x2b))
+		setup_tri_attributes(s, t, rec, x2b, tri_planes);
 }
 
 template <class T>
