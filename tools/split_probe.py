@@ -31,10 +31,18 @@ for G in (1, 2, 4, 8):
     fits = [make(views[i * B // G:(i + 1) * B // G]) for i in range(G)]
     streams = [torch.cuda.Stream() for _ in range(G)]
 
+    JOIN = "--join" in sys.argv  # every step forks from and joins back to the main stream (what a fit loop needs)
+
     def step():
+        main = torch.cuda.current_stream()
         for f, st in zip(fits, streams):
+            if JOIN:
+                st.wait_stream(main)
             with torch.cuda.stream(st):
                 f()
+        if JOIN:
+            for st in streams:
+                main.wait_stream(st)
 
     for _ in range(5):
         step()
@@ -52,4 +60,17 @@ for G in (1, 2, 4, 8):
         step()
     host = (time.perf_counter() - t0) / 40
     torch.cuda.synchronize()
+    if JOIN and "--graph" in sys.argv:
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            step()
+        for _ in range(5):
+            graph.replay()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(40):
+            graph.replay()
+        torch.cuda.synchronize()
+        print(f"   as one HIP graph per step: {(time.perf_counter() - t0) / 40 * 1e3:.4f} ms / step")
     print(f"{G} group(s) of {B // G} views: {best * 1e3:.4f} ms / step ({B * S * S / best / 1e6:.0f} Mpixel/s), host issue time {host * 1e3:.4f} ms")
