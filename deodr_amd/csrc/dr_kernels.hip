@@ -1617,17 +1617,20 @@ __global__ __launch_bounds__(SCAN_BLOCK) void tile_scan_kernel(KParams p)
 	uint32_t ntri = 0, nedge = 0;
 	uint4 ida = make_uint4(0, 0, 0, 0), idb = ida, idc = ida;
 	if (valid)
-	{ // (the head of the tile's inline list is requested with the counters: one round trip, not two; stale ids of a tile that
-	  // received nothing this time are simply not used)
+	{
 		ntri = w.tri_cnt[tile];
 		nedge = w.edge_cnt[tile];
+	}
+	const bool work = (ntri | nedge) != 0;
+	if (work)
+	{ // the head of the tile's inline list, only as far as it is filled (two tiles out of three are empty: requested with the
+	  // counters, these 48 bytes per tile were 6 MB of reads per step for nothing and the kernel took 6.5 instead of 5 us)
 		static_assert(ENTRY_IDS == 12 && K_TRI >= ENTRY_IDS, "three 16-byte pieces of the tile's inline list");
 		const uint4 *ids = (const uint4 *)(w.tri_list + (size_t)tile * K_TRI);
 		ida = ids[0];
-		idb = ids[1];
-		idc = ids[2];
+		idb = ntri > 4 ? ids[1] : ida;
+		idc = ntri > 8 ? ids[2] : ida;
 	}
-	const bool work = (ntri | nedge) != 0;
 	if (work)
 	{ // self-cleaning counters
 		w.tri_cnt[tile] = 0;
