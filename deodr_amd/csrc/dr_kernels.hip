@@ -1263,6 +1263,7 @@ struct PixState
 	double zbest;
 	int kbest;
 	int kind;
+	int slot;	  // position of the winner in the staged batch (= in the tile's list when the tile has one batch)
 	double v[CH]; // colours of the current winner (KIND_INTERP) or u, v, shade awaiting the texture fetch (KIND_TEXTURED)
 };
 
@@ -1428,6 +1429,7 @@ __device__ __forceinline__ void tri_batch(const KParams &p, WaveLds &S, int nb, 
 	DR_BTRACE(10); // depth test done
 	if (jbest >= 0)
 	{ // per-lane reads of the winner's record and planes (LDS, a few distinct slots per tile)
+		st.slot = jbest;
 		const int kind = S.rec[jbest].kind;
 		const double *pl = &S.planes[jbest * 12];
 		const double Z = st.zbest;
@@ -1873,6 +1875,72 @@ __device__ __forceinline__ void fill_share_word(const KParams &p, int bit, int v
 		fill_word<float>(p, view, wi, lane, 0);
 }
 
+// Adjoint of pass 1 for a tile whose triangles are ONE staged batch (S.ids[0 .. ntri), the usual case), untextured: the moments
+//   M[owner][3 q + m] = sum over the owner's pixels of  g_q * {x, y, 1}[m]
+// are a small dense contraction over the 64 pixels of the tile -- (one-hot owner matrix)^T (64 x 16) times the 64 x 12 matrix of
+// per-pixel values -- and the forward raster is bound by vector-ALU issue while its matrix cores idle: sixteen
+// v_mfma_f64_16x16x4_f64 (K = 4 pixels each) can replace the segmented scans, run tables and merge loops of owner_adjoint
+// (about half of its vector instructions).  Operand layout (cdna_hip_programming.md, checked by tools/probes/mfma_f64_probe.hip): lane l
+// feeds A[l & 15][l >> 4] and B[l >> 4][l & 15], and receives D[(l >> 4) + 4 r][l & 15] in register r.  The per-pixel values
+// cross lanes through the (idle) staging area, 32 pixels at a time; the one-hot entries are exact, so only the order of the
+// additions differs from the scan (both differ from the reference's row-by-row sums; tolerance of the parity tests 1e-8).
+// MEASURED AND NOT USED (the product is built with DR_OWNER_MFMA = 0; tools/build_variants.sh can build the other): parity green
+// (all 205 GPU tests), 100 fewer vector instructions per tile -- and the forward raster 14 us SLOWER (85 -> 99 us per 8-view
+// launch): on MI355X the f64 matrix rate equals the f64 vector rate (78.6 TFLOP/s), a 16 x 16 x 4 f64 MFMA holds its SIMD for
+// ~64 cycles, and 16 of them (of whose 16 k multiply-adds ~2.5 k are useful: 3 - 4 owners x 12 moments x 64 pixels) cost more
+// issue time than the ~100 vector instructions they replace.
+#ifndef DR_OWNER_MFMA
+#define DR_OWNER_MFMA 0
+#endif
+typedef double mfma_f64x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void owner_adjoint_mfma(const KParams &p, const ViewPtrs &w, WaveLds &S, int lane, double x, double y, int slot, int ntri,
+												   const double *g)
+{
+	static_assert(sizeof(S.rec) + sizeof(S.planes) >= 32 * 12 * sizeof(double) && sizeof(S.cover) >= 64 && TB == 16, "LDS reuse");
+	const int C = p.C, nm = 3 * p.L.P;
+	double *bm = (double *)&S.rec[0]; // [32 pixels][12]: g_q x, g_q y, g_q of planes q = 0 .. 3
+	uint8_t *jb = &S.cover[0][0];	  // [64 pixels]: slot of the owner, 0xff: none
+	const int col = lane & 15, kq = lane >> 4;
+	jb[lane] = (uint8_t)(slot < 0 ? 0xff : slot);
+	mfma_f64x4 acc = {0, 0, 0, 0};
+#pragma unroll
+	for (int h = 0; h < 2; h++)
+	{
+		lds_sync();
+		if ((lane >> 5) == h)
+		{
+			double *row = bm + (lane & 31) * 12;
+#pragma unroll
+			for (int q = 0; q < CH; q++)
+			{
+				const double v = q < C ? g[q] : 0.0;
+				row[3 * q] = v * x;
+				row[3 * q + 1] = v * y;
+				row[3 * q + 2] = v;
+			}
+		}
+		lds_sync();
+#pragma unroll
+		for (int st = 0; st < 8; st++)
+		{
+			const int pl = 4 * st + kq; // pixel of this lane's A / B entries, inside the half
+			const double a = jb[32 * h + pl] == (uint8_t)col ? 1.0 : 0.0;
+			const double b = col < 12 ? bm[pl * 12 + col] : 0.0;
+			acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+		}
+	}
+#pragma unroll
+	for (int r = 0; r < 4; r++)
+	{ // owner slot kq + 4 r, moment `col`: the 3P moments of an owner are contiguous (one atomic instruction per four owners)
+		const int i = kq + 4 * r;
+		const double v = acc[r];
+#if !(DR_ABLATE & 128)
+		if (i < ntri && col < nm && v != 0)
+			atomic_add_f64(w.tri_acc + (size_t)S.ids[i] * nm + col, v);
+#endif
+	}
+}
+
 // Grid of the staged forward (1-D, one wavefront per workgroup).  Workgroup b: view (b / 8) % n_views,
 // q = (b / 8 / n_views) * 8 + b % 8 in [0, p.tile_blocks); it walks the entries rank(q), rank(q) + tile_blocks, ... of the
 // view's work list (usually one or two).  rank() deals the list to the XCDs in chunks of 64 consecutive entries (workgroup b
@@ -1976,6 +2044,7 @@ __global__ __launch_bounds__(64, DR_FWD_WAVES) void raster_fwd_fast_kernel(KPara
 		st.zbest = INFINITY;
 		st.kbest = -1;
 		st.kind = KIND_NONE;
+		st.slot = 0;
 #pragma unroll
 		for (int cc = 0; cc < CH; cc++)
 			st.v[cc] = 0;
@@ -2212,7 +2281,12 @@ __global__ __launch_bounds__(64, DR_FWD_WAVES) void raster_fwd_fast_kernel(KPara
 			for (int cc = 0; cc < CH; cc++)
 				g[cc] = (cc < C && inb) ? 2 * ((double)(PixT)col[cc] - (double)ob[cc]) : 0.0;
 			lds_sync();
-			if (!(DR_ABLATE & 256))
+			if (DR_ABLATE & 256)
+			{
+			}
+			else if (!TEX && DR_OWNER_MFMA && ntri <= TB)
+				owner_adjoint_mfma(p, w, S, lane, x, y, st.kbest >= 0 ? st.slot : -1, ntri, g);
+			else
 				owner_adjoint<PixT, TEX>(p, w, lane, x, y, st.kbest, st.kbest >= 0 ? st.kind : (int)KIND_NONE, g, tap, L, (double *)&S.rec[0],
 									(uint32_t *)&S.cover[0][0]);
 		}
