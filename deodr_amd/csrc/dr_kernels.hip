@@ -1864,6 +1864,9 @@ __host__ __device__ inline int fill_share(int fill_mode, int bit, int nwords)
 		return 0;
 	return fill_mode == 3 ? (nwords + 1 - bit) / 2 : nwords;
 }
+// workgroups (edge kernel: per view, along grid y, limited to 65535) that stream a share of n words: one word each up to a cap,
+// beyond it (frames of more than ~4 M tiles) every workgroup takes several
+__host__ __device__ inline int fill_share_blocks(int n) { return n < 32768 ? n : 32768; }
 __device__ __forceinline__ void fill_share_word(const KParams &p, int bit, int view, int i, int lane)
 { // the i-th word of the share of kernel `bit`
 	const int wi = p.fill_mode == 3 ? 2 * i + bit : i;
@@ -3411,10 +3414,12 @@ __global__ __launch_bounds__(64, TEX ? 2 : 4) void raster_bwd_edge_kernel(KParam
 	const int lane = threadIdx.x;
 	const ViewPtrs w = view_ptrs(p, view);
 	// the last workgroups of the grid stream the background of this kernel's share of the empty tiles (fill_share)
-	const int walkers = (int)gridDim.y - fill_share(p.fill_mode, 0, p.L.nwords);
+	const int fill_n = fill_share(p.fill_mode, 0, p.L.nwords), fill_blocks = fill_share_blocks(fill_n);
+	const int walkers = (int)gridDim.y - fill_blocks;
 	if ((int)blockIdx.y >= walkers)
 	{
-		fill_share_word(p, 0, view, (int)blockIdx.y - walkers, lane);
+		for (int i = (int)blockIdx.y - walkers; i < fill_n; i += fill_blocks)
+			fill_share_word(p, 0, view, i, lane);
 		return;
 	}
 	const uint32_t n_short = w.edge_tile_cnt[0], n_long = (DR_ABLATE & 65536) ? 0u : w.edge_tile_cnt[CNT_STRIDE],
@@ -3852,7 +3857,7 @@ int launch_adjoint(const DeodrHipScene *sc, KParams &p, hipStream_t st, bool own
 	// persistent waves of the edge kernel: enough to cover a silhouette-heavy single view, few enough that with many views
 	// the waves that find their sub-list exhausted cost nothing
 	const int edge_waves = p.L.ntiles < EDGE_WAVES ? p.L.ntiles : EDGE_WAVES;
-	dim3 edge_grid(sc->n_views, edge_waves + (fast ? fill_share(p.fill_mode, 0, p.L.nwords) : 0));
+	dim3 edge_grid(sc->n_views, edge_waves + (fast ? fill_share_blocks(fill_share(p.fill_mode, 0, p.L.nwords)) : 0));
 	{
 		ScopedKernelTimer t(KID_RASTER_BWD, st);
 		if (sc->pixel_dtype == DEODR_HIP_F64)

@@ -577,3 +577,28 @@ def test_scene_without_triangles_is_rejected_like_the_reference(oracle_api):
     r = HipRasterizer.for_scene(ds)
     with pytest.raises(RuntimeError, match="NULL"):
         r.render(ds, 1.0)
+
+
+@pytest.mark.parametrize("size", [(4096, 4096), (24, 16384)])
+def test_large_frames(oracle_api, size):
+    """4096 x 4096 (262 144 tiles, 8 192 bitmap words) and a 16 384-pixel-wide strip: forward, fit step and adjoint against the checker"""
+    from hip_util import device_scene, rel_err
+    from deodr_amd.hip_renderer import HipRasterizer
+
+    H, W = size
+    s = scenes.soup_scene(n_tri=24, width=W, height=H, seed=9, flat=False)
+    ds = device_scene([s], F32)
+    r = HipRasterizer.for_scene(ds)
+    rs = np.random.RandomState(2)
+    obs = torch.as_tensor(rs.rand(1, H, W, 3), device=ds.device, dtype=F32)
+    image, z, g = r.render_fit(ds, obs, 1.0, check_overflow=True, clear_grads=True)
+    image2, z2 = r.render(ds, 1.0)
+    torch.cuda.synchronize()
+    assert torch.equal(image, image2) and torch.equal(z, z2)
+    ref = checker(oracle_api)
+    img_ref, z_ref = ref.render(s, 1.0)
+    assert np.abs(image[0].cpu().numpy() - img_ref).max() < 1e-5
+    res_b = 2 * (image[0].cpu().numpy().astype(np.float64) - obs[0].cpu().numpy().astype(np.float64))
+    g_ref = ref.grads(s, 1.0, img_ref, z_ref, res_b)
+    for k in ("ij_b", "colors_b"):
+        assert rel_err(g[k][0].cpu().numpy(), g_ref[k]) < 1e-4, k
