@@ -2870,7 +2870,8 @@ __device__ __forceinline__ void owner_adjoint(const KParams &p, const ViewPtrs &
 			if (v != 0)
 			{
 				const int texel = i / C, c = i - texel * C, jv = texel / win_w, ju = texel - jv * win_w;
-				unsafeAtomicAdd(texture_b + (size_t)C * ((win_u0 + ju) + (size_t)p.tex_w * (win_v0 + jv)) + c, (PixT)v);
+				if (!(DR_ABLATE & 1048576)) // (measurement build: no texture-gradient atomics)
+					unsafeAtomicAdd(texture_b + (size_t)C * ((win_u0 + ju) + (size_t)p.tex_w * (win_v0 + jv)) + c, (PixT)v);
 			}
 		}
 		lds_sync(); // tab is reused for the run totals below

@@ -602,3 +602,47 @@ def test_large_frames(oracle_api, size):
     g_ref = ref.grads(s, 1.0, img_ref, z_ref, res_b)
     for k in ("ij_b", "colors_b"):
         assert rel_err(g[k][0].cpu().numpy(), g_ref[k]) < 1e-4, k
+
+
+def test_two_call_path_under_hip_graph_capture(oracle_api):
+    """render + render_backward captured in one HIP graph: the forward-only call forks its background fill onto the library's
+    side stream and joins it back (event record / wait), which stream capture turns into edges of the graph"""
+    from hip_util import device_scene, rel_err
+    from deodr_amd.hip_renderer import HipRasterizer
+
+    s = scenes.sphere_scene(size=256, nu=40, n_rings=40)
+    ds = device_scene(s, F32)
+    r = HipRasterizer.for_scene(ds)
+    n, H, W, Cc = 1, 256, 256, 4
+    image_b = torch.as_tensor(np.random.RandomState(4).randn(n, H, W, Cc).astype(np.float32), device=ds.device)
+    image = torch.empty((n, H, W, Cc), dtype=F32, device=ds.device)
+    z = torch.empty((n, H, W), dtype=F32, device=ds.device)
+    grads = ds.zero_grads()
+
+    def step():
+        for v in grads.values():
+            if v is not None:
+                v.zero_()
+        r.render(ds, 1.0, out=(image, z), check_overflow=False)
+        r.render_backward(ds, image_b=image_b, grads=grads)
+
+    r.render(ds, 1.0, out=(image, z), check_overflow=True)
+    step()
+    torch.cuda.synchronize()
+    eager = (image.clone(), z.clone(), {k: v.clone() for k, v in grads.items() if v is not None})
+    graph = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        step()
+    torch.cuda.current_stream().wait_stream(side)
+    with torch.cuda.graph(graph):
+        step()
+    for _ in range(3):
+        image.zero_()
+        z.zero_()
+        graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(image, eager[0]) and torch.equal(z, eager[1])
+    for k, v in eager[2].items():
+        assert rel_err(grads[k].cpu().numpy(), v.cpu().numpy()) < 1e-12, k
