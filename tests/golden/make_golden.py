@@ -23,6 +23,8 @@ Fixtures
                        reference's tests/test_depth_image_hand_fitting.py:36-42) and, for iteration 0, every intermediate of
                        the Scene3D front half: projected points (distortion camera), depths, silhouette edge flags, the
                        rendered depth image, the vertex / quaternion / translation gradients, the rigid energy and its gradient.
+  deferred_hand.npz    Scene3D.render_deferred of the hand mesh (96 x 80): the depth / face_id / barycentric / normal / luminosity /
+                       xyz / color buffers of one 15-channel soup render at sigma = 0.
   rgb_hand_fit.npz     deodr/examples/rgb_image_hand_fitting.py `run(dl_library="none")`: the image (uint8), background colour,
                        50 energies of MeshRGBFitterWithPose.step and the iteration-0 intermediates (vertex normals,
                        luminosity, rendered image, gradients of vertices, lights and colour).
@@ -228,6 +230,30 @@ def rgb_hand_fit():
     print("rgb hand fit: energies[0], [49] =", energies[0], energies[49])
 
 
+def deferred_hand():
+    """Scene3D.render_deferred (dr.py:1053-1174) of the hand mesh, 96 x 80, every buffer: the stacked-channel (nb_colors = 15)
+    untextured soup render at sigma = 0 that deferred shading uses."""
+    import deodr
+    from deodr import ColoredTriMesh, read_obj
+    from deodr.differentiable_renderer import Scene3D, default_camera
+
+    faces, vertices = read_obj(os.path.join(deodr.data_path, "hand.obj"))
+    mesh = ColoredTriMesh(faces.copy(), vertices=vertices, nb_colors=3)
+    mesh.set_vertices_colors(np.random.RandomState(0).rand(mesh.nb_vertices, 3))
+    rot = np.array([[0.96, 0.0, 0.28], [0.0, -1.0, 0.0], [0.28, 0.0, -0.96]])
+    camera = default_camera(96, 80, 70, mesh.vertices, rot)
+    scene = Scene3D(sigma=0)
+    scene.set_light(light_directional=np.array([-0.1, -0.5, -0.4]), light_ambient=0.3)
+    scene.set_mesh(mesh)
+    scene.set_background_color([0.2, 0.3, 0.4])
+    buffers = scene.render_deferred(camera, depth_scale=0.5)
+    out = {"buf_" + k: np.array(v) for k, v in buffers.items()}
+    out.update(colors=np.array(mesh.vertices_colors), rot=rot, extrinsic=np.array(camera.extrinsic), intrinsic=np.array(camera.intrinsic),
+               order=np.array(list(buffers.keys())))
+    np.savez_compressed(os.path.join(OUT, "deferred_hand.npz"), **out)
+    print("deferred hand:", {k: v.shape for k, v in buffers.items()})
+
+
 if __name__ == "__main__":
     only = sys.argv[1:]
     with tempfile.TemporaryDirectory() as tmp:
@@ -240,3 +266,5 @@ if __name__ == "__main__":
         if not only or "fits" in only:
             depth_hand_fit()
             rgb_hand_fit()
+        if not only or "deferred" in only:
+            deferred_hand()

@@ -402,3 +402,28 @@ def test_silhouette_flags_and_projection_batched_on_device():
         ij_ref, d_ref = scenes.project(c, vertices)
         assert rel(ij[i].cpu(), ij_ref) < 1e-12 and rel(depths[i].cpu(), d_ref) < 1e-12
         assert np.array_equal(flags[i], scenes.silhouette_edgeflags(ij_ref, faces, False))
+
+
+@pytest.mark.gpu
+def test_dropin_scene3d_render_deferred():
+    """Scene3D.render_deferred (dr.py:1053-1174) through the drop-ins: a 15-channel untextured soup render at sigma = 0 (the
+    un-staged kernels: nb_colors > 4), every buffer against the reference's own output (tests/golden/deferred_hand.npz)"""
+    import deodr_amd as deodr
+
+    d = fixture("deferred_hand.npz")
+    vertices, faces = hand()
+    mesh = deodr.ColoredTriMesh(faces.copy(), vertices=vertices, nb_colors=3)
+    mesh.set_vertices_colors(d["colors"])
+    camera = deodr.default_camera(96, 80, 70, mesh.vertices, d["rot"])
+    assert rel(camera.extrinsic, d["extrinsic"]) < 1e-13 and rel(camera.intrinsic, d["intrinsic"]) < 1e-13
+    scene = deodr.Scene3D(sigma=0)
+    scene.set_light(light_directional=np.array([-0.1, -0.5, -0.4]), light_ambient=0.3)
+    scene.set_mesh(mesh)
+    scene.set_background_color([0.2, 0.3, 0.4])
+    buffers = scene.render_deferred(camera, depth_scale=0.5)
+    assert list(buffers.keys()) == [str(k) for k in d["order"]]
+    for k, v in buffers.items():
+        ref = d["buf_" + k]
+        assert v.shape == ref.shape, k
+        assert np.abs(v - ref).max() <= 1e-9 * max(1.0, np.abs(ref).max()), k
+    assert np.array_equal(buffers["face_id"], d["buf_face_id"])  # flat per triangle: exact
