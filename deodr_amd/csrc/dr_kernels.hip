@@ -529,10 +529,10 @@ struct PrimWork
 	bool tri;
 	int view_block; // a block id in [0, prim_blocks(T)) inside the view (housekeeping loops)
 };
-__device__ __forceinline__ PrimWork prim_work(const KParams &p, bool edge_first = DR_EDGE_FIRST)
+__device__ __forceinline__ PrimWork prim_work(const KParams &p, bool edge_first = DR_EDGE_FIRST, int skip = 0)
 {
 	const int TBk = prim_tri_blocks(p.T), EB = prim_blocks(p.T) - TBk, nv = p.n_views;
-	int b = (int)blockIdx.x;
+	int b = (int)blockIdx.x - skip;
 	PrimWork w;
 	const int first = (edge_first ? EB : TBk) * nv;
 	const bool in_first = b < first;
@@ -3416,10 +3416,14 @@ __global__ __launch_bounds__(64, TEX ? 2 : 4) void raster_bwd_edge_kernel(KParam
 	const ViewPtrs w = view_ptrs(p, view);
 	// the last workgroups of the grid stream the background of this kernel's share of the empty tiles (fill_share)
 	const int fill_n = fill_share(p.fill_mode, 0, p.L.nwords), fill_blocks = fill_share_blocks(fill_n);
+#ifndef DR_FILL_FIRST
+#define DR_FILL_FIRST 0 // measurement builds: 1 = the fill workgroups at the head of both grids instead of the tail
+#endif
 	const int walkers = (int)gridDim.y - fill_blocks;
-	if ((int)blockIdx.y >= walkers)
+	const int by = DR_FILL_FIRST ? (int)blockIdx.y - fill_blocks : (int)blockIdx.y; // index among the walkers (< 0: a fill workgroup)
+	if (DR_FILL_FIRST ? by < 0 : by >= walkers)
 	{
-		for (int i = (int)blockIdx.y - walkers; i < fill_n; i += fill_blocks)
+		for (int i = DR_FILL_FIRST ? (int)blockIdx.y : by - walkers; i < fill_n; i += fill_blocks)
 			fill_share_word(p, 0, view, i, lane);
 		return;
 	}
@@ -3430,7 +3434,7 @@ __global__ __launch_bounds__(64, TEX ? 2 : 4) void raster_bwd_edge_kernel(KParam
 	// reverse sweep; those the tile has no use for return at once), then the other tiles with more than PRIO_EDGES edges, then
 	// the rest.
 #pragma nounroll
-	for (uint32_t i = blockIdx.y; i < n_multi + n_long + n_short; i += (uint32_t)walkers)
+	for (uint32_t i = (uint32_t)by; i < n_multi + n_long + n_short; i += (uint32_t)walkers)
 	{
 		int tile, chunk = -1;
 		if (i < n_multi)
@@ -3452,18 +3456,19 @@ __global__ __launch_bounds__(PRIM_BLOCK, DR_PRIM_WAVES) void finalize_kernel(KPa
   // (Lists of the front-facing triangles / drawn edges compacted by the set-up kernel were tried: a quarter as many wavefronts,
   // all lanes busy -- and 32 -> 41 us: the kernel is a chain of dependent round trips, fewer wavefronts overlap fewer of them.)
 	DR_WAVE_TRACE_SCOPE(1);
-	if ((int)blockIdx.x >= p.n_views * prim_blocks(p.T))
-	{ // the last workgroups of the grid stream the background of this kernel's share of the empty tiles (fill_share)
-		const int n = fill_share(p.fill_mode, 1, p.L.nwords);
-		const int gw = ((int)blockIdx.x - p.n_views * prim_blocks(p.T)) * (PRIM_BLOCK / 64) + (int)(threadIdx.x >> 6);
-		if (n > 0 && gw < p.n_views * n)
-			fill_share_word(p, 1, gw / n, gw % n, threadIdx.x & 63);
+	const int fill_n = fill_share(p.fill_mode, 1, p.L.nwords), fill_blocks = (p.n_views * fill_n + PRIM_BLOCK / 64 - 1) / (PRIM_BLOCK / 64);
+	const int fb = DR_FILL_FIRST ? (int)blockIdx.x : (int)blockIdx.x - p.n_views * prim_blocks(p.T); // index among the fill workgroups
+	if (DR_FILL_FIRST ? fb < fill_blocks : fb >= 0)
+	{ // workgroups that stream the background of this kernel's share of the empty tiles (fill_share)
+		const int gw = fb * (PRIM_BLOCK / 64) + (int)(threadIdx.x >> 6);
+		if (fill_n > 0 && gw < p.n_views * fill_n)
+			fill_share_word(p, 1, gw / fill_n, gw % fill_n, threadIdx.x & 63);
 		return;
 	}
 #ifndef DR_FIN_EDGE_FIRST
 #define DR_FIN_EDGE_FIRST 1 // (triangle blocks first: finalize 37.5 -> 43.5 us)
 #endif
-	const PrimWork pw = prim_work(p, DR_FIN_EDGE_FIRST);
+	const PrimWork pw = prim_work(p, DR_FIN_EDGE_FIRST, DR_FILL_FIRST ? fill_blocks : 0);
 	const int view = pw.view;
 	const bool tri_block = pw.tri;
 	const SceneView s = scene_view(p, view);
