@@ -62,7 +62,10 @@ constexpr int PRIO_EDGES = 8; // tiles with more edges than this are listed apar
 // Tiles that receive more than FIRST_PRIMS triangles (or edges) are the long poles of the forward raster: the scan kernel
 // puts them at the head of the work list, so that the 25-50 us waves start at time 0 instead of ending 30 us after every
 // other wave of the kernel.
-constexpr int FIRST_PRIMS = 8;
+#ifndef DR_FIRST_PRIMS
+#define DR_FIRST_PRIMS 8
+#endif
+constexpr int FIRST_PRIMS = DR_FIRST_PRIMS;
 // Lists of the tiles that hold silhouette edges, by edge count (disjoint; written by tile_scan_kernel, walked by
 // raster_bwd_edge_kernel): 0 = 1 .. PRIO_EDGES edges, 1 = PRIO_EDGES + 1 .. TB (one batch), 2 = more than one batch.
 constexpr int EDGE_LISTS = 3;
@@ -200,6 +203,7 @@ struct KParams
 	const void *image_b, *obs, *err_b, *image_in;
 	int aa_err;
 	int n_views;
+	int heavy_share; // staged forward: one workgroup in heavy_share walks the many-primitive tiles (heavy_share_for)
 	int tile_blocks; // staged forward: workgroups per view that walk the work list (multiple of 512, or tiny frames: <= ntiles)
 	int row_group;	 // tile rows per strip dealt to an XCD by the raster kernels (xcd_strip_row); 0: one band per XCD
 	int pix_f64;	 // pixel buffers are double (for the kernels that are not templates on the pixel type)
@@ -1603,7 +1607,20 @@ __device__ __forceinline__ void fill_background_tile(const KParams &p, int view,
 // one per tile of the frame (the waves of the empty tiles used to take a third of its slot-time), and it takes the
 // many-primitive-tile flags and lists (two more dependent atomics per lane) out of the set-up kernel.
 constexpr int SCAN_BLOCK = 256, WORK_CHUNK = 64;
-constexpr int HEAVY_SHARE = 8; // one tile workgroup in HEAVY_SHARE walks the list of the many-primitive tiles
+// One tile workgroup in `heavy_share` walks the list of the many-primitive tiles (the head of the grid: dispatched first).  One in
+// eight, unless the head of all views together would then take more than ~40 % of the chip's wave slots (5 120 at five waves per
+// SIMD): with every slot of the first dispatch round on a 25 - 50 us tile the short tiles -- whose arithmetic hides those tiles'
+// round trips -- start late.  Measured on the 8-view benchmark step: 1/8 0.183 ms, 1/12 0.1775, 1/16 0.1767, 1/24 0.1784; on one
+// 2048^2 view (2 048 head workgroups at 1/8) 1/16 costs 4 %.
+#ifndef DR_HEAVY_SHARE
+#define DR_HEAVY_SHARE 0 // measurement builds: a fixed share
+#endif
+__host__ inline int heavy_share_for(int n_views, int tile_blocks)
+{
+	if (DR_HEAVY_SHARE)
+		return DR_HEAVY_SHARE;
+	return (long long)n_views * (tile_blocks / 8) > 2048 ? 16 : 8;
+}
 
 __global__ __launch_bounds__(SCAN_BLOCK) void tile_scan_kernel(KParams p)
 {
@@ -1952,7 +1969,10 @@ __device__ __forceinline__ void owner_adjoint_mfma(const KParams &p, const ViewP
 __host__ __device__ inline int fwd_tile_blocks(int ntiles)
 { // workgroups per view that walk the work list: a quarter of the tiles (about a third of a frame's tiles hold primitives)
 	const int unit = 8 * WORK_CHUNK;
-	const int g = ((ntiles / 4 + unit - 1) / unit) * unit;
+#ifndef DR_TILE_DIV
+#define DR_TILE_DIV 4
+#endif
+	const int g = ((ntiles / DR_TILE_DIV + unit - 1) / unit) * unit;
 	return g > 0 && g <= ntiles ? g : ntiles; // tiny frames: one workgroup per tile, plain order
 }
 
@@ -1999,11 +2019,11 @@ __global__ __launch_bounds__(64, DR_FWD_WAVES) void raster_fwd_fast_kernel(KPara
 	const bool persp = p.persp;
 	const PixT *texture = (const PixT *)p.texture;
 	WaveLds &S = s_lds[wave];
-	// The first G / HEAVY_SHARE workgroups of a view walk the many-primitive tiles (front of the list), the others the rest (from
+	// The first G / p.heavy_share workgroups of a view walk the many-primitive tiles (front of the list), the others the rest (from
 	// the back): the index of a workgroup's entry does not depend on the counts, so the counts, the entry header and the
 	// entry's triangle ids are all requested at once.
 	// (tiny frames -- G not a multiple of 512 -- have one class only: the scan kernel lists every tile as "other")
-	const int Gh = chunked ? G / HEAVY_SHARE : 0;
+	const int Gh = chunked ? G / p.heavy_share : 0;
 	const bool heavy_list = q < Gh;
 	const int qq = heavy_list ? q : q - Gh, stride = heavy_list ? Gh : G - Gh;
 	const bool chunk_here = chunked && stride % (8 * WORK_CHUNK) == 0;
@@ -3385,7 +3405,7 @@ __global__ __launch_bounds__(64, 6) void raster_bwd_fast_kernel(KParams p)
 	const int view = chunked ? (int)((b >> 3) % p.n_views) : (int)(b % p.n_views);
 	const int q = chunked ? (int)((b >> 3) / p.n_views) * 8 + (int)(b & 7) : (int)(b / p.n_views);
 	const ViewPtrs w = view_ptrs(p, view);
-	const int Gh = chunked ? G / HEAVY_SHARE : 0;
+	const int Gh = chunked ? G / p.heavy_share : 0;
 	const bool heavy_list = q < Gh;
 	const int qq = heavy_list ? q : q - Gh, stride = heavy_list ? Gh : G - Gh;
 	const bool chunk_here = chunked && stride % (8 * WORK_CHUNK) == 0;
@@ -3705,6 +3725,7 @@ void launch_adjoint_raster(const KParams &p, bool fast, bool owner_tiles, dim3 g
 	{
 		KParams q = p;
 		q.tile_blocks = fwd_tile_blocks(p.L.ntiles); // the grid of the forward that built the work list
+		q.heavy_share = heavy_share_for(p.n_views, q.tile_blocks);
 		const dim3 grid((unsigned)p.n_views * (unsigned)q.tile_blocks);
 		if (tex)
 			hipLaunchKernelGGL((raster_bwd_fast_kernel<PixT, true>), grid, dim3(64), 0, st, q);
@@ -3795,6 +3816,7 @@ int launch_forward_staged(const KParams &p, bool fused, hipStream_t stream, hipE
 {
 	KParams q = p;
 	q.tile_blocks = fwd_tile_blocks(p.L.ntiles);
+	q.heavy_share = heavy_share_for(p.n_views, q.tile_blocks);
 	hipLaunchKernelGGL(tile_scan_kernel, dim3((p.L.ntiles + SCAN_BLOCK - 1) / SCAN_BLOCK, p.n_views), dim3(SCAN_BLOCK), 0, stream, q);
 	if (p.fill_mode == 0)
 	{
