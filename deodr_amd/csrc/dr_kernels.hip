@@ -1875,18 +1875,32 @@ __global__ __launch_bounds__(64 * FILL_WAVES) void fill_kernel(KParams p, int ow
 // are mostly idle: the background fill rides on them as extra workgroups instead of a kernel of its own on a forked stream --
 // the fork / join event packets cost the caller's stream two bubbles of ~7 us per step (rocprofv3 kernel trace: scan -> forward,
 // finalize -> next set-up).  Word wi of a view goes to the kernels that take part by parity.
+// When both kernels take part, FILL_EDGE_NUM of every FILL_DEN consecutive words go to the edge-tile kernel, the others to finalize.
+#ifndef DR_FILL_EDGE_NUM
+#define DR_FILL_EDGE_NUM 1
+#endif
+#ifndef DR_FILL_DEN
+#define DR_FILL_DEN 2
+#endif
+constexpr int FILL_EDGE_NUM = DR_FILL_EDGE_NUM, FILL_DEN = DR_FILL_DEN;
+static_assert(FILL_EDGE_NUM > 0 && FILL_EDGE_NUM < FILL_DEN, "both kernels get some");
 __host__ __device__ inline int fill_share(int fill_mode, int bit, int nwords)
 { // bitmap words per view the kernel `bit` (0 edge tiles, 1 finalize) fills
 	if (!(fill_mode & (1 << bit)))
 		return 0;
-	return fill_mode == 3 ? (nwords + 1 - bit) / 2 : nwords;
+	if (fill_mode != 3)
+		return nwords;
+	const int full = nwords / FILL_DEN, rest = nwords - full * FILL_DEN; // whole groups + a partial one
+	const int edge = full * FILL_EDGE_NUM + (rest < FILL_EDGE_NUM ? rest : FILL_EDGE_NUM);
+	return bit == 0 ? edge : nwords - edge;
 }
 // workgroups (edge kernel: per view, along grid y, limited to 65535) that stream a share of n words: one word each up to a cap,
 // beyond it (frames of more than ~4 M tiles) every workgroup takes several
 __host__ __device__ inline int fill_share_blocks(int n) { return n < 32768 ? n : 32768; }
 __device__ __forceinline__ void fill_share_word(const KParams &p, int bit, int view, int i, int lane)
 { // the i-th word of the share of kernel `bit`
-	const int wi = p.fill_mode == 3 ? 2 * i + bit : i;
+	const int per = bit == 0 ? FILL_EDGE_NUM : FILL_DEN - FILL_EDGE_NUM; // words of a group that are this kernel's
+	const int wi = p.fill_mode == 3 ? (i / per) * FILL_DEN + (bit == 0 ? 0 : FILL_EDGE_NUM) + i % per : i;
 	if (wi >= p.L.nwords)
 		return;
 	if (p.pix_f64)
@@ -3708,7 +3722,10 @@ unsigned g_profile_calls = 0; // forwards seen since profiling was enabled
 bool g_force_generic = false; // deodr_hip_force_generic(1): run the un-staged kernels (the parity suite covers both families)
 // Tuning constants (measured in round 1, profiles/README.md); deliberately NOT read from the environment: nothing outside the
 // arguments of a call may change what the call launches.
-constexpr int EDGE_WAVES = 1024; // persistent waves per view of the adjoint's edge kernel
+#ifndef DR_EDGE_WAVES
+#define DR_EDGE_WAVES 1024
+#endif
+constexpr int EDGE_WAVES = DR_EDGE_WAVES; // persistent waves per view of the adjoint's edge kernel
 
 template <class PixT>
 void launch_adjoint_raster(const KParams &p, bool fast, bool owner_tiles, dim3 grid4, dim3 edge_grid, hipStream_t st)
