@@ -511,7 +511,10 @@ __device__ __forceinline__ bool tile_outside_halfplanes(const double *eq, int tx
 // (Workgroups of one wavefront -- 64 triangles, or a span of 256 edge slots compacted by each of four single-wave blocks -- were
 // measured: every wave starts within 10 us instead of 23, and the kernels take 38 / 35 us instead of 35 / 33: they are bound by
 // the memory-side atomics and the arithmetic of the long waves, not by wave slots.)
-constexpr int PRIM_BLOCK = 256;
+#ifndef DR_PRIM_BLOCK
+#define DR_PRIM_BLOCK 256
+#endif
+constexpr int PRIM_BLOCK = DR_PRIM_BLOCK;
 #ifndef DR_PRIM_WAVES
 #define DR_PRIM_WAVES 3 // waves per SIMD the per-primitive kernels are compiled for (4: spills, same time)
 #endif
@@ -1606,7 +1609,10 @@ __device__ __forceinline__ void fill_background_tile(const KParams &p, int view,
 // Two tiles out of three receive nothing: this is what lets the forward launch one wavefront per tile that HAS work instead of
 // one per tile of the frame (the waves of the empty tiles used to take a third of its slot-time), and it takes the
 // many-primitive-tile flags and lists (two more dependent atomics per lane) out of the set-up kernel.
-constexpr int SCAN_BLOCK = 256, WORK_CHUNK = 64;
+#ifndef DR_WORK_CHUNK
+#define DR_WORK_CHUNK 64
+#endif
+constexpr int SCAN_BLOCK = 256, WORK_CHUNK = DR_WORK_CHUNK;
 // One tile workgroup in `heavy_share` walks the list of the many-primitive tiles (the head of the grid: dispatched first).  One in
 // eight, unless the head of all views together would then take more than ~40 % of the chip's wave slots (5 120 at five waves per
 // SIMD): with every slot of the first dispatch round on a 25 - 50 us tile the short tiles -- whose arithmetic hides those tiles'
@@ -3438,8 +3444,11 @@ __global__ __launch_bounds__(64, 6) void raster_bwd_fast_kernel(KParams p)
 	}
 }
 
+#ifndef DR_EDGE_OCC
+#define DR_EDGE_OCC 4 // waves per SIMD of the untextured edge kernel (3: no spills, 5: more) -- swept, 4 stays
+#endif
 template <class PixT, bool TEX>
-__global__ __launch_bounds__(64, TEX ? 2 : 4) void raster_bwd_edge_kernel(KParams p)
+__global__ __launch_bounds__(64, TEX ? 2 : DR_EDGE_OCC) void raster_bwd_edge_kernel(KParams p)
 { // persistent waves over the lists of tiles that hold silhouette edges (built by tile_scan_kernel).  Grid (views, waves):
   // the first waves dispatched are wave 0 of every view, and every wave starts with the many-edged tiles -- the kernel
   // lasts as long as its slowest tile, so those must not start late.  Wave g takes the work items g, g + gridDim.y, ...
