@@ -1617,7 +1617,7 @@ constexpr int SCAN_BLOCK = 256, WORK_CHUNK = DR_WORK_CHUNK;
 // eight, unless the head of all views together would then take more than ~40 % of the chip's wave slots (5 120 at five waves per
 // SIMD): with every slot of the first dispatch round on a 25 - 50 us tile the short tiles -- whose arithmetic hides those tiles'
 // round trips -- start late.  Measured on the 8-view benchmark step: 1/8 0.183 ms, 1/12 0.1775, 1/16 0.1767, 1/24 0.1784; on one
-// 2048^2 view (2 048 head workgroups at 1/8) 1/16 costs 4 %.
+// 2048^2 view (2 048 head workgroups at 1/8) 1/16 costs 4 %; on one 1024^2 view 1/2 0.0775, 1/4 0.0772, 1/8 0.0809, 1/16 0.090 ms.
 #ifndef DR_HEAVY_SHARE
 #define DR_HEAVY_SHARE 0 // measurement builds: a fixed share
 #endif
@@ -1625,7 +1625,12 @@ __host__ inline int heavy_share_for(int n_views, int tile_blocks)
 {
 	if (DR_HEAVY_SHARE)
 		return DR_HEAVY_SHARE;
-	return (long long)n_views * (tile_blocks / 8) > 2048 ? 16 : 8;
+	// ~2 048 head workgroups over all views (40 % of the wave slots), the share a power of two between 1/4 and 1/16
+	const long long want = ((long long)n_views * tile_blocks + 2047) / 2048;
+	int share = 4;
+	while (share < 16 && share < want)
+		share *= 2;
+	return share;
 }
 
 __global__ __launch_bounds__(SCAN_BLOCK) void tile_scan_kernel(KParams p)
