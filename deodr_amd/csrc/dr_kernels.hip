@@ -545,8 +545,12 @@ __device__ __forceinline__ PrimWork prim_work(const KParams &p, bool edge_first 
 	const bool in_first = b < first;
 	if (!in_first)
 		b -= first;
-	w.view = b % nv;
-	w.index = b / nv;
+#ifndef DR_VIEW_MAJOR
+#define DR_VIEW_MAJOR 0 // measurement builds: 1 = all blocks of a view, then the next view (instead of views fastest)
+#endif
+	const int per_view = in_first == edge_first ? EB : TBk; // blocks per view of this block's class
+	w.view = DR_VIEW_MAJOR ? b / per_view : b % nv;
+	w.index = DR_VIEW_MAJOR ? b % per_view : b / nv;
 	w.tri = edge_first ? !in_first : in_first;
 	w.view_block = w.tri ? w.index : TBk + w.index;
 	return w;
