@@ -706,7 +706,7 @@ __global__ __launch_bounds__(PRIM_BLOCK, DR_PRIM_WAVES) void setup_bin_kernel(KP
 				const int tx = tx0 + t % ntx, ty = ty0 + t / ntx, tile = ty * p.L.tiles_x + tx;
 				if (tri_block)
 				{
-					if (!tile_outside_halfplanes<3>(q, tx, ty))
+					if (!tile_outside_halfplanes<3>(q, tx, ty) || (!p.strict && tx == tx0 + ntx - 1))
 						push_tile(w.tri_cnt, w.tri_list, K_TRI, w.tri_pool, p.L.tri_pool_cap, &w.hdr->tri_spill[cur], tile, prim);
 				}
 				else if (!tile_outside_halfplanes<4>(q, tx, ty))
@@ -746,6 +746,11 @@ __global__ __launch_bounds__(PRIM_BLOCK, DR_PRIM_WAVES) void setup_bin_kernel(KP
 			const double eq[9] = {rec.eq[0][0], rec.eq[0][1], rec.eq[0][2], rec.eq[1][0], rec.eq[1][1], rec.eq[1][2], rec.eq[2][0], rec.eq[2][1], rec.eq[2][2]};
 			const int tx0 = x0 / TILE, ty0 = y0 / TILE, ntx = x1 / TILE - tx0 + 1, nty = y1 / TILE - ty0 + 1;
 			const bool large = on_screen && ((ntx + 2) / 3) * ((nty + 2) / 3) > COOP_BLOCKS;
+			// Non-strict fill rule: get_xrange's ceil_div clamps the left end of a row to x_max (H.h:895), so a row whose span lies
+			// wholly between x_max and the rightmost vertex -- or beyond the right border of the frame -- still draws the pixel of
+			// column x_max although that pixel is outside the left edge.  tri_half_span reproduces it; the half-plane test must
+			// then not drop the tiles of that column.
+			const int keep_dx = s.strict ? -1 : ntx - 1;
 			// The slot requests of the first 3 x 3 block of tiles (for the usual small triangle: all of them) leave NOW, before the
 			// attribute planes are formed and the record is stored: that arithmetic and those stores then overlap the round trip
 			// of the requests (5.5 of the 12.6 us of a triangle wavefront, tools/wave_trace.py) instead of preceding it.
@@ -761,7 +766,7 @@ __global__ __launch_bounds__(PRIM_BLOCK, DR_PRIM_WAVES) void setup_bin_kernel(KP
 				for (int q = 0; q < 9; q++)
 				{
 					const int dx = q % 3, dy = q / 3;
-					use0[q] = dx < ntx && dy < nty && !((outside >> q) & 1u);
+					use0[q] = dx < ntx && dy < nty && (!((outside >> q) & 1u) || dx == keep_dx);
 					if (use0[q])
 						slot0[q] = atomicAdd(&w.tri_cnt[(ty0 + dy) * p.L.tiles_x + tx0 + dx], 1u);
 				}
@@ -802,7 +807,7 @@ __global__ __launch_bounds__(PRIM_BLOCK, DR_PRIM_WAVES) void setup_bin_kernel(KP
 					for (int q = 0; q < 9; q++)
 					{
 						const int dx = bx + q % 3, dy = by + q / 3;
-						use[q] = dx < ntx && dy < nty && !((outside >> q) & 1u);
+						use[q] = dx < ntx && dy < nty && (!((outside >> q) & 1u) || dx == keep_dx);
 						slot[q] = 0;
 						if (use[q])
 							slot[q] = atomicAdd(&w.tri_cnt[(ty0 + dy) * p.L.tiles_x + tx0 + dx], 1u);

@@ -252,6 +252,14 @@ def port(fixed=False):
     return _cache["port"]
 
 
+def min_abs_T(reset=True):
+    """Smallest |T| the restatement's adjoint divided by since the last reset (diagnostic: see deodr_oracle_min_abs_T)."""
+    lib = port().lib
+    lib.deodr_oracle_min_abs_T.restype = C.c_double
+    lib.deodr_oracle_min_abs_T.argtypes = [C.c_int]
+    return float(lib.deodr_oracle_min_abs_T(int(reset)))
+
+
 def ref(fixed=False):
     """The real reference (or None when oracle/_ref was never built and /root/reference is absent).
 

@@ -47,6 +47,18 @@ static int g_reference_defects = 1;
 const char *deodr_oracle_last_error(void) { return g_error; }
 void deodr_oracle_set_reference_defects(int on) { g_reference_defects = on; }
 
+/* Diagnostic for the tests: the smallest |T| (edge transparency) met by the adjoint's un-blending since the last reset.  The
+ * reference divides by T there (H.h:1738, 2015: `image = (image - (1 - T) * A) / T`); a pixel centre exactly on the line of a
+ * silhouette edge has T == 0 (NaN gradients) or T ~ 1e-17 (rounding noise divided by T): integer vertex coordinates do that. */
+static double g_min_abs_T = 1e300;
+double deodr_oracle_min_abs_T(int reset)
+{
+	const double v = g_min_abs_T;
+	if (reset)
+		g_min_abs_T = 1e300;
+	return v;
+}
+
 #define MAXC 64 /* channels; the reference heap-allocates per call, we bound it */
 
 /* ---------------------------------------------------------------------------------------------- 3x3 algebra */
@@ -811,6 +823,8 @@ static void do_edge(const OScene *sc, int k, int n, double off, double sigma, do
 			if (!(Z < z_buffer[indx]))
 				continue;
 			const double T = T0y + T_inc * x;
+			if (backward && fabs(T) < g_min_abs_T)
+				g_min_abs_T = fabs(T);
 			double L = 0, UV[2] = {0, 0}, L_B = 0, T_B = 0;
 			double *px = image + nc * indx;
 			if (textured)

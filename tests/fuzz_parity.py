@@ -1,0 +1,113 @@
+"""Randomised parity sweep (not collected by pytest; run on the GPU box):  python tests/fuzz_parity.py [n_scenes]
+
+Random triangle soups of random sizes / densities / flags / channel counts / view counts: forward-only call, one-call fit step
+and two-call adjoint of the HIP library against the CPU checker (oracle/).  Prints the worst errors; exits non-zero on a miss."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.dirname(HERE))
+from deodr_amd import scenes  # noqa: E402
+from deodr_amd.hip_renderer import HipRasterizer  # noqa: E402
+from hip_util import device_scene, rel_err  # noqa: E402
+from oracle import api  # noqa: E402
+
+
+def draw_scene(it, rs, replay=False):
+    """Scene number `it` of the sweep: (views, sigma, pixel dtype, description).  With replay=True the stream `rs` is advanced
+    through scenes 0 .. it-1 first, so that a single scene of a run can be re-created."""
+    for skip in range(it if replay else 0):
+        draw_scene(skip, rs)
+    H, W = int(rs.choice([24, 40, 61, 96, 128, 200])), int(rs.choice([24, 48, 77, 96, 160, 256]))
+    n_tri = int(rs.choice([1, 3, 12, 40, 150, 400]))
+    n_views = int(rs.choice([1, 1, 2, 3, 5]))
+    sigma = float(rs.choice([0.0, 0.7, 1.0, 2.5]))
+    dt = torch.float64 if rs.rand() < 0.5 else torch.float32
+    textured = float(rs.choice([0.0, 0.0, 0.5, 1.0]))
+    tex_size, min_area = int(rs.choice([8, 16, 33])), float(rs.choice([2.0, 30.0, 300.0]))
+    rounded, strict = it % 4 == 1, it % 5 != 2
+    if rounded and not strict:
+        strict = True  # integer vertices under the non-strict rule: the reference's adjoint counts the middle-vertex row twice
+    background_color = None  # one colour for all the views of a scene (the scene holds one)
+    views = []
+    for v in range(n_views):
+        s = scenes.soup_scene(n_tri=n_tri, width=W, height=H, seed=1000 * it + 7, clockwise=bool(it & 1), textured_ratio=textured, flat=False,
+                              texture_size=tex_size, min_area=min_area)
+        if v:  # other views: the same mesh, vertices moved
+            s.ij = s.ij + rs.randn(*s.ij.shape) * 2.0
+        if rounded:
+            s.ij = np.round(s.ij)  # integer vertices: every tie of the fill rule
+        if it % 3 == 0:
+            colour = rs.rand(3)
+            background_color = colour if background_color is None else background_color
+            s.background_image, s.background_color = None, background_color
+        s.strict_edge, s.integer_pixel_centers, s.backface_culling = bool(strict), bool(it % 7 != 3), True
+        views.append(s)
+    desc = (f"H={H} W={W} n_tri={n_tri} views={n_views} sigma={sigma} dt={dt} textured={textured} tex={tex_size} min_area={min_area} round={rounded} "
+            f"bgcolor={background_color is not None} strict={strict} intpix={views[0].integer_pixel_centers} cw={bool(it & 1)}")
+    obs = rs.rand(n_views, H, W, 3)
+    return views, sigma, dt, desc, obs
+
+
+def main(n):
+    ref = api.ref() or api.port()
+    fixed = api.ref(fixed=True) or api.port(fixed=True)
+    worst = dict(image=0.0, ij_b=0.0, colors_b=0.0, uv_b=0.0, texture_b=0.0, flips=0)
+    rs = np.random.RandomState(12345)
+    misses = on_the_line = 0
+    for it in range(n):
+        views, sigma, dt, desc, obs_host = draw_scene(it, rs)
+        n_views, H, W = len(views), views[0].height, views[0].width
+        textured = views[0].textured.any()
+        ds = device_scene(views, dt)
+        r = HipRasterizer.for_scene(ds)
+        obs = torch.as_tensor(obs_host, device=ds.device, dtype=dt)
+        image, z, g = r.render_fit(ds, obs, sigma, check_overflow=True, clear_grads=True)
+        image2, z2 = r.render(ds, sigma)
+        g2 = r.render_backward(ds, residual_obs=obs)
+        torch.cuda.synchronize()
+        assert torch.equal(image, image2) and torch.equal(z, z2), (it, "fit frame != forward-only frame")
+        tol_img, tol = (1e-9, 1e-8) if dt == torch.float64 else (1e-5, 1e-4)
+        uv_ref = tex_ref = 0
+        unchecked = False
+        before = dict(worst)
+        for i, s in enumerate(views):
+            img_ref, z_ref = ref.render(s, sigma)
+            e = np.abs(image[i].cpu().numpy() - img_ref).max()
+            worst["image"] = max(worst["image"], e / tol_img)
+            worst["flips"] += int((np.isinf(z[i].cpu().numpy()) != np.isinf(z_ref)).sum())
+            image_b = 2 * (image[i].cpu().numpy().astype(np.float64) - obs[i].cpu().numpy().astype(np.float64))
+            if "round=True" in desc and sigma > 0:
+                # a pixel centre exactly on the line of a silhouette edge: the reference un-blends with a division by T = 0 (NaN) or
+                # T ~ 1e-15 (rounding noise / T) -- its gradient is not a checker there; the HIP adjoint must still be finite
+                api.min_abs_T()
+                api.port().grads(s, sigma, img_ref.copy(), z_ref, image_b.copy())
+                if api.min_abs_T() < 1e-9:
+                    assert all(bool(torch.isfinite(g[k][i]).all()) for k in ("ij_b", "colors_b")), (it, i, "non-finite gradient")
+                    on_the_line += 1
+                    unchecked = True
+                    continue
+            g_ref, g_fix = ref.grads(s, sigma, img_ref, z_ref, image_b), fixed.grads(s, sigma, img_ref, z_ref, image_b)
+            for k in ("ij_b", "colors_b"):
+                worst[k] = max(worst[k], rel_err(g[k][i].cpu().numpy(), g_ref[k]) / tol, rel_err(g2[k][i].cpu().numpy(), g_ref[k]) / tol)
+            uv_ref = uv_ref + g_ref["uv_b"]
+            tex_ref = tex_ref + g_fix["texture_b"]
+        if textured and not unchecked:
+            worst["uv_b"] = max(worst["uv_b"], rel_err(g["uv_b"].cpu().numpy(), uv_ref) / tol)
+            if g["texture_b"] is not None and np.abs(tex_ref).max() > 0:
+                worst["texture_b"] = max(worst["texture_b"], rel_err(g["texture_b"].cpu().numpy(), tex_ref) / tol)
+        if any(worst[k] > 1 and worst[k] > before[k] for k in worst if k != "flips") or worst["flips"] > before["flips"]:
+            print(f"MISS it={it} {desc}: " + str({k: (round(float(worst[k]), 2)) for k in worst}), flush=True)
+            misses += 1
+            worst.update(before)
+    print(f"({on_the_line} views with a pixel centre on an edge line: gradients only checked for finiteness)")
+    print(f"{n} random scenes, {misses} missed; worst error / tolerance of the others:", {k: (round(float(v), 3) if k != "flips" else v) for k, v in worst.items()})
+    return misses
+
+
+if __name__ == "__main__":
+    sys.exit(1 if main(int(sys.argv[1]) if len(sys.argv) > 1 else 60) else 0)

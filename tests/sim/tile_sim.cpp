@@ -46,6 +46,7 @@ static SceneView view_of(const SimScene *s)
 	v.P = planes_per_prim(s->C);
 	v.tex_h = s->tex_h;
 	v.tex_w = s->tex_w;
+	v.has_texture = s->tex_h > 0 && s->tex_w > 0;
 	v.clockwise = s->clockwise;
 	v.culling = s->culling;
 	v.strict = s->strict;
@@ -90,8 +91,8 @@ void sim_bin_counts(const SimScene *s, int tile, int exact, uint32_t *tri_cnt, u
 			if (x0 <= x1 && y0 <= y1)
 				for (int ty = y0 / tile; ty <= y1 / tile; ty++)
 					for (int tx = x0 / tile; tx <= x1 / tile; tx++)
-						if (!exact || !tile_outside(&rec.eq[0][0], 3, tx, ty, tile))
-							tri_cnt[ty * tiles_x + tx]++;
+						if (!exact || !tile_outside(&rec.eq[0][0], 3, tx, ty, tile) || (!v.strict && tx == x1 / tile))
+							tri_cnt[ty * tiles_x + tx]++; // (the column of x_max under the non-strict rule: see setup_bin_kernel)
 		}
 		for (int n = 0; n < 3; n++)
 		{

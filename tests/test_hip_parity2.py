@@ -646,3 +646,14 @@ def test_two_call_path_under_hip_graph_capture(oracle_api):
     assert torch.equal(image, eager[0]) and torch.equal(z, eager[1])
     for k, v in eager[2].items():
         assert rel_err(grads[k].cpu().numpy(), v.cpu().numpy()) < 1e-12, k
+
+
+@pytest.mark.parametrize("seed,n_tri,size", [(7, 60, (32, 40)), (32007, 150, (200, 96)), (27007, 400, (24, 96))])
+def test_non_strict_rule_draws_the_clamped_column(oracle_api, family, seed, n_tri, size):
+    """strict_edge=False: the reference clamps the left end of a row to x_max (ceil_div, H.h:895), so rows whose span lies
+    between x_max and the rightmost vertex -- or beyond the right border of the frame -- draw the pixel of column x_max although
+    it is outside the left edge.  The tile binning must keep that column (found by tests/fuzz_parity.py: scenes 27 and 32)."""
+    s = scenes.soup_scene(n_tri=n_tri, width=size[1], height=size[0], seed=seed, clockwise=bool(seed & 1), textured_ratio=0.5, flat=False,
+                          texture_size=8, min_area=30.0)
+    s.strict_edge = False
+    compare_all(oracle_api, s, 1.0, F64)

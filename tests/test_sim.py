@@ -55,3 +55,38 @@ def test_span_functions_match_oracle_coverage(oracle_api, case, strict):
         lib.sim_edge_coverage(C.byref(c), 0, n, emask.ctypes.data)
         # the band also extends over the triangle itself only where Z_edge < z (never here: same depth), so compare outside
         assert np.array_equal(emask.astype(bool) & ~np.isfinite(z), band), n
+
+
+@pytest.mark.parametrize("strict", [True, False])
+def test_binning_keeps_every_tile_a_triangle_draws_into(oracle_api, strict):
+    """The half-plane rejection of setup_bin_kernel must never drop a tile the reference's spans reach -- including the pixel of
+    column x_max that the non-strict rule draws OUTSIDE the left edge (ceil_div clamps to x_max, H.h:895): near the rightmost
+    vertex, and along the right border for a triangle that leaves the frame there."""
+    import ctypes as C
+
+    rs = np.random.RandomState(5)
+    lib = sim_util.lib()
+    tile, W, H = 8, 40, 32
+    clamp_cases = 0
+    tris = [[[30.3, 20.7], [48.5, 9.1], [39.9, -2.3]], [[20.2, 14.7], [17.9, 10.4], [31.6, 6.7]]]  # both draw column x_max outside the left edge
+    tris += [(rs.rand(2) * [W, H] + (rs.rand(3, 2) - 0.5) * [W, H] * rs.choice([0.3, 1.0, 2.5])).tolist() for _ in range(300)]
+    for ij in tris:
+        s = one_triangle_scene(ij, W=W, H=H, strict=strict)
+        c, keep = sim_util.sim_scene(s, sigma=1.0)
+        mask = np.zeros((H, W), dtype=np.uint8)
+        lib.sim_tri_coverage(C.byref(c), 0, mask.ctypes.data)
+        tri_cnt, _ = sim_util.bin_counts(s, sigma=1.0, tile=tile, exact=True)
+        tri_cnt = tri_cnt.reshape((H + tile - 1) // tile, (W + tile - 1) // tile)
+        ys, xs = np.nonzero(mask)
+        assert np.all(tri_cnt[ys // tile, xs // tile] == 1), ij
+        # how often the clamp artefact occurs in this sample: drawn pixels left of the left edge by geometry
+        e = np.asarray(ij, dtype=np.float64)
+        inside = np.ones(len(xs), dtype=bool)
+        for a, b in ((0, 1), (1, 2), (2, 0)):
+            cr = (e[b, 0] - e[a, 0]) * (ys - e[a, 1]) - (e[b, 1] - e[a, 1]) * (xs - e[a, 0])
+            inside &= (cr >= 0) if s.clockwise else (cr <= 0)
+        clamp_cases += int((~inside).sum() > 0)
+    if not strict:
+        assert clamp_cases >= 2  # the sample does exercise the artefact
+    else:
+        assert clamp_cases == 0
