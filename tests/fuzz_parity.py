@@ -1,7 +1,9 @@
-"""Randomised parity sweep (not collected by pytest; run on the GPU box):  python tests/fuzz_parity.py [n_scenes]
+"""Randomised parity sweep (not collected by pytest; run on the GPU box):  python tests/fuzz_parity.py [n_scenes [soups|meshes|both]]
 
-Random triangle soups of random sizes / densities / flags / channel counts / view counts: forward-only call, one-call fit step
-and two-call adjoint of the HIP library against the CPU checker (oracle/).  Prints the worst errors; exits non-zero on a miss."""
+Random triangle soups of random sizes / densities / flags / view counts, and random views of bumpy spheres (shared vertices,
+silhouette edges, 1-6 channels, zoomed past the frame): forward-only call, one-call fit step, two-call adjoint, antialiase_error
+forward + adjoint and perspective-correct forward of the HIP library against the CPU checker (oracle/).  Prints the worst errors;
+exits non-zero on a miss."""
 import os
 import sys
 
@@ -109,5 +111,98 @@ def main(n):
     return misses
 
 
+def draw_mesh_scene(it):
+    """Scene number `it` of the mesh sweep: views of a bumpy sphere (shared vertices, silhouette edges only), zoomed so that it may
+    leave the frame; -> (views, sigma, pixel dtype, mode, description)."""
+    rs = np.random.RandomState(7000 + it)
+    H, W = int(rs.choice([32, 64, 100, 150, 256])), int(rs.choice([32, 64, 100, 150, 256]))
+    nu, n_rings = [(6, 5), (12, 10), (24, 16), (40, 30)][rs.randint(4)]
+    nb_colors = int(rs.choice([1, 2, 3, 4, 6]))
+    textured = bool(rs.rand() < 0.4)
+    n_views = int(rs.choice([1, 2, 4]))
+    sigma = float(rs.choice([0.0, 0.5, 1.0, 2.0]))
+    dt = torch.float64 if rs.rand() < 0.5 else torch.float32
+    mode = ["image", "image", "error", "persp"][rs.randint(4)]
+    zoom, fov = float(rs.choice([0.7, 1.0, 1.5])), float(rs.choice([30.0, 60.0]))
+    vertices, faces = scenes.bumpy_sphere(nu, n_rings, bump=float(rs.rand() * 0.3))
+    tilt, views, clockwise, texture_size = rs.rand(2), [], None, int(rs.choice([8, 32]))
+    for v in range(n_views):
+        rot = scenes.rotx(0.2 + tilt[0]) @ scenes.roty(0.1 + tilt[1] + 0.4 * v)
+        s = scenes.mesh_scene(vertices, faces, W, H, nb_colors=nb_colors, rot=rot, fov=fov, seed=it, textured=textured, texture_size=texture_size,
+                              clockwise=clockwise)
+        clockwise = s.clockwise
+        centre = np.array([W / 2.0, H / 2.0])
+        s.ij = centre + (s.ij - centre) * zoom
+        s.integer_pixel_centers = bool(it % 3 != 1)
+        s.perspective_correct = mode == "persp"
+        views.append(s)
+    desc = (f"mesh H={H} W={W} sphere={nu}x{n_rings} C={nb_colors} textured={textured} views={n_views} sigma={sigma} dt={dt} mode={mode} zoom={zoom} "
+            f"fov={fov} intpix={views[0].integer_pixel_centers}")
+    return views, sigma, dt, mode, desc
+
+
+def main_meshes(n):
+    """image mode: as main(); error mode: antialiase_error forward + adjoint against the repaired checker; persp mode: forward only"""
+    ref = api.ref() or api.port()
+    fixed = api.ref(fixed=True) or api.port(fixed=True)
+    worst = dict(image=0.0, err_buffer=0.0, ij_b=0.0, colors_b=0.0, shade_b=0.0, uv_b=0.0, texture_b=0.0, flips=0)
+    misses = 0
+    for it in range(n):
+        views, sigma, dt, mode, desc = draw_mesh_scene(it)
+        rs = np.random.RandomState(9000 + it)
+        n_views, H, W, C = len(views), views[0].height, views[0].width, views[0].nb_colors
+        ds = device_scene(views, dt)
+        r = HipRasterizer.for_scene(ds)
+        obs_host = rs.rand(n_views, H, W, C)
+        err_b_host = rs.rand(n_views, H, W)
+        obs = torch.as_tensor(obs_host, device=ds.device, dtype=dt)
+        tol_img, tol = (1e-9, 1e-8) if dt == torch.float64 else (1e-5, 1e-4)
+        before = dict(worst)
+        sums = dict(uv_b=0, texture_b=0)
+        if mode == "image":
+            image, z, g = r.render_fit(ds, obs, sigma, check_overflow=True, clear_grads=True)
+            g2 = r.render_backward(ds, residual_obs=obs)
+        elif mode == "error":
+            image, z, err = r.render(ds, sigma, True, obs, check_overflow=True)
+            g = g2 = r.render_backward(ds, err_buffer_b=torch.as_tensor(err_b_host, device=ds.device, dtype=dt))
+        else:
+            image, z = r.render(ds, sigma, check_overflow=True)
+            g = g2 = None
+        torch.cuda.synchronize()
+        for i, s in enumerate(views):
+            out_ref = ref.render(s, sigma, mode == "error", obs_host[i] if mode == "error" else None)
+            img_ref, z_ref = out_ref[0], out_ref[1]
+            worst["image"] = max(worst["image"], np.abs(image[i].cpu().numpy() - img_ref).max() / tol_img)
+            worst["flips"] += int((np.isinf(z[i].cpu().numpy()) != np.isinf(z_ref)).sum())
+            if mode == "persp":
+                continue
+            if mode == "error":
+                worst["err_buffer"] = max(worst["err_buffer"], np.abs(err[i].cpu().numpy() - out_ref[2]).max() / (10 * tol_img * max(1.0, out_ref[2].max())))
+                g_fix = fixed.grads(s, sigma, img_ref, z_ref, None, True, obs_host[i], out_ref[2], err_b_host[i])
+                g_ref = g_fix  # defect D2 touches colors_b: every gradient against the repaired checker
+            else:
+                image_b = 2 * (image[i].cpu().numpy().astype(np.float64) - obs[i].cpu().numpy().astype(np.float64))
+                g_ref, g_fix = ref.grads(s, sigma, img_ref, z_ref, image_b), fixed.grads(s, sigma, img_ref, z_ref, image_b)
+            for k in ("ij_b", "colors_b", "shade_b"):
+                for gg in (g, g2):
+                    if np.abs(g_ref[k]).max() > 0 or float(gg[k][i].abs().max()) > 0:
+                        worst[k] = max(worst[k], rel_err(gg[k][i].cpu().numpy(), g_ref[k]) / tol)
+            sums["uv_b"] = sums["uv_b"] + g_ref["uv_b"]
+            sums["texture_b"] = sums["texture_b"] + g_fix["texture_b"]
+        if mode != "persp" and views[0].textured.any():
+            for k in ("uv_b", "texture_b"):
+                if g[k] is not None and np.abs(sums[k]).max() > 0:
+                    worst[k] = max(worst[k], rel_err(g[k].cpu().numpy(), sums[k]) / tol)
+        if any(worst[k] > 1 and worst[k] > before[k] for k in worst if k != "flips") or worst["flips"] > before["flips"]:
+            print(f"MISS it={it} {desc}: " + str({k: (round(float(worst[k]), 2)) for k in worst}), flush=True)
+            misses += 1
+            worst.update(before)
+    print(f"{n} random mesh scenes, {misses} missed; worst error / tolerance of the others:", {k: (round(float(v), 3) if k != "flips" else v) for k, v in worst.items()})
+    return misses
+
+
 if __name__ == "__main__":
-    sys.exit(1 if main(int(sys.argv[1]) if len(sys.argv) > 1 else 60) else 0)
+    count = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+    which = sys.argv[2] if len(sys.argv) > 2 else "both"
+    missed = (main(count) if which in ("both", "soups") else 0) + (main_meshes(count) if which in ("both", "meshes") else 0)
+    sys.exit(1 if missed else 0)
