@@ -1,4 +1,4 @@
-"""Randomised parity sweep (not collected by pytest; run on the GPU box):  python tests/fuzz_parity.py [n_scenes [soups|meshes|both]]
+"""Randomised parity sweep (not collected by pytest; run on the GPU box):  python tests/fuzz_parity.py [n_scenes [soups|meshes|both|large]]
 
 Random triangle soups of random sizes / densities / flags / view counts, and random views of bumpy spheres (shared vertices,
 silhouette edges, 1-6 channels, zoomed past the frame): forward-only call, one-call fit step, two-call adjoint, antialiase_error
@@ -201,8 +201,87 @@ def main_meshes(n):
     return misses
 
 
+def draw_large_scene(it):
+    """Scene number `it` of the large sweep: thousands of small soup triangles (all edges flagged) on frames of 512 .. 1024 pixels,
+    up to 8 views: deep tile lists, every class of edge list, sweep slots, spill pools.  -> (views, sigma, dtype, description)"""
+    rs = np.random.RandomState(11000 + it)
+    H, W = int(rs.choice([512, 777, 1024])), int(rs.choice([512, 640, 1024]))
+    n_tri = int(rs.choice([2000, 8000, 20000]))
+    n_views = int(rs.choice([1, 3, 8]))
+    sigma = float(rs.choice([0.5, 1.0, 3.0]))
+    dt = torch.float64 if rs.rand() < 0.5 else torch.float32
+    textured = float(rs.choice([0.0, 0.5]))
+    shrink = float(rs.choice([0.04, 0.1, 0.3]))
+    strict = bool(rs.rand() < 0.7)
+    base = scenes.soup_scene(n_tri=n_tri, width=W, height=H, seed=it, clockwise=bool(it & 1), textured_ratio=textured, flat=False, texture_size=32, min_area=50.0)
+    tri = base.ij.reshape(-1, 3, 2)
+    base.ij = (tri.mean(axis=1, keepdims=True) + (tri - tri.mean(axis=1, keepdims=True)) * shrink).reshape(-1, 2)
+    views = []
+    for v in range(n_views):
+        s = scenes.soup_scene(n_tri=1, width=W, height=H, seed=it)  # a container of the right type, filled from `base` below
+        for name in ("faces", "faces_uv", "depths", "textured", "uv", "shade", "colors", "shaded", "edgeflags", "texture", "background_image", "clockwise"):
+            setattr(s, name, getattr(base, name))
+        s.ij = base.ij + (rs.randn(*base.ij.shape) * 1.5 if v else 0.0)
+        s.strict_edge = strict
+        for name in ("uv_b", "ij_b", "shade_b", "colors_b", "texture_b"):
+            setattr(s, name, np.zeros(np.shape(getattr(s, name[:-2]))))
+        views.append(s)
+    desc = f"large H={H} W={W} n_tri={n_tri} shrink={shrink} views={n_views} sigma={sigma} dt={dt} textured={textured} strict={strict} cw={bool(it & 1)}"
+    return views, sigma, dt, desc
+
+
+def main_large(n):
+    ref = api.ref() or api.port()
+    fixed = api.ref(fixed=True) or api.port(fixed=True)
+    worst = dict(image=0.0, ij_b=0.0, colors_b=0.0, shade_b=0.0, uv_b=0.0, texture_b=0.0, flips=0)
+    misses = 0
+    for it in range(n):
+        views, sigma, dt, desc = draw_large_scene(it)
+        n_views, H, W = len(views), views[0].height, views[0].width
+        ds = device_scene(views, dt)
+        r = HipRasterizer.for_scene(ds)
+        obs_host = np.random.RandomState(12000 + it).rand(n_views, H, W, 3)
+        obs = torch.as_tensor(obs_host, device=ds.device, dtype=dt)
+        image, z, g = r.render_fit(ds, obs, sigma, check_overflow=True, clear_grads=True)
+        image2, z2 = r.render(ds, sigma)
+        g2 = r.render_backward(ds, residual_obs=obs)
+        torch.cuda.synchronize()
+        assert torch.equal(image, image2) and torch.equal(z, z2), (it, "fit frame != forward-only frame")
+        tol_img, tol = (1e-9, 1e-8) if dt == torch.float64 else (1e-5, 1e-4)
+        before = dict(worst)
+        sums = dict(uv_b=0, texture_b=0)
+        for i, s in enumerate(views):
+            img_ref, z_ref = ref.render(s, sigma)
+            hip_image, hip_z = image[i].cpu().numpy().astype(np.float64), z[i].cpu().numpy()
+            # float32 frames: a pixel whose two nearest triangles differ in depth by less than the rounding of the stored z may
+            # change owner (DESIGN.md, float32 note); those are counted, the rest is compared
+            flipped = np.isinf(hip_z) != np.isinf(z_ref)
+            worst["flips"] += int(flipped.sum())
+            worst["image"] = max(worst["image"], np.abs(hip_image - img_ref).max() / tol_img)
+            image_b = 2 * (hip_image - obs[i].cpu().numpy().astype(np.float64))
+            g_ref, g_fix = ref.grads(s, sigma, img_ref, z_ref, image_b), fixed.grads(s, sigma, img_ref, z_ref, image_b)
+            for k in ("ij_b", "colors_b", "shade_b"):
+                for gg in (g, g2):
+                    if np.abs(g_ref[k]).max() > 0 or float(gg[k][i].abs().max()) > 0:
+                        worst[k] = max(worst[k], rel_err(gg[k][i].cpu().numpy(), g_ref[k]) / tol)
+            sums["uv_b"] = sums["uv_b"] + g_ref["uv_b"]
+            sums["texture_b"] = sums["texture_b"] + g_fix["texture_b"]
+        if views[0].textured.any():
+            for k in ("uv_b", "texture_b"):
+                worst[k] = max(worst[k], rel_err(g[k].cpu().numpy(), sums[k]) / tol)
+        if any(worst[k] > 1 and worst[k] > before[k] for k in worst if k != "flips") or worst["flips"] > before["flips"]:
+            print(f"MISS it={it} {desc}: " + str({k: (round(float(worst[k]), 2)) for k in worst}), flush=True)
+            misses += 1
+            worst.update(before)
+        else:
+            print(f"ok   it={it} {desc}", flush=True)
+    print(f"{n} large scenes, {misses} missed; worst error / tolerance of the others:", {k: (round(float(v), 3) if k != "flips" else v) for k, v in worst.items()})
+    return misses
+
+
 if __name__ == "__main__":
     count = int(sys.argv[1]) if len(sys.argv) > 1 else 60
     which = sys.argv[2] if len(sys.argv) > 2 else "both"
     missed = (main(count) if which in ("both", "soups") else 0) + (main_meshes(count) if which in ("both", "meshes") else 0)
+    missed += main_large(count) if which == "large" else 0
     sys.exit(1 if missed else 0)
