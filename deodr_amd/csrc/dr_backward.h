@@ -1,0 +1,704 @@
+// deodr_amd/csrc/dr_backward.h -- part of the single translation unit dr_kernels.hip (device code, gfx950 / wave64).
+// The LDS-staged adjoint: raster_bwd_fast_kernel (pass 1) and raster_bwd_edge_kernel (pass 2, persistent waves over the edge tiles).
+#pragma once
+
+#include "dr_backward_generic.h"
+
+using namespace dr;
+
+namespace
+{
+
+// ---------------------------------------------------------------------------------- backward raster, LDS-staged fast path
+//
+// nb_colors <= 4, no antialiase_error, at most K_EDGE edges in the tile (other tiles call bwd_tile_generic).
+// Differences from the generic tile: edges are staged / ranked / span-tested exactly as in raster_fwd_fast_kernel, and the
+// segmented reductions "sum over the pixels of a primitive" are done with LDS atomics (ds_add_f64, one slot per distinct
+// primitive of the tile) followed by ONE global atomic per (primitive, moment), issued by 64 lanes in parallel -- instead
+// of a 64-lane butterfly per moment and primitive.
+
+constexpr int NMOM = 12; // moments per owner slot: 3 per channel (or 9 for a textured owner)
+
+struct alignas(16) BwdLds
+{
+	EdgeRec rec[TB];
+	double planes[TB * 12];
+	uint32_t ids[TB];
+	uint8_t cover[TILE][TB];
+	uint32_t order[TB];
+};
+
+__device__ __forceinline__ void lds_add(double *slot, double v)
+{
+	if (v != 0)
+		unsafeAtomicAdd(slot, v);
+}
+
+constexpr int RUNS = 32; // run totals flushed per pass: 32 x 12 doubles fit in the (by then idle) record staging area of the wave
+static_assert(RUNS * NMOM * sizeof(double) <= sizeof(WaveLds::rec) + sizeof(WaveLds::planes) && RUNS * 4 <= sizeof(WaveLds::cover), "LDS reuse");
+
+// Adjoint of pass 1 for one tile: g = dL/d(colour written by pass 1) of this lane's pixel, owned by triangle `owner`.
+// tab (RUNS * NMOM doubles) and own (RUNS words) are LDS scratch of this wave.  All 64 lanes must call it.
+template <class PixT, bool TEX>
+__device__ __forceinline__ void owner_adjoint(const KParams &p, const ViewPtrs &w, int lane, double x, double y, int owner, int kind, const double *g,
+											  const Tap &tap, double L, double *tab, uint32_t *own)
+{
+	const int C = p.C, P = p.L.P;
+	const PixT *texture = (const PixT *)p.texture;
+	PixT *texture_b = (PixT *)p.texture_b;
+	// per-pixel adjoint of the owner's (up to four) attribute planes; its moments  sum v * [x, y, 1]  over the owner's pixels
+	// are what the per-triangle finalize needs
+	double val[CH] = {0, 0, 0, 0};
+	// Texture gradient.  The taps of the 64 pixels of a tile fall into a small window of texels (a magnified texture: a
+	// dozen texels for 768 contributions), and atomics to one address serialise in the L2 at ~80 ns each: when the window
+	// fits the LDS scratch, the contributions are summed there (ds_add_f64) and each touched texel leaves with ONE global
+	// atomic -- "per-tile LDS partials before a single atomicAdd".
+	const bool textured = kind == KIND_TEXTURED && TEX;
+	int fu = 0, fv = 0, win_u0 = 0, win_v0 = 0, win_w = 0, win_h = 0;
+	bool windowed = false;
+	if (texture_b && __ballot(textured))
+	{
+		if (textured)
+		{
+			const int t0 = tap.idx[0] / C;
+			fv = t0 / p.tex_w;
+			fu = t0 - fv * p.tex_w;
+		}
+		int lo_u = textured ? fu : 0x7fffffff, lo_v = textured ? fv : 0x7fffffff, hi_u = textured ? fu : -1, hi_v = textured ? fv : -1;
+#pragma unroll
+		for (int d = 1; d < 64; d <<= 1)
+		{
+			lo_u = min(lo_u, __shfl_xor(lo_u, d, 64));
+			lo_v = min(lo_v, __shfl_xor(lo_v, d, 64));
+			hi_u = max(hi_u, __shfl_xor(hi_u, d, 64));
+			hi_v = max(hi_v, __shfl_xor(hi_v, d, 64));
+		}
+		win_u0 = lo_u, win_v0 = lo_v, win_w = hi_u - lo_u + 2, win_h = hi_v - lo_v + 2;
+		windowed = win_w * win_h * C <= RUNS * NMOM;
+		if (windowed)
+		{
+			lds_sync();
+			for (int i = lane; i < win_w * win_h * C; i += 64)
+				tab[i] = 0;
+			lds_sync();
+		}
+	}
+	if (textured)
+	{ // H.h:1320-1353
+		double L_B = 0, e_B[2] = {0, 0};
+		const int wbase = ((fv - win_v0) * win_w + (fu - win_u0)) * C;
+#pragma unroll
+		for (int cc = 0; cc < CH; cc++)
+			if (cc < C)
+			{
+				const double i00 = ldp(texture, tap.idx[0] + cc), i10 = ldp(texture, tap.idx[1] + cc);
+				const double i01 = ldp(texture, tap.idx[2] + cc), i11 = ldp(texture, tap.idx[3] + cc);
+				L_B += g[cc] * bilinear_mix(tap, i00, i10, i01, i11);
+				double wgt[4];
+				bilinear_mix_adjoint(tap, g[cc] * L, i00, i10, i01, i11, wgt, e_B);
+				if (windowed)
+				{
+					lds_add(&tab[wbase + cc], wgt[0]);
+					lds_add(&tab[wbase + C + cc], wgt[1]);
+					lds_add(&tab[wbase + win_w * C + cc], wgt[2]);
+					lds_add(&tab[wbase + win_w * C + C + cc], wgt[3]);
+				}
+				else if (texture_b)
+					texture_scatter(texture_b, tap, cc, wgt);
+			}
+		val[0] = tap.out[0] ? 0.0 : e_B[0];
+		val[1] = tap.out[1] ? 0.0 : e_B[1];
+		val[2] = L_B;
+	}
+	if (windowed)
+	{
+		lds_sync();
+		for (int i = lane; i < win_w * win_h * C; i += 64)
+		{
+			const double v = tab[i];
+			if (v != 0)
+			{
+				const int texel = i / C, c = i - texel * C, jv = texel / win_w, ju = texel - jv * win_w;
+				if (!(DR_ABLATE & 1048576)) // (measurement build: no texture-gradient atomics)
+					unsafeAtomicAdd(texture_b + (size_t)C * ((win_u0 + ju) + (size_t)p.tex_w * (win_v0 + jv)) + c, (PixT)v);
+			}
+		}
+		lds_sync(); // tab is reused for the run totals below
+	}
+	if (kind == KIND_INTERP)
+	{ // H.h:1024-1037
+#pragma unroll
+		for (int cc = 0; cc < CH; cc++)
+			if (cc < C)
+				val[cc] = g[cc];
+	}
+	// a run lies in one pixel row, so its y moment is y times its plain sum: two scanned values per plane, not three
+	constexpr int NSCAN = 2 * CH;
+	double sc[NSCAN];
+#pragma unroll
+	for (int q = 0; q < CH; q++)
+	{
+		sc[2 * q] = val[q] * x;
+		sc[2 * q + 1] = val[q];
+	}
+	// Segmented reduction over the pixels of each owner.  Inside a pixel row a triangle's pixels are runs of consecutive
+	// lanes, so: head-flag segmented inclusive scan over the 8 lanes of every row (3 DPP steps on the VALU, no LDS),
+	// then the last lane of each run adds the run total to the owner's accumulator (one global atomic per moment and run).
+	const int nm = 3 * P; // moments per owner in the global accumulator (P = max(C, 3) planes)
+	const int lx = lane & 7;
+	const int oid = (owner >= 0 && kind != KIND_NONE) ? owner : -1;
+	const int left_oid = dpp_i<0x111>(oid); // evaluated by ALL lanes: a DPP move under a divergent branch reads 0 from disabled lanes
+	const bool head = (lx == 0) | (left_oid != oid);
+	int f = head ? 1 : 0;
+#define DR_SEG_STEP(CTRL)                                                                                                    \
+	{                                                                                                                        \
+		const int tf = dpp_i<CTRL>(f);                                                                                       \
+		double t[NSCAN];                                                                                                     \
+		_Pragma("unroll") for (int i = 0; i < NSCAN; i++) t[i] = dpp_d<CTRL>(sc[i]);                                         \
+		/* the DPP moves above run with every lane enabled (a disabled source lane reads as 0); only the adds are masked */   \
+		if (!f)                                                                                                              \
+		{                                                                                                                    \
+			_Pragma("unroll") for (int i = 0; i < NSCAN; i++) sc[i] += t[i];                                                 \
+		}                                                                                                                    \
+		f = f ? f : tf;                                                                                                      \
+	}
+	DR_SEG_STEP(0x111)
+	DR_SEG_STEP(0x112)
+	DR_SEG_STEP(0x114)
+#undef DR_SEG_STEP
+	const int right_head = dpp_i<0x101>(head ? 1 : 0);
+	const bool tail = (lx == 7) | (right_head != 0);
+	// Run totals go through LDS so that the global atomics are issued moment-major by 64 lanes at once: the cost of an atomic
+	// instruction is per distinct cache line it touches, and the 3P moments of one owner are contiguous.
+	const bool emit = tail && oid >= 0;
+	unsigned long long emask = __ballot(emit);
+	while (emask)
+	{
+		const int my_run = __popcll(emask & ((1ull << lane) - 1ull));
+		const bool sel = ((emask >> lane) & 1ull) && my_run < RUNS;
+		const int total = __popcll(emask);
+		const int nrun = total < RUNS ? total : RUNS;
+		lds_sync();
+		if (sel)
+		{
+			own[my_run] = (uint32_t)oid;
+#pragma unroll
+			for (int q = 0; q < CH; q++)
+			{
+				tab[my_run * NMOM + 3 * q] = sc[2 * q];
+				tab[my_run * NMOM + 3 * q + 1] = sc[2 * q + 1] * y;
+				tab[my_run * NMOM + 3 * q + 2] = sc[2 * q + 1];
+			}
+		}
+		lds_sync();
+		// Runs of the same owner (one per pixel row it crosses) are merged before they leave the tile: lane 12 j + m sums moment m
+		// over the runs of the j-th distinct owner, five owners per atomic instruction.
+		const uint32_t own_l = lane < nrun ? own[lane] : 0xffffffffu;
+		uint32_t rem = (uint32_t)__ballot(lane < nrun);
+		while (rem)
+		{
+			constexpr int G = 5;
+			uint32_t gid[G], gmask[G];
+#pragma unroll
+			for (int j = 0; j < G; j++)
+			{
+				gid[j] = 0;
+				gmask[j] = 0;
+				if (rem)
+				{
+					const int lead = __ffs((int)rem) - 1;
+					gid[j] = (uint32_t)__builtin_amdgcn_readlane((int)own_l, lead);
+					gmask[j] = (uint32_t)__ballot(own_l == gid[j]) & rem;
+					rem &= ~gmask[j];
+				}
+			}
+			const int j = lane / NMOM, m = lane - j * NMOM;
+			uint32_t o = 0, mask = 0;
+#pragma unroll
+			for (int q = 0; q < G; q++)
+			{
+				o = j == q ? gid[q] : o;
+				mask = j == q ? gmask[q] : mask;
+			}
+			double acc = 0;
+			while (mask)
+			{
+				const int r = __ffs((int)mask) - 1;
+				mask &= mask - 1;
+				acc += tab[r * NMOM + m];
+			}
+#if !(DR_ABLATE & 128)
+			if (m < nm && acc != 0)
+				atomic_add_f64(w.tri_acc + (size_t)o * nm + m, acc);
+#endif
+		}
+		emask &= ~__ballot(sel);
+	}
+}
+
+// One tile of the adjoint.  EDGES = false: tiles without silhouette edges (the edge code is compiled out: half the
+// registers, twice the resident waves to hide the memory latency); EDGES = true: the tiles that have some.
+template <class PixT, bool EDGES, bool TEX>
+__device__ __forceinline__ void bwd_fast_tile(const KParams &p, const ViewPtrs &w, int view, int tx, int ty, int lane, BwdLds &S, EdgeSort *es, // es: only for EDGES
+											  int chunk = -1)
+{ // chunk >= 0: this wavefront is one of CHUNKS that may share the reverse sweep of a many-edged tile (batch `chunk` of it)
+	const int W = p.W, H = p.H, C = p.C, P = p.L.P;
+	const PixT *texture = (const PixT *)p.texture;
+	PixT *texture_b = (PixT *)p.texture_b;
+	const int tile = ty * p.L.tiles_x + tx;
+	const int x0 = tx * TILE, y0 = ty * TILE;
+	const int px = x0 + (lane & 7), py = y0 + (lane >> 3);
+	const bool inb = px < W && py < H;
+	const size_t pix = (size_t)py * W + px;
+	const size_t vpix = (size_t)view * H * W + pix;
+	const double x = px, y = py;
+	// the owner ids are requested together with the tile's edge count (one memory round trip instead of two)
+	const int32_t raw_owner = inb ? w.face_id[pix] : -1;
+	const uint32_t raw_nedge = (uint32_t)uniform((int)w.edge_saved[tile]);
+	const uint32_t sweep_slot = EDGES ? (uint32_t)uniform((int)w.edge_slot[tile]) : 0u;
+	const int nedge = (int)(raw_nedge & ~SWEEP_SAVED);
+	const bool sweep_saved = EDGES && (raw_nedge & SWEEP_SAVED) && sweep_slot;
+	if ((nedge > 0) != EDGES)
+		return; // the other kernel's tile
+	// batches of the reverse sweep this wavefront runs: all of them, or -- when the forward saved the colour after every batch
+	// -- only batch `chunk`
+	const int nbatch_all = (nedge + TB - 1) / TB;
+	uint32_t snap = 0;
+	if (EDGES && sweep_saved && chunk >= 0 && nbatch_all > 1)
+		snap = (uint32_t)uniform((int)*(const uint32_t *)(w.edge_sweep + (size_t)(sweep_slot - 1) * SWEEP_BYTES + SWEEP_SNAP));
+	const bool chunked = snap != 0;
+	if (EDGES && (chunked ? chunk >= nbatch_all : chunk > 0))
+		return; // nothing for this wavefront: the tile has fewer batches, or its sweep is not shared
+	const int b_hi = chunked ? chunk : nbatch_all - 1, b_lo = chunked ? chunk : 0;
+#ifdef DR_TILE_TRACE
+	uint32_t tr[8] = {0x7fc0beefu, (uint32_t)nedge, 0, 0, 0, 0, 0, 0};
+	const uint64_t tr0 = __builtin_readcyclecounter();
+#define DR_TRACE(i) tr[i] = (uint32_t)(__builtin_readcyclecounter() - tr0)
+#else
+#define DR_TRACE(i)
+#endif
+	int n_edges = 0;
+	if (EDGES && sweep_saved)
+	{ // the forward saved the blending order with its sweep
+		const uint32_t *order = (const uint32_t *)(w.edge_sweep + (size_t)(sweep_slot - 1) * SWEEP_BYTES + SWEEP_ORDER);
+		lds_sync();
+		for (int i = lane; i < nedge; i += 64)
+			es->sorted[i] = order[i];
+		lds_sync();
+		n_edges = nedge;
+	}
+	else if (EDGES)
+		n_edges = gather_sorted_edges(*es, w, p, tile, nedge, lane);
+	DR_TRACE(2);
+	if (EDGES && n_edges < 0)
+	{ // more than EMAX edges in one tile (or pool overflow): the un-staged code, right here (pathological and slow, but no
+	  // queue and no extra launch for the tiles that never exist in a real scene)
+		lds_sync();
+		bwd_tile_generic_impl<PixT, true, TEX>(p, view, tx, ty, lane, (volatile uint32_t *)es->sorted);
+		lds_sync();
+		return;
+	}
+	int owner = -1, kind = KIND_NONE;
+	unpack_owner(raw_owner, owner, kind);
+	if (__ballot(owner >= 0) == 0 && nedge == 0)
+		return;
+
+	double g[CH];
+	{
+		if (p.image_b)
+		{
+			const PixT *gin = (const PixT *)p.image_b + vpix * C;
+#pragma unroll
+			for (int cc = 0; cc < CH; cc++)
+				g[cc] = (cc < C && inb) ? (double)gin[cc] : 0.0;
+		}
+		else
+		{ // residual mode: dL/dimage of L = sum (image - obs)^2 formed on the fly from the rendered image and the observation
+			const PixT *im = (const PixT *)p.image_in + vpix * C, *ob = (const PixT *)p.obs + vpix * C;
+#pragma unroll
+			for (int cc = 0; cc < CH; cc++)
+				g[cc] = (cc < C && inb) ? 2 * ((double)im[cc] - (double)ob[cc]) : 0.0;
+		}
+	}
+	// what pass 1 left at this pixel
+	const double *planes = nullptr;
+	double zown = INFINITY;
+	Tap tap;
+	double L = 0, UV[2] = {0, 0};
+	if (owner >= 0)
+	{
+		planes = w.tri_planes + (size_t)owner * 3 * P;
+		if (kind == KIND_TEXTURED && TEX)
+			textured_tap(planes, x, y, false, 0.0, p.tex_w, p.tex_h, C, tap, L, UV);
+	}
+
+	// ---- adjoint of pass 2 (near -> far), TB staged edges at a time
+	if (EDGES && n_edges > 0)
+	{
+		// depth and un-antialiased colour of the pixel (only needed by the forward sweep and by the replay fallback)
+		double base[CH] = {0, 0, 0, 0};
+		auto pixel_base = [&]() {
+			if (owner >= 0)
+			{
+				zown = plane_at(w.tri_rec[owner].xZ, x, y);
+#pragma unroll
+				for (int cc = 0; cc < CH; cc++)
+					if (cc < C)
+						base[cc] = kind == KIND_TEXTURED && TEX ? textured_channel(texture, tap, cc) * L : interp_channel(planes, cc, x, y, false, 0.0);
+			}
+			else if (inb)
+			{
+#pragma unroll
+				for (int cc = 0; cc < CH; cc++)
+					if (cc < C)
+						base[cc] = background_channel<PixT>(p, view, pix, cc);
+			}
+		};
+		// pass A, far -> near: which edges are drawn over this pixel (bit j of tm[b] = edge 16 b + j in blending order)
+		// and the antialiased colour they leave -- read back when the forward raster saved its own sweep of this tile
+		uint32_t tm[EMAX / TB] = {0, 0, 0, 0, 0, 0, 0, 0};
+		static_assert(EMAX / TB == 8, "tm[] initialiser");
+		double cur[CH] = {0, 0, 0, 0};
+		const int nbatch = (n_edges + TB - 1) / TB;
+		bool have_base = !sweep_saved;
+		if (sweep_saved)
+		{
+			const char *slot = w.edge_sweep + (size_t)(sweep_slot - 1) * SWEEP_BYTES;
+			// the colour after the last batch this wavefront un-blends: the tile's final colour, or a snapshot
+			const double *after = (chunked && b_hi < nbatch - 1)
+									  ? (const double *)(w.edge_snap + (size_t)(snap - 1) * SNAP_BYTES) + (size_t)b_hi * CH * 64
+									  : (const double *)slot;
+#pragma unroll
+			for (int cc = 0; cc < CH; cc++)
+				cur[cc] = after[cc * 64 + lane];
+#pragma unroll
+			for (int q = 0; q < EMAX / TB; q++)
+				tm[q] = q < nbatch ? ((const uint16_t *)(slot + CH * 64 * sizeof(double)))[q * 64 + lane] : 0u;
+		}
+		else
+		{
+			pixel_base();
+#pragma unroll
+			for (int cc = 0; cc < CH; cc++)
+				cur[cc] = base[cc];
+		}
+		for (int b = 0; b < nbatch && !sweep_saved; b++)
+		{
+			const int first = b * TB, nb = n_edges - first < TB ? n_edges - first : TB;
+			const uint32_t ecov = stage_edge_batch(*(WaveLds *)&S, *es, w, P, first, nb, lane, x0, y0, W, inb);
+			uint32_t tmb = 0;
+			for (int j = 0; j < nb; j++)
+			{
+				const bool c = (ecov >> j) & 1u;
+				if (__ballot(c) == 0)
+					continue;
+				const EdgeRec &eq = S.rec[j];
+				if (c && plane_at(eq.xZ, x, y) < zown)
+				{
+					tmb |= 1u << j;
+					const double *qp = &S.planes[j * 12];
+					const double Tq = plane_at(eq.x2t, x, y);
+					Tap qtap;
+					double qL = 0, qUV[2];
+					if (eq.kind == KIND_TEXTURED && TEX)
+						textured_tap(qp, x, y, false, 0.0, p.tex_w, p.tex_h, C, qtap, qL, qUV);
+#pragma unroll
+					for (int cc = 0; cc < CH; cc++)
+						if (cc < C)
+						{
+							cur[cc] *= Tq;
+							cur[cc] += (1 - Tq) * edge_channel<PixT, TEX>(eq, qp, texture, qtap, qL, cc, x, y, false, 0.0);
+						}
+				}
+			}
+#pragma unroll
+			for (int bb = 0; bb < EMAX / TB; bb++)
+				tm[bb] = bb == b ? tmb : tm[bb];
+		}
+		DR_TRACE(3);
+		if (chunked && b_hi < nbatch - 1)
+		{ // the gradient that reaches batch b_hi has been attenuated by every nearer edge drawn over the pixel.  The transparency
+		  // planes of those edges are gathered into the (still idle) staging area with ONE round of loads: read from memory inside
+		  // the loop they were a dependent round trip per edge -- 34 of them for the first batch of a 50-edge tile, the longest
+		  // wavefront of the kernel (tools/tile_trace.py: 41 k cycles)
+			const int r0 = (b_hi + 1) * TB;
+			double *xt = (double *)&S.rec[0];
+			static_assert(sizeof(S.rec) + sizeof(S.planes) >= 3 * sizeof(double) * EMAX, "room for the transparency planes of a tile's edges");
+			lds_sync();
+			for (int i = lane; i < n_edges - r0; i += 64)
+			{
+				const EdgeRec &eq = w.edge_rec[es->sorted[r0 + i]];
+				xt[3 * i] = eq.x2t[0];
+				xt[3 * i + 1] = eq.x2t[1];
+				xt[3 * i + 2] = eq.x2t[2];
+			}
+			lds_sync();
+			for (int r = r0; r < n_edges; r++)
+			{
+				uint32_t bits = 0;
+#pragma unroll
+				for (int bb = 0; bb < EMAX / TB; bb++)
+					bits = bb == (r / TB) ? tm[bb] : bits;
+				const double Tq = plane_at(xt + 3 * (r - r0), x, y);
+				if ((bits >> (r % TB)) & 1u)
+				{
+#pragma unroll
+					for (int cc = 0; cc < CH; cc++)
+						g[cc] *= Tq;
+				}
+			}
+		}
+		// pass B, near -> far (H.h:2961-3052)
+		for (int b = b_hi; b >= b_lo; b--)
+		{
+			const int first = b * TB, nb = n_edges - first < TB ? n_edges - first : TB;
+			if (b < nbatch - 1 || sweep_saved) // the records of pass A's last batch (if it ran) are still in LDS
+			{
+				lds_sync();
+				if (lane < nb)
+					S.ids[lane] = es->sorted[first + lane];
+				lds_sync();
+				stage_batch(*(WaveLds *)&S, w.edge_rec, w.edge_planes, P, nb, lane);
+				lds_sync();
+			}
+			uint32_t tmb = 0;
+#pragma unroll
+			for (int bb = 0; bb < EMAX / TB; bb++)
+				tmb = bb == b ? tm[bb] : tmb;
+			for (int r = nb - 1; r >= 0; r--)
+			{
+				const bool hit = (tmb >> r) & 1u;
+				if (__ballot(hit) == 0)
+					continue;
+				const EdgeRec &e = S.rec[r];
+				const double *ep = &S.planes[r * 12];
+				// colour before this edge: un-blend like the reference (H.h:1738) when T is safely away from 0, otherwise
+				// replay every earlier edge from the un-antialiased colour (the reference yields inf / NaN there)
+				double prev[CH];
+				const double Tr_here = hit ? plane_at(e.x2t, x, y) : 1.0;
+				const bool need_replay = hit && !(Tr_here > 1e-6);
+#pragma unroll
+				for (int cc = 0; cc < CH; cc++)
+					prev[cc] = base[cc];
+				if (hit && !need_replay)
+				{
+					Tap utap;
+					double uL = 0, uUV[2];
+					if (e.kind == KIND_TEXTURED && TEX)
+						textured_tap(ep, x, y, false, 0.0, p.tex_w, p.tex_h, C, utap, uL, uUV);
+					const double inv_T = 1 / Tr_here; // one division for the C channels (the reference divides each: 1 ulp apart)
+#pragma unroll
+					for (int cc = 0; cc < CH; cc++)
+						if (cc < C)
+						{
+							prev[cc] = (cur[cc] - (1 - Tr_here) * edge_channel<PixT, TEX>(e, ep, texture, utap, uL, cc, x, y, false, 0.0)) * inv_T;
+							cur[cc] = prev[cc];
+						}
+				}
+				if (__ballot(need_replay))
+				{ // measure-zero event (pixel centre within 1e-6 sigma of the edge line): records straight from memory
+					if (!have_base)
+					{
+						pixel_base();
+						have_base = true;
+					}
+#pragma unroll
+					for (int cc = 0; cc < CH; cc++)
+						prev[cc] = need_replay ? base[cc] : prev[cc];
+					const int upto = first + r;
+					for (int q = 0; q < upto; q++)
+					{
+						uint32_t tq = 0;
+#pragma unroll
+						for (int bb = 0; bb < EMAX / TB; bb++)
+							tq = bb == (q / TB) ? tm[bb] : tq;
+						if (!need_replay || !((tq >> (q % TB)) & 1u))
+							continue;
+						const uint32_t sq = es->sorted[q];
+						const EdgeRec &eq = w.edge_rec[sq];
+						const double *qp = w.edge_planes + (size_t)sq * 3 * P;
+						const double Tq = plane_at(eq.x2t, x, y);
+						Tap qtap;
+						double qL = 0, qUV[2];
+						if (eq.kind == KIND_TEXTURED && TEX)
+							textured_tap(qp, x, y, false, 0.0, p.tex_w, p.tex_h, C, qtap, qL, qUV);
+#pragma unroll
+						for (int cc = 0; cc < CH; cc++)
+							if (cc < C)
+							{
+								prev[cc] *= Tq;
+								prev[cc] += (1 - Tq) * edge_channel<PixT, TEX>(eq, qp, texture, qtap, qL, cc, x, y, false, 0.0);
+							}
+					}
+					if (need_replay)
+					{
+#pragma unroll
+						for (int cc = 0; cc < CH; cc++)
+							cur[cc] = prev[cc];
+					}
+				}
+				// per-pixel plane adjoints of this edge (0 where it does not touch the pixel) ...
+				double pb[5] = {0, 0, 0, 0, 0}; // planes 0..3 (colours, or u, v, shade) and the transparency plane
+				if (hit)
+				{
+					const double Tr = Tr_here;
+					double T_B = 0;
+					if (e.kind == KIND_TEXTURED && TEX)
+					{ // H.h:2006-2021
+						Tap etap;
+						double eL, eUV[2], L_B = 0, e_B[2] = {0, 0};
+						textured_tap(ep, x, y, false, 0.0, p.tex_w, p.tex_h, C, etap, eL, eUV);
+#pragma unroll
+						for (int cc = 0; cc < CH; cc++)
+							if (cc < C)
+							{
+								const double i00 = ldp(texture, etap.idx[0] + cc), i10 = ldp(texture, etap.idx[1] + cc);
+								const double i01 = ldp(texture, etap.idx[2] + cc), i11 = ldp(texture, etap.idx[3] + cc);
+								const double A = bilinear_mix(etap, i00, i10, i01, i11);
+								T_B += g[cc] * (prev[cc] - A * eL);
+								L_B += g[cc] * (1 - Tr) * A;
+								double wgt[4];
+								bilinear_mix_adjoint(etap, eL * (1 - Tr) * g[cc], i00, i10, i01, i11, wgt, e_B);
+								if (texture_b)
+									texture_scatter(texture_b, etap, cc, wgt);
+								g[cc] *= Tr;
+							}
+						pb[0] = etap.out[0] ? 0.0 : e_B[0];
+						pb[1] = etap.out[1] ? 0.0 : e_B[1];
+						pb[2] = L_B;
+					}
+					else
+					{ // H.h:1726-1746
+#pragma unroll
+						for (int cc = 0; cc < CH; cc++)
+							if (cc < C)
+							{
+								const double A = interp_channel(ep, cc, x, y, false, 0.0);
+								T_B += g[cc] * (prev[cc] - A);
+								pb[cc] = (1 - Tr) * g[cc];
+								g[cc] *= Tr;
+							}
+					}
+					pb[4] = T_B;
+				}
+				// ... reduced over the tile on the VALU (DPP), then ONE atomic instruction (15 lanes) per edge and tile
+				double *eacc = w.edge_acc + (size_t)S.ids[r] * (3 * P + 3);
+				double mv[16]; // lane 3 * pl + m ends up with moment m of plane pl
+#pragma unroll
+				for (int pl = 0; pl < 5; pl++)
+				{
+					mv[3 * pl] = pb[pl] * x;
+					mv[3 * pl + 1] = pb[pl] * y;
+					mv[3 * pl + 2] = pb[pl];
+				}
+				mv[15] = 0;
+				const double esum = wave_sum16(mv, lane);
+				if (lane < 15 && esum != 0 && (lane >= 12 || lane < 3 * P))
+				{
+					const int pl = lane / 3, m = lane - 3 * pl;
+					atomic_add_f64(eacc + (pl == 4 ? 3 * P : 3 * pl) + m, esum);
+				}
+			}
+		}
+	}
+
+	DR_TRACE(4);
+	if (EDGES && b_lo > 0)
+		return; // the wavefront that ran batch 0 (the farthest edges) holds the gradient that reaches pass 1
+	// ---- adjoint of pass 1: g now belongs to the triangle that owns the pixel
+	owner_adjoint<PixT, TEX>(p, w, lane, x, y, owner, kind, g, tap, L, (double *)&S.rec[0], (uint32_t *)&S.cover[0][0]);
+#ifdef DR_TILE_TRACE
+	DR_TRACE(5);
+	if (EDGES && lane < 8)
+	{
+		uint32_t v = 0;
+		for (int i = 0; i < 8; i++)
+			v = lane == i ? tr[i] : v;
+		((uint32_t *)p.image_in)[((size_t)view * H * W + (size_t)y0 * W + x0) * C + lane] = v; // C == 4: the first two pixels of the tile
+	}
+#endif
+#undef DR_TRACE
+}
+
+template <class PixT, bool TEX>
+__global__ __launch_bounds__(64, 6) void raster_bwd_fast_kernel(KParams p)
+{ // (two-call path) the forward's work list of the non-empty tiles, walked exactly as raster_fwd_fast_kernel walks it (same grid,
+  // same entry of the list for the same workgroup); the tiles with silhouette edges are left to raster_bwd_edge_kernel.  One
+  // wavefront per tile OF THE FRAME, which found out from the tile bitmap that two out of three had nothing to do, took ~51 us
+  // per 8-view launch; this one ~43 (two-call step 0.254 -> 0.246 ms).
+	__shared__ BwdLds s_lds;
+	const int lane = threadIdx.x & 63;
+	const int G = p.tile_blocks;
+	const long long b = blockIdx.x;
+	const bool chunked = G % (8 * WORK_CHUNK) == 0;
+	const int view = chunked ? (int)((b >> 3) % p.n_views) : (int)(b % p.n_views);
+	const int q = chunked ? (int)((b >> 3) / p.n_views) * 8 + (int)(b & 7) : (int)(b / p.n_views);
+	const ViewPtrs w = view_ptrs(p, view);
+	const int Gh = chunked ? G / p.heavy_share : 0;
+	const bool heavy_list = q < Gh;
+	const int qq = heavy_list ? q : q - Gh, stride = heavy_list ? Gh : G - Gh;
+	const bool chunk_here = chunked && stride % (8 * WORK_CHUNK) == 0;
+	uint32_t rank = chunk_here ? (uint32_t)((((qq >> 3) / WORK_CHUNK) * 8 + (qq & 7)) * WORK_CHUNK + (qq >> 3) % WORK_CHUNK) : (uint32_t)qq;
+	const uint32_t n_work = w.hdr->work_count[heavy_list ? 0 : 1];
+	for (; rank < n_work; rank += (uint32_t)stride)
+	{
+		const WorkEntry &entry = w.work_list[heavy_list ? rank : (uint32_t)p.L.ntiles - 1u - rank];
+		const int tile = uniform((int)entry.tile);
+		if (uniform((int)entry.nedge) != 0)
+			continue;
+		int ln = lane;
+		asm volatile("" : "+v"(ln)); // (see raster_fwd_fast_kernel: nothing lane-dependent is carried across the loop)
+		bwd_fast_tile<PixT, false, TEX>(p, w, view, tile % p.L.tiles_x, tile / p.L.tiles_x, ln, s_lds, nullptr);
+		lds_sync();
+	}
+}
+
+#ifndef DR_EDGE_OCC
+#define DR_EDGE_OCC 4 // waves per SIMD of the untextured edge kernel (3: no spills, 5: more) -- swept, 4 stays
+#endif
+template <class PixT, bool TEX>
+__global__ __launch_bounds__(64, TEX ? 2 : DR_EDGE_OCC) void raster_bwd_edge_kernel(KParams p)
+{ // persistent waves over the lists of tiles that hold silhouette edges (built by tile_scan_kernel).  Grid (views, waves):
+  // the first waves dispatched are wave 0 of every view, and every wave starts with the many-edged tiles -- the kernel
+  // lasts as long as its slowest tile, so those must not start late.  Wave g takes the work items g, g + gridDim.y, ...
+	__shared__ BwdLds s_lds;
+	__shared__ EdgeSort s_es;
+	const int view = blockIdx.x;
+	const int lane = threadIdx.x;
+	const ViewPtrs w = view_ptrs(p, view);
+	// the last workgroups of the grid stream the background of this kernel's share of the empty tiles (fill_share)
+	const int fill_n = fill_share(p.fill_mode, 0, p.L.nwords), fill_blocks = fill_share_blocks(fill_n);
+#ifndef DR_FILL_FIRST
+#define DR_FILL_FIRST 0 // measurement builds: 1 = the fill workgroups at the head of both grids instead of the tail
+#endif
+	const int walkers = (int)gridDim.y - fill_blocks;
+	const int by = DR_FILL_FIRST ? (int)blockIdx.y - fill_blocks : (int)blockIdx.y; // index among the walkers (< 0: a fill workgroup)
+	if (DR_FILL_FIRST ? by < 0 : by >= walkers)
+	{
+		for (int i = DR_FILL_FIRST ? (int)blockIdx.y : by - walkers; i < fill_n; i += fill_blocks)
+			fill_share_word(p, 0, view, i, lane);
+		return;
+	}
+	const uint32_t n_short = w.edge_tile_cnt[0], n_long = (DR_ABLATE & 65536) ? 0u : w.edge_tile_cnt[CNT_STRIDE],
+				   n_multi = (DR_ABLATE & 32768) ? 0u : w.edge_tile_cnt[2 * CNT_STRIDE] * CHUNKS; // (measurement builds: without the multi-batch / the 9-16-edge tiles)
+	const uint32_t *shorts = w.edge_tiles, *longs = w.edge_tiles + p.L.ntiles, *multi = w.edge_tiles + 2 * (size_t)p.L.ntiles;
+	// Work items: first the tiles with more than one batch of edges, each offered to CHUNKS wavefronts (one per batch of its
+	// reverse sweep; those the tile has no use for return at once), then the other tiles with more than PRIO_EDGES edges, then
+	// the rest.
+#pragma nounroll
+	for (uint32_t i = (uint32_t)by; i < n_multi + n_long + n_short; i += (uint32_t)walkers)
+	{
+		int tile, chunk = -1;
+		if (i < n_multi)
+			tile = (int)multi[i / CHUNKS], chunk = (int)(i % CHUNKS);
+		else if (i < n_multi + n_long)
+			tile = (int)longs[i - n_multi];
+		else
+			tile = (int)shorts[i - n_multi - n_long];
+		tile = uniform(tile);
+		bwd_fast_tile<PixT, true, TEX>(p, w, view, tile % p.L.tiles_x, tile / p.L.tiles_x, lane, s_lds, &s_es, chunk);
+		lds_sync();
+	}
+}
+
+} // namespace

@@ -1,0 +1,1124 @@
+// deodr_amd/csrc/dr_forward.h -- part of the single translation unit dr_kernels.hip (device code, gfx950 / wave64).
+// The LDS-staged forward: tile_scan_kernel (work lists), background fill, raster_fwd_fast_kernel (+ the fused adjoint of pass 1).
+#pragma once
+
+#include "dr_forward_generic.h"
+
+using namespace dr;
+
+namespace
+{
+
+// ---------------------------------------------------------------------------------- forward raster, LDS-staged fast path
+//
+// Same arithmetic as raster_fwd_kernel, restructured for latency: the tile's primitives are fetched with ONE batched
+// load (ids -> 128-byte records + planes, 16 B per lane) into LDS instead of one dependent global round trip per
+// primitive; the reference's scanline spans (two double divisions each, H.h:864-906) are computed once per
+// (primitive, row) by lane = primitive_slot * 8 + row -- not once per pixel -- and exchanged as 8-bit column masks;
+// the depth test and shading then read plane coefficients as LDS broadcasts.  Handles nb_colors <= 4 without
+// antialiase_error; everything else runs on raster_fwd_kernel.
+
+constexpr int TB = 16; // triangles (or edges) staged per batch: small, so that LDS never limits the number of resident waves
+
+struct alignas(16) WaveLds
+{
+	TriRec rec[TB];			   // EdgeRec has the same size and is staged in the same place
+	double planes[TB * 12];	   // 3 * P doubles per primitive, P <= 4
+	uint32_t ids[TB];
+	uint8_t cover[TILE][TB];   // [row][primitive] -> bit x set when the primitive covers column x of the row
+	uint32_t order[TB];
+};
+
+
+struct PixState
+{
+	double zbest;
+	int kbest;
+	int kind;
+	int slot;	  // position of the winner in the staged batch (= in the tile's list when the tile has one batch)
+	double v[CH]; // colours of the current winner (KIND_INTERP) or u, v, shade awaiting the texture fetch (KIND_TEXTURED)
+};
+
+__device__ __forceinline__ void lds_sync()
+{ // the 64 lanes of a wave exchange data through LDS: order the compiler, the hardware executes DS ops in order
+	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+	__builtin_amdgcn_wave_barrier();
+	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__device__ __forceinline__ uint32_t column_mask(int xb, int xe, int x0)
+{
+	int lo = (xb > x0 ? xb : x0) - x0, hi = (xe < x0 + TILE - 1 ? xe : x0 + TILE - 1) - x0;
+	if (lo > hi)
+		return 0;
+	return ((1u << (hi + 1)) - 1u) & ~((1u << lo) - 1u);
+}
+
+// bit j of the result = bit `lx` of byte j of the 32-byte row `bytes` (coverage of my column by primitive j)
+__device__ __forceinline__ uint32_t gather_column_bits(const uint8_t *row_bytes, int lx)
+{
+	uint32_t wd[TB / 4];
+#pragma unroll
+	for (int i = 0; i < TB / 16; i++)
+	{
+		const uint4 a = ((const uint4 *)row_bytes)[i];
+		wd[4 * i] = a.x, wd[4 * i + 1] = a.y, wd[4 * i + 2] = a.z, wd[4 * i + 3] = a.w;
+	}
+	uint32_t m = 0;
+#pragma unroll
+	for (int i = 0; i < TB / 4; i++)
+	{
+		uint32_t t = (wd[i] >> lx) & 0x01010101u;
+		m |= (((t * 0x01020408u) >> 24) & 0xfu) << (4 * i);
+	}
+	return m;
+}
+
+// stage `nb` primitives whose ids are in S.ids: records (128 B each, 8 lanes x 16 B) and planes (3P doubles each).
+// Every global load is issued before the first LDS store: ONE memory round trip per batch (a rolled loop over the planes
+// paid one per 64 doubles, i.e. two or three for a batch of more than five primitives).
+template <class Rec>
+__device__ __forceinline__ void stage_batch(WaveLds &S, const Rec *recs, const double *planes, int P, int nb, int lane)
+{
+	static_assert(TB == 16, "two record pieces and three plane doubles per lane");
+	const int piece = lane & 7;
+	const int np = 3 * P, total = nb * np; // np = 9 or 12
+	const int j0 = lane >> 3, j1 = 8 + (lane >> 3);
+	const int i0 = lane, i1 = lane + 64, i2 = lane + 128;
+	const int a0 = np == 12 ? i0 / 12 : i0 / 9, a1 = np == 12 ? i1 / 12 : i1 / 9, a2 = np == 12 ? i2 / 12 : i2 / 9;
+	const int c0 = i0 - a0 * np, c1 = i1 - a1 * np, c2 = i2 - a2 * np;
+	uint4 r0 = make_uint4(0, 0, 0, 0), r1 = r0;
+	double v0 = 0, v1 = 0, v2 = 0;
+	if (j0 < nb)
+		r0 = ((const uint4 *)(recs + S.ids[j0]))[piece];
+	if (j1 < nb)
+		r1 = ((const uint4 *)(recs + S.ids[j1]))[piece];
+	if (i0 < total)
+		v0 = planes[(size_t)S.ids[a0] * np + c0];
+	if (i1 < total)
+		v1 = planes[(size_t)S.ids[a1] * np + c1];
+	if (i2 < total)
+		v2 = planes[(size_t)S.ids[a2] * np + c2];
+	if (j0 < nb)
+		((uint4 *)&S.rec[j0])[piece] = r0;
+	if (j1 < nb)
+		((uint4 *)&S.rec[j1])[piece] = r1;
+	if (i0 < total)
+		S.planes[a0 * 12 + c0] = v0;
+	if (i1 < total)
+		S.planes[a1 * 12 + c1] = v1;
+	if (i2 < total)
+		S.planes[a2 * 12 + c2] = v2;
+}
+
+#ifdef DR_FWD_TRACE
+#define DR_TRACE_ARGS , uint32_t *ftr, uint64_t ftr0
+#define DR_TRACE_PASS , ftr, ftr0
+#define DR_BTRACE(i)                                                                                                         \
+	if (ftr[i] == 0)                                                                                                         \
+	ftr[i] = (uint32_t)(__builtin_readcyclecounter() - ftr0)
+#else
+#define DR_TRACE_ARGS
+#define DR_TRACE_PASS
+#define DR_BTRACE(i)
+#endif
+template <bool TEX>
+__device__ __forceinline__ void tri_batch(const KParams &p, WaveLds &S, int nb, int lane, int x0, int y0, bool inb, PixState &st DR_TRACE_ARGS)
+{
+	DR_BTRACE(8); // records staged (first batch)
+	const int W = p.W, H = p.H, C = p.C;
+	const bool persp = p.persp, strict = p.strict;
+	// spans: lane = slot * 8 + row
+#pragma unroll
+	for (int q = 0; q < TB / 8; q++)
+	{
+		const int j = q * 8 + (lane >> 3), r = lane & 7;
+		uint32_t m = 0;
+		if (j < nb)
+		{
+			const TriRec &rec = S.rec[j];
+			if (DR_ABLATE & 512)
+				m = 0xffu;
+			else if (rec.kind != KIND_NONE)
+			{
+				// A row lies in one half of the triangle (above or below its middle vertex), so one span (two divisions, not
+				// four) per (triangle, row); only the non-strict fill rule puts the middle-vertex row in both halves.
+				const int yy = y0 + r;
+				const bool in0 = yy >= rec.y_begin[0] && yy <= rec.y_end[0], in1 = yy >= rec.y_begin[1] && yy <= rec.y_end[1];
+				int xb, xe;
+				tri_half_span(rec, in0 ? 0 : 1, yy, W, H, strict, xb, xe);
+				m = column_mask(xb, xe, x0);
+				if (DR_ABLATE & 16384)
+				{ // measurement: the span arithmetic a second time (its cost = the difference in instruction counts)
+					int yy2 = yy;
+					asm volatile("" : "+v"(yy2));
+					int xb2, xe2;
+					tri_half_span(rec, in0 ? 0 : 1, yy2, W, H, strict, xb2, xe2);
+					m &= column_mask(xb2, xe2, x0);
+				}
+				if (__ballot(in0 && in1))
+				{
+					if (in0 && in1)
+					{
+						tri_half_span(rec, 1, yy, W, H, strict, xb, xe);
+						m |= column_mask(xb, xe, x0);
+					}
+				}
+			}
+		}
+		if (j < TB)
+			S.cover[r][j] = (uint8_t)m;
+	}
+	DR_BTRACE(9); // spans computed
+	lds_sync();
+	const int lx = lane & 7, row = lane >> 3;
+	uint32_t mine = gather_column_bits(&S.cover[row][0], lx);
+	if (!inb)
+		mine = 0;
+	const double x = x0 + lx, y = y0 + row;
+	// Depth test: every lane walks the triangles that cover ITS pixel (bits of `mine`), not the triangles of the batch -- with
+	// back-face culling a pixel is covered by one triangle, rarely two, so the wavefront makes one or two passes instead of one
+	// per triangle of the batch (the 93-triangle tile at the limb of the sphere: 96 -> ~12).  The winner is remembered by its slot
+	// and shaded ONCE after the loop.  Lane-varying LDS addresses: a few distinct records per pass.
+	int jbest = -1;
+	uint32_t todo = mine;
+	while (__ballot(todo != 0))
+	{
+		const bool act = todo != 0;
+		const int j = act ? __ffs((int)todo) - 1 : 0;
+		todo &= todo - 1;
+		double Z = plane_at(S.rec[j].xZ, x, y);
+		if (persp)
+			Z = 1 / Z;
+		const int k = (int)S.ids[j];
+		if (act && (Z < st.zbest || (Z == st.zbest && k < st.kbest)))
+		{
+			st.zbest = Z;
+			st.kbest = k;
+			jbest = j;
+		}
+	}
+	DR_BTRACE(10); // depth test done
+	if (jbest >= 0)
+	{ // per-lane reads of the winner's record and planes (LDS, a few distinct slots per tile)
+		st.slot = jbest;
+		const int kind = S.rec[jbest].kind;
+		const double *pl = &S.planes[jbest * 12];
+		const double Z = st.zbest;
+		st.kind = kind;
+		if (kind == KIND_TEXTURED && TEX)
+		{
+			st.v[0] = plane_at(pl, x, y);
+			st.v[1] = plane_at(pl + 3, x, y);
+			st.v[2] = plane_at(pl + 6, x, y);
+			if (persp)
+			{
+				st.v[2] = st.v[2] * Z;
+				st.v[0] = st.v[0] * Z;
+				st.v[1] = st.v[1] * Z;
+			}
+		}
+		else
+		{
+#pragma unroll
+			for (int cc = 0; cc < CH; cc++)
+				if (cc < C)
+					st.v[cc] = interp_channel(pl, cc, x, y, persp, Z);
+		}
+	}
+	lds_sync(); // the next batch overwrites the staging area
+}
+
+constexpr int EMAX = 128; // silhouette edges of one tile the staged kernels can order; more -> generic / deferred path (a
+						  // single 90-edge tile in the deferred kernel took 5 ms)
+
+struct EdgeSort
+{
+	double keys[EMAX];
+	uint32_t ids[EMAX];
+	uint32_t sorted[EMAX];
+};
+
+// All edges of the tile (inline list + its pairs in the spill pool), ordered far -> near (ties by slot) into es.sorted.
+// Returns their number, or -1 when there are more than EMAX (or the pool overflowed and some are missing).
+__device__ __forceinline__ int gather_sorted_edges(EdgeSort &es, const ViewPtrs &w, const KParams &p, int tile, int nedge, int lane)
+{
+	const int n_inline = nedge < K_EDGE ? nedge : K_EDGE;
+	if (lane < n_inline)
+		es.ids[lane] = w.edge_list[(size_t)tile * K_EDGE + lane];
+	int fill = n_inline;
+	if (nedge > K_EDGE)
+	{
+		if (nedge > EMAX)
+			return -1;
+		uint32_t spill_n = w.hdr->edge_spill[w.hdr->cur];
+		if (spill_n > p.L.edge_pool_cap)
+			spill_n = p.L.edge_pool_cap;
+		for (uint32_t i0 = 0; i0 < spill_n; i0 += 64)
+		{
+			const uint2 pr = (i0 + lane < spill_n) ? w.edge_pool[i0 + lane] : make_uint2(0xffffffffu, 0u);
+			const unsigned long long m = __ballot((int)pr.x == tile);
+			const int cnt = __popcll(m);
+			if (fill + cnt > EMAX)
+				return -1;
+			if ((m >> lane) & 1ull)
+				es.ids[fill + __popcll(m & ((1ull << lane) - 1ull))] = pr.y;
+			fill += cnt;
+		}
+		if (fill != nedge)
+			return -1; // pairs lost to a pool overflow: the host repeats the call with a larger pool
+	}
+	lds_sync();
+	for (int i = lane; i < fill; i += 64)
+		es.keys[i] = w.edge_rec[es.ids[i]].key;
+	lds_sync();
+	for (int i = lane; i < fill; i += 64)
+	{
+		const double key = es.keys[i];
+		const uint32_t slot = es.ids[i];
+		int rank = 0;
+		for (int j = 0; j < fill; j++)
+			rank += edge_before(es.keys[j], es.ids[j], key, slot) ? 1 : 0;
+		es.sorted[rank] = slot;
+	}
+	lds_sync();
+	return fill;
+}
+
+// stage edges sorted[first .. first + nb) and turn their scanline spans into column masks; returns, per pixel, the
+// 32-bit mask of the batch's edges whose band covers it
+__device__ __forceinline__ uint32_t stage_edge_batch(WaveLds &S, const EdgeSort &es, const ViewPtrs &w, int P, int first, int nb, int lane, int x0,
+													 int y0, int W, bool inb)
+{
+	lds_sync();
+	if (lane < nb)
+		S.ids[lane] = es.sorted[first + lane];
+	lds_sync();
+	stage_batch(S, w.edge_rec, w.edge_planes, P, nb, lane);
+	lds_sync();
+	const EdgeRec *erec = (const EdgeRec *)S.rec;
+#pragma unroll
+	for (int q = 0; q < TB / 8; q++)
+	{
+		const int j = q * 8 + (lane >> 3), r = lane & 7;
+		uint32_t m = 0;
+		if (j < nb)
+		{
+			const EdgeRec &e = erec[j];
+			const int yy = y0 + r;
+			if (yy >= e.y_begin && yy <= e.y_end)
+			{
+				int xb, xe;
+				edge_row_span(e, yy, W, xb, xe);
+				m = column_mask(xb, xe, x0);
+			}
+		}
+		S.cover[r][j] = (uint8_t)m;
+	}
+	lds_sync();
+	return inb ? gather_column_bits(&S.cover[lane >> 3][0], lane & 7) : 0u;
+}
+
+template <class PixT, bool TEX>
+__device__ __forceinline__ void owner_adjoint(const KParams &p, const ViewPtrs &w, int lane, double x, double y, int owner, int kind, const double *g,
+											  const Tap &tap, double L, double *tab, uint32_t *own);
+
+// Background of one tile that received no primitive: colour, depth = +inf, no owner (H.h:2728-2744).
+template <class PixT>
+__device__ __forceinline__ void fill_background_tile(const KParams &p, int view, int32_t *face_id, int tx, int ty, int lane, const double *bgc,
+													 int owners)
+{ // owners: 1 = also the owner ids (none), 0 = not, -1 = colour only (the caller writes depth and owners of four tiles at once)
+	const int W = p.W, H = p.H, C = p.C;
+	const int px = tx * TILE + (lane & 7), py = ty * TILE + (lane >> 3);
+	if (px >= W || py >= H)
+		return;
+	const size_t pix = (size_t)py * W + px;
+	const size_t vpix = (size_t)view * H * W + pix;
+	if (p.image)
+	{
+		PixT *out = (PixT *)p.image + vpix * C;
+		double col[CH];
+#pragma unroll
+		for (int cc = 0; cc < CH; cc++)
+			col[cc] = (cc < C && p.bg_image) ? (double)((const PixT *)p.bg_image)[vpix * C + cc] : bgc[cc];
+		if (C == 4)
+		{
+			typedef PixT V4 __attribute__((ext_vector_type(4)));
+			const V4 v = {(PixT)col[0], (PixT)col[1], (PixT)col[2], (PixT)col[3]};
+			__builtin_nontemporal_store(v, (V4 *)out);
+		}
+		else
+		{
+#pragma unroll
+			for (int cc = 0; cc < CH; cc++)
+				if (cc < C)
+					__builtin_nontemporal_store((PixT)col[cc], out + cc);
+		}
+	}
+	if (owners < 0)
+		return;
+	if (p.zbuf)
+		__builtin_nontemporal_store((PixT)INFINITY, (PixT *)p.zbuf + vpix);
+	if (owners)
+		__builtin_nontemporal_store((int32_t)-1, face_id + pix);
+}
+
+// ------------------------------------------------------------------------------------------------ tile scan
+//
+// Between set-up and the staged forward raster: one thread per tile turns the per-tile counters that binning left into
+//   * the work list of the forward: one uint4 {tile, triangles, edges, sweep slot} per NON-EMPTY tile -- the tiles with more
+//     than FIRST_PRIMS triangles or edges from the front of the array (the long poles start first), the others from the back;
+//   * the tile bitmap (bit = the tile received a primitive) that the fill waves of the forward and the adjoint's owner-tile
+//     kernel read;
+//   * edge_saved[tile] (edge count + whether the forward will save its sweep), and the counters zeroed for the next forward.
+// Two tiles out of three receive nothing: this is what lets the forward launch one wavefront per tile that HAS work instead of
+// one per tile of the frame (the waves of the empty tiles used to take a third of its slot-time), and it takes the
+// many-primitive-tile flags and lists (two more dependent atomics per lane) out of the set-up kernel.
+#ifndef DR_WORK_CHUNK
+#define DR_WORK_CHUNK 64
+#endif
+constexpr int SCAN_BLOCK = 256, WORK_CHUNK = DR_WORK_CHUNK;
+// One tile workgroup in `heavy_share` walks the list of the many-primitive tiles (the head of the grid: dispatched first).  One in
+// eight, unless the head of all views together would then take more than ~40 % of the chip's wave slots (5 120 at five waves per
+// SIMD): with every slot of the first dispatch round on a 25 - 50 us tile the short tiles -- whose arithmetic hides those tiles'
+// round trips -- start late.  Measured on the 8-view benchmark step: 1/8 0.183 ms, 1/12 0.1775, 1/16 0.1767, 1/24 0.1784; on one
+// 2048^2 view (2 048 head workgroups at 1/8) 1/16 costs 4 %; on one 1024^2 view 1/2 0.0775, 1/4 0.0772, 1/8 0.0809, 1/16 0.090 ms.
+#ifndef DR_HEAVY_SHARE
+#define DR_HEAVY_SHARE 0 // measurement builds: a fixed share
+#endif
+__host__ inline int heavy_share_for(int n_views, int tile_blocks)
+{
+	if (DR_HEAVY_SHARE)
+		return DR_HEAVY_SHARE;
+	// ~2 048 head workgroups over all views (40 % of the wave slots), the share a power of two between 1/4 and 1/16
+	const long long want = ((long long)n_views * tile_blocks + 2047) / 2048;
+	int share = 4;
+	while (share < 16 && share < want)
+		share *= 2;
+	return share;
+}
+
+__global__ __launch_bounds__(SCAN_BLOCK) void tile_scan_kernel(KParams p)
+{
+	// classes compacted by this kernel: 0 many-primitive tiles (front of the work list), 1 the other non-empty tiles (back of it),
+	// 2 .. 4 the three lists of edge tiles, 5 every edge tile (its rank is the tile's slot in edge_sweep)
+	constexpr int NCLS = 3 + EDGE_LISTS;
+	__shared__ uint32_t s_cnt[NCLS][SCAN_BLOCK / 64];
+	__shared__ uint32_t s_base[NCLS];
+	const int view = blockIdx.y;
+	const ViewPtrs w = view_ptrs(p, view);
+	const int tile = blockIdx.x * SCAN_BLOCK + threadIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	const bool valid = tile < p.L.ntiles;
+	uint32_t ntri = 0, nedge = 0;
+	uint4 ida = make_uint4(0, 0, 0, 0), idb = ida, idc = ida;
+	if (valid)
+	{
+		ntri = w.tri_cnt[tile];
+		nedge = w.edge_cnt[tile];
+	}
+	const bool work = (ntri | nedge) != 0;
+	if (work)
+	{ // the head of the tile's inline list, only as far as it is filled (two tiles out of three are empty: requested with the
+	  // counters, these 48 bytes per tile were 6 MB of reads per step for nothing and the kernel took 6.5 instead of 5 us)
+		static_assert(ENTRY_IDS == 12 && K_TRI >= ENTRY_IDS, "three 16-byte pieces of the tile's inline list");
+		const uint4 *ids = (const uint4 *)(w.tri_list + (size_t)tile * K_TRI);
+		ida = ids[0];
+		idb = ntri > 4 ? ids[1] : ida;
+		idc = ntri > 8 ? ids[2] : ida;
+	}
+	if (work)
+	{ // self-cleaning counters
+		w.tri_cnt[tile] = 0;
+		w.edge_cnt[tile] = 0;
+	}
+	const unsigned long long wm = __ballot(work);
+	if (lane == 0 && valid)
+		w.tile_bits[tile >> 5] = (uint32_t)wm;
+	if (lane == 32 && valid)
+		w.tile_bits[tile >> 5] = (uint32_t)(wm >> 32);
+	// ---- compaction: rank inside the wavefront, wavefront totals through LDS, ONE atomic per class and block
+	const bool heavy = work && p.tile_blocks % (8 * WORK_CHUNK) == 0 && (ntri > (uint32_t)FIRST_PRIMS || nedge > (uint32_t)FIRST_PRIMS);
+	const int elist = nedge == 0 ? -1 : (nedge <= (uint32_t)PRIO_EDGES ? 0 : (nedge <= (uint32_t)TB ? 1 : 2));
+	unsigned long long m[NCLS];
+	m[0] = __ballot(heavy);
+	m[1] = wm & ~m[0];
+#pragma unroll
+	for (int c = 0; c < EDGE_LISTS; c++)
+		m[2 + c] = __ballot(elist == c);
+	m[2 + EDGE_LISTS] = __ballot(nedge > 0);
+	const unsigned long long below = (1ull << lane) - 1ull;
+	if (lane < NCLS)
+	{
+		unsigned long long mine = 0;
+#pragma unroll
+		for (int c = 0; c < NCLS; c++)
+			mine = lane == c ? m[c] : mine;
+		s_cnt[lane][wave] = (uint32_t)__popcll(mine);
+	}
+	__syncthreads();
+	if (threadIdx.x < NCLS)
+	{
+		uint32_t total = 0;
+#pragma unroll
+		for (int i = 0; i < SCAN_BLOCK / 64; i++)
+			total += s_cnt[threadIdx.x][i];
+		uint32_t *counter = threadIdx.x < 2 ? &w.hdr->work_count[threadIdx.x] : &w.edge_tile_cnt[(threadIdx.x - 2) * CNT_STRIDE];
+		s_base[threadIdx.x] = total ? atomicAdd(counter, total) : 0u;
+	}
+	__syncthreads();
+	auto position = [&](int c, unsigned long long members) { // of this thread in class c (the thread must belong to it)
+		uint32_t at = s_base[c];
+		for (int i = 0; i < wave; i++)
+			at += s_cnt[c][i];
+		return at + (uint32_t)__popcll(members & below);
+	};
+	// the adjoint finds the edge count, and whether the forward sweep over the edges is saved, in edge_saved
+	uint32_t sweep_slot = 0;
+	if (nedge > 0)
+	{
+		const uint32_t at = position(2 + EDGE_LISTS, m[2 + EDGE_LISTS]);
+		const uint32_t slot_word = at < (uint32_t)p.L.sweep_cap ? at + 1u : 0u;
+		w.edge_slot[tile] = slot_word; // always written: a stale value must never be read
+		sweep_slot = (nedge <= (uint32_t)EMAX && !p.persp) ? slot_word : 0u;
+		static_assert(EDGE_LISTS == 3, "select below");
+		w.edge_tiles[(size_t)elist * p.L.ntiles + position(2 + elist, elist == 0 ? m[2] : (elist == 1 ? m[3] : m[4]))] = (uint32_t)tile;
+	}
+	if (valid)
+		w.edge_saved[tile] = nedge | (sweep_slot ? SWEEP_SAVED : 0u);
+	if (work)
+	{
+		WorkEntry &e = heavy ? w.work_list[position(0, m[0])] : w.work_list[(uint32_t)p.L.ntiles - 1u - position(1, m[1])];
+		uint4 *out = (uint4 *)&e;
+		out[0] = make_uint4((uint32_t)tile, ntri, nedge, sweep_slot);
+		out[1] = ida;
+		out[2] = idb;
+		out[3] = idc;
+	}
+}
+
+// ------------------------------------------------------------------------------------------------ background fill
+//
+// The background of the tiles that received no primitive (two out of three): 110 MB of plain stores per 8-view step that
+// depend on nothing but the tile bitmap.  As workgroups of the forward raster they cost it 22 us: a fill wave lives as long as
+// the store queue lets it, and it holds one of the forward's (register-fat) wave slots while it does.  As a kernel of its own,
+// with 24 registers per lane, launched on a side stream right after the scan, its waves fit into the registers and wave
+// slots the forward / edge / finalize kernels leave unused, and the stores drain while those kernels compute.
+// One wavefront per bitmap word (32 tiles).  Four consecutive empty tiles of a tile row share one 16-byte-per-lane store of
+// depth (and of owner ids): 128 contiguous bytes per pixel row instead of 4 x 32.
+constexpr int FILL_WAVES = 4; // wavefronts (bitmap words) per workgroup
+
+// Background of the run of empty tiles [txa, txb) of tile row ty.  Every pixel row of the run is ONE contiguous range of the
+// frame (image: (txb - txa) * 8 * C elements, depth / owner ids: (txb - txa) * 8), written in 16-byte pieces by consecutive
+// lanes whatever the channel count -- per tile and per channel (three strided 4-byte stores per lane for C = 3) the fill of a
+// 1024^2 x 8-view batch of the hand mesh ran at 1 TB/s.  Needs W % 8 == 0 (16-byte alignment of every piece).
+template <class PixT>
+__device__ __forceinline__ void fill_run(const KParams &p, int view, int32_t *face_id, int ty, int txa, int txb, int lane, const double *bgc, int owners)
+{
+	constexpr int E = 16 / (int)sizeof(PixT); // elements per piece
+	typedef PixT VE __attribute__((ext_vector_type(E)));
+	typedef int32_t I4 __attribute__((ext_vector_type(4)));
+	const int W = p.W, H = p.H, C = p.C;
+	const int x0 = txa * TILE, npx = (txb * TILE < W ? txb * TILE : W) - x0, y0 = ty * TILE, rows = H - y0 < TILE ? H - y0 : TILE;
+	// f(row, piece) for the `rows` x n pieces of a plane, consecutive lanes on consecutive pieces; no integer division in the loop
+	// (the fill waves live on store issue: every instruction between two stores counts)
+	auto for_pieces = [&](int n, auto f) {
+		if (n >= 64)
+		{
+			for (int row = 0; row < rows; row++)
+				for (int piece = lane; piece < n; piece += 64)
+					f(row, piece);
+			return;
+		}
+		const float rn = 1.0f / (float)n; // rows * n <= 8 * 63: exact after one correction step
+		for (int idx = lane; idx < rows * n; idx += 64)
+		{
+			int row = (int)((float)idx * rn), piece = idx - row * n;
+			if (piece < 0)
+				row--, piece += n;
+			if (piece >= n)
+				row++, piece -= n;
+			f(row, piece);
+		}
+	};
+	if (p.image)
+	{
+		PixT *img = (PixT *)p.image + ((size_t)view * H * W + (size_t)y0 * W + x0) * C;
+		const PixT *bgi = p.bg_image ? (const PixT *)p.bg_image + ((size_t)view * H * W + (size_t)y0 * W + x0) * C : nullptr;
+		const size_t row_stride = (size_t)W * C;
+		const int n = npx * C / E; // pieces per pixel row (npx is a multiple of 8: whole pieces)
+		auto pattern = [&](int piece) { // the background colour as it falls on piece `piece` of a row
+			VE v;
+			int ph = C == 3 ? (piece * E) % 3 : ((piece * E) & (C - 1)); // channel of the piece's first element
+#pragma unroll
+			for (int j = 0; j < E; j++)
+			{
+				v[j] = (PixT)(ph == 0 ? bgc[0] : (ph == 1 ? bgc[1] : (ph == 2 ? bgc[2] : bgc[3])));
+				ph = ph + 1 == C ? 0 : ph + 1;
+			}
+			return v;
+		};
+		if (n >= 64 && !bgi)
+		{ // the usual long run of a colour background: a lane's pieces lane, lane + 64, ... of a row see the pattern with period 3
+		  // (period 1 unless C = 3), so the three vectors are formed once and the loop is a store and a pointer increment
+			const VE v0 = pattern(lane), v1 = pattern(lane + 64), v2 = pattern(lane + 128);
+			for (int row = 0; row < rows; row++)
+			{
+				PixT *out = img + (size_t)row * row_stride + (size_t)lane * E;
+				int piece = lane;
+				for (; piece + 128 < n; piece += 192, out += 192 * E)
+				{
+					__builtin_nontemporal_store(v0, (VE *)out);
+					__builtin_nontemporal_store(v1, (VE *)(out + 64 * E));
+					__builtin_nontemporal_store(v2, (VE *)(out + 128 * E));
+				}
+				if (piece < n)
+					__builtin_nontemporal_store(v0, (VE *)out);
+				if (piece + 64 < n)
+					__builtin_nontemporal_store(v1, (VE *)(out + 64 * E));
+			}
+		}
+		else
+			for_pieces(n, [&](int row, int piece) {
+				const size_t at = (size_t)row * row_stride + (size_t)piece * E;
+				__builtin_nontemporal_store(bgi ? *(const VE *)(bgi + at) : pattern(piece), (VE *)(img + at));
+			});
+	}
+	if (p.zbuf)
+	{
+		VE inf;
+#pragma unroll
+		for (int j = 0; j < E; j++)
+			inf[j] = (PixT)INFINITY;
+		PixT *zb = (PixT *)p.zbuf + (size_t)view * H * W + (size_t)y0 * W + x0;
+		for_pieces(npx / E, [&](int row, int piece) { __builtin_nontemporal_store(inf, (VE *)(zb + (size_t)row * W + piece * E)); });
+	}
+	if (owners)
+	{
+		const I4 none = {-1, -1, -1, -1};
+		int32_t *own = face_id + (size_t)y0 * W + x0;
+		for_pieces(npx / 4, [&](int row, int piece) { __builtin_nontemporal_store(none, (I4 *)(own + (size_t)row * W + piece * 4)); });
+	}
+}
+
+template <class PixT>
+__device__ __forceinline__ void fill_word(const KParams &p, int view, int wi, int lane, int owners)
+{ // background of the empty tiles of bitmap word wi of the view (one wavefront)
+	const ViewPtrs w = view_ptrs(p, view);
+	const int base = wi * 32, valid = p.L.ntiles - base < 32 ? p.L.ntiles - base : 32;
+	uint32_t empty = ~w.tile_bits[wi] & (valid == 32 ? 0xffffffffu : (1u << valid) - 1u);
+	empty = (uint32_t)uniform((int)empty);
+	if (!empty)
+		return;
+	const int C = p.C;
+	double bgc[CH] = {0, 0, 0, 0};
+	if (!p.bg_image)
+	{
+#pragma unroll
+		for (int cc = 0; cc < CH; cc++)
+			if (cc < C)
+				bgc[cc] = (double)((const PixT *)p.bg_color)[cc];
+	}
+	if ((p.W & 7) == 0)
+	{ // maximal runs of empty tiles inside one tile row
+		while (empty)
+		{
+			const int a = __ffs((int)empty) - 1;
+			const uint32_t rest = ~(empty >> a);			   // bit i clear: tile a + i is empty
+			int len = rest ? __ffs((int)rest) - 1 : 32 - a; // (all ones above a: the run goes to the end of the word)
+			const int t0 = base + a, ty = t0 / p.L.tiles_x, tx = t0 - ty * p.L.tiles_x;
+			if (tx + len > p.L.tiles_x)
+				len = p.L.tiles_x - tx; // the rest of the run lies in the next tile row
+			fill_run<PixT>(p, view, w.face_id, ty, tx, tx + len, lane, bgc, owners);
+			empty &= len >= 32 ? 0u : ~(((1u << len) - 1u) << a);
+		}
+		return;
+	}
+	for (int i = 0; i < 32; i++) // ragged frame width: tile by tile
+		if ((empty >> i) & 1u)
+			fill_background_tile<PixT>(p, view, w.face_id, (base + i) % p.L.tiles_x, (base + i) / p.L.tiles_x, lane, bgc, owners);
+}
+
+template <class PixT>
+__global__ __launch_bounds__(64 * FILL_WAVES) void fill_kernel(KParams p, int owners)
+{
+	const int gw = blockIdx.x * FILL_WAVES + (threadIdx.x >> 6);
+	if (gw >= p.n_views * p.L.nwords)
+		return;
+	fill_word<PixT>(p, gw / p.L.nwords, gw % p.L.nwords, threadIdx.x & 63, owners);
+}
+
+// A fit step has two latency-bound kernels after the forward raster (edge tiles, finalize) whose wave slots and store bandwidth
+// are mostly idle: the background fill rides on them as extra workgroups instead of a kernel of its own on a forked stream --
+// the fork / join event packets cost the caller's stream two bubbles of ~7 us per step (rocprofv3 kernel trace: scan -> forward,
+// finalize -> next set-up).  Word wi of a view goes to the kernels that take part by parity.
+// When both kernels take part, FILL_EDGE_NUM of every FILL_DEN consecutive words go to the edge-tile kernel, the others to finalize.
+#ifndef DR_FILL_EDGE_NUM
+#define DR_FILL_EDGE_NUM 1
+#endif
+#ifndef DR_FILL_DEN
+#define DR_FILL_DEN 2
+#endif
+constexpr int FILL_EDGE_NUM = DR_FILL_EDGE_NUM, FILL_DEN = DR_FILL_DEN;
+static_assert(FILL_EDGE_NUM > 0 && FILL_EDGE_NUM < FILL_DEN, "both kernels get some");
+__host__ __device__ inline int fill_share(int fill_mode, int bit, int nwords)
+{ // bitmap words per view the kernel `bit` (0 edge tiles, 1 finalize) fills
+	if (!(fill_mode & (1 << bit)))
+		return 0;
+	if (fill_mode != 3)
+		return nwords;
+	const int full = nwords / FILL_DEN, rest = nwords - full * FILL_DEN; // whole groups + a partial one
+	const int edge = full * FILL_EDGE_NUM + (rest < FILL_EDGE_NUM ? rest : FILL_EDGE_NUM);
+	return bit == 0 ? edge : nwords - edge;
+}
+// workgroups (edge kernel: per view, along grid y, limited to 65535) that stream a share of n words: one word each up to a cap,
+// beyond it (frames of more than ~4 M tiles) every workgroup takes several
+__host__ __device__ inline int fill_share_blocks(int n) { return n < 32768 ? n : 32768; }
+__device__ __forceinline__ void fill_share_word(const KParams &p, int bit, int view, int i, int lane)
+{ // the i-th word of the share of kernel `bit`
+	const int per = bit == 0 ? FILL_EDGE_NUM : FILL_DEN - FILL_EDGE_NUM; // words of a group that are this kernel's
+	const int wi = p.fill_mode == 3 ? (i / per) * FILL_DEN + (bit == 0 ? 0 : FILL_EDGE_NUM) + i % per : i;
+	if (wi >= p.L.nwords)
+		return;
+	if (p.pix_f64)
+		fill_word<double>(p, view, wi, lane, 0);
+	else
+		fill_word<float>(p, view, wi, lane, 0);
+}
+
+// Adjoint of pass 1 for a tile whose triangles are ONE staged batch (S.ids[0 .. ntri), the usual case), untextured: the moments
+//   M[owner][3 q + m] = sum over the owner's pixels of  g_q * {x, y, 1}[m]
+// are a small dense contraction over the 64 pixels of the tile -- (one-hot owner matrix)^T (64 x 16) times the 64 x 12 matrix of
+// per-pixel values -- and the forward raster is bound by vector-ALU issue while its matrix cores idle: sixteen
+// v_mfma_f64_16x16x4_f64 (K = 4 pixels each) can replace the segmented scans, run tables and merge loops of owner_adjoint
+// (about half of its vector instructions).  Operand layout (cdna_hip_programming.md, checked by tools/probes/mfma_f64_probe.hip): lane l
+// feeds A[l & 15][l >> 4] and B[l >> 4][l & 15], and receives D[(l >> 4) + 4 r][l & 15] in register r.  The per-pixel values
+// cross lanes through the (idle) staging area, 32 pixels at a time; the one-hot entries are exact, so only the order of the
+// additions differs from the scan (both differ from the reference's row-by-row sums; tolerance of the parity tests 1e-8).
+// MEASURED AND NOT USED (the product is built with DR_OWNER_MFMA = 0; tools/build_variants.sh can build the other): parity green
+// (all 205 GPU tests), 100 fewer vector instructions per tile -- and the forward raster 14 us SLOWER (85 -> 99 us per 8-view
+// launch): on MI355X the f64 matrix rate equals the f64 vector rate (78.6 TFLOP/s), a 16 x 16 x 4 f64 MFMA holds its SIMD for
+// ~64 cycles, and 16 of them (of whose 16 k multiply-adds ~2.5 k are useful: 3 - 4 owners x 12 moments x 64 pixels) cost more
+// issue time than the ~100 vector instructions they replace.
+#ifndef DR_OWNER_MFMA
+#define DR_OWNER_MFMA 0
+#endif
+typedef double mfma_f64x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void owner_adjoint_mfma(const KParams &p, const ViewPtrs &w, WaveLds &S, int lane, double x, double y, int slot, int ntri,
+												   const double *g)
+{
+	static_assert(sizeof(S.rec) + sizeof(S.planes) >= 32 * 12 * sizeof(double) && sizeof(S.cover) >= 64 && TB == 16, "LDS reuse");
+	const int C = p.C, nm = 3 * p.L.P;
+	double *bm = (double *)&S.rec[0]; // [32 pixels][12]: g_q x, g_q y, g_q of planes q = 0 .. 3
+	uint8_t *jb = &S.cover[0][0];	  // [64 pixels]: slot of the owner, 0xff: none
+	const int col = lane & 15, kq = lane >> 4;
+	jb[lane] = (uint8_t)(slot < 0 ? 0xff : slot);
+	mfma_f64x4 acc = {0, 0, 0, 0};
+#pragma unroll
+	for (int h = 0; h < 2; h++)
+	{
+		lds_sync();
+		if ((lane >> 5) == h)
+		{
+			double *row = bm + (lane & 31) * 12;
+#pragma unroll
+			for (int q = 0; q < CH; q++)
+			{
+				const double v = q < C ? g[q] : 0.0;
+				row[3 * q] = v * x;
+				row[3 * q + 1] = v * y;
+				row[3 * q + 2] = v;
+			}
+		}
+		lds_sync();
+#pragma unroll
+		for (int st = 0; st < 8; st++)
+		{
+			const int pl = 4 * st + kq; // pixel of this lane's A / B entries, inside the half
+			const double a = jb[32 * h + pl] == (uint8_t)col ? 1.0 : 0.0;
+			const double b = col < 12 ? bm[pl * 12 + col] : 0.0;
+			acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+		}
+	}
+#pragma unroll
+	for (int r = 0; r < 4; r++)
+	{ // owner slot kq + 4 r, moment `col`: the 3P moments of an owner are contiguous (one atomic instruction per four owners)
+		const int i = kq + 4 * r;
+		const double v = acc[r];
+#if !(DR_ABLATE & 128)
+		if (i < ntri && col < nm && v != 0)
+			atomic_add_f64(w.tri_acc + (size_t)S.ids[i] * nm + col, v);
+#endif
+	}
+}
+
+// Grid of the staged forward (1-D, one wavefront per workgroup).  Workgroup b: view (b / 8) % n_views,
+// q = (b / 8 / n_views) * 8 + b % 8 in [0, p.tile_blocks); it walks the entries rank(q), rank(q) + tile_blocks, ... of the
+// view's work list (usually one or two).  rank() deals the list to the XCDs in chunks of 64 consecutive entries (workgroup b
+// runs on XCD b % 8; consecutive entries are neighbouring tiles, which share triangle records and should share an L2).
+
+__host__ __device__ inline int fwd_tile_blocks(int ntiles)
+{ // workgroups per view that walk the work list: a quarter of the tiles (about a third of a frame's tiles hold primitives)
+	const int unit = 8 * WORK_CHUNK;
+#ifndef DR_TILE_DIV
+#define DR_TILE_DIV 4
+#endif
+	const int g = ((ntiles / DR_TILE_DIV + unit - 1) / unit) * unit;
+	return g > 0 && g <= ntiles ? g : ntiles; // tiny frames: one workgroup per tile, plain order
+}
+
+// FUSED: the forward of a fit step.  The loss is L = sum (image - obs)^2, so dL/dimage is known the moment a pixel is
+// resolved: tiles without silhouette edges back-propagate into their owners' accumulators right here (no second pass over the
+// frame, no owner buffer round trip -- the owner ids of those tiles are not even written); tiles with edges are left to
+// raster_bwd_edge_kernel.
+// Waves per SIMD the staged forward is compiled for: without texture code it fits five (96 registers), with it four
+// (tools/build_variants.sh builds the neighbours: -DDR_FWD_WAVES=n forces n for both).
+#ifndef DR_FWD_WAVES
+#define DR_FWD_WAVES (TEX ? 4 : 5)
+#endif
+template <class PixT, bool FUSED, bool TEX>
+__global__ __launch_bounds__(64, DR_FWD_WAVES) void raster_fwd_fast_kernel(KParams p)
+{
+	DR_WAVE_TRACE_SCOPE(2);
+	__shared__ WaveLds s_lds[1];
+	__shared__ EdgeSort s_es[1];
+#ifdef DR_FWD_TRACE
+	// per-tile phase timing (tools/fwd_trace.py): eight counters over the first row of the tile in the z buffer
+	uint32_t ftr[16] = {0x7fc0f00du, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#define DR_FTRACE(i) ftr[i] = (uint32_t)(__builtin_readcyclecounter() - ftr0)
+#else
+#define DR_FTRACE(i)
+#endif
+	constexpr int wave = 0;
+	const int lane0 = threadIdx.x & 63;
+	const int G = p.tile_blocks;
+	const long long b = blockIdx.x;
+	int view, q;
+	const bool chunked = G % (8 * WORK_CHUNK) == 0;
+	if (chunked)
+	{
+		view = (int)((b >> 3) % p.n_views);
+		q = (int)((b >> 3) / p.n_views) * 8 + (int)(b & 7);
+	}
+	else
+	{
+		view = (int)(b % p.n_views);
+		q = (int)(b / p.n_views);
+	}
+	const ViewPtrs w = view_ptrs(p, view);
+	const int W = p.W, H = p.H, C = p.C, P = p.L.P;
+	const bool persp = p.persp;
+	const PixT *texture = (const PixT *)p.texture;
+	WaveLds &S = s_lds[wave];
+	// The first G / p.heavy_share workgroups of a view walk the many-primitive tiles (front of the list), the others the rest (from
+	// the back): the index of a workgroup's entry does not depend on the counts, so the counts, the entry header and the
+	// entry's triangle ids are all requested at once.
+	// (tiny frames -- G not a multiple of 512 -- have one class only: the scan kernel lists every tile as "other")
+	const int Gh = chunked ? G / p.heavy_share : 0;
+	const bool heavy_list = q < Gh;
+	const int qq = heavy_list ? q : q - Gh, stride = heavy_list ? Gh : G - Gh;
+	const bool chunk_here = chunked && stride % (8 * WORK_CHUNK) == 0;
+	uint32_t rank = chunk_here ? (uint32_t)((((qq >> 3) / WORK_CHUNK) * 8 + (qq & 7)) * WORK_CHUNK + (qq >> 3) % WORK_CHUNK) : (uint32_t)qq;
+	const uint32_t n_work = w.hdr->work_count[heavy_list ? 0 : 1];
+	for (; rank < n_work; rank += (uint32_t)stride)
+	{
+#ifdef DR_FWD_TRACE
+		const uint64_t ftr0 = __builtin_readcyclecounter();
+		ftr[8] = ftr[9] = ftr[10] = ftr[11] = ftr[12] = 0;
+#endif
+		// (the lane index is made opaque per iteration: otherwise every lane-dependent address of the body is hoisted out of the
+		// loop and kept -- spilled -- in registers across it: + 150 VGPRs for a loop that usually runs once or twice)
+		int lane = lane0;
+		asm volatile("" : "+v"(lane));
+		const WorkEntry &entry = w.work_list[heavy_list ? rank : (uint32_t)p.L.ntiles - 1u - rank];
+		const uint32_t ids12 = entry.ids[lane < ENTRY_IDS ? lane : 0];
+		const int tile = uniform((int)entry.tile), ntri = uniform((int)entry.ntri), nedge = uniform((int)entry.nedge);
+		const uint32_t sweep_slot = (uint32_t)uniform((int)entry.sweep_slot);
+		const int tx = tile % p.L.tiles_x, ty = tile / p.L.tiles_x;
+		const int x0 = tx * TILE, y0 = ty * TILE;
+		const int px = x0 + (lane & 7), py = y0 + (lane >> 3);
+		const bool inb = px < W && py < H;
+		const size_t pix = (size_t)py * W + px;
+		const size_t vpix = (size_t)view * H * W + pix;
+		const double x = px, y = py;
+		// more than ENTRY_IDS triangles: the rest of the inline list (one more round trip, one tile in ten)
+		const uint32_t list_entry = ntri <= ENTRY_IDS ? ids12 : w.tri_list[(size_t)tile * K_TRI + (lane & (K_TRI - 1))];
+		{
+		{
+		PixT ob[CH] = {0, 0, 0, 0};
+		if (FUSED && ntri > 0 && nedge == 0 && inb)
+		{ // requested now, used after the last triangle
+			const PixT *o = (const PixT *)p.obs + vpix * C;
+#pragma unroll
+			for (int cc = 0; cc < CH; cc++)
+				if (cc < C)
+					ob[cc] = o[cc];
+		}
+		PixState st;
+		st.zbest = INFINITY;
+		st.kbest = -1;
+		st.kind = KIND_NONE;
+		st.slot = 0;
+#pragma unroll
+		for (int cc = 0; cc < CH; cc++)
+			st.v[cc] = 0;
+#ifdef DR_FWD_TRACE
+		ftr[1] = (uint32_t)ntri | ((uint32_t)nedge << 16);
+#endif
+		DR_FTRACE(2); // counters arrived
+		// ---- pass 1
+		if (ntri > 0)
+		{
+			const int n_inline = ntri < K_TRI ? ntri : K_TRI;
+			for (int base = 0; base < n_inline; base += TB)
+			{
+				const int nb = n_inline - base < TB ? n_inline - base : TB;
+				if (lane >= base && lane < base + nb)
+					S.ids[lane - base] = list_entry;
+				lds_sync();
+				stage_batch(S, w.tri_rec, w.tri_planes, P, nb, lane);
+				lds_sync();
+				tri_batch<TEX>(p, S, nb, lane, x0, y0, inb, st DR_TRACE_PASS);
+			}
+			if (ntri > K_TRI)
+			{ // spilled pairs of this tile: compact them out of the pool, TB at a time
+				uint32_t spill_n = w.hdr->tri_spill[w.hdr->cur];
+				if (spill_n > p.L.tri_pool_cap)
+					spill_n = p.L.tri_pool_cap;
+				int fill = 0;
+				for (uint32_t i0 = 0; i0 < spill_n; i0 += 64)
+				{
+					const uint2 pr = (i0 + lane < spill_n) ? w.tri_pool[i0 + lane] : make_uint2(0xffffffffu, 0u);
+					unsigned long long m = __ballot((int)pr.x == tile);
+					while (m)
+					{
+						const int room = TB - fill;
+						const int cnt = __popcll(m);
+						// lanes whose pair matches take consecutive slots; at most `room` of them this round
+						const int rank = __popcll(m & ((1ull << lane) - 1ull));
+						const bool sel = ((m >> lane) & 1ull) && rank < room;
+						if (sel)
+							S.ids[fill + rank] = pr.y;
+						const unsigned long long taken = __ballot(sel);
+						m &= ~taken;
+						fill += cnt < room ? cnt : room;
+						if (fill == TB)
+						{
+							lds_sync();
+							stage_batch(S, w.tri_rec, w.tri_planes, P, TB, lane);
+							lds_sync();
+							tri_batch<TEX>(p, S, TB, lane, x0, y0, inb, st DR_TRACE_PASS);
+							fill = 0;
+						}
+					}
+				}
+				if (fill > 0)
+				{
+					lds_sync();
+					stage_batch(S, w.tri_rec, w.tri_planes, P, fill, lane);
+					lds_sync();
+					tri_batch<TEX>(p, S, fill, lane, x0, y0, inb, st DR_TRACE_PASS);
+				}
+			}
+		}
+		DR_FTRACE(3); // pass 1 done
+		// ---- resolve the winner's colour
+		double col[CH];
+#pragma unroll
+		for (int cc = 0; cc < CH; cc++)
+			col[cc] = st.v[cc];
+		if (st.kbest < 0)
+		{
+#pragma unroll
+			for (int cc = 0; cc < CH; cc++)
+				col[cc] = (cc < C && inb) ? background_channel<PixT>(p, view, pix, cc) : 0.0;
+		}
+		Tap tap;
+		double L = 0;
+		if (st.kbest >= 0 && st.kind == KIND_TEXTURED && TEX)
+		{
+			bilinear_tap(p.tex_w, p.tex_h, st.v[0], st.v[1], C, tap);
+			L = st.v[2];
+#pragma unroll
+			for (int cc = 0; cc < CH; cc++)
+				col[cc] = cc < C ? textured_channel(texture, tap, cc) * L : 0.0;
+		}
+		// ---- pass 2: edges far -> near, TB at a time (H.h:2839-2900)
+		int n_edges = 0;
+		if (nedge > 0)
+			n_edges = gather_sorted_edges(s_es[wave], w, p, tile, nedge, lane);
+		if (n_edges > 0)
+		{
+			static_assert(EMAX == 128 && TB == 16, "layout of the saved masks: one 16-bit word per batch of 16 edges");
+			uint32_t snap = 0; // 1 + index of this tile's per-batch snapshots
+			if (sweep_slot)
+			{ // the blending order of the tile's edges: the adjoint need not gather and sort them again
+				for (int i = lane; i < n_edges; i += 64)
+					((uint32_t *)(w.edge_sweep + (size_t)(sweep_slot - 1) * SWEEP_BYTES + SWEEP_ORDER))[i] = s_es[wave].sorted[i];
+				if (n_edges > TB)
+				{
+					uint32_t at = 0;
+					if (lane == 0)
+						at = atomicAdd(&w.hdr->snap_count[w.hdr->cur], 1u);
+					at = (uint32_t)uniform((int)at);
+					snap = at < (uint32_t)SNAP_CAP ? at + 1 : 0u;
+				}
+				if (lane == 0)
+					*(uint32_t *)(w.edge_sweep + (size_t)(sweep_slot - 1) * SWEEP_BYTES + SWEEP_SNAP) = snap;
+			}
+			const EdgeRec *erec = (const EdgeRec *)S.rec;
+			for (int first = 0; first < n_edges; first += TB)
+			{
+				const int nb = n_edges - first < TB ? n_edges - first : TB;
+				const uint32_t ecov = stage_edge_batch(S, s_es[wave], w, P, first, nb, lane, x0, y0, W, inb);
+				uint32_t drawn_batch = 0;
+				for (int j = 0; j < nb; j++)
+				{
+					const bool c = (ecov >> j) & 1u;
+					if (__ballot(c) == 0)
+						continue;
+					const EdgeRec &e = erec[j];
+					double Ze = plane_at(e.xZ, x, y);
+					if (persp)
+						Ze = 1 / Ze;
+					if (c && Ze < st.zbest)
+					{
+						drawn_batch |= 1u << j;
+						const double *ep = &S.planes[j * 12];
+						const double Tr = plane_at(e.x2t, x, y);
+						Tap etap;
+						double eL = 0, eUV[2];
+						if (e.kind == KIND_TEXTURED && TEX)
+							textured_tap(ep, x, y, persp, Ze, p.tex_w, p.tex_h, C, etap, eL, eUV);
+#pragma unroll
+						for (int cc = 0; cc < CH; cc++)
+							if (cc < C)
+							{
+								const double A = edge_channel<PixT, TEX>(e, ep, texture, etap, eL, cc, x, y, persp, Ze);
+								col[cc] *= Tr;
+								col[cc] += (1 - Tr) * A;
+							}
+					}
+				}
+				if (sweep_slot) // bit j: edge first + j of the blending order is drawn over this pixel
+					((uint16_t *)(w.edge_sweep + (size_t)(sweep_slot - 1) * SWEEP_BYTES + CH * 64 * sizeof(double)))[(first / TB) * 64 + lane] =
+						(uint16_t)drawn_batch;
+				if (snap && first + TB < n_edges)
+				{ // the colour after this batch: where the reverse sweep of the previous (farther) batches starts
+					double *shot = (double *)(w.edge_snap + (size_t)(snap - 1) * SNAP_BYTES) + (size_t)(first / TB) * CH * 64;
+#pragma unroll
+					for (int cc = 0; cc < CH; cc++)
+						shot[cc * 64 + lane] = col[cc];
+				}
+			}
+			if (sweep_slot)
+			{ // with the masks, what the adjoint's forward sweep would recompute: the antialiased colour in double
+				double *slot = (double *)(w.edge_sweep + (size_t)(sweep_slot - 1) * SWEEP_BYTES);
+#pragma unroll
+				for (int cc = 0; cc < CH; cc++)
+					slot[cc * 64 + lane] = col[cc];
+			}
+		}
+		else if (n_edges < 0)
+		{ // more than EMAX edges in one tile: ordered search through list + pool, records straight from memory
+			uint32_t edge_spill_n = w.hdr->edge_spill[w.hdr->cur];
+			if (edge_spill_n > p.L.edge_pool_cap)
+				edge_spill_n = p.L.edge_pool_cap;
+			EdgeCursor cur = {0, 0};
+			for (int r = 0; r < nedge; r++)
+			{
+				EdgeCursor f;
+				const uint32_t slot = next_edge(w, tile, nedge, edge_spill_n, r == 0, cur, false, lane, f);
+				cur = f;
+				if (slot == 0xffffffffu)
+					break;
+				const EdgeRec &e = w.edge_rec[slot];
+				if (edge_touches(e, px, py, W, persp, st.zbest, inb))
+				{
+					const double *ep = w.edge_planes + (size_t)slot * 3 * P;
+					double Ze = plane_at(e.xZ, x, y);
+					if (persp)
+						Ze = 1 / Ze;
+					const double Tr = plane_at(e.x2t, x, y);
+					Tap etap;
+					double eL = 0, eUV[2];
+					if (e.kind == KIND_TEXTURED && TEX)
+						textured_tap(ep, x, y, persp, Ze, p.tex_w, p.tex_h, C, etap, eL, eUV);
+#pragma unroll
+					for (int cc = 0; cc < CH; cc++)
+						if (cc < C)
+						{
+							const double A = edge_channel<PixT, TEX>(e, ep, texture, etap, eL, cc, x, y, persp, Ze);
+							col[cc] *= Tr;
+							col[cc] += (1 - Tr) * A;
+						}
+				}
+			}
+		}
+		DR_FTRACE(4); // colour resolved, edges blended
+		// ---- one write per pixel
+		if (inb && !(DR_ABLATE & 4))
+		{
+			if (p.image)
+			{
+				PixT *out = (PixT *)p.image + vpix * C;
+				// streaming (non-temporal) stores: the frame is written once and not re-read by this kernel, keep L2 for records
+				if (C == 4)
+				{
+					typedef PixT V4 __attribute__((ext_vector_type(4)));
+					const V4 v = {(PixT)col[0], (PixT)col[1], (PixT)col[2], (PixT)col[3]};
+					__builtin_nontemporal_store(v, (V4 *)out);
+				}
+				else
+				{
+#pragma unroll
+					for (int cc = 0; cc < CH; cc++)
+						if (cc < C)
+							__builtin_nontemporal_store((PixT)col[cc], out + cc);
+				}
+			}
+			if (p.zbuf)
+				__builtin_nontemporal_store((PixT)st.zbest, (PixT *)p.zbuf + vpix);
+			// a fused forward back-propagates through a tile without edges right below: nobody reads its owner ids again
+			if (!FUSED || nedge > 0)
+				__builtin_nontemporal_store(pack_owner(st.kbest, st.kind), w.face_id + pix);
+		}
+		DR_FTRACE(5); // frame stores issued
+		if (FUSED && nedge == 0 && __ballot(st.kbest >= 0) != 0)
+		{ // same residual as raster_bwd_fast_kernel forms from the stored frame: the colour is rounded to the pixel type first
+			double g[CH];
+#pragma unroll
+			for (int cc = 0; cc < CH; cc++)
+				asm volatile("" : "+v"(ob[cc])); // the observation stays in the pixel type until here: converted to double right
+												 // after its load, it was spilled (four doubles per lane) through the whole of pass 1
+#pragma unroll
+			for (int cc = 0; cc < CH; cc++)
+				g[cc] = (cc < C && inb) ? 2 * ((double)(PixT)col[cc] - (double)ob[cc]) : 0.0;
+			lds_sync();
+			if (DR_ABLATE & 256)
+			{
+			}
+			else if (!TEX && DR_OWNER_MFMA && ntri <= TB)
+				owner_adjoint_mfma(p, w, S, lane, x, y, st.kbest >= 0 ? st.slot : -1, ntri, g);
+			else
+				owner_adjoint<PixT, TEX>(p, w, lane, x, y, st.kbest, st.kbest >= 0 ? st.kind : (int)KIND_NONE, g, tap, L, (double *)&S.rec[0],
+									(uint32_t *)&S.cover[0][0]);
+		}
+#ifdef DR_FWD_TRACE
+		DR_FTRACE(6); // adjoint of pass 1 issued
+		if (lane < 16 && p.zbuf)
+		{
+			uint32_t v = 0;
+			for (int i = 0; i < 16; i++)
+				v = lane == i ? ftr[i] : v;
+			((uint32_t *)p.zbuf)[(size_t)view * H * W + (size_t)(y0 + (lane >> 3)) * W + x0 + (lane & 7)] = v;
+		}
+#endif
+		}
+		}
+		lds_sync(); // the next tile of this wavefront reuses the staging area
+	}
+	if (q == 0 && threadIdx.x == 0)
+		close_epoch(p, w, FUSED);
+}
+
+} // namespace

@@ -1,0 +1,483 @@
+// deodr_amd/csrc/dr_setup.h -- part of the single translation unit dr_kernels.hip (device code, gfx950 / wave64).
+// setup_bin_kernel: per-primitive set-up (cull, stencils, planes, edge records), index checks, binning into 8 x 8 tiles.
+#pragma once
+
+#include "dr_workspace.h"
+
+using namespace dr;
+
+namespace
+{
+
+// ----------------------------------------------------------------------------------------------------- set-up + bin
+
+__device__ __forceinline__ void place_in_tile(uint32_t *list, int cap_inline, uint2 *pool, uint32_t pool_cap, uint32_t *spill, int tile,
+											  uint32_t prim, uint32_t slot)
+{
+	if (slot < (uint32_t)cap_inline)
+		list[(size_t)tile * cap_inline + slot] = prim;
+	else
+	{
+		uint32_t o = atomicAdd(spill, 1u);
+		if (o < pool_cap)
+			pool[o] = make_uint2((uint32_t)tile, prim);
+	}
+}
+
+// The same rejection for the 3 x 3 block of tiles whose first tile is (tx0, ty0): bit 3 dy + dx of the result is set when tile
+// (tx0 + dx, ty0 + dy) is clearly outside one of the N half-planes.  The corner where a half-plane function is largest
+// is the same in every tile, so a x and b y are formed once per column / row of tiles (the per-tile form above costs
+// ~20 operations per half-plane and tile, and binning was half of the arithmetic of the set-up kernel).  The slack uses the
+// largest scale of the block, i.e. it is at least as cautious as the per-tile test.
+template <int N>
+__device__ __forceinline__ uint32_t tiles3x3_outside_halfplanes(const double *eq, int tx0, int ty0)
+{
+	uint32_t out = 0;
+	const double xmax = (tx0 + 2) * TILE + (TILE - 1), ymax = (ty0 + 2) * TILE + (TILE - 1);
+#pragma unroll
+	for (int k = 0; k < N; k++)
+	{
+		const double a = eq[3 * k], b = eq[3 * k + 1], c = eq[3 * k + 2];
+		const double limit = -1e-9 * (fabs(a) * xmax + fabs(b) * ymax + fabs(c)) - 1e-12;
+		const double cx = tx0 * TILE + (a > 0 ? TILE - 1 : 0), cy = ty0 * TILE + (b > 0 ? TILE - 1 : 0);
+		double ax[3], by[3];
+#pragma unroll
+		for (int d = 0; d < 3; d++)
+		{
+			ax[d] = a * (cx + d * TILE);
+			by[d] = b * (cy + d * TILE) + c;
+		}
+#pragma unroll
+		for (int q = 0; q < 9; q++)
+			out |= (ax[q % 3] + by[q / 3] < limit) ? (1u << q) : 0u;
+	}
+	return out;
+}
+
+__device__ __forceinline__ uint32_t push_tile(uint32_t *cnt, uint32_t *list, int cap_inline, uint2 *pool, uint32_t pool_cap, uint32_t *spill,
+											  int tile, uint32_t prim)
+{
+	const uint32_t slot = atomicAdd(&cnt[tile], 1u);
+	place_in_tile(list, cap_inline, pool, pool_cap, spill, tile, prim, slot);
+	return slot; // 0: first primitive of the tile
+}
+
+// Conservative rejection for binning: a primitive covers a pixel only where every one of its half-plane functions
+// E = a x + b y + c is >= 0 (or > 0); if some E is clearly negative on all four corner pixels of the tile, no pixel of the
+// tile can be covered.  The slack keeps the test safe against the rounding of the exact span arithmetic used later.
+template <int N>
+__device__ __forceinline__ bool tile_outside_halfplanes(const double *eq, int tx, int ty)
+{
+	const double xa = tx * TILE, xb = tx * TILE + (TILE - 1), ya = ty * TILE, yb = ty * TILE + (TILE - 1);
+#pragma unroll
+	for (int k = 0; k < N; k++)
+	{
+		const double a = eq[3 * k], b = eq[3 * k + 1], c = eq[3 * k + 2];
+		const double emax = a * (a > 0 ? xb : xa) + b * (b > 0 ? yb : ya) + c;
+		const double scale = fabs(a) * xb + fabs(b) * yb + fabs(c);
+		if (emax < -1e-9 * scale - 1e-12)
+			return true;
+	}
+	return false;
+}
+
+// Work split of the per-primitive kernels (set-up, finalize).  Triangle blocks take PRIM_BLOCK triangles each.  The
+// other blocks take PRIM_BLOCK edge slots (3 k + n) each, of which only the few per cent flagged as silhouette edges need
+// work: the block compacts them through LDS so that they fill the lanes of its first wavefront(s) and the others retire at
+// once (one thread per slot left ~2 busy lanes in almost every wavefront of the long edge path).
+// (Workgroups of one wavefront -- 64 triangles, or a span of 256 edge slots compacted by each of four single-wave blocks -- were
+// measured: every wave starts within 10 us instead of 23, and the kernels take 38 / 35 us instead of 35 / 33: they are bound by
+// the memory-side atomics and the arithmetic of the long waves, not by wave slots.)
+#ifndef DR_PRIM_BLOCK
+#define DR_PRIM_BLOCK 256
+#endif
+constexpr int PRIM_BLOCK = DR_PRIM_BLOCK;
+#ifndef DR_PRIM_WAVES
+#define DR_PRIM_WAVES 3 // waves per SIMD the per-primitive kernels are compiled for (4: spills, same time)
+#endif
+constexpr int COOP_BLOCKS = 8; // 3 x 3-tile blocks of a bounding box one thread bins by itself
+
+__host__ __device__ inline int prim_tri_blocks(int T) { return (T + PRIM_BLOCK - 1) / PRIM_BLOCK; }
+__host__ __device__ inline int prim_blocks(int T) { return prim_tri_blocks(T) + (3 * T + PRIM_BLOCK - 1) / PRIM_BLOCK; }
+
+// Grid of the per-primitive kernels: 1-D, n_views * prim_blocks(T) workgroups.  The edge-slot blocks of every view come first,
+// then the triangle blocks (views fastest inside each class): the wavefront that works on flagged edges is the longest
+// dependent chain of both kernels (13 - 20 us against 3 us for a triangle wavefront, tools/wave_trace.py), and dispatched after
+// the triangle blocks it was the 15 us tail of the kernel.
+#ifndef DR_EDGE_FIRST
+#define DR_EDGE_FIRST 1
+#endif
+struct PrimWork
+{
+	int view, index; // index of the block inside its class
+	bool tri;
+	int view_block; // a block id in [0, prim_blocks(T)) inside the view (housekeeping loops)
+};
+__device__ __forceinline__ PrimWork prim_work(const KParams &p, bool edge_first = DR_EDGE_FIRST, int skip = 0)
+{
+	const int TBk = prim_tri_blocks(p.T), EB = prim_blocks(p.T) - TBk, nv = p.n_views;
+	int b = (int)blockIdx.x - skip;
+	PrimWork w;
+	const int first = (edge_first ? EB : TBk) * nv;
+	const bool in_first = b < first;
+	if (!in_first)
+		b -= first;
+#ifndef DR_VIEW_MAJOR
+#define DR_VIEW_MAJOR 0 // measurement builds: 1 = all blocks of a view, then the next view (instead of views fastest)
+#endif
+	const int per_view = in_first == edge_first ? EB : TBk; // blocks per view of this block's class
+	w.view = DR_VIEW_MAJOR ? b / per_view : b % nv;
+	w.index = DR_VIEW_MAJOR ? b % per_view : b / nv;
+	w.tri = edge_first ? !in_first : in_first;
+	w.view_block = w.tri ? w.index : TBk + w.index;
+	return w;
+}
+
+// -> the slot this thread works on, or -1.  Called by every thread of an edge block.
+__device__ __forceinline__ int compact_flagged_slots(const KParams &p, const uint8_t *edgeflags, int edge_block)
+{
+	__shared__ uint32_t s_slots[PRIM_BLOCK];
+	__shared__ uint32_t s_count[PRIM_BLOCK / 64];
+	const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+	const int slot = edge_block * PRIM_BLOCK + tid;
+	const bool flagged = p.sigma > 0 && slot < 3 * p.T && edgeflags[slot] != 0;
+	const unsigned long long m = __ballot(flagged);
+	if (lane == 0)
+		s_count[wave] = (uint32_t)__popcll(m);
+	__syncthreads();
+	uint32_t before = 0, total = 0;
+#pragma unroll
+	for (int i = 0; i < PRIM_BLOCK / 64; i++)
+	{
+		const uint32_t c = s_count[i];
+		before += i < wave ? c : 0u;
+		total += c;
+	}
+	if (flagged)
+		s_slots[before + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)slot;
+	__syncthreads();
+	return (uint32_t)tid < total ? (int)s_slots[tid] : -1;
+}
+
+#ifdef DR_WAVE_TRACE
+// timeline of the per-primitive kernels: [wave slot] = (start, end) in 10 ns ticks of the constant 100 MHz counter
+__device__ unsigned long long g_wave_trace[3][1 << 18][2]; // 0 set-up, 1 finalize, 2 forward raster
+__device__ unsigned long long g_wave_phase[4][1 << 16][8];  // 0 set-up, 1 finalize: time stamps inside the wavefronts that work on edges
+struct WaveTrace
+{
+	int which;
+	unsigned long long t0;
+	__device__ void phase(int i, int tri = 0) const
+	{
+		if ((threadIdx.x & 63) == 0 && which < 2)
+		{
+			const unsigned id = (blockIdx.y * gridDim.x + blockIdx.x) * (blockDim.x >> 6) + (threadIdx.x >> 6);
+			if (id < (1u << 16))
+			{
+				if (i == 1)
+					g_wave_phase[which + 2 * tri][id][0] = t0;
+				g_wave_phase[which + 2 * tri][id][i] = __builtin_amdgcn_s_memrealtime();
+			}
+		}
+	}
+	__device__ WaveTrace(int w) : which(w), t0(__builtin_amdgcn_s_memrealtime()) { phase(0); }
+	__device__ ~WaveTrace()
+	{
+		if ((threadIdx.x & 63) == 0)
+		{
+			const unsigned id = (blockIdx.y * gridDim.x + blockIdx.x) * (blockDim.x >> 6) + (threadIdx.x >> 6);
+			if (id < (1u << 18))
+			{
+				g_wave_trace[which][id][0] = t0;
+				g_wave_trace[which][id][1] = __builtin_amdgcn_s_memrealtime();
+			}
+		}
+	}
+};
+#define DR_WAVE_TRACE_SCOPE(w) WaveTrace wave_trace_scope(w)
+#define DR_WAVE_PHASE(i) wave_trace_scope.phase(i)
+#define DR_WAVE_PHASE_T(i) wave_trace_scope.phase(i, 1)
+#else
+#define DR_WAVE_TRACE_SCOPE(w)
+#define DR_WAVE_PHASE(i)
+#define DR_WAVE_PHASE_T(i)
+#endif
+
+__global__ __launch_bounds__(PRIM_BLOCK, DR_PRIM_WAVES) void setup_bin_kernel(KParams p)
+{
+	DR_WAVE_TRACE_SCOPE(0);
+	const PrimWork pw = prim_work(p);
+	const int view = pw.view;
+	const int item = pw.view_block * PRIM_BLOCK + threadIdx.x; // only an id for the housekeeping below
+	const int n_items = prim_blocks(p.T) * PRIM_BLOCK;
+	const bool tri_block = pw.tri;
+	const SceneView s = scene_view(p, view);
+	const ViewPtrs w = view_ptrs(p, view);
+	const uint32_t cur = w.hdr->epoch & 1u; // stable during this kernel: only the forward raster advances the epoch
+	if (item == 0)
+	{
+		w.hdr->cur = cur;
+		w.hdr->tri_spill[1 - cur] = 0;
+		w.hdr->edge_spill[1 - cur] = 0;
+		w.hdr->snap_count[1 - cur] = 0;
+		w.hdr->work_count[0] = w.hdr->work_count[1] = 0; // filled by tile_scan_kernel, read by the forward raster
+	}
+	if (item <= EDGE_LISTS) // appended to by tile_scan_kernel, the next kernel on the stream
+		w.edge_tile_cnt[item * CNT_STRIDE] = 0;
+	if (p.clear_grads && view == 0 && p.uv_b)
+		for (int v = item; v < 2 * p.Vuv; v += n_items)
+		{ // shared by the views: zeroed once
+			if (p.vtx_f64)
+				((double *)p.uv_b)[v] = 0;
+			else
+				((float *)p.uv_b)[v] = 0;
+		}
+	if (p.clear_grads)
+		for (int v = item; v < p.V; v += n_items)
+		{ // nothing accumulates into them before finalize_kernel, two kernels later
+			const size_t at = (size_t)view * p.V + v;
+			if (p.vtx_f64)
+			{
+				if (p.ij_b)
+					((double2 *)p.ij_b)[at] = make_double2(0, 0);
+				if (p.shade_b)
+					((double *)p.shade_b)[at] = 0;
+				if (p.colors_b)
+					for (int c = 0; c < p.C; c++)
+						((double *)p.colors_b)[at * p.C + c] = 0;
+			}
+			else
+			{
+				if (p.ij_b)
+					((float2 *)p.ij_b)[at] = make_float2(0, 0);
+				if (p.shade_b)
+					((float *)p.shade_b)[at] = 0;
+				if (p.colors_b)
+					for (int c = 0; c < p.C; c++)
+						((float *)p.colors_b)[at * p.C + c] = 0;
+			}
+		}
+	// Records are built in registers and leave with one 128-byte store: the binning below reads the local copy (reading a
+	// record back from HBM right after writing it costs a full memory round trip per field), a culled triangle only gets its two
+	// flags written, an edge slot that is not a silhouette edge nothing at all.
+	// A primitive whose bounding box needs more than COOP_BLOCKS blocks of 3 x 3 tiles is not binned by its own thread
+	// (hundreds of dependent atomic round trips in one lane: 0.3 ms of set-up for a 1 000-triangle mesh filling a 1024^2
+	// frame) but handed to the whole wavefront below: its half-planes and box are kept here.  Smaller ones stay with their
+	// thread (all threads at once beat the wavefront working through its large primitives one after the other).
+	const int lane = threadIdx.x & 63;
+	// ---- the large primitives of this wavefront, one after the other, 64 tiles of the bounding box at a time
+	auto bin_large = [&](bool big, const double *hp, int btx0, int bty0, int bntx, int bnty, int bprim) {
+		unsigned long long todo = __ballot(big);
+		while (todo)
+		{
+			const int src = __ffsll((long long)todo) - 1;
+			todo &= todo - 1;
+			double q[12];
+#pragma unroll
+			for (int i = 0; i < 12; i++)
+				q[i] = __shfl(hp[i], src, 64);
+			const int tx0 = __shfl(btx0, src, 64), ty0 = __shfl(bty0, src, 64), ntx = __shfl(bntx, src, 64), nty = __shfl(bnty, src, 64);
+			const uint32_t prim = (uint32_t)__shfl(bprim, src, 64);
+			for (int t = lane; t < ntx * nty; t += 64)
+			{
+				const int tx = tx0 + t % ntx, ty = ty0 + t / ntx, tile = ty * p.L.tiles_x + tx;
+				if (tri_block)
+				{
+					if (!tile_outside_halfplanes<3>(q, tx, ty) || (!p.strict && tx == tx0 + ntx - 1))
+						push_tile(w.tri_cnt, w.tri_list, K_TRI, w.tri_pool, p.L.tri_pool_cap, &w.hdr->tri_spill[cur], tile, prim);
+				}
+				else if (!tile_outside_halfplanes<4>(q, tx, ty))
+					push_tile(w.edge_cnt, w.edge_list, K_EDGE, w.edge_pool, p.L.edge_pool_cap, &w.hdr->edge_spill[cur], tile, prim);
+			}
+		}
+	};
+	if (tri_block)
+	{
+		bool big = false;
+		double hp[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+		int btx0 = 0, bty0 = 0, bntx = 0, bnty = 0, bprim = 0;
+		do
+		{
+			const int k = pw.index * PRIM_BLOCK + threadIdx.x;
+			if (k >= p.T)
+				break;
+			TriInputs t;
+			TriRec rec;
+			TriRec &out = w.tri_rec[k];
+			if (const uint32_t bad = load_triangle(s, k, t, true))
+			{ // checkSceneValid (H.h:2700-2712): the triangle is dropped and the sticky error word tells the host
+				atomicOr(&w.hdr->scene_errors, bad);
+				w.tri_flag[k] = 0;
+				break;
+			}
+			DR_WAVE_PHASE_T(1); // inputs (?)
+			double x2b[9];
+			const bool drawn = setup_tri_geometry(s, t, rec, x2b) && rec.kind != KIND_NONE;
+			w.tri_flag[k] = (uint8_t)(rec.kind | (rec.front ? 4 : 0));
+			if (!drawn)
+				break; // culled (or textured without shading): its record is never read -- the raster kernels reach records
+					   // through the tile lists, the finalize kernel looks at tri_flag first
+			const int x0 = rec.x_min < 0 ? 0 : rec.x_min, x1 = rec.x_max > s.W - 1 ? s.W - 1 : rec.x_max;
+			const int y0 = rec.y_begin[0] < 0 ? 0 : rec.y_begin[0], y1 = rec.y_end[1] > s.H - 1 ? s.H - 1 : rec.y_end[1];
+			const bool on_screen = !(x0 > x1 || y0 > y1 || (DR_ABLATE & 2048));
+			const double eq[9] = {rec.eq[0][0], rec.eq[0][1], rec.eq[0][2], rec.eq[1][0], rec.eq[1][1], rec.eq[1][2], rec.eq[2][0], rec.eq[2][1], rec.eq[2][2]};
+			const int tx0 = x0 / TILE, ty0 = y0 / TILE, ntx = x1 / TILE - tx0 + 1, nty = y1 / TILE - ty0 + 1;
+			const bool large = on_screen && ((ntx + 2) / 3) * ((nty + 2) / 3) > COOP_BLOCKS;
+			// Non-strict fill rule: get_xrange's ceil_div clamps the left end of a row to x_max (H.h:895), so a row whose span lies
+			// wholly between x_max and the rightmost vertex -- or beyond the right border of the frame -- still draws the pixel of
+			// column x_max although that pixel is outside the left edge.  tri_half_span reproduces it; the half-plane test must
+			// then not drop the tiles of that column.
+			const int keep_dx = s.strict ? -1 : ntx - 1;
+			// The slot requests of the first 3 x 3 block of tiles (for the usual small triangle: all of them) leave NOW, before the
+			// attribute planes are formed and the record is stored: that arithmetic and those stores then overlap the round trip
+			// of the requests (5.5 of the 12.6 us of a triangle wavefront, tools/wave_trace.py) instead of preceding it.
+			uint32_t slot0[9];
+			bool use0[9];
+#pragma unroll
+			for (int q = 0; q < 9; q++)
+				use0[q] = false, slot0[q] = 0;
+			if (on_screen && !large)
+			{
+				const uint32_t outside = tiles3x3_outside_halfplanes<3>(eq, tx0, ty0);
+#pragma unroll
+				for (int q = 0; q < 9; q++)
+				{
+					const int dx = q % 3, dy = q / 3;
+					use0[q] = dx < ntx && dy < nty && (!((outside >> q) & 1u) || dx == keep_dx);
+					if (use0[q])
+						slot0[q] = atomicAdd(&w.tri_cnt[(ty0 + dy) * p.L.tiles_x + tx0 + dx], 1u);
+				}
+			}
+			setup_tri_attributes(s, t, rec, x2b, w.tri_planes + (size_t)k * 3 * s.P);
+			DR_WAVE_PHASE_T(2); // record computed
+			rec.pad0[0] = rec.pad0[1] = 0;
+			rec.pad1[0] = rec.pad1[1] = rec.pad1[2] = 0;
+			if (!(DR_ABLATE & 4096))
+				out = rec;
+			if (!on_screen)
+				break;
+			if (large)
+			{
+				big = true;
+#pragma unroll
+				for (int i = 0; i < 9; i++)
+					hp[i] = eq[i];
+				btx0 = tx0, bty0 = ty0, bntx = ntx, bnty = nty, bprim = k;
+				break;
+			}
+			DR_WAVE_PHASE_T(3); // record stored
+#pragma unroll
+			for (int q = 0; q < 9; q++)
+				if (use0[q])
+				{
+					const int tile = (ty0 + q / 3) * p.L.tiles_x + tx0 + q % 3;
+					place_in_tile(w.tri_list, K_TRI, w.tri_pool, p.L.tri_pool_cap, &w.hdr->tri_spill[cur], tile, (uint32_t)k, slot0[q]);
+				}
+			// the other 3 x 3 blocks of a wider box, the slot requests of a block all in flight together
+			for (int by = 0; by < nty; by += 3)
+				for (int bx = by == 0 ? 3 : 0; bx < ntx; bx += 3)
+				{
+					uint32_t slot[9];
+					bool use[9];
+					const uint32_t outside = tiles3x3_outside_halfplanes<3>(eq, tx0 + bx, ty0 + by);
+#pragma unroll
+					for (int q = 0; q < 9; q++)
+					{
+						const int dx = bx + q % 3, dy = by + q / 3;
+						use[q] = dx < ntx && dy < nty && (!((outside >> q) & 1u) || dx == keep_dx);
+						slot[q] = 0;
+						if (use[q])
+							slot[q] = atomicAdd(&w.tri_cnt[(ty0 + dy) * p.L.tiles_x + tx0 + dx], 1u);
+					}
+#pragma unroll
+					for (int q = 0; q < 9; q++)
+						if (use[q])
+						{
+							const int tile = (ty0 + by + q / 3) * p.L.tiles_x + tx0 + bx + q % 3;
+							place_in_tile(w.tri_list, K_TRI, w.tri_pool, p.L.tri_pool_cap, &w.hdr->tri_spill[cur], tile, (uint32_t)k, slot[q]);
+						}
+				}
+		} while (false);
+		DR_WAVE_PHASE_T(4);
+		bin_large(big, hp, btx0, bty0, bntx, bnty, bprim);
+		return;
+	}
+	// nothing is written for the ~97 % of slots that are not silhouette edges: records are only reached through the
+	// tile lists, and finalize_kernel works from the same flags
+	const int slot = compact_flagged_slots(p, s.edgeflags, pw.index);
+	DR_WAVE_PHASE(1); // flags compacted
+	{
+		bool big = false;
+		double hp[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+		int btx0 = 0, bty0 = 0, bntx = 0, bnty = 0, bprim = 0;
+		do
+		{
+			if (slot < 0)
+				break;
+			const int k = slot / 3, n = slot - 3 * k;
+			TriInputs t;
+			EdgeRec e;
+			EdgeRec &eout = w.edge_rec[slot];
+			if (load_triangle(s, k, t, true))
+			{ // invalid indices (reported by the triangle's own thread)
+				eout.kind = KIND_NONE;
+				break;
+			}
+			DR_WAVE_PHASE(2); // inputs arrived (?)
+			// (the finalize inputs go straight to memory: kept in registers until the record is complete they cost the kernel a
+			// wave per SIMD; those of an edge that turns out not to be drawn are never read)
+			setup_edge_only(s, t, k, n, e, w.edge_planes + (size_t)slot * 3 * s.P, &w.edge_fin[slot]);
+			DR_WAVE_PHASE(3); // record computed
+			if (e.kind == KIND_NONE)
+			{
+				eout.kind = KIND_NONE;
+				break;
+			}
+			for (int i = 0; i < 7; i++)
+				e.pad0[i] = 0;
+			eout = e;
+			DR_WAVE_PHASE(4); // record stored
+			if (e.x_begin > e.x_end || e.y_begin > e.y_end)
+				break;
+			const double band[12] = {e.x2b[0], e.x2b[1], e.x2b[2], e.x2b[3], e.x2b[4], e.x2b[5], e.x2t[0], e.x2t[1], e.x2t[2],
+									 -e.x2t[0], -e.x2t[1], 1 - e.x2t[2]}; // the four half-planes of the band, H.h:1418-1435
+			const int tx0 = e.x_begin / TILE, ty0 = e.y_begin / TILE, ntx = e.x_end / TILE - tx0 + 1, nty = e.y_end / TILE - ty0 + 1;
+			if (((ntx + 2) / 3) * ((nty + 2) / 3) > COOP_BLOCKS)
+			{
+				big = true;
+#pragma unroll
+				for (int i = 0; i < 12; i++)
+					hp[i] = band[i];
+				btx0 = tx0, bty0 = ty0, bntx = ntx, bnty = nty, bprim = slot;
+				break;
+			}
+			for (int by = 0; by < nty; by += 3)
+				for (int bx = 0; bx < ntx; bx += 3)
+				{
+					uint32_t got[9];
+					bool use[9];
+					const uint32_t outside = tiles3x3_outside_halfplanes<4>(band, tx0 + bx, ty0 + by);
+#pragma unroll
+					for (int q = 0; q < 9; q++)
+					{
+						const int dx = bx + q % 3, dy = by + q / 3;
+						use[q] = dx < ntx && dy < nty && !((outside >> q) & 1u);
+						got[q] = 1;
+						if (use[q])
+							got[q] = atomicAdd(&w.edge_cnt[(ty0 + dy) * p.L.tiles_x + tx0 + dx], 1u);
+					}
+#pragma unroll
+					for (int q = 0; q < 9; q++)
+						if (use[q])
+						{
+							const int tile = (ty0 + by + q / 3) * p.L.tiles_x + tx0 + bx + q % 3;
+							place_in_tile(w.edge_list, K_EDGE, w.edge_pool, p.L.edge_pool_cap, &w.hdr->edge_spill[cur], tile, (uint32_t)slot, got[q]);
+						}
+				}
+		} while (false);
+		DR_WAVE_PHASE(5); // own binning done
+		bin_large(big, hp, btx0, bty0, bntx, bnty, bprim);
+	}
+}
+
+} // namespace
