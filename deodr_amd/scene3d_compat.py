@@ -48,6 +48,30 @@ class Camera:
     def get_center(self):
         return -self.extrinsic[:3, :3].T.dot(self.extrinsic[:, 3])
 
+    # small host-side helpers of the reference class (dr.py:280-310, 443-451): exporters and viewers call them
+    def _fov(self, axis, size):
+        assert self.intrinsic[axis, 2] == size / 2, "the principal point must be the image centre"
+        return float(np.degrees(2 * np.arctan(size / (2 * self.intrinsic[axis, axis]))))
+
+    xfov = property(lambda self: self._fov(0, self.width), doc="horizontal field of view in degrees")
+    yfov = property(lambda self: self._fov(1, self.height), doc="vertical field of view in degrees")
+
+    def camera_to_world_mtx_4x4(self):
+        m = np.eye(4)
+        m[:3, :3], m[:3, 3] = self.extrinsic[:, :3].T, self.get_center()
+        return m
+
+    def left_mul_intrinsic(self, projected):
+        assert projected.ndim == 2 and projected.shape[-1] == 2
+        return projected.dot(self.intrinsic[:2, :2].T) + self.intrinsic[:2, 2]
+
+    def column_stack(self, values):
+        return np.column_stack(values)
+
+    def __repr__(self):
+        fields = ("width", "height", "extrinsic", "intrinsic", "distortion")
+        return "<Camera>\n" + "".join(f"{name}:\n{getattr(self, name)}\n" for name in fields)
+
     def project_points(self, points_3d, return_depths=True, store_backward=None):
         pts = torch.as_tensor(np.asarray(points_3d, dtype=np.float64), device=_device()).requires_grad_(store_backward is not None)
         ij, depths = self.on_device().project_points(pts)
@@ -133,6 +157,34 @@ class Scene3D:
     def clear_gradients(self):
         assert self.mesh is not None
         self.mesh._vertices_b = np.zeros((self.mesh.nb_vertices, 3))
+
+    # ---- lighting on its own (dr.py:814-850) ------------------------------------------------------------------------------
+
+    def compute_vertices_luminosity(self):
+        """max(0, -n . l) + ambient per vertex from ``mesh.vertex_normals``, through the device op (its graph is kept for
+        :meth:`compute_vertices_luminosity_backward`)"""
+        assert self.mesh is not None
+        dev = _device()
+        normals = torch.as_tensor(np.asarray(self.mesh.vertex_normals, dtype=np.float64), device=dev).requires_grad_(True)
+        ambient = torch.as_tensor(float(self.light_ambient), dtype=torch.float64, device=dev).requires_grad_(True)
+        light = None
+        if self.light_directional is None:
+            out = torch.zeros(normals.shape[0], dtype=torch.float64, device=dev) + ambient
+        else:
+            light = torch.as_tensor(np.asarray(self.light_directional, dtype=np.float64), device=dev).requires_grad_(True)
+            out = torch.relu(-(normals * light).sum(-1)) + ambient
+        self._luminosity_graph = (out, normals, light, ambient)
+        return out.detach().cpu().numpy()
+
+    def compute_vertices_luminosity_backward(self, vertices_luminosity_b):
+        """-> ``light_directional_b``, ``vertex_normals_b``, ``light_ambient_b`` (same attributes as the reference)"""
+        out, normals, light, ambient = self._luminosity_graph
+        seed = torch.as_tensor(np.asarray(vertices_luminosity_b, dtype=np.float64), device=out.device)
+        leaves = [ambient] + ([normals, light] if light is not None else [])
+        grads = torch.autograd.grad([out], leaves, [seed], retain_graph=True)
+        self.light_ambient_b = float(grads[0])
+        if light is not None:
+            self.vertex_normals_b, self.light_directional_b = grads[1].cpu().numpy(), grads[2].cpu().numpy()
 
     # ---- forward ---------------------------------------------------------------------------------------------------------
 

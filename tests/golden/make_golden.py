@@ -254,6 +254,37 @@ def deferred_hand():
     print("deferred hand:", {k: v.shape for k, v in buffers.items()})
 
 
+def scene3d_helpers():
+    """The small public members of Camera / Scene3D around the render calls (dr.py:280-310, 443-451, 814-850): fields of view,
+    camera-to-world matrix, left_mul_intrinsic, repr; compute_vertices_luminosity and its adjoint on the hand mesh."""
+    import deodr
+    from deodr import ColoredTriMesh, read_obj
+    from deodr.differentiable_renderer import Scene3D, default_camera
+
+    faces, vertices = read_obj(os.path.join(deodr.data_path, "hand.obj"))
+    mesh = ColoredTriMesh(faces.copy(), vertices=vertices, nb_colors=3)
+    rot = np.array([[0.96, 0.0, 0.28], [0.0, -1.0, 0.0], [0.28, 0.0, -0.96]])
+    camera = default_camera(96, 80, 70, mesh.vertices, rot)
+    rs = np.random.RandomState(3)
+    points = rs.randn(7, 2)
+    scene = Scene3D(sigma=1)
+    light = np.array([-0.1, -0.5, -0.4])
+    scene.set_light(light_directional=light, light_ambient=0.3)
+    scene.set_mesh(mesh)
+    mesh.compute_vertex_normals()
+    scene.store_backward_current = {}
+    luminosity = scene.compute_vertices_luminosity()
+    luminosity_b = rs.randn(mesh.nb_vertices)
+    scene.compute_vertices_luminosity_backward(luminosity_b)
+    np.savez_compressed(
+        os.path.join(OUT, "scene3d_helpers.npz"), rot=rot, xfov=camera.xfov, yfov=camera.yfov, camera_to_world=camera.camera_to_world_mtx_4x4(),
+        points=points, left_mul_intrinsic=camera.left_mul_intrinsic(points), repr=np.array(repr(camera)), light=light,
+        vertex_normals=np.array(mesh.vertex_normals), luminosity=luminosity, luminosity_b=luminosity_b,
+        light_directional_b=np.array(scene.light_directional_b), vertex_normals_b=np.array(scene.vertex_normals_b), light_ambient_b=scene.light_ambient_b,
+    )  # fmt: skip
+    print("scene3d helpers: xfov, yfov =", camera.xfov, camera.yfov)
+
+
 if __name__ == "__main__":
     only = sys.argv[1:]
     with tempfile.TemporaryDirectory() as tmp:
@@ -268,3 +299,5 @@ if __name__ == "__main__":
             rgb_hand_fit()
         if not only or "deferred" in only:
             deferred_hand()
+        if not only or "helpers" in only:
+            scene3d_helpers()

@@ -40,6 +40,24 @@ def rel(a, b):
 # ------------------------------------------------------------------------------------------------------------ CPU part
 
 
+def test_compat_camera_helpers_cpu():
+    """fields of view, camera-to-world matrix, left_mul_intrinsic, repr of the drop-in Camera against the reference's own values
+    (tests/golden/scene3d_helpers.npz); plain NumPy members, no device involved"""
+    import deodr_amd as deodr
+
+    d = fixture("scene3d_helpers.npz")
+    vertices, _ = hand()
+    camera = deodr.default_camera(96, 80, 70, vertices, d["rot"])
+    assert abs(camera.xfov - float(d["xfov"])) < 1e-12 and abs(camera.yfov - float(d["yfov"])) < 1e-12
+    assert rel(camera.camera_to_world_mtx_4x4(), d["camera_to_world"]) < 1e-13
+    assert rel(camera.left_mul_intrinsic(d["points"]), d["left_mul_intrinsic"]) < 1e-13
+    assert repr(camera) == str(d["repr"])
+    assert np.array_equal(camera.column_stack((np.arange(3), np.ones(3))), np.column_stack((np.arange(3), np.ones(3))))
+    off_centre = deodr.Camera(camera.extrinsic, camera.intrinsic + np.array([[0, 0, 1.0], [0, 0, 0], [0, 0, 0]]), 80, 96)
+    with pytest.raises(AssertionError):
+        off_centre.xfov
+
+
 def test_projection_distortion_forward_and_adjoint_cpu():
     """DeviceCamera.project_points with OpenCV distortion (dr.py:341-395) and its adjoint (dr.py:397-438, here autograd)"""
     from deodr_amd.scene3d import DeviceCamera
@@ -427,3 +445,27 @@ def test_dropin_scene3d_render_deferred():
         assert v.shape == ref.shape, k
         assert np.abs(v - ref).max() <= 1e-9 * max(1.0, np.abs(ref).max()), k
     assert np.array_equal(buffers["face_id"], d["buf_face_id"])  # flat per triangle: exact
+
+
+@pytest.mark.gpu
+def test_dropin_scene3d_luminosity_and_adjoint():
+    """Scene3D.compute_vertices_luminosity / _backward (dr.py:814-850) against the reference's values on the hand mesh"""
+    import deodr_amd as deodr
+
+    d = fixture("scene3d_helpers.npz")
+    vertices, faces = hand()
+    mesh = deodr.ColoredTriMesh(faces.copy(), vertices=vertices, nb_colors=3)
+    mesh.compute_vertex_normals()
+    assert rel(mesh.vertex_normals, d["vertex_normals"]) < 1e-12
+    scene = deodr.Scene3D(sigma=1)
+    scene.set_light(light_directional=d["light"], light_ambient=0.3)
+    scene.set_mesh(mesh)
+    assert rel(scene.compute_vertices_luminosity(), d["luminosity"]) < 1e-12
+    scene.compute_vertices_luminosity_backward(d["luminosity_b"])
+    assert rel(scene.light_directional_b, d["light_directional_b"]) < 1e-12
+    assert rel(scene.vertex_normals_b, d["vertex_normals_b"]) < 1e-12
+    assert abs(scene.light_ambient_b - float(d["light_ambient_b"])) < 1e-10
+    scene.set_light(light_directional=None, light_ambient=0.3)
+    assert np.allclose(scene.compute_vertices_luminosity(), 0.3)
+    scene.compute_vertices_luminosity_backward(d["luminosity_b"])
+    assert abs(scene.light_ambient_b - d["luminosity_b"].sum()) < 1e-10
