@@ -90,3 +90,61 @@ def test_binning_keeps_every_tile_a_triangle_draws_into(oracle_api, strict):
         assert clamp_cases >= 2  # the sample does exercise the artefact
     else:
         assert clamp_cases == 0
+
+
+@pytest.mark.parametrize("strict", [True, False])
+@pytest.mark.parametrize("sigma", [0.5, 1.0, 3.0])
+def test_binning_keeps_every_tile_an_edge_band_draws_into(oracle_api, strict, sigma):
+    """Same property for the silhouette edges: the four half-planes of the band (bary0 > 0, bary1 > 0, 0 < T < 1) must not
+    reject a tile that get_edge_xrange_from_ineq (H.h:2620-2648) reaches, including bands leaving the frame on every side and
+    integer vertex coordinates (pixel centres exactly on the band's border lines)."""
+    import ctypes as C
+
+    rs = np.random.RandomState(11)
+    lib = sim_util.lib()
+    tile, W, H = 8, 40, 32
+    tris = [(rs.rand(2) * [W, H] + (rs.rand(3, 2) - 0.5) * [W, H] * rs.choice([0.3, 1.0, 2.5])) for _ in range(200)]
+    tris += [np.round(t) for t in tris[:60]]
+    drawn = 0
+    for ij in tris:
+        for n in range(3):
+            s = one_triangle_scene(ij, W=W, H=H, strict=strict, edgeflags=tuple(i == n for i in range(3)))
+            c, keep = sim_util.sim_scene(s, sigma=sigma)
+            mask = np.zeros((H, W), dtype=np.uint8)
+            lib.sim_edge_coverage(C.byref(c), 0, n, mask.ctypes.data)
+            _, edge_cnt = sim_util.bin_counts(s, sigma=sigma, tile=tile, exact=True)
+            edge_cnt = edge_cnt.reshape((H + tile - 1) // tile, (W + tile - 1) // tile)
+            ys, xs = np.nonzero(mask)
+            drawn += len(ys)
+            assert np.all(edge_cnt[ys // tile, xs // tile] == 1), (np.asarray(ij).tolist(), n)
+    assert drawn > 1000
+
+
+@pytest.mark.parametrize("strict", [True, False])
+def test_span_functions_match_oracle_coverage_random(oracle_api, strict):
+    """test_span_functions_match_oracle_coverage over 300 random triangles (a third with integer vertices, many leaving the frame):
+    triangle coverage and the band of every edge, pixel for pixel against what the checker draws"""
+    import ctypes as C
+
+    rs = np.random.RandomState(21)
+    lib = sim_util.lib()
+    rnd = oracle_api.ref() or oracle_api.port()
+    W, H, sigma = 40, 32, 1.5
+    tris = [(rs.rand(2) * [W, H] + (rs.rand(3, 2) - 0.5) * [W, H] * rs.choice([0.3, 1.0, 2.5])) for _ in range(200)]
+    tris += [np.round(t) for t in tris[:100]]
+    for ij in tris:
+        s = one_triangle_scene(ij, W=W, H=H, strict=strict)
+        if abs(np.linalg.det(np.column_stack((np.asarray(ij), np.ones(3))))) < 1e-9:
+            continue  # three integer vertices on a line
+        c, keep = sim_util.sim_scene(s, sigma=sigma)
+        image, z = rnd.render(s, 0.0)
+        mask = np.zeros((H, W), dtype=np.uint8)
+        lib.sim_tri_coverage(C.byref(c), 0, mask.ctypes.data)
+        assert np.array_equal(mask.astype(bool), np.isfinite(z)), np.asarray(ij).tolist()
+        for n in range(3):
+            s1 = one_triangle_scene(ij, W=W, H=H, strict=strict, edgeflags=tuple(i == n for i in range(3)))
+            image1, _ = rnd.render(s1, sigma)
+            band = (np.abs(image1[:, :, 0] - image[:, :, 0]) > 0) & ~np.isfinite(z)
+            emask = np.zeros((H, W), dtype=np.uint8)
+            lib.sim_edge_coverage(C.byref(c), 0, n, emask.ctypes.data)
+            assert np.array_equal(emask.astype(bool) & ~np.isfinite(z), band), (np.asarray(ij).tolist(), n)
