@@ -122,7 +122,7 @@ def draw_mesh_scene(it):
     n_views = int(rs.choice([1, 2, 4]))
     sigma = float(rs.choice([0.0, 0.5, 1.0, 2.0]))
     dt = torch.float64 if rs.rand() < 0.5 else torch.float32
-    mode = ["image", "image", "error", "persp"][rs.randint(4)]
+    mode = ["image", "image", "error", "persp", "noculling"][rs.randint(5)]  # the last two: forward only, like the reference
     zoom, fov = float(rs.choice([0.7, 1.0, 1.5])), float(rs.choice([30.0, 60.0]))
     vertices, faces = scenes.bumpy_sphere(nu, n_rings, bump=float(rs.rand() * 0.3))
     tilt, views, clockwise, texture_size = rs.rand(2), [], None, int(rs.choice([8, 32]))
@@ -135,6 +135,7 @@ def draw_mesh_scene(it):
         s.ij = centre + (s.ij - centre) * zoom
         s.integer_pixel_centers = bool(it % 3 != 1)
         s.perspective_correct = mode == "persp"
+        s.backface_culling = mode != "noculling"
         views.append(s)
     desc = (f"mesh H={H} W={W} sphere={nu}x{n_rings} C={nb_colors} textured={textured} views={n_views} sigma={sigma} dt={dt} mode={mode} zoom={zoom} "
             f"fov={fov} intpix={views[0].integer_pixel_centers}")
@@ -142,7 +143,8 @@ def draw_mesh_scene(it):
 
 
 def main_meshes(n):
-    """image mode: as main(); error mode: antialiase_error forward + adjoint against the repaired checker; persp mode: forward only"""
+    """image mode: as main(); error mode: antialiase_error forward + adjoint against the repaired checker; persp / noculling modes
+    (perspective_correct=True / backface_culling=False): forward only, the reference has no adjoint for them"""
     ref = api.ref() or api.port()
     fixed = api.ref(fixed=True) or api.port(fixed=True)
     worst = dict(image=0.0, err_buffer=0.0, ij_b=0.0, colors_b=0.0, shade_b=0.0, uv_b=0.0, texture_b=0.0, flips=0)
@@ -174,7 +176,7 @@ def main_meshes(n):
             img_ref, z_ref = out_ref[0], out_ref[1]
             worst["image"] = max(worst["image"], np.abs(image[i].cpu().numpy() - img_ref).max() / tol_img)
             worst["flips"] += int((np.isinf(z[i].cpu().numpy()) != np.isinf(z_ref)).sum())
-            if mode == "persp":
+            if mode in ("persp", "noculling"):
                 continue
             if mode == "error":
                 worst["err_buffer"] = max(worst["err_buffer"], np.abs(err[i].cpu().numpy() - out_ref[2]).max() / (10 * tol_img * max(1.0, out_ref[2].max())))
@@ -189,7 +191,7 @@ def main_meshes(n):
                         worst[k] = max(worst[k], rel_err(gg[k][i].cpu().numpy(), g_ref[k]) / tol)
             sums["uv_b"] = sums["uv_b"] + g_ref["uv_b"]
             sums["texture_b"] = sums["texture_b"] + g_fix["texture_b"]
-        if mode != "persp" and views[0].textured.any():
+        if mode in ("image", "error") and views[0].textured.any():
             for k in ("uv_b", "texture_b"):
                 if g[k] is not None and np.abs(sums[k]).max() > 0:
                     worst[k] = max(worst[k], rel_err(g[k].cpu().numpy(), sums[k]) / tol)
