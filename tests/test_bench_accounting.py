@@ -1,0 +1,37 @@
+"""CPU check of bench.py's roofline accounting: however the frame bytes are distributed over the kernel groups, a step is charged
+exactly the algorithmic bytes of SURVEY.md section 8d (B_fwd + B_bwd per view), and the CPU-baseline helpers run without a GPU."""
+
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402
+
+
+def survey_bytes(H, W, C, T, V):
+    b_fwd = 4 * (H * W * (C + 1) + V * (2 + 1 + C) + 3 * T)
+    b_bwd = 4 * (H * W * C + H * W + V * (2 + 1 + C) + 3 * T + V * (2 + C))
+    return b_fwd + b_bwd
+
+
+def test_every_accounting_charges_the_survey_bytes():
+    H, W, C, T, V, n = 1024, 1024, 4, 20000, 10002, 8
+    want = n * survey_bytes(H, W, C, T, V)
+    two_call = bench.algorithmic_bytes(H, W, C, T, V, n, fused=False)
+    assert sum(two_call.values()) == want
+    whole_frame = bench.algorithmic_bytes(H, W, C, T, V, n, fused=True)
+    assert sum(whole_frame.values()) == want and whole_frame["raster_bwd_kernel"] == 0
+    for frac in (0.0, 0.385, 1.0):
+        by_census = bench.algorithmic_bytes(H, W, C, T, V, n, fused=True, nonempty_frac=frac)
+        assert abs(sum(by_census.values()) - want) < 1e-6 * want
+        frame = 4 * H * W * (C + 1) * n
+        assert abs(by_census["raster_fwd_kernel"] - 2 * frame * frac) < 1e-6 * frame
+        assert abs(by_census["not_moved"] - frame * (1 - frac)) < 1e-6 * frame
+    # the number quoted in DESIGN.md / VERDICT.md for the bench configuration: 345.8 MB per 8-view step
+    assert abs(want / 1e6 - 345.8) < 0.1
+
+
+def test_cpu_model_string():
+    assert isinstance(bench.cpu_model(), str) and bench.cpu_model()
