@@ -237,7 +237,10 @@ def main():
 
     import __graft_entry__ as g
 
-    g.build_hip()
+    if dist is None or local_rank == 0:
+        g.build_hip()  # a no-op when the in-tree library is up to date; never by several ranks at once
+    if dist is not None:
+        dist.barrier()
     from deodr_amd import scenes
     from deodr_amd import hip_renderer as hr
     from deodr_amd.hip_renderer import DeviceScene, HipRasterizer
@@ -416,6 +419,7 @@ def main():
     else:
         result_line = None
     if dist is not None:
+        dist.barrier()  # rank 0 has finished its read-backs before any rank tears the communicator down
         dist.destroy_process_group()
     if result_line is not None:  # the ONE JSON line, last thing on stdout
         sys.stdout.flush()
