@@ -115,6 +115,11 @@ def _stream(device=None):
     return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 
+def _count(a):
+    """number of elements of an array OR a tensor (np.size of a tensor is its bound `size` method, not a number)"""
+    return 0 if a is None else int(a.numel()) if torch.is_tensor(a) else int(np.size(a))
+
+
 def _on(t, device, dtype, shape, what):
     """`t` as a contiguous tensor of `dtype` on `device` with `shape` (no copy when it already is one)."""
     if not torch.is_tensor(t):
@@ -155,7 +160,7 @@ class DeviceScene:
         self.flags = dict(clockwise=bool(clockwise), backface_culling=bool(backface_culling), strict_edge=bool(strict_edge),
                           perspective_correct=bool(perspective_correct), integer_pixel_centers=bool(integer_pixel_centers))  # fmt: skip
         self.texture = None
-        if texture is not None and np.size(texture) > 0:
+        if _count(texture) > 0:
             self.texture = as_t(texture, pixel_dtype)
         self.background_color = None if background_color is None else as_t(background_color, pixel_dtype).reshape(-1)
         self.background_image = None if background_image is None else as_t(background_image, pixel_dtype)
@@ -540,6 +545,6 @@ def renderSceneBCpp(scene, sigma, image, z_buffer, image_b=None, antialiase_erro
     for name in ("uv_b", "ij_b", "shade_b", "colors_b", "texture_b"):
         new = g[name]
         old = getattr(scene, name, None)
-        if new is None or old is None or np.size(old) == 0:
+        if new is None or old is None or _count(old) == 0:
             continue
         setattr(scene, name, _np(old, np.float64) + new.cpu().numpy().reshape(np.shape(old)))

@@ -14,7 +14,7 @@ device (the image then stays there) or on the CPU (results are copied back, refe
 import numpy as np
 import torch
 
-from ..hip_renderer import DeviceScene, HipRasterizer
+from ..hip_renderer import DeviceScene, HipRasterizer, _count
 
 
 def _to_np(a):
@@ -51,7 +51,7 @@ def _device_state(scene, device, pixel_dtype):
         ds = DeviceScene(
             _to_np(s.faces), _to_np(s.faces_uv), _to_np(s.textured), _to_np(s.shaded), _to_np(s.uv), _to_np(s.ij)[None],
             _to_np(s.depths)[None], _to_np(s.colors)[None], _to_np(s.shade)[None], _to_np(s.edgeflags)[None], s.height, s.width,
-            texture=_to_np(s.texture) if np.size(s.texture) else None,
+            texture=_to_np(s.texture) if _count(s.texture) else None,
             background_color=None if s.background_color is None else _to_np(s.background_color), background_image=bgi,
             clockwise=s.clockwise, backface_culling=s.backface_culling, strict_edge=s.strict_edge,
             perspective_correct=s.perspective_correct, integer_pixel_centers=s.integer_pixel_centers, vertex_dtype=torch.float64,
@@ -70,7 +70,7 @@ def _device_state(scene, device, pixel_dtype):
         if k == "uv":
             ds.uv = torch.as_tensor(_to_np(new)).to(device=ds.device, dtype=ds.vertex_dtype).reshape(-1, 2).contiguous()
         elif k == "texture":
-            ds.texture = torch.as_tensor(_to_np(new)).to(device=ds.device, dtype=pixel_dtype).contiguous() if np.size(new) else None
+            ds.texture = torch.as_tensor(_to_np(new)).to(device=ds.device, dtype=pixel_dtype).contiguous() if _count(new) else None
         elif k == "background_color":
             ds.background_color = None if new is None else torch.as_tensor(_to_np(new)).to(device=ds.device, dtype=pixel_dtype).reshape(-1)
         else:

@@ -25,6 +25,9 @@ Fixtures
                        rendered depth image, the vertex / quaternion / translation gradients, the rigid energy and its gradient.
   deferred_hand.npz    Scene3D.render_deferred of the hand mesh (96 x 80): the depth / face_id / barycentric / normal / luminosity /
                        xyz / color buffers of one 15-channel soup render at sigma = 0.
+  duck.npz             the scene of the reference's tests/test_render_mesh.py::test_render_mesh_duck: textured duck mesh (assembled as
+                       ColoredTriMesh.from_trimesh does), distorted camera, the float image the reference renders and its stored
+                       uint8 test image deodr/data/test/duck.png (equal, checked at generation).
   rgb_hand_fit.npz     deodr/examples/rgb_image_hand_fitting.py `run(dl_library="none")`: the image (uint8), background colour,
                        50 energies of MeshRGBFitterWithPose.step and the iteration-0 intermediates (vertex normals,
                        luminosity, rendered image, gradients of vertices, lights and colour).
@@ -254,6 +257,66 @@ def deferred_hand():
     print("deferred hand:", {k: v.shape for k, v in buffers.items()})
 
 
+def read_textured_obj(path):
+    """v / vt / f v/vt/vn records of a Wavefront file -> (vertices, uv in [0,1], per-corner vertex ids, per-corner uv ids)"""
+    v, vt, fv, ft = [], [], [], []
+    for line in open(path):
+        p = line.split()
+        if not p:
+            continue
+        if p[0] == "v":
+            v.append([float(x) for x in p[1:4]])
+        elif p[0] == "vt":
+            vt.append([float(x) for x in p[1:3]])
+        elif p[0] == "f":
+            corners = [c.split("/") for c in p[1:]]
+            assert len(corners) == 3
+            fv.append([int(c[0]) - 1 for c in corners])
+            ft.append([int(c[1]) - 1 for c in corners])
+    return np.array(v), np.array(vt), np.array(fv), np.array(ft)
+
+
+def duck():
+    """The scene of the reference's tests/test_render_mesh.py::test_render_mesh_duck (deodr/examples/render_mesh.py:17-58 at
+    320 x 240): textured duck, camera with radial distortion, directional light, sigma = 1.  The mesh is assembled here the way
+    ColoredTriMesh.from_trimesh does (triangulated_mesh.py:369-438: texture / 255, uv = (u W, (1 - v) H) - 0.5, vertices merged
+    with np.unique, faces_uv = the un-merged corner ids) -- trimesh itself is not installed, so the result is CHECKED against
+    the reference's stored image deodr/data/test/duck.png before anything is written."""
+    from PIL import Image
+    from scipy.spatial.transform import Rotation
+
+    import deodr
+    from deodr import ColoredTriMesh
+    from deodr.differentiable_renderer import Scene3D, default_camera
+
+    v, vt, fv, ft = read_textured_obj(os.path.join(deodr.data_path, "duck.obj"))
+    texture_u8 = np.asarray(Image.open(os.path.join(deodr.data_path, "duck.png")))[:, :, :3]
+    texture = texture_u8 / 255
+    uv = np.column_stack((vt[:, 0] * texture.shape[1], (1 - vt[:, 1]) * texture.shape[0])) - 0.5
+    vertices, inverse = np.unique(v, axis=0, return_inverse=True)
+    faces = inverse.reshape(-1)[fv].astype(np.uint32)
+    mesh = ColoredTriMesh(faces, vertices, clockwise=False, faces_uv=ft.astype(np.uint32), uv=uv, texture=texture)
+    width, height = 320, 240
+    rot = Rotation.from_euler("xyz", [180, 0, 0], degrees=True).as_matrix()
+    camera = default_camera(width, height, 80, mesh.vertices, rot)
+    camera.distortion = np.array([-0.5, 0.5, 0, 0, 0])
+    scene = Scene3D()
+    scene.set_light(light_directional=0.3 * np.array([1, -1, 0]), light_ambient=0)
+    scene.set_mesh(mesh)
+    scene.set_background_color(np.array((0.8, 0.8, 0.8)))
+    image = scene.render(camera)
+    stored = np.asarray(Image.open(os.path.join(deodr.data_path, "test", "duck.png")))[:, :, :3]
+    worst = int(np.abs(stored.astype(int) - (image * 255).astype(np.uint8).astype(int)).max())
+    print("duck: largest difference with the reference's stored test image:", worst, "grey levels")
+    assert worst == 0, "the mesh assembled here is not the one the reference's test renders"
+    np.savez_compressed(
+        os.path.join(OUT, "duck.npz"), vertices=vertices, faces=faces, uv=uv, faces_uv=ft.astype(np.uint32), texture_u8=texture_u8, rot=rot,
+        extrinsic=np.array(camera.extrinsic), intrinsic=np.array(camera.intrinsic), distortion=np.array(camera.distortion),
+        image=image.astype(np.float32), image_sha256=np.array(sha(image)), stored_u8=stored,
+        ij=np.array(scene.scene_2d.ij) if getattr(scene, "scene_2d", None) is not None and hasattr(scene.scene_2d, "ij") else np.zeros(0),
+    )  # fmt: skip
+
+
 def scene3d_helpers():
     """The small public members of Camera / Scene3D around the render calls (dr.py:280-310, 443-451, 814-850): fields of view,
     camera-to-world matrix, left_mul_intrinsic, repr; compute_vertices_luminosity and its adjoint on the hand mesh."""
@@ -301,3 +364,5 @@ if __name__ == "__main__":
             deferred_hand()
         if not only or "helpers" in only:
             scene3d_helpers()
+        if not only or "duck" in only:
+            duck()

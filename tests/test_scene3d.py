@@ -78,6 +78,49 @@ def test_projection_distortion_forward_and_adjoint_cpu():
     assert rel(ij2[0], expect) < 1e-13
 
 
+def duck_fixture():
+    d = fixture("duck.npz")
+    return d, d["texture_u8"] / 255
+
+
+def test_reference_duck_test_front_half_cpu(oracle_api):
+    """The scene of the reference's tests/test_render_mesh.py::test_render_mesh_duck (textured duck, camera with radial
+    distortion, directional light, sigma = 1, 320 x 240; tests/golden/duck.npz): the device front half on CPU tensors -- projection
+    with distortion, vertex normals, luminosity, silhouette flags -- assembled into the Scene2D the reference builds (dr.py:896-983)
+    and rasterized by the CPU checker must give the reference's image, i.e. its stored test image deodr/data/test/duck.png."""
+    from deodr_amd import Scene2D
+    from deodr_amd.scene3d import DeviceCamera, DeviceMesh, Scene3DDevice
+
+    d, texture = duck_fixture()
+    mesh = DeviceMesh(d["faces"], d["vertices"], clockwise=False, uv=d["uv"], faces_uv=d["faces_uv"], texture=texture, device="cpu")
+    cam = DeviceCamera(d["extrinsic"], d["intrinsic"], 240, 320, d["distortion"], device="cpu")
+    scene = Scene3DDevice()
+    scene.set_mesh(mesh)
+    scene.set_light(0.3 * np.array([1.0, -1.0, 0.0]), 0.0)
+    ij, depths = cam.project_points(mesh.vertices)
+    shade = scene.vertices_luminosity(mesh.vertices)
+    flags = mesh.topology.edge_on_silhouette(ij)
+    T, V = len(d["faces"]), len(d["vertices"])
+    s2 = Scene2D(
+        faces=d["faces"].astype(np.uint32), faces_uv=d["faces_uv"].astype(np.uint32), ij=ij[0].numpy(), depths=depths[0].numpy(),
+        textured=np.ones(T, dtype=bool), uv=d["uv"], shade=shade.numpy(), colors=np.zeros((V, 3)), shaded=np.ones(T, dtype=bool),
+        edgeflags=flags[0].numpy().astype(bool), height=240, width=320, nb_colors=3, texture=texture, background_color=np.array([0.8, 0.8, 0.8]),
+        clockwise=False, backface_culling=True,
+    )  # fmt: skip
+    image, _ = (oracle_api.ref() or oracle_api.port()).render(s2, 1.0)
+    assert np.abs(image - d["image"]).max() < 1e-6  # the fixture keeps the reference's image in float32
+    assert np.abs((image * 255).astype(np.uint8).astype(int) - d["stored_u8"].astype(int)).max() == 0  # the reference test's own assertion
+
+
+def test_element_count_of_arrays_and_tensors_cpu():
+    """np.size of a tensor is a bound method, not a number: the scene containers count elements through one helper (a texture given
+    as a device tensor -- what Scene3DDevice passes for a textured mesh -- used to raise in DeviceScene)"""
+    from deodr_amd.hip_renderer import _count
+
+    assert _count(None) == 0 and _count(np.zeros((0, 0))) == 0 and _count(np.zeros((4, 4, 3))) == 48
+    assert _count(torch.zeros(2, 3)) == 6 and _count(torch.zeros(0, 0, 3)) == 0
+
+
 def test_silhouette_flags_cpu():
     """edge_on_silhouette (triangulated_mesh.py:153-166): exactly the reference's flags, also batched over views"""
     from deodr_amd.scene3d import MeshTopology
@@ -469,3 +512,26 @@ def test_dropin_scene3d_luminosity_and_adjoint():
     assert np.allclose(scene.compute_vertices_luminosity(), 0.3)
     scene.compute_vertices_luminosity_backward(d["luminosity_b"])
     assert abs(scene.light_ambient_b - d["luminosity_b"].sum()) < 1e-10
+
+
+@pytest.mark.gpu
+def test_reference_duck_test_through_the_dropins():
+    """The reference's tests/test_render_mesh.py::test_render_mesh_duck through the drop-in classes and the HIP rasterizer: the
+    textured duck (ColoredTriMesh with uv / faces_uv / texture), `default_camera` + radial distortion, `Scene3D.render` -- compared
+    with the image the reference renders and with its stored test image (exact in uint8, the reference test's assertion)."""
+    import deodr_amd as deodr
+
+    d, texture = duck_fixture()
+    mesh = deodr.ColoredTriMesh(d["faces"], d["vertices"], clockwise=False, faces_uv=d["faces_uv"], uv=d["uv"], texture=texture)
+    camera = deodr.default_camera(320, 240, 80, mesh.vertices, d["rot"])
+    assert rel(camera.extrinsic, d["extrinsic"]) < 1e-13 and rel(camera.intrinsic, d["intrinsic"]) < 1e-13
+    camera.distortion = np.array([-0.5, 0.5, 0, 0, 0])
+    scene = deodr.Scene3D()
+    scene.set_light(light_directional=0.3 * np.array([1, -1, 0]), light_ambient=0)
+    scene.set_mesh(mesh)
+    scene.set_background_color(np.array((0.8, 0.8, 0.8)))
+    image = scene.render(camera)
+    assert image.shape == (240, 320, 3)
+    assert np.abs(image - d["image"]).max() < 1e-6
+    different = (image * 255).astype(np.uint8).astype(int) - d["stored_u8"].astype(int)
+    assert np.abs(different).max() <= 1 and np.count_nonzero(different) <= 3  # a value within 1e-13 of a grey-level boundary may round the other way
