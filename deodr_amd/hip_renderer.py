@@ -427,6 +427,8 @@ class HipRasterizer:
         has run on the workspace since (two renders in one autograd graph), the forward state is recomputed from ``ds``
         instead of being trusted (pass that forward's ``sigma`` too)."""
         self._check_scene(ds)
+        if self._last is None:
+            raise RuntimeError("deodr_hip: render_backward called before any render on this workspace")
         last_ds, last_sigma, aa, obs_t, image, _err, gen, fused = self._last
         sigma = last_sigma if sigma is None else float(sigma)
         n, H, W, Cc = ds.n_views, ds.height, ds.width, ds.nb_colors
@@ -487,7 +489,7 @@ def _device_scene(scene, nb_colors):
 
 
 def _rasterizer_for(ds):
-    key = (ds.nb_triangles, ds.height, ds.width, ds.nb_colors)
+    key = (ds.nb_triangles, ds.height, ds.width, ds.nb_colors, str(ds.device))
     if key not in _ctx_cache:
         if len(_ctx_cache) > 8:
             _ctx_cache.clear()
