@@ -222,9 +222,14 @@ class MeshRGBFitterWithPoseMultiFrame(MeshRGBFitterWithPose):
     views shard across the ranks (``deodr_amd.distributed.shard_views``): each rank holds the poses of its own views, the shared
     parameters are replicated, and the only communication per step is one all-reduce of the packed shared gradients + energy."""
 
+    # the reference's multi-frame class has its own constants (mesh_fitter.py:391-416): smaller pose steps, more damping, a nearer
+    # camera that does not follow translation_init, and a data term weighted by cdata / number of views
+    step_factor_quaternion, step_factor_translation = 0.00005, 0.00004
+
     def __init__(self, vertices, faces, euler_init, translation_init, default_color, default_light_directional, default_light_ambient, cregu=2000,
-                 inertia=0.96, damping=0.05, update_lights=True, update_color=True, device="cuda", pixel_dtype=torch.float64, group=None):  # fmt: skip
+                 cdata=1, inertia=0.97, damping=0.15, update_lights=True, update_color=True, device="cuda", pixel_dtype=torch.float64, group=None):  # fmt: skip
         euler_init, translation_init = np.atleast_2d(euler_init), np.atleast_2d(translation_init)
+        self.cdata = cdata
         self.n_views_total = max(len(euler_init), len(translation_init))
         import torch.distributed as dist
 
@@ -234,7 +239,15 @@ class MeshRGBFitterWithPoseMultiFrame(MeshRGBFitterWithPose):
         pick = lambda a: np.broadcast_to(a, (self.n_views_total, a.shape[1]))[self.my_views]
         super().__init__(vertices, faces, pick(euler_init), pick(translation_init), default_color, default_light_directional, default_light_ambient,
                          cregu, inertia, damping, update_lights, update_color, device, pixel_dtype, n_poses=len(self.my_views))  # fmt: skip
+        self.camera_center = self.object_center + np.array([0, 0, 6]) * self.object_radius
         self._packed = None
+
+    def _data_energy(self, image):
+        """(cdata / number of views) * sum over THIS rank's views of the squared residual (mesh_fitter.py:533-548; the reference
+        compares row `idframe` of the rendered image with the target there -- a defect, the image of the frame is meant --
+        and is followed as repaired, see tests/golden/make_golden.py::rgb_multiview_fit)"""
+        diff_image = ((image - self.mesh_image) ** 2).sum(dim=-1)
+        return (self.cdata / self.n_views_total) * diff_image.sum(), diff_image
 
     def set_images(self, mesh_images, focal=None, distortion=None):
         """``mesh_images``: the images of ALL views (every rank keeps only its own)"""
