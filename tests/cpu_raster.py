@@ -74,10 +74,14 @@ def _rasterize_with_checker(checker):
 
 @contextlib.contextmanager
 def emulate(checker):
-    """within the block Scene3DDevice rasterizes with `checker` (an oracle.api renderer) on CPU tensors"""
-    saved = Scene3DDevice._rasterize
+    """within the block Scene3DDevice rasterizes with `checker` (an oracle.api renderer) on CPU tensors, and the NumPy-level drop-ins
+    of deodr_amd.scene3d_compat put their tensors on the CPU"""
+    from deodr_amd import scene3d_compat
+
+    saved = Scene3DDevice._rasterize, scene3d_compat._device
     Scene3DDevice._rasterize = _rasterize_with_checker(checker)
+    scene3d_compat._device = lambda: torch.device("cpu")
     try:
         yield
     finally:
-        Scene3DDevice._rasterize = saved
+        Scene3DDevice._rasterize, scene3d_compat._device = saved

@@ -431,15 +431,14 @@ def normalize_backward(x, xn_b):
     return (xn_b - x * np.sum(xn_b * x) * inv_n**2) * inv_n
 
 
-@pytest.mark.gpu
-def test_dropin_scene3d_depth_intermediates():
+def check_dropin_scene3d_depth_intermediates(device):
     """NumPy-level drop-ins (deodr_amd.Scene3D / Camera / ColoredTriMesh) on iteration 0 of the reference's depth fit: projected
     points, silhouette flags, depth image, and the vertex gradient of render_depth_backward"""
     from deodr_amd import Camera, ColoredTriMesh, Scene3D
 
     d, depth_image = depth_inputs()
     _, faces = hand()
-    mesh = ColoredTriMesh(faces, vertices=d["it0_vertices_transformed"], colors=np.zeros((526, 0)))
+    mesh = ColoredTriMesh(faces, vertices=d["it0_vertices_transformed"], colors=np.zeros((526, 0)), device=device)
     scene = Scene3D()
     scene.set_mesh(mesh)
     scene.set_background_color(np.array([1.0]))
@@ -457,8 +456,7 @@ def test_dropin_scene3d_depth_intermediates():
     assert rel(mesh._vertices_b, d["it0_vertices_transformed_b"]) < 1e-8
 
 
-@pytest.mark.gpu
-def test_dropin_scene3d_rgb_intermediates():
+def check_dropin_scene3d_rgb_intermediates(device):
     """Scene3D.render / render_backward with lights (iteration 0 of the reference's colour fit): image, vertex / light / colour
     gradients -- the result attributes the reference's fitters read (mesh_fitter.py:291-296)"""
     from deodr_amd import Camera, ColoredTriMesh, Scene3D
@@ -466,7 +464,7 @@ def test_dropin_scene3d_rgb_intermediates():
     d = fixture("rgb_hand_fit.npz")
     _, faces = hand()
     image_obs = d["image_u8"].astype(np.float64) / 255
-    mesh = ColoredTriMesh(faces, vertices=d["it0_vertices_transformed"], nb_colors=3)
+    mesh = ColoredTriMesh(faces, vertices=d["it0_vertices_transformed"], nb_colors=3, device=device)
     mesh.set_vertices_colors(np.tile(d["default_color"], (526, 1)))
     scene = Scene3D()
     scene.set_mesh(mesh)
@@ -484,8 +482,7 @@ def test_dropin_scene3d_rgb_intermediates():
     assert abs(scene.light_ambient_b - float(d["it0_light_ambient_b"])) < 1e-8 * abs(float(d["it0_light_ambient_b"]))
 
 
-@pytest.mark.gpu
-def test_reference_fit_loop_runs_on_the_dropins():
+def check_reference_fit_loop_runs_on_the_dropins(device):
     """The reference's MeshDepthFitter.step (deodr/mesh_fitter.py:139-196), restated here against deodr_amd's Scene3D / Camera /
     ColoredTriMesh / LaplacianRigidEnergy instead of DEODR's: 50 iterations reproduce the reference's own energy curve, whose
     last value is the golden of the reference's tests/test_depth_image_hand_fitting.py:36-42 (251.32711113...)."""
@@ -493,7 +490,7 @@ def test_reference_fit_loop_runs_on_the_dropins():
 
     d, depth_image = depth_inputs()
     vertices0, faces = hand()
-    mesh = ColoredTriMesh(faces, vertices=vertices0, colors=np.zeros((526, 0)))
+    mesh = ColoredTriMesh(faces, vertices=vertices0, colors=np.zeros((526, 0)), device=device)
     scene = Scene3D()
     scene.set_mesh(mesh)
     scene.set_background_color(np.array([1.0]))
@@ -657,15 +654,14 @@ def test_dropin_scene3d_luminosity_and_adjoint():
     assert abs(scene.light_ambient_b - d["luminosity_b"].sum()) < 1e-10
 
 
-@pytest.mark.gpu
-def test_reference_duck_test_through_the_dropins():
-    """The reference's tests/test_render_mesh.py::test_render_mesh_duck through the drop-in classes and the HIP rasterizer: the
+def check_reference_duck_test_through_the_dropins(device):
+    """The reference's tests/test_render_mesh.py::test_render_mesh_duck through the drop-in classes and the rasterizer: the
     textured duck (ColoredTriMesh with uv / faces_uv / texture), `default_camera` + radial distortion, `Scene3D.render` -- compared
     with the image the reference renders and with its stored test image (exact in uint8, the reference test's assertion)."""
     import deodr_amd as deodr
 
     d, texture = duck_fixture()
-    mesh = deodr.ColoredTriMesh(d["faces"], d["vertices"], clockwise=False, faces_uv=d["faces_uv"], uv=d["uv"], texture=texture)
+    mesh = deodr.ColoredTriMesh(d["faces"], d["vertices"], clockwise=False, faces_uv=d["faces_uv"], uv=d["uv"], texture=texture, device=device)
     camera = deodr.default_camera(320, 240, 80, mesh.vertices, d["rot"])
     assert rel(camera.extrinsic, d["extrinsic"]) < 1e-13 and rel(camera.intrinsic, d["intrinsic"]) < 1e-13
     camera.distortion = np.array([-0.5, 0.5, 0, 0, 0])
@@ -678,3 +674,23 @@ def test_reference_duck_test_through_the_dropins():
     assert np.abs(image - d["image"]).max() < 1e-6
     different = (image * 255).astype(np.uint8).astype(int) - d["stored_u8"].astype(int)
     assert np.abs(different).max() <= 1 and np.count_nonzero(different) <= 3  # a value within 1e-13 of a grey-level boundary may round the other way
+
+
+DROPIN_CHECKS = [check_dropin_scene3d_depth_intermediates, check_dropin_scene3d_rgb_intermediates, check_reference_fit_loop_runs_on_the_dropins,
+                 check_reference_duck_test_through_the_dropins]  # fmt: skip
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("check", DROPIN_CHECKS, ids=lambda f: f.__name__[6:])
+def test_dropins_on_the_device(check):
+    """the NumPy-level Scene3D / Camera / ColoredTriMesh / LaplacianRigidEnergy drop-ins over the HIP rasterizer"""
+    check("cuda")
+
+
+@pytest.mark.parametrize("check", DROPIN_CHECKS, ids=lambda f: f.__name__[6:])
+def test_dropins_on_cpu_tensors(oracle_api, check):
+    """the same checks in the CPU suite: CPU tensors, the checker as rasterizer (tests/cpu_raster.py)"""
+    import cpu_raster
+
+    with cpu_raster.emulate(oracle_api.ref() or oracle_api.port()):
+        check("cpu")
