@@ -115,6 +115,14 @@ def _stream(device=None):
     return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 
+def _resolve_device(device):
+    """the ROCm device a scene or a workspace lives on (there is no CPU path: anything else is refused)"""
+    dev = torch.device(device)
+    if dev.type != "cuda":
+        raise RuntimeError("deodr_amd needs a ROCm device; there is no CPU path")
+    return torch.device("cuda", torch.cuda.current_device()) if dev.index is None else dev
+
+
 def _count(a):
     """number of elements of an array OR a tensor (np.size of a tensor is its bound `size` method, not a number)"""
     return 0 if a is None else int(a.numel()) if torch.is_tensor(a) else int(np.size(a))
@@ -144,11 +152,7 @@ class DeviceScene:
                  background_color=None, background_image=None, clockwise=False, backface_culling=True, strict_edge=True,
                  perspective_correct=False, integer_pixel_centers=True, vertex_dtype=torch.float64, pixel_dtype=torch.float32,
                  device="cuda", validate=True):  # fmt: skip
-        dev = torch.device(device)
-        if dev.type != "cuda":
-            raise RuntimeError("deodr_amd needs a ROCm device; there is no CPU path")
-        if dev.index is None:
-            dev = torch.device("cuda", torch.cuda.current_device())
+        dev = _resolve_device(device)
         self.device, self.vertex_dtype, self.pixel_dtype = dev, vertex_dtype, pixel_dtype
         as_t = lambda a, dt: torch.as_tensor(np.asarray(a) if not torch.is_tensor(a) else a).to(device=dev, dtype=dt).contiguous()
         self.faces = as_t(np.asarray(faces).astype(np.int64) if not torch.is_tensor(faces) else faces, torch.int32)
@@ -250,9 +254,7 @@ class HipRasterizer:
 
     def __init__(self, nb_triangles, height, width, nb_colors, n_views=1, device="cuda", pool_pairs=0, poll_every=8):
         self.dims = (int(nb_triangles), int(height), int(width), int(nb_colors), int(n_views))
-        self.device = torch.device(device)
-        if self.device.index is None:
-            self.device = torch.device("cuda", torch.cuda.current_device())
+        self.device = _resolve_device(device)
         self.poll_every = int(poll_every)
         self.generation = 0
         self._alloc(pool_pairs)

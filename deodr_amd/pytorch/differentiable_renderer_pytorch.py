@@ -14,7 +14,7 @@ device (the image then stays there) or on the CPU (results are copied back, refe
 import numpy as np
 import torch
 
-from ..hip_renderer import DeviceScene, HipRasterizer, _count
+from ..hip_renderer import DeviceScene, HipRasterizer, _count, _resolve_device
 
 
 def _to_np(a):
@@ -86,7 +86,7 @@ class TorchDifferentiableRenderer2DFunc(torch.autograd.Function):
     def forward(ctx, ij, colors, scene):
         s = scene.scene_2d
         on_device = ij.is_cuda
-        device = ij.device if on_device else torch.device("cuda", torch.cuda.current_device())
+        device = ij.device if on_device else _resolve_device("cuda")
         pixel_dtype = torch.float32 if (on_device and colors.dtype == torch.float32) else torch.float64
         ds, r = _device_state(scene, device, pixel_dtype)
         to_t = lambda a: a.detach() if torch.is_tensor(a) else torch.as_tensor(np.asarray(a))
