@@ -148,6 +148,59 @@ class MeshDepthFitter(_PoseFitter):
         return float(energy.detach()), depth.cpu().numpy(), diff_image.cpu().numpy()
 
 
+class MeshDepthFitterEnergy(torch.nn.Module):
+    """The depth-fit energy as a module whose parameters are the vertices, the pose quaternion and the translation: ``forward()``
+    renders and returns data + rigid energy, for any ``torch.optim`` optimizer (deodr/pytorch/mesh_fitter_pytorch.py:34-121).
+    Same model as :class:`MeshDepthFitter` (the reference's module also reverses the winding of ``faces``, a leftover: not done here)."""
+
+    def __init__(self, vertices, faces, euler_init, translation_init, cregu=2000, device="cuda", pixel_dtype=torch.float64):
+        super().__init__()
+        self._fit = MeshDepthFitter(vertices, faces, euler_init, translation_init, cregu=cregu, device=device, pixel_dtype=pixel_dtype)
+        f = self._fit
+        self._vertices = torch.nn.Parameter(f.vertices_init.clone())
+        self.quaternion = torch.nn.Parameter(f.transform_quaternion_init[0].clone())
+        self.translation = torch.nn.Parameter(f.transform_translation_init[0].clone())
+        self.set_max_depth, self.set_depth_scale, self.set_image = f.set_max_depth, f.set_depth_scale, f.set_image
+
+    def forward(self):
+        f = self._fit
+        f.vertices_leaf, f.transform_quaternion_leaf, f.transform_translation_leaf = self._vertices, self.quaternion[None], self.translation[None]
+        e_data, _e_rigid, _g_rigid, depth, diff_image = f.energy()
+        e_rigid, _ = f.rigid_energy.evaluate(self._vertices)  # differentiable: the optimizer needs its gradient through autograd
+        self.depth, self.diff_image = depth.detach(), diff_image.detach()
+        self.loss = e_data + e_rigid
+        return self.loss
+
+
+class MeshDepthFitterPytorchOptim:
+    """L-BFGS (one inner iteration per step) on :class:`MeshDepthFitterEnergy` (deodr/pytorch/mesh_fitter_pytorch.py:124-170)"""
+
+    def __init__(self, vertices, faces, euler_init, translation_init, cregu=2000, lr=0.8, device="cuda", pixel_dtype=torch.float64):
+        self.energy = MeshDepthFitterEnergy(vertices, faces, euler_init, translation_init, cregu, device=device, pixel_dtype=pixel_dtype)
+        self.optimizer = torch.optim.LBFGS(self.energy.parameters(), lr=lr, max_iter=1)
+
+    def set_image(self, depth_image, focal=None, distortion=None):
+        self.energy.set_image(depth_image, focal=focal, distortion=distortion)
+
+    def set_max_depth(self, max_depth):
+        self.energy.set_max_depth(max_depth)
+
+    def set_depth_scale(self, depth_scale):
+        self.energy.set_depth_scale(depth_scale)
+
+    def step(self):
+        """-> (energy tensor, synthetic depth [H,W], squared difference [H,W] as NumPy)"""
+
+        def closure():
+            self.optimizer.zero_grad()
+            loss = self.energy()
+            loss.backward()
+            return loss
+
+        self.optimizer.step(closure)
+        return self.energy.loss.detach(), self.energy.depth.cpu().numpy(), self.energy.diff_image.cpu().numpy()
+
+
 class MeshRGBFitterWithPose(_PoseFitter):
     """Fit a deformable mesh, its pose, a directional + ambient light and one colour to a colour image (mesh_fitter.py:199-376)."""
 

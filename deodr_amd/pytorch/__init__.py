@@ -3,7 +3,13 @@ camera / scene / mesh / energy / fitter classes -- all of them device-resident h
 versions convert to NumPy around every render, deodr/pytorch/differentiable_renderer_pytorch.py:52-54, and evaluate the rigid
 energy with SciPy on the host, deodr/pytorch/laplacian_rigid_energy_pytorch.py:38-46)."""
 
-from ..mesh_fitter import MeshDepthFitter, MeshRGBFitterWithPose, MeshRGBFitterWithPoseMultiFrame  # noqa: F401
+from ..mesh_fitter import (  # noqa: F401
+    MeshDepthFitter,
+    MeshDepthFitterEnergy,
+    MeshDepthFitterPytorchOptim,
+    MeshRGBFitterWithPose,
+    MeshRGBFitterWithPoseMultiFrame,
+)
 from ..scene3d import DeviceCamera as CameraPytorch  # noqa: F401  (extrinsic, intrinsic, height, width, distortion=None)
 from ..scene3d import DeviceMesh, LaplacianRigidEnergyDevice
 from ..scene3d import Scene3DDevice as Scene3DPytorch  # noqa: F401
