@@ -601,23 +601,6 @@ def test_device_rgb_fitter_follows_reference_energies():
 
 
 @pytest.mark.gpu
-def test_multiview_fitter_one_batched_launch_equals_single_views():
-    """MeshRGBFitterWithPoseMultiFrame on the device: see check_multiview_equals_single_views"""
-    check_multiview_equals_single_views("cuda")
-
-
-@pytest.mark.gpu
-def test_torch_optimizer_depth_fit_on_the_device():
-    check_torch_optimizer_depth_fit("cuda")
-
-
-@pytest.mark.gpu
-def test_multiview_fitter_follows_the_repaired_reference():
-    """MeshRGBFitterWithPoseMultiFrame on the device: see check_multiview_fit_against_reference"""
-    check_multiview_fit_against_reference("cuda")
-
-
-@pytest.mark.gpu
 def test_silhouette_flags_and_projection_batched_on_device():
     """the device ops on ROCm tensors, 8 views in one call, against per-view NumPy restatements of the reference's formulas"""
     from deodr_amd import scenes
@@ -724,3 +707,20 @@ def test_dropins_on_cpu_tensors(oracle_api, check):
 
     with cpu_raster.emulate(oracle_api.ref() or oracle_api.port()):
         check("cpu")
+
+
+@pytest.mark.gpu
+def test_multiview_fitter_one_batched_launch_equals_single_views():
+    """MeshRGBFitterWithPoseMultiFrame on the device: see check_multiview_equals_single_views"""
+    check_multiview_equals_single_views("cuda")
+
+
+@pytest.mark.gpu
+def test_torch_optimizer_depth_fit_on_the_device():
+    check_torch_optimizer_depth_fit("cuda")
+
+
+@pytest.mark.gpu
+def test_multiview_fitter_follows_the_repaired_reference():
+    """MeshRGBFitterWithPoseMultiFrame on the device: see check_multiview_fit_against_reference"""
+    check_multiview_fit_against_reference("cuda")
