@@ -138,6 +138,8 @@ class FakeLib:
             else:
                 seed = 2 * (out[0] - ob) if image_b is None else image_b[i].astype(np.float64)
                 g = self.repaired.grads(s, sigma, out[0], out[1], seed)
+            # (where the reference divides by an edge transparency of 0 its gradient is NaN; the library returns finite numbers there)
+            g = {k: np.nan_to_num(v) for k, v in g.items()}
             a["ij_b"][i] += g["ij_b"]
             a["colors_b"][i] += g["colors_b"]
             a["shade_b"][i] += g["shade_b"]

@@ -196,3 +196,14 @@ def test_textured_mesh_through_scene3d_and_the_rasterizer_objects(fake):
     scene.clear_gradients()
     scene.render_backward(np.ones_like(image))  # the adjoint reaches vertices and lights through the same objects
     assert np.isfinite(mesh._vertices_b).all() and np.abs(mesh._vertices_b).max() > 0 and np.isfinite(scene.light_directional_b).all()
+
+
+def test_the_randomised_sweep_harness_runs(fake, capsys):
+    """tests/fuzz_parity.py (run by hand on the GPU box) end to end with the checker on both sides: every mode of both sweeps executes
+    and reports no miss -- so a mistake in the harness is found here, not on GPU time"""
+    import fuzz_parity
+
+    assert fuzz_parity.main(8) == 0
+    assert fuzz_parity.main_meshes(10) == 0
+    out = capsys.readouterr().out
+    assert "8 random scenes, 0 missed" in out and "10 random mesh scenes, 0 missed" in out
