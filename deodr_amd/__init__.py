@@ -12,7 +12,7 @@ from .differentiable_renderer import Scene2D, Scene2DBase, renderScene, renderSc
 _LAZY = {  # the 3-D level (needs torch + the device): imported on first use, `import deodr_amd` stays light
     "Camera": "scene3d_compat", "PerspectiveCamera": "scene3d_compat", "default_camera": "scene3d_compat", "Scene3D": "scene3d_compat",
     "ColoredTriMesh": "triangulated_mesh", "TriMesh": "triangulated_mesh", "TriMeshAdjacencies": "triangulated_mesh",
-    "LaplacianRigidEnergy": "laplacian_rigid_energy",
+    "LaplacianRigidEnergy": "laplacian_rigid_energy", "read_obj": "obj", "save_obj": "obj",
 }  # fmt: skip
 
 

@@ -112,6 +112,25 @@ def test_reference_duck_test_front_half_cpu(oracle_api):
     assert np.abs((image * 255).astype(np.uint8).astype(int) - d["stored_u8"].astype(int)).max() == 0  # the reference test's own assertion
 
 
+def test_read_and_save_obj_cpu(tmp_path):
+    """deodr_amd.read_obj / save_obj (deodr/obj.py): v / f records, corners with texture and normal indices, relative indices,
+    a continued line; where the reference tree is at hand, its hand.obj gives the arrays of tests/golden/hand_mesh.npz"""
+    import deodr_amd as deodr
+
+    path = tmp_path / "m.obj"
+    path.write_text("# comment\nv 0 0 0\nv 1 0 0\nvt 0.5 0.5\nvn 0 0 1\nv 0 1 0\nv 0 0 1.5\nf 1/1/1 2/1/1 3/1/1\nf -1 -2 \\\n -4\nf 1//1 4//1 2//1\n")
+    faces, vertices = deodr.read_obj(str(path))
+    assert vertices.tolist() == [[0, 0, 0], [1, 0, 0], [0, 1, 0], [0, 0, 1.5]] and faces.tolist() == [[0, 1, 2], [3, 2, 0], [0, 3, 1]]
+    v, f = hand()
+    deodr.save_obj(str(tmp_path / "hand.obj"), v, f)
+    f2, v2 = deodr.read_obj(str(tmp_path / "hand.obj"))
+    assert np.array_equal(f2, f) and np.array_equal(v2, v)
+    reference_hand = "/root/reference/deodr/data/hand.obj"
+    if os.path.exists(reference_hand):
+        f3, v3 = deodr.read_obj(reference_hand)
+        assert np.array_equal(f3, f) and np.array_equal(v3, v)
+
+
 def test_element_count_of_arrays_and_tensors_cpu():
     """np.size of a tensor is a bound method, not a number: the scene containers count elements through one helper (a texture given
     as a device tensor -- what Scene3DDevice passes for a textured mesh -- used to raise in DeviceScene)"""
