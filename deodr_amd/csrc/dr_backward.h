@@ -2,7 +2,7 @@
 // The LDS-staged adjoint: raster_bwd_fast_kernel (pass 1) and raster_bwd_edge_kernel (pass 2, persistent waves over the edge tiles).
 #pragma once
 
-#include "dr_backward_generic.h"
+#include "dr_finalize_tri.h"
 
 using namespace dr;
 
@@ -640,6 +640,8 @@ __global__ __launch_bounds__(64, 6) void raster_bwd_fast_kernel(KParams p)
 	const bool chunk_here = chunked && stride % (8 * WORK_CHUNK) == 0;
 	uint32_t rank = chunk_here ? (uint32_t)((((qq >> 3) / WORK_CHUNK) * 8 + (qq & 7)) * WORK_CHUNK + (qq >> 3) % WORK_CHUNK) : (uint32_t)qq;
 	const uint32_t n_work = w.hdr->work_count[heavy_list ? 0 : 1];
+	if (q == 0 && lane == 0)
+		w.hdr->late_count = 0; // (a second adjoint on the same forward state: the edge-tile kernel, next on the stream, appends again)
 	for (; rank < n_work; rank += (uint32_t)stride)
 	{
 		const WorkEntry &entry = w.work_list[heavy_list ? rank : (uint32_t)p.L.ntiles - 1u - rank];
@@ -671,11 +673,18 @@ __global__ __launch_bounds__(64, TEX ? 2 : DR_EDGE_OCC) void raster_bwd_edge_ker
 #ifndef DR_FILL_FIRST
 #define DR_FILL_FIRST 0 // measurement builds: 1 = the fill workgroups at the head of both grids instead of the tail
 #endif
-	const int walkers = (int)gridDim.y - fill_blocks;
+	// grid y: [walkers][early-finalize workgroups, one per 64 triangles][fill workgroups]
+	const int early_blocks = p.early_fin ? (p.T + 63) / 64 : 0;
+	const int walkers = (int)gridDim.y - fill_blocks - early_blocks;
 	const int by = DR_FILL_FIRST ? (int)blockIdx.y - fill_blocks : (int)blockIdx.y; // index among the walkers (< 0: a fill workgroup)
-	if (DR_FILL_FIRST ? by < 0 : by >= walkers)
+	if (by >= walkers && by < walkers + early_blocks)
 	{
-		for (int i = DR_FILL_FIRST ? (int)blockIdx.y : by - walkers; i < fill_n; i += fill_blocks)
+		finalize_early(p, view, (by - walkers) * 64, lane);
+		return;
+	}
+	if (DR_FILL_FIRST ? by < 0 : by >= walkers + early_blocks)
+	{
+		for (int i = DR_FILL_FIRST ? (int)blockIdx.y : by - walkers - early_blocks; i < fill_n; i += fill_blocks)
 			fill_share_word(p, 0, view, i, lane);
 		return;
 	}

@@ -819,6 +819,7 @@ __global__ __launch_bounds__(64, DR_FWD_WAVES) void raster_fwd_fast_kernel(KPara
 	const bool chunk_here = chunked && stride % (8 * WORK_CHUNK) == 0;
 	uint32_t rank = chunk_here ? (uint32_t)((((qq >> 3) / WORK_CHUNK) * 8 + (qq & 7)) * WORK_CHUNK + (qq >> 3) % WORK_CHUNK) : (uint32_t)qq;
 	const uint32_t n_work = w.hdr->work_count[heavy_list ? 0 : 1];
+	const uint32_t fwd_id = w.hdr->fwd_id; // stamp of this forward (written by its set-up kernel)
 	for (; rank < n_work; rank += (uint32_t)stride)
 	{
 #ifdef DR_FWD_TRACE
@@ -869,6 +870,10 @@ __global__ __launch_bounds__(64, DR_FWD_WAVES) void raster_fwd_fast_kernel(KPara
 		if (ntri > 0)
 		{
 			const int n_inline = ntri < K_TRI ? ntri : K_TRI;
+			// A tile with silhouette edges is back-propagated by the adjoint's edge-tile kernel: its triangles are stamped, so that
+			// everybody else's accumulators can be finalized while that kernel runs (finalize_early)
+			if (nedge > 0 && lane < n_inline)
+				w.tri_stamp[list_entry] = fwd_id;
 			for (int base = 0; base < n_inline; base += TB)
 			{
 				const int nb = n_inline - base < TB ? n_inline - base : TB;
@@ -897,7 +902,11 @@ __global__ __launch_bounds__(64, DR_FWD_WAVES) void raster_fwd_fast_kernel(KPara
 						const int rank = __popcll(m & ((1ull << lane) - 1ull));
 						const bool sel = ((m >> lane) & 1ull) && rank < room;
 						if (sel)
+						{
 							S.ids[fill + rank] = pr.y;
+							if (nedge > 0)
+								w.tri_stamp[pr.y] = fwd_id;
+						}
 						const unsigned long long taken = __ballot(sel);
 						m &= ~taken;
 						fill += cnt < room ? cnt : room;

@@ -333,6 +333,8 @@ int launch_forward(const DeodrHipScene *sc, KParams &p, hipStream_t stream, hipE
 	if (p.T > 0)
 	{
 		dim3 grid((unsigned)prim_blocks(p.T) * (unsigned)n_views);
+		if (p.fill_mode == 4)
+			grid.x += (unsigned)n_views * (unsigned)frame_fill_blocks(p.H, p.W, p.C, p.pix_f64 != 0);
 		ScopedKernelTimer t(KID_SETUP, stream);
 		hipLaunchKernelGGL(setup_bin_kernel, grid, dim3(PRIM_BLOCK), 0, stream, p);
 	}
@@ -363,7 +365,12 @@ int launch_adjoint(const DeodrHipScene *sc, KParams &p, hipStream_t st, bool own
 	// persistent waves of the edge kernel: enough to cover a silhouette-heavy single view, few enough that with many views
 	// the waves that find their sub-list exhausted cost nothing
 	const int edge_waves = p.L.ntiles < EDGE_WAVES ? p.L.ntiles : EDGE_WAVES;
-	dim3 edge_grid(sc->n_views, edge_waves + (fast ? fill_share_blocks(fill_share(p.fill_mode, 0, p.L.nwords)) : 0));
+	// the edge-tile kernel's launch also finalizes the triangles that no edge tile lists (finalize_early): one workgroup per 64
+#ifndef DR_EARLY_FIN
+#define DR_EARLY_FIN 0 // (1: finalize_early on the edge-tile kernel; measured +7 us on the 8-view step, see profiles/README.md)
+#endif
+	p.early_fin = DR_EARLY_FIN && fast && p.sigma > 0 && p.T > 0 && (p.T + 63) / 64 <= 16384;
+	dim3 edge_grid(sc->n_views, edge_waves + (p.early_fin ? (p.T + 63) / 64 : 0) + (fast ? fill_share_blocks(fill_share(p.fill_mode, 0, p.L.nwords)) : 0));
 	{
 		ScopedKernelTimer t(KID_RASTER_BWD, st);
 		if (sc->pixel_dtype == DEODR_HIP_F64)
@@ -533,6 +540,11 @@ int deodr_hip_render_scene_fit(const DeodrHipScene *sc, void *image, void *z_buf
 #define DR_FILL_MASK 3 // measurement builds: 0 side stream, 1 edge kernel only, 2 finalize only
 #endif
 	p.fill_mode = fused ? (((sigma > 0 ? 1 : 0) | (p.T > 0 ? 2 : 0)) & DR_FILL_MASK) : 0;
+#ifndef DR_SETUP_FILL
+#define DR_SETUP_FILL 0
+#endif
+	if (DR_SETUP_FILL && fused && p.T > 0 && ((size_t)p.H * p.W * p.C * (p.pix_f64 ? 8 : 4)) % 16 == 0 && ((size_t)p.H * p.W * (p.pix_f64 ? 8 : 4)) % 16 == 0)
+		p.fill_mode = 4; // (experiment) the whole frame's background by extra workgroups of the set-up kernel
 	note_forward(workspace, fused);
 	hipEvent_t join = nullptr;
 	if (launch_forward(sc, p, st, &join, fused))
