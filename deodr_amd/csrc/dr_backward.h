@@ -2,7 +2,7 @@
 // The LDS-staged adjoint: raster_bwd_fast_kernel (pass 1) and raster_bwd_edge_kernel (pass 2, persistent waves over the edge tiles).
 #pragma once
 
-#include "dr_finalize_tri.h"
+#include "dr_backward_generic.h"
 
 using namespace dr;
 
@@ -236,6 +236,174 @@ __device__ __forceinline__ void owner_adjoint(const KParams &p, const ViewPtrs &
 	}
 }
 
+// Adjoint of pass 2 for the batches b_hi .. b_lo of a tile's blending order (near -> far, H.h:2961-3052), shared by the edge-tile
+// kernel of the two-call path and by the fused forward of a fit step.  On entry: es.sorted = the blending order, tm[b] = mask of the
+// edges of batch b drawn over this lane's pixel, cur = the pixel's colour after batch b_hi, g = dL/d(that colour); on exit g is the
+// gradient that reaches the colour before batch b_lo, cur that colour.  top_staged: the records of batch b_hi are still in S.
+// pixel_base(base) fills the un-antialiased colour of the pixel when a replay needs it (have_base says whether it already did).
+template <class PixT, bool TEX, class Lds, class BaseFn>
+__device__ __forceinline__ void edge_reverse_sweep(const KParams &p, const ViewPtrs &w, Lds &S, const EdgeSort *es, int lane, double x, double y, int n_edges,
+												   int b_hi, int b_lo, bool top_staged, const uint32_t (&tm)[EMAX / TB], double (&cur)[CH], double (&g)[CH],
+												   double (&base)[CH], bool &have_base, BaseFn pixel_base)
+{
+	const int C = p.C, P = p.L.P;
+	const PixT *texture = (const PixT *)p.texture;
+	PixT *texture_b = (PixT *)p.texture_b;
+	const EdgeRec *erec = (const EdgeRec *)&S.rec[0]; // (the staging area holds EdgeRec and TriRec alike: same size)
+	// pass B, near -> far (H.h:2961-3052)
+	for (int b = b_hi; b >= b_lo; b--)
+	{
+		const int first = b * TB, nb = n_edges - first < TB ? n_edges - first : TB;
+		if (b < b_hi || !top_staged) // (the records of the batch the caller swept last may still be in LDS)
+		{
+			lds_sync();
+			if (lane < nb)
+				S.ids[lane] = es->sorted[first + lane];
+			lds_sync();
+			stage_batch(*(WaveLds *)&S, w.edge_rec, w.edge_planes, P, nb, lane);
+			lds_sync();
+		}
+		uint32_t tmb = 0;
+#pragma unroll
+		for (int bb = 0; bb < EMAX / TB; bb++)
+			tmb = bb == b ? tm[bb] : tmb;
+		for (int r = nb - 1; r >= 0; r--)
+		{
+			const bool hit = (tmb >> r) & 1u;
+			if (__ballot(hit) == 0)
+				continue;
+			const EdgeRec &e = erec[r];
+			const double *ep = &S.planes[r * 12];
+			// colour before this edge: un-blend like the reference (H.h:1738) when T is safely away from 0, otherwise
+			// replay every earlier edge from the un-antialiased colour (the reference yields inf / NaN there)
+			double prev[CH];
+			const double Tr_here = hit ? plane_at(e.x2t, x, y) : 1.0;
+			const bool need_replay = hit && !(Tr_here > 1e-6);
+#pragma unroll
+			for (int cc = 0; cc < CH; cc++)
+				prev[cc] = base[cc];
+			if (hit && !need_replay)
+			{
+				Tap utap;
+				double uL = 0, uUV[2];
+				if (e.kind == KIND_TEXTURED && TEX)
+					textured_tap(ep, x, y, false, 0.0, p.tex_w, p.tex_h, C, utap, uL, uUV);
+				const double inv_T = 1 / Tr_here; // one division for the C channels (the reference divides each: 1 ulp apart)
+#pragma unroll
+				for (int cc = 0; cc < CH; cc++)
+					if (cc < C)
+					{
+						prev[cc] = (cur[cc] - (1 - Tr_here) * edge_channel<PixT, TEX>(e, ep, texture, utap, uL, cc, x, y, false, 0.0)) * inv_T;
+						cur[cc] = prev[cc];
+					}
+			}
+			if (__ballot(need_replay))
+			{ // measure-zero event (pixel centre within 1e-6 sigma of the edge line): records straight from memory
+				if (!have_base)
+				{
+					pixel_base();
+					have_base = true;
+				}
+#pragma unroll
+				for (int cc = 0; cc < CH; cc++)
+					prev[cc] = need_replay ? base[cc] : prev[cc];
+				const int upto = first + r;
+				for (int q = 0; q < upto; q++)
+				{
+					uint32_t tq = 0;
+#pragma unroll
+					for (int bb = 0; bb < EMAX / TB; bb++)
+						tq = bb == (q / TB) ? tm[bb] : tq;
+					if (!need_replay || !((tq >> (q % TB)) & 1u))
+						continue;
+					const uint32_t sq = es->sorted[q];
+					const EdgeRec &eq = w.edge_rec[sq];
+					const double *qp = w.edge_planes + (size_t)sq * 3 * P;
+					const double Tq = plane_at(eq.x2t, x, y);
+					Tap qtap;
+					double qL = 0, qUV[2];
+					if (eq.kind == KIND_TEXTURED && TEX)
+						textured_tap(qp, x, y, false, 0.0, p.tex_w, p.tex_h, C, qtap, qL, qUV);
+#pragma unroll
+					for (int cc = 0; cc < CH; cc++)
+						if (cc < C)
+						{
+							prev[cc] *= Tq;
+							prev[cc] += (1 - Tq) * edge_channel<PixT, TEX>(eq, qp, texture, qtap, qL, cc, x, y, false, 0.0);
+						}
+				}
+				if (need_replay)
+				{
+#pragma unroll
+					for (int cc = 0; cc < CH; cc++)
+						cur[cc] = prev[cc];
+				}
+			}
+			// per-pixel plane adjoints of this edge (0 where it does not touch the pixel) ...
+			double pb[5] = {0, 0, 0, 0, 0}; // planes 0..3 (colours, or u, v, shade) and the transparency plane
+			if (hit)
+			{
+				const double Tr = Tr_here;
+				double T_B = 0;
+				if (e.kind == KIND_TEXTURED && TEX)
+				{ // H.h:2006-2021
+					Tap etap;
+					double eL, eUV[2], L_B = 0, e_B[2] = {0, 0};
+					textured_tap(ep, x, y, false, 0.0, p.tex_w, p.tex_h, C, etap, eL, eUV);
+#pragma unroll
+					for (int cc = 0; cc < CH; cc++)
+						if (cc < C)
+						{
+							const double i00 = ldp(texture, etap.idx[0] + cc), i10 = ldp(texture, etap.idx[1] + cc);
+							const double i01 = ldp(texture, etap.idx[2] + cc), i11 = ldp(texture, etap.idx[3] + cc);
+							const double A = bilinear_mix(etap, i00, i10, i01, i11);
+							T_B += g[cc] * (prev[cc] - A * eL);
+							L_B += g[cc] * (1 - Tr) * A;
+							double wgt[4];
+							bilinear_mix_adjoint(etap, eL * (1 - Tr) * g[cc], i00, i10, i01, i11, wgt, e_B);
+							if (texture_b)
+								texture_scatter(texture_b, etap, cc, wgt);
+							g[cc] *= Tr;
+						}
+					pb[0] = etap.out[0] ? 0.0 : e_B[0];
+					pb[1] = etap.out[1] ? 0.0 : e_B[1];
+					pb[2] = L_B;
+				}
+				else
+				{ // H.h:1726-1746
+#pragma unroll
+					for (int cc = 0; cc < CH; cc++)
+						if (cc < C)
+						{
+							const double A = interp_channel(ep, cc, x, y, false, 0.0);
+							T_B += g[cc] * (prev[cc] - A);
+							pb[cc] = (1 - Tr) * g[cc];
+							g[cc] *= Tr;
+						}
+				}
+				pb[4] = T_B;
+			}
+			// ... reduced over the tile on the VALU (DPP), then ONE atomic instruction (15 lanes) per edge and tile
+			double *eacc = w.edge_acc + (size_t)S.ids[r] * (3 * P + 3);
+			double mv[16]; // lane 3 * pl + m ends up with moment m of plane pl
+#pragma unroll
+			for (int pl = 0; pl < 5; pl++)
+			{
+				mv[3 * pl] = pb[pl] * x;
+				mv[3 * pl + 1] = pb[pl] * y;
+				mv[3 * pl + 2] = pb[pl];
+			}
+			mv[15] = 0;
+			const double esum = wave_sum16(mv, lane);
+			if (lane < 15 && esum != 0 && (lane >= 12 || lane < 3 * P))
+			{
+				const int pl = lane / 3, m = lane - 3 * pl;
+				atomic_add_f64(eacc + (pl == 4 ? 3 * P : 3 * pl) + m, esum);
+			}
+		}
+	}
+}
+
 // One tile of the adjoint.  EDGES = false: tiles without silhouette edges (the edge code is compiled out: half the
 // registers, twice the resident waves to hide the memory latency); EDGES = true: the tiles that have some.
 template <class PixT, bool EDGES, bool TEX>
@@ -449,157 +617,7 @@ __device__ __forceinline__ void bwd_fast_tile(const KParams &p, const ViewPtrs &
 			}
 		}
 		// pass B, near -> far (H.h:2961-3052)
-		for (int b = b_hi; b >= b_lo; b--)
-		{
-			const int first = b * TB, nb = n_edges - first < TB ? n_edges - first : TB;
-			if (b < nbatch - 1 || sweep_saved) // the records of pass A's last batch (if it ran) are still in LDS
-			{
-				lds_sync();
-				if (lane < nb)
-					S.ids[lane] = es->sorted[first + lane];
-				lds_sync();
-				stage_batch(*(WaveLds *)&S, w.edge_rec, w.edge_planes, P, nb, lane);
-				lds_sync();
-			}
-			uint32_t tmb = 0;
-#pragma unroll
-			for (int bb = 0; bb < EMAX / TB; bb++)
-				tmb = bb == b ? tm[bb] : tmb;
-			for (int r = nb - 1; r >= 0; r--)
-			{
-				const bool hit = (tmb >> r) & 1u;
-				if (__ballot(hit) == 0)
-					continue;
-				const EdgeRec &e = S.rec[r];
-				const double *ep = &S.planes[r * 12];
-				// colour before this edge: un-blend like the reference (H.h:1738) when T is safely away from 0, otherwise
-				// replay every earlier edge from the un-antialiased colour (the reference yields inf / NaN there)
-				double prev[CH];
-				const double Tr_here = hit ? plane_at(e.x2t, x, y) : 1.0;
-				const bool need_replay = hit && !(Tr_here > 1e-6);
-#pragma unroll
-				for (int cc = 0; cc < CH; cc++)
-					prev[cc] = base[cc];
-				if (hit && !need_replay)
-				{
-					Tap utap;
-					double uL = 0, uUV[2];
-					if (e.kind == KIND_TEXTURED && TEX)
-						textured_tap(ep, x, y, false, 0.0, p.tex_w, p.tex_h, C, utap, uL, uUV);
-					const double inv_T = 1 / Tr_here; // one division for the C channels (the reference divides each: 1 ulp apart)
-#pragma unroll
-					for (int cc = 0; cc < CH; cc++)
-						if (cc < C)
-						{
-							prev[cc] = (cur[cc] - (1 - Tr_here) * edge_channel<PixT, TEX>(e, ep, texture, utap, uL, cc, x, y, false, 0.0)) * inv_T;
-							cur[cc] = prev[cc];
-						}
-				}
-				if (__ballot(need_replay))
-				{ // measure-zero event (pixel centre within 1e-6 sigma of the edge line): records straight from memory
-					if (!have_base)
-					{
-						pixel_base();
-						have_base = true;
-					}
-#pragma unroll
-					for (int cc = 0; cc < CH; cc++)
-						prev[cc] = need_replay ? base[cc] : prev[cc];
-					const int upto = first + r;
-					for (int q = 0; q < upto; q++)
-					{
-						uint32_t tq = 0;
-#pragma unroll
-						for (int bb = 0; bb < EMAX / TB; bb++)
-							tq = bb == (q / TB) ? tm[bb] : tq;
-						if (!need_replay || !((tq >> (q % TB)) & 1u))
-							continue;
-						const uint32_t sq = es->sorted[q];
-						const EdgeRec &eq = w.edge_rec[sq];
-						const double *qp = w.edge_planes + (size_t)sq * 3 * P;
-						const double Tq = plane_at(eq.x2t, x, y);
-						Tap qtap;
-						double qL = 0, qUV[2];
-						if (eq.kind == KIND_TEXTURED && TEX)
-							textured_tap(qp, x, y, false, 0.0, p.tex_w, p.tex_h, C, qtap, qL, qUV);
-#pragma unroll
-						for (int cc = 0; cc < CH; cc++)
-							if (cc < C)
-							{
-								prev[cc] *= Tq;
-								prev[cc] += (1 - Tq) * edge_channel<PixT, TEX>(eq, qp, texture, qtap, qL, cc, x, y, false, 0.0);
-							}
-					}
-					if (need_replay)
-					{
-#pragma unroll
-						for (int cc = 0; cc < CH; cc++)
-							cur[cc] = prev[cc];
-					}
-				}
-				// per-pixel plane adjoints of this edge (0 where it does not touch the pixel) ...
-				double pb[5] = {0, 0, 0, 0, 0}; // planes 0..3 (colours, or u, v, shade) and the transparency plane
-				if (hit)
-				{
-					const double Tr = Tr_here;
-					double T_B = 0;
-					if (e.kind == KIND_TEXTURED && TEX)
-					{ // H.h:2006-2021
-						Tap etap;
-						double eL, eUV[2], L_B = 0, e_B[2] = {0, 0};
-						textured_tap(ep, x, y, false, 0.0, p.tex_w, p.tex_h, C, etap, eL, eUV);
-#pragma unroll
-						for (int cc = 0; cc < CH; cc++)
-							if (cc < C)
-							{
-								const double i00 = ldp(texture, etap.idx[0] + cc), i10 = ldp(texture, etap.idx[1] + cc);
-								const double i01 = ldp(texture, etap.idx[2] + cc), i11 = ldp(texture, etap.idx[3] + cc);
-								const double A = bilinear_mix(etap, i00, i10, i01, i11);
-								T_B += g[cc] * (prev[cc] - A * eL);
-								L_B += g[cc] * (1 - Tr) * A;
-								double wgt[4];
-								bilinear_mix_adjoint(etap, eL * (1 - Tr) * g[cc], i00, i10, i01, i11, wgt, e_B);
-								if (texture_b)
-									texture_scatter(texture_b, etap, cc, wgt);
-								g[cc] *= Tr;
-							}
-						pb[0] = etap.out[0] ? 0.0 : e_B[0];
-						pb[1] = etap.out[1] ? 0.0 : e_B[1];
-						pb[2] = L_B;
-					}
-					else
-					{ // H.h:1726-1746
-#pragma unroll
-						for (int cc = 0; cc < CH; cc++)
-							if (cc < C)
-							{
-								const double A = interp_channel(ep, cc, x, y, false, 0.0);
-								T_B += g[cc] * (prev[cc] - A);
-								pb[cc] = (1 - Tr) * g[cc];
-								g[cc] *= Tr;
-							}
-					}
-					pb[4] = T_B;
-				}
-				// ... reduced over the tile on the VALU (DPP), then ONE atomic instruction (15 lanes) per edge and tile
-				double *eacc = w.edge_acc + (size_t)S.ids[r] * (3 * P + 3);
-				double mv[16]; // lane 3 * pl + m ends up with moment m of plane pl
-#pragma unroll
-				for (int pl = 0; pl < 5; pl++)
-				{
-					mv[3 * pl] = pb[pl] * x;
-					mv[3 * pl + 1] = pb[pl] * y;
-					mv[3 * pl + 2] = pb[pl];
-				}
-				mv[15] = 0;
-				const double esum = wave_sum16(mv, lane);
-				if (lane < 15 && esum != 0 && (lane >= 12 || lane < 3 * P))
-				{
-					const int pl = lane / 3, m = lane - 3 * pl;
-					atomic_add_f64(eacc + (pl == 4 ? 3 * P : 3 * pl) + m, esum);
-				}
-			}
-		}
+		edge_reverse_sweep<PixT, TEX>(p, w, S, es, lane, x, y, n_edges, b_hi, b_lo, !sweep_saved && b_hi == nbatch - 1, tm, cur, g, base, have_base, pixel_base);
 	}
 
 	DR_TRACE(4);
@@ -640,8 +658,6 @@ __global__ __launch_bounds__(64, 6) void raster_bwd_fast_kernel(KParams p)
 	const bool chunk_here = chunked && stride % (8 * WORK_CHUNK) == 0;
 	uint32_t rank = chunk_here ? (uint32_t)((((qq >> 3) / WORK_CHUNK) * 8 + (qq & 7)) * WORK_CHUNK + (qq >> 3) % WORK_CHUNK) : (uint32_t)qq;
 	const uint32_t n_work = w.hdr->work_count[heavy_list ? 0 : 1];
-	if (q == 0 && lane == 0)
-		w.hdr->late_count = 0; // (a second adjoint on the same forward state: the edge-tile kernel, next on the stream, appends again)
 	for (; rank < n_work; rank += (uint32_t)stride)
 	{
 		const WorkEntry &entry = w.work_list[heavy_list ? rank : (uint32_t)p.L.ntiles - 1u - rank];
@@ -673,18 +689,11 @@ __global__ __launch_bounds__(64, TEX ? 2 : DR_EDGE_OCC) void raster_bwd_edge_ker
 #ifndef DR_FILL_FIRST
 #define DR_FILL_FIRST 0 // measurement builds: 1 = the fill workgroups at the head of both grids instead of the tail
 #endif
-	// grid y: [walkers][early-finalize workgroups, one per 64 triangles][fill workgroups]
-	const int early_blocks = p.early_fin ? (p.T + 63) / 64 : 0;
-	const int walkers = (int)gridDim.y - fill_blocks - early_blocks;
+	const int walkers = (int)gridDim.y - fill_blocks;
 	const int by = DR_FILL_FIRST ? (int)blockIdx.y - fill_blocks : (int)blockIdx.y; // index among the walkers (< 0: a fill workgroup)
-	if (by >= walkers && by < walkers + early_blocks)
+	if (DR_FILL_FIRST ? by < 0 : by >= walkers)
 	{
-		finalize_early(p, view, (by - walkers) * 64, lane);
-		return;
-	}
-	if (DR_FILL_FIRST ? by < 0 : by >= walkers + early_blocks)
-	{
-		for (int i = DR_FILL_FIRST ? (int)blockIdx.y : by - walkers - early_blocks; i < fill_n; i += fill_blocks)
+		for (int i = DR_FILL_FIRST ? (int)blockIdx.y : by - walkers; i < fill_n; i += fill_blocks)
 			fill_share_word(p, 0, view, i, lane);
 		return;
 	}

@@ -33,17 +33,13 @@ __global__ __launch_bounds__(PRIM_BLOCK, DR_PRIM_WAVES) void finalize_kernel(KPa
 	const bool tri_block = pw.tri;
 	const SceneView s = scene_view(p, view);
 	const ViewPtrs w = view_ptrs(p, view);
-	const GradView g = grad_view(p, view);
+	const size_t es = p.vtx_f64 ? 8 : 4;
+	GradView g;
+	g.ij_b = (char *)p.ij_b + (size_t)view * p.V * 2 * es;
+	g.colors_b = (char *)p.colors_b + (size_t)view * p.V * p.C * es;
+	g.shade_b = (char *)p.shade_b + (size_t)view * p.V * es;
+	g.uv_b = p.uv_b;
 	const int P = s.P;
-	if (tri_block && p.early_fin)
-	{ // the triangles finalize_early left: listed with their vertex indices (one round trip, then accumulators + vertices)
-		const uint32_t i = (uint32_t)pw.index * PRIM_BLOCK + threadIdx.x;
-		if (i >= w.hdr->late_count)
-			return;
-		const uint4 e = w.late_list[i];
-		finalize_tri_thread(p, s, w, g, (int)(e.x & 0x3fffffffu), (int)(e.x >> 30), e.y, e.z, e.w);
-		return;
-	}
 	if (tri_block)
 	{
 		const int k = pw.index * PRIM_BLOCK + threadIdx.x;
@@ -53,12 +49,27 @@ __global__ __launch_bounds__(PRIM_BLOCK, DR_PRIM_WAVES) void finalize_kernel(KPa
 		// condition keeps the compiler from sinking the loads below it (an index never has its top bit set: V < 2^31)
 		const uint32_t flag = w.tri_flag[k];
 		const uint32_t f0 = p.faces[3 * (size_t)k], f1 = p.faces[3 * (size_t)k + 1], f2 = p.faces[3 * (size_t)k + 2];
+		double *acc = w.tri_acc + (size_t)k * 3 * P;
 		if (!(flag & 4u) || (flag & 3u) == KIND_NONE || (int32_t)(f0 | f1 | f2) < 0)
 			return; // culled triangles own no accumulators
 		DR_WAVE_PHASE_T(1); // flags + indices arrived
-		finalize_tri_thread(p, s, w, g, k, (int)(flag & 3u), f0, f1, f2);
+		AtomicSink sink = {s, g, {f0, f1, f2}, {p.faces_uv[3 * (size_t)k], p.faces_uv[3 * (size_t)k + 1], p.faces_uv[3 * (size_t)k + 2]}};
+		if (P <= 4)
+		{ // a register copy of the accumulators: all twelve loads in flight together (read through the pointer, each plane's
+		  // loads would wait behind the atomics of the plane before: they might alias)
+			double la[12];
+#pragma unroll
+			for (int i = 0; i < 12; i++)
+				la[i] = i < 3 * P ? acc[i] : 0.0;
+			finalize_triangle<true>(s, k, (int)(flag & 3u), la, sink);
+		}
+		else
+			finalize_triangle<false>(s, k, (int)(flag & 3u), acc, sink);
 		// (merging the adjoints of the triangles of a wavefront that share a vertex in an LDS table before they leave -- a third
 		// fewer atomic requests at the memory side -- was measured: 34 -> 35 us)
+		DR_WAVE_PHASE_T(2); // arithmetic done, atomics issued
+		for (int i = 0; i < 3 * P; i++)
+			acc[i] = 0; // self-cleaning accumulators
 		DR_WAVE_PHASE_T(3);
 		return;
 	}

@@ -323,6 +323,14 @@ template <class PixT, bool TEX>
 __device__ __forceinline__ void owner_adjoint(const KParams &p, const ViewPtrs &w, int lane, double x, double y, int owner, int kind, const double *g,
 											  const Tap &tap, double L, double *tab, uint32_t *own);
 
+// (dr_backward.h) adjoint of pass 2 for batches b_hi .. b_lo of a tile's blending order; (dr_backward_generic.h) the un-staged adjoint
+template <class PixT, bool TEX, class Lds, class BaseFn>
+__device__ __forceinline__ void edge_reverse_sweep(const KParams &p, const ViewPtrs &w, Lds &S, const EdgeSort *es, int lane, double x, double y, int n_edges,
+												   int b_hi, int b_lo, bool top_staged, const uint32_t (&tm)[EMAX / TB], double (&cur)[CH], double (&g)[CH],
+												   double (&base)[CH], bool &have_base, BaseFn pixel_base);
+template <class PixT, bool LEAN, bool TEX>
+__device__ __forceinline__ void bwd_tile_generic_impl(const KParams &p, int view, int tx, int ty, int lane, volatile uint32_t *order);
+
 // Background of one tile that received no primitive: colour, depth = +inf, no owner (H.h:2728-2744).
 template <class PixT>
 __device__ __forceinline__ void fill_background_tile(const KParams &p, int view, int32_t *face_id, int tx, int ty, int lane, const double *bgc,
@@ -386,12 +394,14 @@ constexpr int SCAN_BLOCK = 256, WORK_CHUNK = DR_WORK_CHUNK;
 #ifndef DR_HEAVY_SHARE
 #define DR_HEAVY_SHARE 0 // measurement builds: a fixed share
 #endif
-__host__ inline int heavy_share_for(int n_views, int tile_blocks)
+__host__ inline int heavy_share_for(int n_views, int tile_blocks, bool fuse_edges)
 {
 	if (DR_HEAVY_SHARE)
 		return DR_HEAVY_SHARE;
-	// ~2 048 head workgroups over all views (40 % of the wave slots), the share a power of two between 1/4 and 1/16
-	const long long want = ((long long)n_views * tile_blocks + 2047) / 2048;
+	// ~2 048 head workgroups over all views (40 % of the wave slots), the share a power of two between 1/4 and 1/16.  Twice as many
+	// when the head also holds every tile with silhouette edges and runs their adjoint (a fit step: ~1 000 head entries per view of
+	// the benchmark scene, 20 - 60 us each -- with 256 walkers per view the forward ended 14 us after its last short tile)
+	const long long want = ((long long)n_views * tile_blocks + (fuse_edges ? 4095 : 2047)) / (fuse_edges ? 4096 : 2048);
 	int share = 4;
 	while (share < 16 && share < want)
 		share *= 2;
@@ -437,7 +447,10 @@ __global__ __launch_bounds__(SCAN_BLOCK) void tile_scan_kernel(KParams p)
 	if (lane == 32 && valid)
 		w.tile_bits[tile >> 5] = (uint32_t)(wm >> 32);
 	// ---- compaction: rank inside the wavefront, wavefront totals through LDS, ONE atomic per class and block
-	const bool heavy = work && p.tile_blocks % (8 * WORK_CHUNK) == 0 && (ntri > (uint32_t)FIRST_PRIMS || nedge > (uint32_t)FIRST_PRIMS);
+	// (fit step with fused edge tiles: every tile with edges is a long wavefront -- forward, reverse sweep, pass 1 -- and must be in
+	// the head of the list, which the workgroups compiled for that adjoint walk)
+	const bool heavy = work && p.tile_blocks % (8 * WORK_CHUNK) == 0 &&
+					   (ntri > (uint32_t)FIRST_PRIMS || nedge > (uint32_t)(p.fuse_edges ? 0 : FIRST_PRIMS));
 	const int elist = nedge == 0 ? -1 : (nedge <= (uint32_t)PRIO_EDGES ? 0 : (nedge <= (uint32_t)TB ? 1 : 2));
 	unsigned long long m[NCLS];
 	m[0] = __ballot(heavy);
@@ -479,7 +492,7 @@ __global__ __launch_bounds__(SCAN_BLOCK) void tile_scan_kernel(KParams p)
 		const uint32_t at = position(2 + EDGE_LISTS, m[2 + EDGE_LISTS]);
 		const uint32_t slot_word = at < (uint32_t)p.L.sweep_cap ? at + 1u : 0u;
 		w.edge_slot[tile] = slot_word; // always written: a stale value must never be read
-		sweep_slot = (nedge <= (uint32_t)EMAX && !p.persp) ? slot_word : 0u;
+		sweep_slot = (nedge <= (uint32_t)EMAX && !p.persp && !p.fuse_edges) ? slot_word : 0u; // (fused: nothing is saved for a later kernel)
 		static_assert(EDGE_LISTS == 3, "select below");
 		w.edge_tiles[(size_t)elist * p.L.ntiles + position(2 + elist, elist == 0 ? m[2] : (elist == 1 ? m[3] : m[4]))] = (uint32_t)tile;
 	}
@@ -647,36 +660,53 @@ __global__ __launch_bounds__(64 * FILL_WAVES) void fill_kernel(KParams p, int ow
 	fill_word<PixT>(p, gw / p.L.nwords, gw % p.L.nwords, threadIdx.x & 63, owners);
 }
 
-// A fit step has two latency-bound kernels after the forward raster (edge tiles, finalize) whose wave slots and store bandwidth
-// are mostly idle: the background fill rides on them as extra workgroups instead of a kernel of its own on a forked stream --
-// the fork / join event packets cost the caller's stream two bubbles of ~7 us per step (rocprofv3 kernel trace: scan -> forward,
-// finalize -> next set-up).  Word wi of a view goes to the kernels that take part by parity.
-// When both kernels take part, FILL_EDGE_NUM of every FILL_DEN consecutive words go to the edge-tile kernel, the others to finalize.
-#ifndef DR_FILL_EDGE_NUM
-#define DR_FILL_EDGE_NUM 1
+// The background fill of a fit step rides on the step's other kernels as extra workgroups instead of being a kernel of its own on a
+// forked stream -- the fork / join event packets cost the caller's stream two bubbles of ~7 us per step (rocprofv3 kernel trace: scan
+// -> forward, finalize -> next set-up).  Which kernels take part is p.fill_mode (bit 0: raster_bwd_edge_kernel, bit 1: finalize_kernel,
+// bit 2: the staged forward raster itself); the bitmap words of a view are dealt to them in proportion to FILL_W.  The fill is
+// 110 MB of stores per 8-view step at the ~3 TB/s the store path sustains, i.e. ~37 us of bandwidth time wherever it goes: only the
+// forward raster (issue-bound, ~95 us, 0.6 TB/s of stores of its own) is long enough to hide most of it; finalize_kernel (bound by
+// the latency of its round trips) hides a part (all of it there: + 11 us).
+#ifndef DR_FILL_W_EDGE
+#define DR_FILL_W_EDGE 1
 #endif
-#ifndef DR_FILL_DEN
-#define DR_FILL_DEN 2
+#ifndef DR_FILL_W_FIN
+#define DR_FILL_W_FIN 1
 #endif
-constexpr int FILL_EDGE_NUM = DR_FILL_EDGE_NUM, FILL_DEN = DR_FILL_DEN;
-static_assert(FILL_EDGE_NUM > 0 && FILL_EDGE_NUM < FILL_DEN, "both kernels get some");
+#ifndef DR_FILL_W_FWD
+#define DR_FILL_W_FWD 2
+#endif
+__host__ __device__ inline int fill_weight(int bit) { return bit == 0 ? DR_FILL_W_EDGE : (bit == 1 ? DR_FILL_W_FIN : DR_FILL_W_FWD); }
+__host__ __device__ inline void fill_split(int fill_mode, int bit, int &den, int &off)
+{ // of every `den` consecutive bitmap words, the fill_weight(bit) words starting at `off` are kernel `bit`'s
+	den = off = 0;
+	for (int k = 0; k < 3; k++)
+		if (fill_mode & (1 << k))
+		{
+			if (k < bit)
+				off += fill_weight(k);
+			den += fill_weight(k);
+		}
+}
 __host__ __device__ inline int fill_share(int fill_mode, int bit, int nwords)
-{ // bitmap words per view the kernel `bit` (0 edge tiles, 1 finalize) fills
+{ // bitmap words per view the kernel `bit` fills
 	if (!(fill_mode & (1 << bit)))
 		return 0;
-	if (fill_mode != 3)
-		return nwords;
-	const int full = nwords / FILL_DEN, rest = nwords - full * FILL_DEN; // whole groups + a partial one
-	const int edge = full * FILL_EDGE_NUM + (rest < FILL_EDGE_NUM ? rest : FILL_EDGE_NUM);
-	return bit == 0 ? edge : nwords - edge;
+	int den, off;
+	fill_split(fill_mode, bit, den, off);
+	const int full = nwords / den, rest = nwords - full * den, w = fill_weight(bit);
+	const int extra = rest - off < 0 ? 0 : (rest - off > w ? w : rest - off);
+	return full * w + extra;
 }
 // workgroups (edge kernel: per view, along grid y, limited to 65535) that stream a share of n words: one word each up to a cap,
 // beyond it (frames of more than ~4 M tiles) every workgroup takes several
 __host__ __device__ inline int fill_share_blocks(int n) { return n < 32768 ? n : 32768; }
 __device__ __forceinline__ void fill_share_word(const KParams &p, int bit, int view, int i, int lane)
 { // the i-th word of the share of kernel `bit`
-	const int per = bit == 0 ? FILL_EDGE_NUM : FILL_DEN - FILL_EDGE_NUM; // words of a group that are this kernel's
-	const int wi = p.fill_mode == 3 ? (i / per) * FILL_DEN + (bit == 0 ? 0 : FILL_EDGE_NUM) + i % per : i;
+	int den, off;
+	fill_split(p.fill_mode, bit, den, off);
+	const int w = fill_weight(bit);
+	const int wi = (i / w) * den + off + i % w;
 	if (wi >= p.L.nwords)
 		return;
 	if (p.pix_f64)
@@ -775,12 +805,23 @@ __host__ __device__ inline int fwd_tile_blocks(int ntiles)
 #ifndef DR_FWD_WAVES
 #define DR_FWD_WAVES (TEX ? 4 : 5)
 #endif
-template <class PixT, bool FUSED, bool TEX>
-__global__ __launch_bounds__(64, DR_FWD_WAVES) void raster_fwd_fast_kernel(KParams p)
+// Code-generation modes of the tile walker.  A fit step (FUSED) back-propagates EVERY tile in the forward launch: the scan kernel puts
+// the tiles that hold silhouette edges at the head of the work list, and the workgroups that walk the head run the instance that
+// can do their adjoint too (FWD_EDGE_ADJ: reverse sweep over the tile's edges, then pass 1) while all the other workgroups run an
+// instance without any edge code (FWD_NO_EDGES).  Two instances in one kernel, chosen per workgroup, instead of a branch inside one
+// loop: the edge adjoint needs ~40 registers more than the rest, and as a branch of the common loop (or as a function called from
+// it) it cost EVERY tile spills on its path (forward 83 -> 90 us before the first edge tile was fused); as a disjoint path its
+// spills stay with the one workgroup in sixteen that walks the head.
+enum FwdMode
+{
+	FWD_PLAIN = 0,	  // forward only (or adjoint left to the two-call path): pass 2 saves its sweep for raster_bwd_edge_kernel
+	FWD_EDGE_ADJ = 1, // fit step, head of the list: tiles with edges are back-propagated here as well
+	FWD_NO_EDGES = 2, // fit step, rest of the list: no tile has an edge
+};
+template <class PixT, bool FUSED, bool TEX, int MODE>
+__device__ __forceinline__ void fwd_tiles(const KParams &p, WaveLds *s_lds, EdgeSort *s_es)
 {
 	DR_WAVE_TRACE_SCOPE(2);
-	__shared__ WaveLds s_lds[1];
-	__shared__ EdgeSort s_es[1];
 #ifdef DR_FWD_TRACE
 	// per-tile phase timing (tools/fwd_trace.py): eight counters over the first row of the tile in the z buffer
 	uint32_t ftr[16] = {0x7fc0f00du, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -819,7 +860,6 @@ __global__ __launch_bounds__(64, DR_FWD_WAVES) void raster_fwd_fast_kernel(KPara
 	const bool chunk_here = chunked && stride % (8 * WORK_CHUNK) == 0;
 	uint32_t rank = chunk_here ? (uint32_t)((((qq >> 3) / WORK_CHUNK) * 8 + (qq & 7)) * WORK_CHUNK + (qq >> 3) % WORK_CHUNK) : (uint32_t)qq;
 	const uint32_t n_work = w.hdr->work_count[heavy_list ? 0 : 1];
-	const uint32_t fwd_id = w.hdr->fwd_id; // stamp of this forward (written by its set-up kernel)
 	for (; rank < n_work; rank += (uint32_t)stride)
 	{
 #ifdef DR_FWD_TRACE
@@ -832,7 +872,7 @@ __global__ __launch_bounds__(64, DR_FWD_WAVES) void raster_fwd_fast_kernel(KPara
 		asm volatile("" : "+v"(lane));
 		const WorkEntry &entry = w.work_list[heavy_list ? rank : (uint32_t)p.L.ntiles - 1u - rank];
 		const uint32_t ids12 = entry.ids[lane < ENTRY_IDS ? lane : 0];
-		const int tile = uniform((int)entry.tile), ntri = uniform((int)entry.ntri), nedge = uniform((int)entry.nedge);
+		const int tile = uniform((int)entry.tile), ntri = uniform((int)entry.ntri), nedge = MODE == FWD_NO_EDGES ? 0 : uniform((int)entry.nedge);
 		const uint32_t sweep_slot = (uint32_t)uniform((int)entry.sweep_slot);
 		const int tx = tile % p.L.tiles_x, ty = tile / p.L.tiles_x;
 		const int x0 = tx * TILE, y0 = ty * TILE;
@@ -846,7 +886,8 @@ __global__ __launch_bounds__(64, DR_FWD_WAVES) void raster_fwd_fast_kernel(KPara
 		{
 		{
 		PixT ob[CH] = {0, 0, 0, 0};
-		if (FUSED && ntri > 0 && nedge == 0 && inb)
+		constexpr bool fuse_edges = MODE == FWD_EDGE_ADJ; // tiles with silhouette edges are back-propagated right here as well
+		if (FUSED && inb && (nedge == 0 ? ntri > 0 : fuse_edges))
 		{ // requested now, used after the last triangle
 			const PixT *o = (const PixT *)p.obs + vpix * C;
 #pragma unroll
@@ -870,10 +911,6 @@ __global__ __launch_bounds__(64, DR_FWD_WAVES) void raster_fwd_fast_kernel(KPara
 		if (ntri > 0)
 		{
 			const int n_inline = ntri < K_TRI ? ntri : K_TRI;
-			// A tile with silhouette edges is back-propagated by the adjoint's edge-tile kernel: its triangles are stamped, so that
-			// everybody else's accumulators can be finalized while that kernel runs (finalize_early)
-			if (nedge > 0 && lane < n_inline)
-				w.tri_stamp[list_entry] = fwd_id;
 			for (int base = 0; base < n_inline; base += TB)
 			{
 				const int nb = n_inline - base < TB ? n_inline - base : TB;
@@ -902,11 +939,7 @@ __global__ __launch_bounds__(64, DR_FWD_WAVES) void raster_fwd_fast_kernel(KPara
 						const int rank = __popcll(m & ((1ull << lane) - 1ull));
 						const bool sel = ((m >> lane) & 1ull) && rank < room;
 						if (sel)
-						{
 							S.ids[fill + rank] = pr.y;
-							if (nedge > 0)
-								w.tri_stamp[pr.y] = fwd_id;
-						}
 						const unsigned long long taken = __ballot(sel);
 						m &= ~taken;
 						fill += cnt < room ? cnt : room;
@@ -953,6 +986,7 @@ __global__ __launch_bounds__(64, DR_FWD_WAVES) void raster_fwd_fast_kernel(KPara
 		}
 		// ---- pass 2: edges far -> near, TB at a time (H.h:2839-2900)
 		int n_edges = 0;
+		uint32_t tm[EMAX / TB] = {0, 0, 0, 0, 0, 0, 0, 0}; // (fused adjoint) bit j of tm[b]: edge 16 b + j of the blending order is drawn over this pixel
 		if (nedge > 0)
 			n_edges = gather_sorted_edges(s_es[wave], w, p, tile, nedge, lane);
 		if (n_edges > 0)
@@ -1007,6 +1041,12 @@ __global__ __launch_bounds__(64, DR_FWD_WAVES) void raster_fwd_fast_kernel(KPara
 								col[cc] += (1 - Tr) * A;
 							}
 					}
+				}
+				if (fuse_edges)
+				{
+#pragma unroll
+					for (int bb = 0; bb < EMAX / TB; bb++)
+						tm[bb] = bb == first / TB ? drawn_batch : tm[bb];
 				}
 				if (sweep_slot) // bit j: edge first + j of the blending order is drawn over this pixel
 					((uint16_t *)(w.edge_sweep + (size_t)(sweep_slot - 1) * SWEEP_BYTES + CH * 64 * sizeof(double)))[(first / TB) * 64 + lane] =
@@ -1088,10 +1128,55 @@ __global__ __launch_bounds__(64, DR_FWD_WAVES) void raster_fwd_fast_kernel(KPara
 			if (p.zbuf)
 				__builtin_nontemporal_store((PixT)st.zbest, (PixT *)p.zbuf + vpix);
 			// a fused forward back-propagates through a tile without edges right below: nobody reads its owner ids again
-			if (!FUSED || nedge > 0)
+			// (nor those of a tile with edges when its adjoint is fused too -- except the pathological tile of more than EMAX edges,
+			// whose adjoint runs on the un-staged code and reads them)
+			if (!FUSED || (nedge > 0 && (!fuse_edges || n_edges < 0)))
 				__builtin_nontemporal_store(pack_owner(st.kbest, st.kind), w.face_id + pix);
 		}
 		DR_FTRACE(5); // frame stores issued
+		if (fuse_edges && nedge > 0)
+		{ // ---- adjoint of a tile with silhouette edges, in the same wavefront: reverse sweep over its edges (near -> far), then pass 1.
+		  // Nothing is saved for a later kernel (no sweep, no snapshots, no owner ids) and the latency of this long dependent chain
+		  // hides among the thousands of short tiles of the same launch instead of being a kernel of its own (31 us per 8-view step).
+			double g[CH], base[CH] = {0, 0, 0, 0};
+#pragma unroll
+			for (int cc = 0; cc < CH; cc++)
+				g[cc] = (cc < C && inb) ? 2 * ((double)(PixT)col[cc] - (double)ob[cc]) : 0.0;
+			if (n_edges > 0)
+			{
+				bool have_base = false;
+				auto pixel_base = [&]() { // the un-antialiased colour (only a replay over an edge of transparency ~0 needs it)
+					if (st.kbest >= 0)
+					{
+						const double *planes = w.tri_planes + (size_t)st.kbest * 3 * P;
+#pragma unroll
+						for (int cc = 0; cc < CH; cc++)
+							if (cc < C)
+								base[cc] = (st.kind == KIND_TEXTURED && TEX) ? textured_channel(texture, tap, cc) * L : interp_channel(planes, cc, x, y, false, 0.0);
+					}
+					else if (inb)
+					{
+#pragma unroll
+						for (int cc = 0; cc < CH; cc++)
+							if (cc < C)
+								base[cc] = background_channel<PixT>(p, view, pix, cc);
+					}
+				};
+				const int nbatch = (n_edges + TB - 1) / TB;
+				lds_sync();
+				edge_reverse_sweep<PixT, TEX>(p, w, S, &s_es[wave], lane, x, y, n_edges, nbatch - 1, 0, true, tm, col, g, base, have_base, pixel_base);
+				lds_sync();
+				owner_adjoint<PixT, TEX>(p, w, lane, x, y, st.kbest, st.kbest >= 0 ? st.kind : (int)KIND_NONE, g, tap, L, (double *)&S.rec[0],
+										(uint32_t *)&S.cover[0][0]);
+			}
+			else if (n_edges < 0)
+			{ // more than EMAX edges in one tile: the un-staged adjoint reads the frame and the owner ids this wavefront has just written
+				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+				__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+				lds_sync();
+				bwd_tile_generic_impl<PixT, true, TEX>(p, view, tx, ty, lane, (volatile uint32_t *)s_es[wave].sorted);
+			}
+		}
 		if (FUSED && nedge == 0 && __ballot(st.kbest >= 0) != 0)
 		{ // same residual as raster_bwd_fast_kernel forms from the stored frame: the colour is rounded to the pixel type first
 			double g[CH];
@@ -1128,6 +1213,35 @@ __global__ __launch_bounds__(64, DR_FWD_WAVES) void raster_fwd_fast_kernel(KPara
 	}
 	if (q == 0 && threadIdx.x == 0)
 		close_epoch(p, w, FUSED);
+}
+
+#ifndef DR_FUSE_EDGES
+#define DR_FUSE_EDGES 1 // (measurement builds: 0 = the tiles with silhouette edges of a fit step wait for raster_bwd_edge_kernel, as in round 2)
+#endif
+template <class PixT, bool FUSED, bool TEX>
+__global__ __launch_bounds__(64, DR_FWD_WAVES) void raster_fwd_fast_kernel(KParams p)
+{
+	__shared__ WaveLds s_lds[1];
+	__shared__ EdgeSort s_es[1];
+	if ((long long)blockIdx.x >= (long long)p.n_views * p.tile_blocks)
+	{ // the last workgroups of the grid stream the background of this kernel's share of the empty tiles (fill_share)
+		const int fi = (int)((long long)blockIdx.x - (long long)p.n_views * p.tile_blocks);
+		fill_share_word(p, 2, fi % p.n_views, fi / p.n_views, threadIdx.x & 63);
+		return;
+	}
+	if (FUSED && DR_FUSE_EDGES)
+	{ // (p.fuse_edges is set: the host and the scan kernel follow the same build constant)
+		const int G = p.tile_blocks;
+		const long long b = blockIdx.x;
+		const bool chunked = G % (8 * WORK_CHUNK) == 0;
+		const int q = chunked ? (int)((b >> 3) / p.n_views) * 8 + (int)(b & 7) : 0;
+		if (chunked && q >= G / p.heavy_share)
+			fwd_tiles<PixT, FUSED, TEX, FWD_NO_EDGES>(p, s_lds, s_es); // the rest of the list: no tile with edges
+		else
+			fwd_tiles<PixT, FUSED, TEX, FWD_EDGE_ADJ>(p, s_lds, s_es); // the head (tiny frames: the whole list)
+	}
+	else
+		fwd_tiles<PixT, FUSED, TEX, FWD_PLAIN>(p, s_lds, s_es);
 }
 
 } // namespace

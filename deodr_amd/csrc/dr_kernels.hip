@@ -200,7 +200,7 @@ void launch_adjoint_raster(const KParams &p, bool fast, bool owner_tiles, dim3 g
 	{
 		KParams q = p;
 		q.tile_blocks = fwd_tile_blocks(p.L.ntiles); // the grid of the forward that built the work list
-		q.heavy_share = heavy_share_for(p.n_views, q.tile_blocks);
+		q.heavy_share = heavy_share_for(p.n_views, q.tile_blocks, false);
 		const dim3 grid((unsigned)p.n_views * (unsigned)q.tile_blocks);
 		if (tex)
 			hipLaunchKernelGGL((raster_bwd_fast_kernel<PixT, true>), grid, dim3(64), 0, st, q);
@@ -208,7 +208,7 @@ void launch_adjoint_raster(const KParams &p, bool fast, bool owner_tiles, dim3 g
 			hipLaunchKernelGGL((raster_bwd_fast_kernel<PixT, false>), grid, dim3(64), 0, st, q);
 	}
 	// (running the two kernels side by side on a forked stream was measured: no gain, the edge kernel just stretches)
-	if (p.sigma > 0)
+	if (p.sigma > 0 && !p.fuse_edges) // (a fit step back-propagates the tiles with edges inside its forward raster)
 	{
 		if (tex)
 			hipLaunchKernelGGL((raster_bwd_edge_kernel<PixT, true>), edge_grid, dim3(64), 0, st, p);
@@ -291,7 +291,7 @@ int launch_forward_staged(const KParams &p, bool fused, hipStream_t stream, hipE
 {
 	KParams q = p;
 	q.tile_blocks = fwd_tile_blocks(p.L.ntiles);
-	q.heavy_share = heavy_share_for(p.n_views, q.tile_blocks);
+	q.heavy_share = heavy_share_for(p.n_views, q.tile_blocks, fused && p.fuse_edges);
 	hipLaunchKernelGGL(tile_scan_kernel, dim3((p.L.ntiles + SCAN_BLOCK - 1) / SCAN_BLOCK, p.n_views), dim3(SCAN_BLOCK), 0, stream, q);
 	if (p.fill_mode == 0)
 	{
@@ -305,7 +305,8 @@ int launch_forward_staged(const KParams &p, bool fused, hipStream_t stream, hipE
 			return 1;
 		*join = ss.join;
 	}
-	const dim3 grid((unsigned)p.n_views * (unsigned)q.tile_blocks);
+	// (+ the workgroups that stream this kernel's share of the background of the empty tiles, one bitmap word each)
+	const dim3 grid((unsigned)p.n_views * (unsigned)q.tile_blocks + (unsigned)p.n_views * (unsigned)fill_share(p.fill_mode, 2, p.L.nwords));
 	const bool tex = p.texture != nullptr; // (see launch_adjoint_raster)
 	if (fused && tex)
 		hipLaunchKernelGGL((raster_fwd_fast_kernel<PixT, true, true>), grid, dim3(64), 0, stream, q);
@@ -333,8 +334,6 @@ int launch_forward(const DeodrHipScene *sc, KParams &p, hipStream_t stream, hipE
 	if (p.T > 0)
 	{
 		dim3 grid((unsigned)prim_blocks(p.T) * (unsigned)n_views);
-		if (p.fill_mode == 4)
-			grid.x += (unsigned)n_views * (unsigned)frame_fill_blocks(p.H, p.W, p.C, p.pix_f64 != 0);
 		ScopedKernelTimer t(KID_SETUP, stream);
 		hipLaunchKernelGGL(setup_bin_kernel, grid, dim3(PRIM_BLOCK), 0, stream, p);
 	}
@@ -365,12 +364,7 @@ int launch_adjoint(const DeodrHipScene *sc, KParams &p, hipStream_t st, bool own
 	// persistent waves of the edge kernel: enough to cover a silhouette-heavy single view, few enough that with many views
 	// the waves that find their sub-list exhausted cost nothing
 	const int edge_waves = p.L.ntiles < EDGE_WAVES ? p.L.ntiles : EDGE_WAVES;
-	// the edge-tile kernel's launch also finalizes the triangles that no edge tile lists (finalize_early): one workgroup per 64
-#ifndef DR_EARLY_FIN
-#define DR_EARLY_FIN 0 // (1: finalize_early on the edge-tile kernel; measured +7 us on the 8-view step, see profiles/README.md)
-#endif
-	p.early_fin = DR_EARLY_FIN && fast && p.sigma > 0 && p.T > 0 && (p.T + 63) / 64 <= 16384;
-	dim3 edge_grid(sc->n_views, edge_waves + (p.early_fin ? (p.T + 63) / 64 : 0) + (fast ? fill_share_blocks(fill_share(p.fill_mode, 0, p.L.nwords)) : 0));
+	dim3 edge_grid(sc->n_views, edge_waves + (fast ? fill_share_blocks(fill_share(p.fill_mode, 0, p.L.nwords)) : 0));
 	{
 		ScopedKernelTimer t(KID_RASTER_BWD, st);
 		if (sc->pixel_dtype == DEODR_HIP_F64)
@@ -537,14 +531,10 @@ int deodr_hip_render_scene_fit(const DeodrHipScene *sc, void *image, void *z_buf
 	const bool fused = p.C <= CH && !g_force_generic;
 	// the background of the empty tiles rides on the adjoint's kernels (fill_share); without any of them: the side stream
 #ifndef DR_FILL_MASK
-#define DR_FILL_MASK 3 // measurement builds: 0 side stream, 1 edge kernel only, 2 finalize only
+#define DR_FILL_MASK 7 // measurement builds: 0 side stream, 1 edge kernel only, 2 finalize only, 4 forward raster only
 #endif
-	p.fill_mode = fused ? (((sigma > 0 ? 1 : 0) | (p.T > 0 ? 2 : 0)) & DR_FILL_MASK) : 0;
-#ifndef DR_SETUP_FILL
-#define DR_SETUP_FILL 0
-#endif
-	if (DR_SETUP_FILL && fused && p.T > 0 && ((size_t)p.H * p.W * p.C * (p.pix_f64 ? 8 : 4)) % 16 == 0 && ((size_t)p.H * p.W * (p.pix_f64 ? 8 : 4)) % 16 == 0)
-		p.fill_mode = 4; // (experiment) the whole frame's background by extra workgroups of the set-up kernel
+	p.fuse_edges = DR_FUSE_EDGES && fused;
+	p.fill_mode = fused ? ((((sigma > 0 && !p.fuse_edges) ? 1 : 0) | (p.T > 0 ? 2 : 0) | (p.T > 0 ? 4 : 0)) & DR_FILL_MASK) : 0;
 	note_forward(workspace, fused);
 	hipEvent_t join = nullptr;
 	if (launch_forward(sc, p, st, &join, fused))

@@ -203,87 +203,9 @@ struct WaveTrace
 #define DR_WAVE_PHASE_T(i)
 #endif
 
-// ---- whole-frame background (fill_mode 4): extra workgroups at the END of the set-up kernel's grid write the background colour (or
-// image) and depth = +inf of EVERY pixel of every view as one linear stream of 16-byte pieces; the forward raster, two launches
-// later, overwrites the pixels of the tiles that hold primitives.  Set-up is bound by the latency of its dependent round trips and
-// moves 40 MB: the store bandwidth of the chip is idle while it runs.
-constexpr int FRAME_PIECES = 8; // 16-byte pieces per thread
-__host__ __device__ inline long long frame_fill_pieces(int H, int W, int C, bool f64)
-{ // per view: image, then depth
-	const long long ps = f64 ? 8 : 4;
-	return ((long long)H * W * C * ps + (long long)H * W * ps) / 16;
-}
-__host__ __device__ inline int frame_fill_blocks(int H, int W, int C, bool f64)
-{
-	const long long per_block = (long long)PRIM_BLOCK * FRAME_PIECES;
-	return (int)((frame_fill_pieces(H, W, C, f64) + per_block - 1) / per_block);
-}
-template <class PixT>
-__device__ __forceinline__ void frame_fill_block(const KParams &p, int view, int block)
-{
-	constexpr int E = 16 / (int)sizeof(PixT);
-	typedef PixT VE __attribute__((ext_vector_type(E)));
-	const int C = p.C;
-	const long long n_img = (long long)p.H * p.W * C / E, n_all = frame_fill_pieces(p.H, p.W, C, sizeof(PixT) == 8);
-	PixT *img = (PixT *)p.image + (size_t)view * p.H * p.W * C;
-	PixT *zb = (PixT *)p.zbuf + (size_t)view * p.H * p.W;
-	const PixT *bgi = p.bg_image ? (const PixT *)p.bg_image + (size_t)view * p.H * p.W * C : nullptr;
-	PixT bgc[CH] = {0, 0, 0, 0};
-	if (!bgi)
-	{
-#pragma unroll
-		for (int cc = 0; cc < CH; cc++)
-			if (cc < C)
-				bgc[cc] = ((const PixT *)p.bg_color)[cc];
-	}
-	VE inf;
-#pragma unroll
-	for (int j = 0; j < E; j++)
-		inf[j] = (PixT)INFINITY;
-	const long long base = (long long)block * PRIM_BLOCK * FRAME_PIECES + threadIdx.x;
-#pragma unroll
-	for (int it = 0; it < FRAME_PIECES; it++)
-	{
-		const long long piece = base + (long long)it * PRIM_BLOCK; // consecutive lanes on consecutive pieces
-		if (piece >= n_all)
-			break;
-		if (piece >= n_img)
-		{
-			if (p.zbuf)
-				__builtin_nontemporal_store(inf, (VE *)zb + (piece - n_img));
-			continue;
-		}
-		if (!p.image)
-			continue;
-		VE v;
-		if (bgi)
-			v = ((const VE *)bgi)[piece];
-		else
-		{
-			int ph = (int)((piece * E) % C); // channel of the piece's first element
-#pragma unroll
-			for (int j = 0; j < E; j++)
-			{
-				v[j] = ph == 0 ? bgc[0] : (ph == 1 ? bgc[1] : (ph == 2 ? bgc[2] : bgc[3]));
-				ph = ph + 1 == C ? 0 : ph + 1;
-			}
-		}
-		__builtin_nontemporal_store(v, (VE *)img + piece);
-	}
-}
-
 __global__ __launch_bounds__(PRIM_BLOCK, DR_PRIM_WAVES) void setup_bin_kernel(KParams p)
 {
 	DR_WAVE_TRACE_SCOPE(0);
-	if (p.fill_mode == 4 && (int)blockIdx.x >= p.n_views * prim_blocks(p.T))
-	{
-		const int fb = (int)blockIdx.x - p.n_views * prim_blocks(p.T), per_view = frame_fill_blocks(p.H, p.W, p.C, p.pix_f64 != 0);
-		if (p.pix_f64)
-			frame_fill_block<double>(p, fb % p.n_views, fb / p.n_views);
-		else
-			frame_fill_block<float>(p, fb % p.n_views, fb / p.n_views);
-		return;
-	}
 	const PrimWork pw = prim_work(p);
 	const int view = pw.view;
 	const int item = pw.view_block * PRIM_BLOCK + threadIdx.x; // only an id for the housekeeping below
@@ -298,8 +220,6 @@ __global__ __launch_bounds__(PRIM_BLOCK, DR_PRIM_WAVES) void setup_bin_kernel(KP
 		w.hdr->tri_spill[1 - cur] = 0;
 		w.hdr->edge_spill[1 - cur] = 0;
 		w.hdr->snap_count[1 - cur] = 0;
-		w.hdr->fwd_id = w.hdr->epoch + 1u; // the stamp of this forward (tri_stamp)
-		w.hdr->late_count = 0;
 		w.hdr->work_count[0] = w.hdr->work_count[1] = 0; // filled by tile_scan_kernel, read by the forward raster
 	}
 	if (item <= EDGE_LISTS) // appended to by tile_scan_kernel, the next kernel on the stream

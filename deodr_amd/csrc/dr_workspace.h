@@ -65,7 +65,7 @@ struct alignas(64) WorkEntry
 };
 static_assert(sizeof(WorkEntry) == 64, "");
 
-struct WsHeader // 128 bytes per view at the start of the view's workspace (its first 64 bytes are the status block the host may poll)
+struct WsHeader // 64 bytes per view at the start of the view's workspace (also the status block the host may poll)
 {
 	// Spill counters are double-buffered by the parity of `epoch` (one forward = one epoch): the set-up kernel of a forward
 	// counts into [cur] and clears [1 - cur] for the next forward, so no memset node and no last-block ticket is needed.
@@ -81,12 +81,8 @@ struct WsHeader // 128 bytes per view at the start of the view's workspace (its 
 	uint32_t all_needed_max, all_scene_errors;
 	uint32_t work_count[2]; // entries of the forward's work list: [0] many-primitive tiles (from the front), [1] the others (from the back)
 	uint32_t pad[1];
-	// ---- beyond the status block
-	uint32_t fwd_id;	 // 1 + epoch of the forward whose state the workspace holds (written by its set-up kernel): what tri_stamp is compared with
-	uint32_t late_count; // entries of late_list (finalize_early: front-facing triangles that own pixels in tiles with silhouette edges)
-	uint32_t pad2[14];
 };
-static_assert(sizeof(WsHeader) == 128, "");
+static_assert(sizeof(WsHeader) == 64, "");
 static_assert(offsetof(WsHeader, all_needed_max) == 4 * DEODR_HIP_STATUS_WORD_NEEDED_PAIRS &&
 				  offsetof(WsHeader, all_scene_errors) == 4 * DEODR_HIP_STATUS_WORD_SCENE_ERRORS &&
 				  (int)dr::SCENE_ERR_FACES == DEODR_HIP_ERR_FACES && (int)dr::SCENE_ERR_FACES_UV == DEODR_HIP_ERR_FACES_UV &&
@@ -98,7 +94,7 @@ struct Layout
 	size_t hdr, tri_rec, tri_planes, tri_acc, edge_rec, edge_planes, edge_acc, tri_cnt, edge_cnt, edge_saved, tri_list, edge_list, tri_pool,
 		edge_pool, face_id, tile_bits, tri_flag, work_list, edge_tile_cnt, edge_tiles, edge_slot, edge_sweep, edge_snap, view_bytes;
 	uint32_t tri_pool_cap, edge_pool_cap;
-	size_t edge_fin, tri_stamp, late_list;
+	size_t edge_fin;
 	int tiles_x, tiles_y, ntiles, nwords, P, sweep_cap;
 };
 
@@ -155,11 +151,6 @@ Layout make_layout(int T, int H, int W, int C, size_t pool_pairs)
 	// instead of three -- indices, vertices, record)
 	L.edge_fin = take(sizeof(EdgeFin) * 3 * (size_t)T);
 	L.edge_snap = take(SNAP_BYTES * SNAP_CAP);
-	// Early finalize (see finalize_early in dr_finalize.h): tri_stamp[k] == fwd_id when triangle k is listed in a tile that holds
-	// silhouette edges, i.e. when the adjoint's edge-tile kernel may still add to its accumulators (stamped by the forward raster);
-	// late_list = those of them that take part in the adjoint, compacted for the final finalize_kernel
-	L.tri_stamp = take(sizeof(uint32_t) * (size_t)T);
-	L.late_list = take(sizeof(uint4) * (size_t)T); // {triangle, its three vertex indices}: the late finalize starts after ONE round trip
 	L.view_bytes = o;
 	return L;
 }
@@ -187,7 +178,7 @@ struct KParams
 	// Background fill of a fit step (see fill_word): 0 = by fill_kernel on the side stream; otherwise by extra workgroups of the
 	// adjoint's kernels -- bit 0: raster_bwd_edge_kernel takes part, bit 1: finalize_kernel does (both: even / odd bitmap words)
 	int fill_mode;
-	int early_fin;	 // the adjoint's edge-tile kernel also finalizes the triangles no edge tile lists (finalize_early); finalize_kernel the others
+	int fuse_edges;	 // fit step: the forward raster also runs the adjoint of the tiles that hold silhouette edges (no edge-tile kernel)
 	int clear_grads; // the set-up kernel zeroes the per-view gradient arrays (a fit step that wants fresh gradients: no separate fills)
 	// workspace
 	char *ws;
@@ -211,8 +202,6 @@ struct ViewPtrs
 	WorkEntry *work_list;
 	uint32_t *edge_tile_cnt, *edge_tiles; // tiles with silhouette edges: EDGE_LISTS (+ 1) counters, EDGE_LISTS lists of ntiles entries
 	EdgeFin *edge_fin;
-	uint32_t *tri_stamp;
-	uint4 *late_list;
 };
 
 __device__ __forceinline__ ViewPtrs view_ptrs(const KParams &p, int view)
@@ -241,8 +230,6 @@ __device__ __forceinline__ ViewPtrs view_ptrs(const KParams &p, int view)
 	v.work_list = (WorkEntry *)(b + p.L.work_list);
 	v.edge_slot = (uint32_t *)(b + p.L.edge_slot);
 	v.edge_fin = (EdgeFin *)(b + p.L.edge_fin);
-	v.tri_stamp = (uint32_t *)(b + p.L.tri_stamp);
-	v.late_list = (uint4 *)(b + p.L.late_list);
 	v.edge_sweep = b + p.L.edge_sweep;
 	v.edge_snap = b + p.L.edge_snap;
 	return v;
