@@ -386,6 +386,11 @@ __device__ __forceinline__ void fill_background_tile(const KParams &p, int view,
 #define DR_WORK_CHUNK 64
 #endif
 constexpr int SCAN_BLOCK = 256, WORK_CHUNK = DR_WORK_CHUNK;
+#ifndef DR_PAIR_TILES
+#define DR_PAIR_TILES 1 // (measurement builds: 0 = one tile per wavefront everywhere, as in round 2)
+#endif
+constexpr uint32_t PAIR_FLAG = 0x80000000u; // in WorkEntry::tile of a pair of tiles (fwd_pair_tiles); then WorkEntry::ntri = nA | nB << 16
+static_assert(FIRST_PRIMS <= 8, "a paired tile carries at most eight triangle ids (two 16-byte pieces of its inline list)");
 // One tile workgroup in `heavy_share` walks the list of the many-primitive tiles (the head of the grid: dispatched first).  One in
 // eight, unless the head of all views together would then take more than ~40 % of the chip's wave slots (5 120 at five waves per
 // SIMD): with every slot of the first dispatch round on a 25 - 50 us tile the short tiles -- whose arithmetic hides those tiles'
@@ -452,9 +457,23 @@ __global__ __launch_bounds__(SCAN_BLOCK) void tile_scan_kernel(KParams p)
 	const bool heavy = work && p.tile_blocks % (8 * WORK_CHUNK) == 0 &&
 					   (ntri > (uint32_t)FIRST_PRIMS || nedge > (uint32_t)(p.fuse_edges ? 0 : FIRST_PRIMS));
 	const int elist = nedge == 0 ? -1 : (nedge <= (uint32_t)PRIO_EDGES ? 0 : (nedge <= (uint32_t)TB ? 1 : 2));
+	// Pairs for fwd_pair_tiles (fit step, untextured scene, even number of tile columns so that the left tile of a pair is an even
+	// lane and its right neighbour the next lane): tiles (2 i, 2 i + 1) of a tile row, both with triangles, neither with an edge nor
+	// in the head of the list, at most ENTRY_IDS triangles together.  The left tile's thread lists the pair, the right one's only
+	// adds its triangle ids to that entry.
+	bool pair_left = false, pair_right = false;
+	uint32_t ntri_right = 0;
+	if (DR_PAIR_TILES && p.fuse_edges && !p.texture && (p.L.tiles_x & 1) == 0 && p.tile_blocks % (8 * WORK_CHUNK) == 0)
+	{
+		const bool plain = work && !heavy && nedge == 0 && ntri > 0;
+		const uint32_t n_next = (uint32_t)__shfl_down((int)(plain ? ntri : 0u), 1, 64), n_prev = (uint32_t)__shfl_up((int)(plain ? ntri : 0u), 1, 64);
+		pair_left = plain && !(lane & 1) && n_next > 0 && ntri + n_next <= (uint32_t)ENTRY_IDS;
+		pair_right = plain && (lane & 1) && n_prev > 0 && ntri + n_prev <= (uint32_t)ENTRY_IDS;
+		ntri_right = n_next;
+	}
 	unsigned long long m[NCLS];
 	m[0] = __ballot(heavy);
-	m[1] = wm & ~m[0];
+	m[1] = wm & ~m[0] & ~__ballot(pair_right);
 #pragma unroll
 	for (int c = 0; c < EDGE_LISTS; c++)
 		m[2 + c] = __ballot(elist == c);
@@ -498,9 +517,31 @@ __global__ __launch_bounds__(SCAN_BLOCK) void tile_scan_kernel(KParams p)
 	}
 	if (valid)
 		w.edge_saved[tile] = nedge | (sweep_slot ? SWEEP_SAVED : 0u);
-	if (work)
+	// (every lane takes part in the exchange: the right tile of a pair needs the position of the left tile's entry)
+	const uint32_t my_pos = (work && !heavy && !pair_right) ? (uint32_t)p.L.ntiles - 1u - position(1, m[1]) : 0u;
+	const uint32_t left_pos = (uint32_t)__shfl_up((int)my_pos, 1, 64), left_ntri = (uint32_t)__shfl_up((int)ntri, 1, 64);
+	if (pair_right)
+	{ // this tile's ids behind the left tile's, in the left tile's entry
+		uint32_t *ids = w.work_list[left_pos].ids + left_ntri;
+		const uint32_t mine[8] = {ida.x, ida.y, ida.z, ida.w, idb.x, idb.y, idb.z, idb.w};
+#pragma unroll
+		for (int j = 0; j < 8; j++) // (a paired tile is not in the head: at most FIRST_PRIMS = 8 triangles)
+			if ((uint32_t)j < ntri)
+				ids[j] = mine[j];
+	}
+	else if (pair_left)
 	{
-		WorkEntry &e = heavy ? w.work_list[position(0, m[0])] : w.work_list[(uint32_t)p.L.ntiles - 1u - position(1, m[1])];
+		WorkEntry &e = w.work_list[my_pos];
+		((uint4 *)&e)[0] = make_uint4((uint32_t)tile | PAIR_FLAG, ntri | (ntri_right << 16), 0u, 0u);
+		const uint32_t mine[8] = {ida.x, ida.y, ida.z, ida.w, idb.x, idb.y, idb.z, idb.w};
+#pragma unroll
+		for (int j = 0; j < 8; j++)
+			if ((uint32_t)j < ntri)
+				e.ids[j] = mine[j];
+	}
+	else if (work)
+	{
+		WorkEntry &e = heavy ? w.work_list[position(0, m[0])] : w.work_list[my_pos];
 		uint4 *out = (uint4 *)&e;
 		out[0] = make_uint4((uint32_t)tile, ntri, nedge, sweep_slot);
 		out[1] = ida;
@@ -805,6 +846,189 @@ __host__ __device__ inline int fwd_tile_blocks(int ntiles)
 #ifndef DR_FWD_WAVES
 #define DR_FWD_WAVES (TEX ? 4 : 5)
 #endif
+// Two horizontally adjacent tiles in one wavefront, two pixels per lane (lane = row * 8 + column: pixel `column` of the left tile A
+// and pixel `column` of the right tile B).  For the pairs the scan kernel forms -- both tiles non-empty, no silhouette edge, at
+// most ENTRY_IDS triangles together, untextured scene, fit step -- the per-TILE costs of the walker are paid once for 128 pixels:
+// the work entry and the batched gather of records and planes (one memory round trip), the scanline spans (lane = slot * 8 + row:
+// twelve slots still fit the two passes a single tile makes) and the exchange of the column masks.  tools/fwd_trace.py: of the
+// 12.8 k cycles of a tile without edges 1.5 k are the prologue, 2.6 k the staging, 2.3 k the spans; 84 % of those tiles of the
+// benchmark scene pair up.  A slot belongs to ONE of the two tiles (slots 0 .. nA - 1 to A, the others to B: binning is exact, a
+// triangle listed only in A covers no pixel of B; a triangle listed in both has two slots), so coverage, depth test -- min (Z,
+// index) per pixel -- and therefore every result are those of the two tiles walked one after the other.
+template <class PixT>
+__device__ __forceinline__ void fwd_pair_tiles(const KParams &p, const ViewPtrs &w, WaveLds &S, int view, int lane, int tile, int nA, int nB, uint32_t my_id)
+{
+	const int W = p.W, H = p.H, C = p.C, P = p.L.P;
+	const bool strict = p.strict;
+	const int tx = tile % p.L.tiles_x, ty = tile / p.L.tiles_x;
+	const int x0 = tx * TILE, y0 = ty * TILE;
+	const int lx = lane & 7, row = lane >> 3;
+	const int py = y0 + row, pxA = x0 + lx, pxB = x0 + TILE + lx;
+	const bool inbA = pxA < W && py < H, inbB = pxB < W && py < H;
+	const size_t pixA = (size_t)py * W + pxA, pixB = pixA + TILE;
+	const size_t vbase = (size_t)view * H * W;
+	const double y = py, xA = pxA, xB = pxB;
+	const int nb = nA + nB;
+	// observation of both pixels: requested now, used after the depth test
+	PixT obA[CH] = {0, 0, 0, 0}, obB[CH] = {0, 0, 0, 0};
+	if (inbA)
+	{
+		const PixT *o = (const PixT *)p.obs + (vbase + pixA) * C;
+#pragma unroll
+		for (int cc = 0; cc < CH; cc++)
+			if (cc < C)
+				obA[cc] = o[cc];
+	}
+	if (inbB)
+	{
+		const PixT *o = (const PixT *)p.obs + (vbase + pixB) * C;
+#pragma unroll
+		for (int cc = 0; cc < CH; cc++)
+			if (cc < C)
+				obB[cc] = o[cc];
+	}
+	if (lane < nb)
+		S.ids[lane] = my_id;
+	lds_sync();
+	stage_batch(S, w.tri_rec, w.tri_planes, P, nb, lane);
+	lds_sync();
+	// spans: lane = slot * 8 + row, against the columns of the slot's own tile
+#pragma unroll
+	for (int q = 0; q < TB / 8; q++)
+	{
+		const int j = q * 8 + (lane >> 3), r = lane & 7;
+		uint32_t m = 0;
+		if (j < nb)
+		{
+			const TriRec &rec = S.rec[j];
+			if (rec.kind != KIND_NONE)
+			{
+				const int yy = y0 + r, xs = j < nA ? x0 : x0 + TILE;
+				const bool in0 = yy >= rec.y_begin[0] && yy <= rec.y_end[0], in1 = yy >= rec.y_begin[1] && yy <= rec.y_end[1];
+				int xb, xe;
+				tri_half_span(rec, in0 ? 0 : 1, yy, W, H, strict, xb, xe);
+				m = column_mask(xb, xe, xs);
+				if (__ballot(in0 && in1))
+				{
+					if (in0 && in1)
+					{ // (only the non-strict fill rule puts the middle-vertex row in both halves)
+						tri_half_span(rec, 1, yy, W, H, strict, xb, xe);
+						m |= column_mask(xb, xe, xs);
+					}
+				}
+			}
+		}
+		S.cover[r][j] = (uint8_t)m;
+	}
+	lds_sync();
+	const uint32_t cov = gather_column_bits(&S.cover[row][0], lx) & ((1u << nb) - 1u), maskA = (1u << nA) - 1u;
+	uint32_t todoA = inbA ? cov & maskA : 0u, todoB = inbB ? cov & ~maskA : 0u;
+	// depth test: each lane walks the triangles that cover its two pixels; winner = min (Z, index) (H.h:961 in index order)
+	double zA = INFINITY, zB = INFINITY;
+	int kA = -1, kB = -1, jA = -1, jB = -1;
+	while (__ballot((todoA | todoB) != 0))
+	{
+		{
+			const bool act = todoA != 0;
+			const int j = act ? __ffs((int)todoA) - 1 : 0;
+			todoA &= todoA - 1;
+			const double Z = plane_at(S.rec[j].xZ, xA, y);
+			const int k = (int)S.ids[j];
+			if (act && (Z < zA || (Z == zA && k < kA)))
+				zA = Z, kA = k, jA = j;
+		}
+		{
+			const bool act = todoB != 0;
+			const int j = act ? __ffs((int)todoB) - 1 : nA;
+			todoB &= todoB - 1;
+			const double Z = plane_at(S.rec[j].xZ, xB, y);
+			const int k = (int)S.ids[j];
+			if (act && (Z < zB || (Z == zB && k < kB)))
+				zB = Z, kB = k, jB = j;
+		}
+	}
+	// colours (no texture in a scene whose tiles are paired; perspective_correct excludes the adjoint, hence a fit step)
+	double colA[CH] = {0, 0, 0, 0}, colB[CH] = {0, 0, 0, 0};
+	int kindA = KIND_NONE, kindB = KIND_NONE;
+	if (jA >= 0)
+	{
+		kindA = S.rec[jA].kind;
+		const double *pl = &S.planes[jA * 12];
+#pragma unroll
+		for (int cc = 0; cc < CH; cc++)
+			if (cc < C)
+				colA[cc] = interp_channel(pl, cc, xA, y, false, 0.0);
+	}
+	else if (inbA)
+	{
+#pragma unroll
+		for (int cc = 0; cc < CH; cc++)
+			if (cc < C)
+				colA[cc] = background_channel<PixT>(p, view, pixA, cc);
+	}
+	if (jB >= 0)
+	{
+		kindB = S.rec[jB].kind;
+		const double *pl = &S.planes[jB * 12];
+#pragma unroll
+		for (int cc = 0; cc < CH; cc++)
+			if (cc < C)
+				colB[cc] = interp_channel(pl, cc, xB, y, false, 0.0);
+	}
+	else if (inbB)
+	{
+#pragma unroll
+		for (int cc = 0; cc < CH; cc++)
+			if (cc < C)
+				colB[cc] = background_channel<PixT>(p, view, pixB, cc);
+	}
+	// one write per pixel (streaming stores)
+	auto store_pixel = [&](bool inb, size_t pix, const double *col, double z) {
+		if (!inb)
+			return;
+		if (p.image)
+		{
+			PixT *out = (PixT *)p.image + (vbase + pix) * C;
+			if (C == 4)
+			{
+				typedef PixT V4 __attribute__((ext_vector_type(4)));
+				const V4 v = {(PixT)col[0], (PixT)col[1], (PixT)col[2], (PixT)col[3]};
+				__builtin_nontemporal_store(v, (V4 *)out);
+			}
+			else
+			{
+#pragma unroll
+				for (int cc = 0; cc < CH; cc++)
+					if (cc < C)
+						__builtin_nontemporal_store((PixT)col[cc], out + cc);
+			}
+		}
+		if (p.zbuf)
+			__builtin_nontemporal_store((PixT)z, (PixT *)p.zbuf + vbase + pix);
+	};
+	store_pixel(inbA, pixA, colA, zA);
+	store_pixel(inbB, pixB, colB, zB);
+	// adjoint of pass 1 for L = sum (image - obs)^2: the colour is rounded to the pixel type first, like the stored frame
+	Tap no_tap;
+	double g[CH];
+	if (__ballot(kA >= 0) != 0)
+	{
+#pragma unroll
+		for (int cc = 0; cc < CH; cc++)
+			g[cc] = (cc < C && inbA) ? 2 * ((double)(PixT)colA[cc] - (double)obA[cc]) : 0.0;
+		lds_sync();
+		owner_adjoint<PixT, false>(p, w, lane, xA, y, kA, kindA, g, no_tap, 0.0, (double *)&S.rec[0], (uint32_t *)&S.cover[0][0]);
+	}
+	if (__ballot(kB >= 0) != 0)
+	{
+#pragma unroll
+		for (int cc = 0; cc < CH; cc++)
+			g[cc] = (cc < C && inbB) ? 2 * ((double)(PixT)colB[cc] - (double)obB[cc]) : 0.0;
+		lds_sync();
+		owner_adjoint<PixT, false>(p, w, lane, xB, y, kB, kindB, g, no_tap, 0.0, (double *)&S.rec[0], (uint32_t *)&S.cover[0][0]);
+	}
+}
+
 // Code-generation modes of the tile walker.  A fit step (FUSED) back-propagates EVERY tile in the forward launch: the scan kernel puts
 // the tiles that hold silhouette edges at the head of the work list, and the workgroups that walk the head run the instance that
 // can do their adjoint too (FWD_EDGE_ADJ: reverse sweep over the tile's edges, then pass 1) while all the other workgroups run an
@@ -872,6 +1096,13 @@ __device__ __forceinline__ void fwd_tiles(const KParams &p, WaveLds *s_lds, Edge
 		asm volatile("" : "+v"(lane));
 		const WorkEntry &entry = w.work_list[heavy_list ? rank : (uint32_t)p.L.ntiles - 1u - rank];
 		const uint32_t ids12 = entry.ids[lane < ENTRY_IDS ? lane : 0];
+		if (FUSED && !TEX && MODE == FWD_NO_EDGES && ((uint32_t)uniform((int)entry.tile) & PAIR_FLAG))
+		{ // two adjacent tiles, two pixels per lane (the scan kernel pairs them up: fwd_pair_tiles)
+			const uint32_t nn = (uint32_t)uniform((int)entry.ntri);
+			fwd_pair_tiles<PixT>(p, w, S, view, lane, (int)((uint32_t)uniform((int)entry.tile) & ~PAIR_FLAG), (int)(nn & 0xffffu), (int)(nn >> 16), ids12);
+			lds_sync();
+			continue;
+		}
 		const int tile = uniform((int)entry.tile), ntri = uniform((int)entry.ntri), nedge = MODE == FWD_NO_EDGES ? 0 : uniform((int)entry.nedge);
 		const uint32_t sweep_slot = (uint32_t)uniform((int)entry.sweep_slot);
 		const int tx = tile % p.L.tiles_x, ty = tile / p.L.tiles_x;

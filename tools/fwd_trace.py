@@ -44,3 +44,19 @@ for lo, hi in [(1, 4), (5, 8), (9, 16), (17, 32), (33, 1000)]:
     m = sel & (ntri >= lo) & (ntri <= hi)
     if m.any():
         print("ntri %3d-%3d: %6d tiles, pass 1 mean %7.0f, whole tile mean %7.0f" % (lo, hi, m.sum(), d[m, 1].mean(), t[m, 4].mean()))
+# tiles with silhouette edges (a fit step runs their adjoint in the same wavefront): whole-tile cycles by size, and the longest
+e = nedge > 0
+if e.any():
+    whole, fwd = t[:, 4], t[:, 3]
+    print("tiles with edges: whole tile cycles mean %7.0f p50 %7.0f p90 %7.0f max %7.0f;  up to the frame stores mean %7.0f  (adjoint: the difference)" % (
+        whole[e].mean(), *np.percentile(whole[e], [50, 90]), whole[e].max(), fwd[e].mean()))
+    for lo, hi in [(1, 2), (3, 8), (9, 16), (17, 1000)]:
+        m = e & (nedge >= lo) & (nedge <= hi)
+        if m.any():
+            print("nedge %3d-%3d: %6d tiles, ntri mean %5.1f, forward part mean %7.0f, adjoint part mean %7.0f, whole max %7.0f" % (
+                lo, hi, m.sum(), ntri[m].mean(), fwd[m].mean(), (whole - fwd)[m].mean(), whole[m].max()))
+    top = np.argsort(-whole)[:12]
+    print("longest tiles (ntri, nedge, forward part, whole):", [(int(ntri[i]), int(nedge[i]), int(fwd[i]), int(whole[i])) for i in top])
+    d2 = np.diff(np.concatenate([np.zeros((len(t), 1), np.int64), t], 1), axis=1)
+    for i in top[:4]:
+        print("   phases of (%d tri, %d edges):" % (ntri[i], nedge[i]), d2[i].tolist())
