@@ -12,13 +12,18 @@ multi-view fitter does on the host at deodr/mesh_fitter.py:518-527).  Views shar
 collective, per-GPU work is fixed as N grows ("weak").
 
 The JSON line carries, besides the driver's contract:
-  roofline      dominant kernel group (largest summed hipEvent time; "raster_fwd_kernel" = tile scan + forward raster,
-                "raster_bwd_kernel" = edge tiles + half of the background fill, "finalize_kernel" = finalize + the other half):
-                achieved = SURVEY.md 8d bytes of the pixels that group processes (float32 buffers) / its average duration,
-                measured with hipEvents on the launch stream inside the timed region; `frac_whole_frame_charge` = round 1's
-                accounting (every frame byte of the step charged to the forward raster); `whole_step` = all of SURVEY 8d's
-                bytes / the step time -- the number the north star's 40 % is about
+  roofline      dominant kernel group (largest summed hipEvent time; "raster_fwd_kernel" = tile scan + forward raster -- which in a
+                fit step also back-propagates every tile and streams two thirds of the background fill --, "finalize_kernel" =
+                finalize + the last third of the fill): achieved = SURVEY.md 8d bytes that group moves (float32 buffers) / its
+                average duration, measured with hipEvents on the launch stream inside the timed region; `peak` = 8 TB/s (spec),
+                `peak_measured` / `frac_of_measured` = against the copy ceiling of THIS box (hbm_probe); `whole_step` = all of
+                SURVEY 8d's bytes / the step time (the number the north star's 40 % is about) and `frac_moved_bytes` = only the
+                bytes somebody actually moves
+  parity        views 0 and last of the TIMED launch compared with oracle/_ref after the timed region (image 1e-5, gradients
+                1e-4 of the largest reference entry): the number belongs to a correct result
+  hbm_probe     device-to-device copy / write-only / read-only bandwidth of this box (1 GiB buffers)
   single_view   the same fit step for ONE view (latency case): eager and replayed from a captured HIP graph
+  other_configs fit-step time of BASELINE configs[1], [3], [4] (outside the timed headline; skipped with --no-other-configs)
   cpu_baseline  the reference's own CPU path (oracle/_ref = unmodified header, g++ -O2) on the host of the GPU box: one
                 thread, and one process per view on min(views, cores) cores; bounded samples (rank 0, N = 1 only)
 """
@@ -40,29 +45,116 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/
 KERNELS = ["setup_bin_kernel", "raster_fwd_kernel", "raster_bwd_kernel", "finalize_kernel"]
 
 
+FILL_W_FIN, FILL_W_FWD = 1, 2  # background fill of a fit step: words dealt finalize : forward raster (dr_forward.h DR_FILL_W_*)
+
+
 def algorithmic_bytes(H, W, C, T, V, n_views, fused, nonempty_frac=None):
     """Per LAUNCH algorithmic HBM bytes of each kernel group, float32 buffers (untextured, colour background).
 
     B_fwd = 4 [H W (C+1) + V (2+1+C) + 3T]      B_bwd = 4 [H W C + H W + V (2+1+C) + 3T + V (2+C)]
     split by the kernel that moves them.  Two-call path: forward raster = frame term of B_fwd, adjoint raster = frame term of
-    B_bwd.  Fused fit step: the forward raster does both frame terms for the pixels of the NON-EMPTY tiles (it writes image + z
-    and reads the observation where the two-pass adjoint reads image_b; `nonempty_frac` = their share of the frame, counted from
-    the tile bitmap of the run); the image + z of the empty tiles (background, depth = inf) are streamed by the fill shares of the
-    edge-tile and finalize kernels, half each; the adjoint's frame term of the empty tiles is moved by nobody (no owner: nothing
-    to back-propagate) and is reported as `not_moved`.  With nonempty_frac=None every frame byte of the fit step is charged to
-    the forward raster (round 1's accounting)."""
+    B_bwd.  Fit step: the forward raster does both frame terms for the pixels of the NON-EMPTY tiles (it writes image + z and
+    reads the observation where the two-pass adjoint reads image_b; `nonempty_frac` = their share of the frame, counted from the
+    tile bitmap of the run) and back-propagates them, tiles with silhouette edges included; the image + z of the empty tiles
+    (background, depth = inf) are streamed by extra workgroups of the forward raster (2/3) and of finalize (1/3); the adjoint's
+    frame term of the empty tiles is moved by nobody (no owner: nothing to back-propagate) and is reported as `not_moved`."""
     px = H * W
     frame = 4 * px * (C + 1)
     setup, fin = 4 * (V * (3 + C) + 3 * T), 4 * (V * (3 + C) + 3 * T + V * (2 + C))
     if not fused:
         per_view = {"setup_bin_kernel": setup, "raster_fwd_kernel": frame, "raster_bwd_kernel": frame, "finalize_kernel": fin}
-    elif nonempty_frac is None:
-        per_view = {"setup_bin_kernel": setup, "raster_fwd_kernel": 2 * frame, "raster_bwd_kernel": 0, "finalize_kernel": fin}
     else:
-        f = nonempty_frac
-        per_view = {"setup_bin_kernel": setup, "raster_fwd_kernel": 2 * frame * f, "raster_bwd_kernel": 0.5 * frame * (1 - f),
-                    "finalize_kernel": fin + 0.5 * frame * (1 - f), "not_moved": frame * (1 - f)}  # fmt: skip
+        f = 1.0 if nonempty_frac is None else nonempty_frac
+        wf, wn = FILL_W_FWD / (FILL_W_FWD + FILL_W_FIN), FILL_W_FIN / (FILL_W_FWD + FILL_W_FIN)
+        per_view = {"setup_bin_kernel": setup, "raster_fwd_kernel": 2 * frame * f + wf * frame * (1 - f), "raster_bwd_kernel": 0,
+                    "finalize_kernel": fin + wn * frame * (1 - f), "not_moved": frame * (1 - f)}  # fmt: skip
     return {k: v * n_views for k, v in per_view.items()}
+
+
+def hbm_probe(dev, nbytes=1 << 30, reps=10):
+    """Copy / write-only / read-only bandwidth of this box (GB/s): the ceilings SURVEY.md section 8d asks to report next to the
+    8 TB/s of the data sheet.  torch device kernels on 1 GiB buffers, hipEvent timing, best of `reps`."""
+    a = torch.empty(nbytes // 4, dtype=torch.float32, device=dev).normal_()
+    b = torch.empty_like(a)
+    out = {}
+    for name, fn, moved in (("copy", lambda: b.copy_(a), 2 * nbytes), ("write", lambda: b.fill_(1.0), nbytes), ("read", lambda: a.sum(), nbytes)):
+        fn()
+        best = 1e9
+        for _ in range(reps):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            fn()
+            e1.record()
+            e1.synchronize()
+            best = min(best, e0.elapsed_time(e1) * 1e-3)
+        out[name + "_GBps"] = moved / best / 1e9
+    del a, b
+    return out
+
+
+def parity_check(views, which, image, z, grads, obs):
+    """Views `which` of the timed launch against oracle/_ref (the reference's own code): max |image - ref|, gradients relative to the
+    largest reference entry -- the tolerances of the north star (1e-5 / 1e-4, float32 pixel buffers)."""
+    from oracle import api
+
+    ref = api.ref() or api.port()
+    out = {"checker": "oracle/_ref (unmodified reference header)" if api.ref() is not None else "oracle/deodr_oracle.c", "views": list(which)}
+    worst = {"image": 0.0, "z": 0.0, "ij_b": 0.0, "colors_b": 0.0}
+    for i in which:
+        s = views[i]
+        im_ref, z_ref = ref.render(s, 1.0)
+        im = image[i].cpu().numpy().astype(np.float64)
+        zz = z[i].cpu().numpy().astype(np.float64)
+        g_ref = ref.grads(s, 1.0, im_ref, z_ref, 2 * (im - obs[i].cpu().numpy().astype(np.float64)))
+        fin = np.isfinite(z_ref)
+        worst["image"] = max(worst["image"], float(np.abs(im - im_ref).max()))
+        worst["z"] = max(worst["z"], float(np.abs(zz[fin] - z_ref[fin]).max()) if fin.any() else 0.0, float((np.isfinite(zz) != fin).sum()))
+        for k in ("ij_b", "colors_b"):
+            r = g_ref[k]
+            worst[k] = max(worst[k], float(np.abs(grads[k][i].cpu().numpy() - r).max() / max(np.abs(r).max(), 1e-30)))
+    out.update({"max_abs_err_image": worst["image"], "max_abs_err_z": worst["z"], "rel_err_ij_b": worst["ij_b"], "rel_err_colors_b": worst["colors_b"],
+                "tolerances": {"image": 1e-5, "gradients": 1e-4}})  # fmt: skip
+    out["ok"] = bool(worst["image"] < 1e-5 and worst["z"] < 1e-3 and worst["ij_b"] < 1e-4 and worst["colors_b"] < 1e-4)
+    return out
+
+
+def other_configs(dev):
+    """Fit-step time of the other BASELINE configurations (same code path: deodr_hip_render_scene_fit, float32 pixel buffers)."""
+    from deodr_amd import scenes
+    from deodr_amd.hip_renderer import DeviceScene, HipRasterizer
+
+    gold = os.path.join(ROOT, "tests", "golden", "hand_mesh.npz")
+    big = dict(size=2048, nu=224, n_rings=224, nb_colors=3, textured=True, texture_size=1024)
+    cases = [
+        ("configs[1] 1024^2 hand mesh textured, 1 view", lambda: [scenes.hand_scene(gold, size=1024, angle=0.2, textured=True)], 30),
+        ("configs[3] 1024^2 hand mesh, 8 views", lambda: [scenes.hand_scene(gold, size=1024, angle=float(a), textured=False) for a in np.linspace(-0.5, 0.5, 8)], 30),
+        ("configs[4] 2048^2 100k-triangle shape, 1024^2 texture, 8 views", lambda: [scenes.sphere_scene(angle=float(a), **big) for a in np.linspace(-0.5, 0.5, 8)], 10),
+    ]  # fmt: skip
+    out = []
+    for name, make, steps in cases:
+        views = make()
+        s0 = views[0]
+        stack = lambda n: np.stack([np.asarray(getattr(v, n)) for v in views])
+        ds = DeviceScene(
+            s0.faces, s0.faces_uv, s0.textured, s0.shaded, s0.uv, stack("ij"), stack("depths"), stack("colors"), stack("shade"), stack("edgeflags"),
+            s0.height, s0.width, texture=s0.texture if np.size(s0.texture) else None, background_color=s0.background_color,
+            background_image=None if s0.background_image is None else stack("background_image"), clockwise=s0.clockwise,
+            vertex_dtype=torch.float64, pixel_dtype=torch.float32, device=dev,
+        )  # fmt: skip
+        r = HipRasterizer.for_scene(ds)
+        n, H, W, Cc = ds.n_views, ds.height, ds.width, ds.nb_colors
+        obs = torch.rand((n, H, W, Cc), dtype=torch.float32, device=dev)
+        image = torch.empty((n, H, W, Cc), dtype=torch.float32, device=dev)
+        z = torch.empty((n, H, W), dtype=torch.float32, device=dev)
+        grads = ds.zero_grads()
+        fit = lambda: r.render_fit(ds, obs, 1.0, grads=grads, out=(image, z), check_overflow=False, clear_grads=True)
+        r.render(ds, 1.0, out=(image, z), check_overflow=True)
+        for _ in range(5):
+            fit()
+        dt = timed_steps(fit, steps)
+        out.append({"config": name, "views": n, "ms_per_step": dt * 1e3, "Mpixels_s": n * H * W / dt / 1e6})
+        del ds, r, obs, image, z, grads
+    return out
 
 
 def cpu_model():
@@ -196,6 +288,8 @@ def main():
     ap.add_argument("--sigma", type=float, default=1.0, help="edge-overdraw width (the metric configuration uses 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-single-view", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true")
+    ap.add_argument("--no-parity-check", action="store_true")
     ap.add_argument("--time-every", type=int, default=20, help="steps between two steps whose kernels are timed with hipEvents (0: never)")
     ap.add_argument("--two-pass", action="store_true", help="render and render_backward as two calls (default: the fused fit step, same outputs)")
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed even for one rank (exercises the RCCL path)")
@@ -372,7 +466,7 @@ def main():
             print(f"bench: tile census unavailable ({e!r})", file=sys.stderr)
         fused = not args.two_pass
         ntiles = B * ((S + 7) // 8) ** 2
-        alg_8d = algorithmic_bytes(S, S, Cc, T, V, B, fused)  # SURVEY 8d, every frame byte of a fit step charged to the forward raster
+        alg_8d = algorithmic_bytes(S, S, Cc, T, V, B, fused)  # every frame byte of the step
         alg = algorithmic_bytes(S, S, Cc, T, V, B, fused, nonempty / ntiles if (fused and nonempty is not None) else None)
         per_kernel = {}
         for i, k in enumerate(KERNELS):
@@ -387,8 +481,10 @@ def main():
             traffic = (json.load(open(tpath)).get(dom) or {}).get("bytes_per_launch")
         kernel_ms = sum(v["avg_ms"] for v in per_kernel.values())
         step_s = dt / args.steps
-        dom_ms = per_kernel[dom]["avg_ms"]
-        whole = sum(alg_8d.values())
+        whole = sum(v for k, v in alg_8d.items() if k != "not_moved")
+        moved = sum(v for k, v in alg.items() if k != "not_moved")
+        probe = hbm_probe(dev)
+        peak_meas = probe["copy_GBps"]
         out = {
             "metric": "Mpixels/s forward+backward, 1024^2 20k-tri scene", "value": px / dt / 1e6, "unit": "Mpixels/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": step_s * 1e3,
@@ -399,18 +495,28 @@ def main():
                        "views_per_gpu": B, "global_views": B * world, "env_overrides": overrides,
                        "nonempty_tiles": nonempty, "edge_tiles": edge_tiles, "tiles": ntiles,
                        "parallelism": f"views sharded {B}/GPU" + (", 1 RCCL all-reduce of the shared gradient per step" if world > 1 else "")},
-            # dominant kernel group (largest hipEvent time).  achieved / frac: the SURVEY 8d bytes of the pixels THIS group processes
-            # (fit step: both frame terms of the non-empty tiles) / its average duration.  frac_whole_frame_charge: round 1's
-            # accounting -- every frame byte of the step charged to it -- kept for comparison, although the background of the empty
-            # tiles is now written by the fill shares of the edge-tile and finalize kernels.  whole_step: all of SURVEY 8d's
-            # bytes / the step time -- the number the north star's 40 % is about.
+            # dominant kernel group (largest hipEvent time).  achieved / frac: the SURVEY 8d bytes THIS group moves / its average
+            # duration, against the 8 TB/s of the data sheet; frac_of_measured: against the copy bandwidth measured on this box.
+            # whole_step: all of SURVEY 8d's bytes / the step time (the north star's 40 % is about this number); frac_moved_bytes:
+            # only the bytes somebody moves (the adjoint's frame term of the empty tiles is moved by nobody).
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": per_kernel[dom]["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": (per_kernel[dom]["GBps"] or 0) / HBM_PEAK_GBS, "traffic": traffic,
-                         "frac_whole_frame_charge": alg_8d[dom] / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if dom_ms > 0 else None,
-                         "whole_step": {"alg_bytes": whole, "GBps": whole / step_s / 1e9, "frac": whole / step_s / 1e9 / HBM_PEAK_GBS},
+                         "peak_measured": peak_meas, "frac_of_measured": (per_kernel[dom]["GBps"] or 0) / peak_meas,
+                         "whole_step": {"alg_bytes": whole, "GBps": whole / step_s / 1e9, "frac": whole / step_s / 1e9 / HBM_PEAK_GBS,
+                                        "frac_of_measured": whole / step_s / 1e9 / peak_meas, "moved_bytes": moved,
+                                        "frac_moved_bytes": moved / step_s / 1e9 / HBM_PEAK_GBS},
                          "not_moved_bytes": alg.get("not_moved"),
                          "kernel_time_fraction_of_step": kernel_ms / (step_s * 1e3), "per_kernel": per_kernel},
+            "hbm_probe": probe,
         }  # fmt: skip
+        if not args.no_parity_check:
+            # the launch that was timed (its last step's outputs are still in image / z / the gradient set it wrote), views 0 and last
+            last = grads_pp[(it[0] - 1) % len(grads_pp)]
+            out["parity"] = parity_check(views, sorted({0, B - 1}), image, z, last, obs_views)
+            out["parity_checked"] = out["parity"]["ok"]
+            assert out["parity"]["ok"], f"bench: the timed launch does not match the checker: {out['parity']}"
+        if world == 1 and not args.no_other_configs:
+            out["other_configs"] = other_configs(dev)
         if world == 1 and not args.no_single_view:
             out["single_view"] = single_view_latency(scenes, DeviceScene, HipRasterizer, dev, S, args.sigma, obs)
         if world == 1 and not args.no_cpu_baseline:

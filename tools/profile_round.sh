@@ -8,9 +8,9 @@ mkdir -p $OUT
 python bench.py > $OUT/bench.json 2> $OUT/bench.err
 tail -c 600 $OUT/bench.json; echo
 cd /tmp && export TMPDIR=/tmp
-timeout -k 5 240 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o k -- python $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-single-view > $OUT/stats.log 2>&1
-timeout -k 5 240 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch -o p -- python $GRAFT_REPO_ROOT/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-single-view > $OUT/fetch.log 2>&1
-timeout -k 5 240 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/write -o p -- python $GRAFT_REPO_ROOT/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-single-view > $OUT/write.log 2>&1
+timeout -k 5 240 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o k -- python $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-single-view --no-other-configs --no-parity-check > $OUT/stats.log 2>&1
+timeout -k 5 240 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch -o p -- python $GRAFT_REPO_ROOT/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-single-view --no-other-configs --no-parity-check > $OUT/fetch.log 2>&1
+timeout -k 5 240 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/write -o p -- python $GRAFT_REPO_ROOT/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-single-view --no-other-configs --no-parity-check > $OUT/write.log 2>&1
 python - <<PY
 import csv, glob, json, collections
 out = "$OUT"
