@@ -10,10 +10,10 @@ from ..mesh_fitter import (  # noqa: F401
     MeshRGBFitterWithPose,
     MeshRGBFitterWithPoseMultiFrame,
 )
-from ..scene3d import DeviceCamera as CameraPytorch  # noqa: F401  (extrinsic, intrinsic, height, width, distortion=None)
-from ..scene3d import DeviceMesh, LaplacianRigidEnergyDevice
-from ..scene3d import Scene3DDevice as Scene3DPytorch  # noqa: F401
+from ..scene3d import DeviceCamera, DeviceMesh, LaplacianRigidEnergyDevice, Scene3DDevice  # noqa: F401  (the batched classes, n views per call)
 from .differentiable_renderer_pytorch import (  # noqa: F401
+    CameraPytorch,  # one view, the reference's shapes (over DeviceCamera)
+    Scene3DPytorch,  # one view, the reference's shapes (over Scene3DDevice)
     TorchDifferentiableRender2D,
     TorchDifferentiableRenderer2DFunc,
     TorchDifferentiableRenderViews,

@@ -168,3 +168,122 @@ class TorchRenderViewsL2LossFunc(torch.autograd.Function):
 
 def TorchRenderViewsL2Loss(ij, colors, obs, device_scene, rasterizer, sigma=1.0):
     return TorchRenderViewsL2LossFunc.apply(ij, colors, obs, device_scene, rasterizer, sigma)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# single-view classes with the reference's shapes (deodr/pytorch/differentiable_renderer_pytorch.py:13-38, 84-109)
+
+
+class CameraPytorch:
+    """ONE pinhole camera (+ OpenCV distortion) with the signatures and shapes of the reference's ``CameraPytorch``:
+    ``project_points(points_3d [V,3]) -> (ij [V,2], depths [V])``, ``world_to_camera([V,3]) -> [V,3]``.
+
+    A thin view of the batched :class:`deodr_amd.scene3d.DeviceCamera` (kept as ``.batched``): the algebra runs on the ROCm
+    device and the results come back on the device of the input tensor, so that code written for the reference's CPU tensors
+    (deodr/pytorch/mesh_fitter_pytorch.py:106-114, 279-283) runs unchanged."""
+
+    def __init__(self, extrinsic, intrinsic, height, width, distortion=None):
+        self.extrinsic, self.intrinsic = np.asarray(extrinsic, dtype=np.float64), np.asarray(intrinsic, dtype=np.float64)
+        self.height, self.width = int(height), int(width)
+        self.distortion = None if distortion is None else np.asarray(distortion, dtype=np.float64)
+        self._batched = None
+
+    def batched(self, device):
+        from ..scene3d import DeviceCamera
+
+        if self._batched is None or self._batched.device != torch.device(device):
+            self._batched = DeviceCamera(self.extrinsic, self.intrinsic, self.height, self.width, self.distortion, device)
+        return self._batched
+
+    def world_to_camera(self, points_3d):
+        assert isinstance(points_3d, torch.Tensor)
+        dev = _compute_device(points_3d)
+        return self.batched(dev).world_to_camera(points_3d.to(dev))[0].to(points_3d.device)
+
+    def project_points(self, points_3d, return_depths=True):
+        assert isinstance(points_3d, torch.Tensor)
+        dev = _compute_device(points_3d)
+        ij, depths = self.batched(dev).project_points(points_3d.to(dev))
+        ij, depths = ij[0].to(points_3d.device), depths[0].to(points_3d.device)
+        return (ij, depths) if return_depths else ij
+
+    def get_center(self):
+        return -self.extrinsic[:3, :3].T.dot(self.extrinsic[:, 3])
+
+
+def _compute_device(t):
+    """where the work of a call happens: the tensor's own device when it already lives on a ROCm device, the current one otherwise"""
+    return t.device if t.is_cuda else _resolve_device("cuda")
+
+
+class Scene3DPytorch:
+    """ONE view per call with the reference's shapes (``render -> [H,W,C]``, ``render_depth -> [H,W,1]``), over the batched
+    :class:`deodr_amd.scene3d.Scene3DDevice` (kept as ``.batched``).
+
+    ``set_mesh`` takes a :class:`deodr_amd.scene3d.DeviceMesh` or any object with the attributes of the reference's
+    ``ColoredTriMeshPytorch`` (``faces``, ``vertices`` -- a tensor that may require grad --, ``clockwise``, ``vertices_colors``,
+    ``uv`` / ``faces_uv`` / ``texture``): its connectivity is analysed once, its current vertices / colours are picked up at every
+    render, and gradients flow back to them through autograd.  Images come back on the device of ``mesh.vertices`` (the
+    reference's fitters work on CPU tensors and call ``.numpy()`` on the results)."""
+
+    def __init__(self, sigma=1.0, perspective_correct=False, integer_pixel_centers=True):
+        from ..scene3d import Scene3DDevice
+
+        self.batched = Scene3DDevice(sigma=sigma, perspective_correct=perspective_correct, integer_pixel_centers=integer_pixel_centers)
+        self.mesh = None
+        self._dev_mesh = None
+        self.light_directional, self.light_ambient = None, 0.0
+
+    sigma = property(lambda self: self.batched.sigma, lambda self, v: setattr(self.batched, "sigma", float(v)))
+
+    def set_mesh(self, mesh):
+        self.mesh, self._dev_mesh = mesh, None
+
+    def set_light(self, light_directional, light_ambient):
+        self.light_directional, self.light_ambient = light_directional, light_ambient
+
+    def set_background_color(self, background_color):
+        self.batched.set_background_color(background_color)
+
+    def set_background_image(self, background_image):
+        self.batched.set_background_image(background_image)
+
+    def _sync(self):
+        """the device-side twin of ``self.mesh`` with the mesh's CURRENT vertices and colours -> (twin, device of the results)"""
+        from ..scene3d import DeviceMesh
+
+        m = self.mesh
+        assert m is not None, "You need to provide a mesh first."
+        if isinstance(m, DeviceMesh):
+            self.batched.set_mesh(m)
+            return m, m.vertices.device
+        v = m.vertices if torch.is_tensor(m.vertices) else torch.as_tensor(np.asarray(m.vertices, dtype=np.float64))
+        dev = _compute_device(v)
+        if self._dev_mesh is None or self._dev_mesh.device != dev:
+            uv, tex = getattr(m, "uv", None), getattr(m, "texture", None)
+            self._dev_mesh = DeviceMesh(np.asarray(m.faces), v.detach(), clockwise=bool(getattr(m, "clockwise", False)), uv=uv,
+                                        faces_uv=getattr(m, "faces_uv", None) if uv is not None else None, texture=tex, device=dev)  # fmt: skip
+        d = self._dev_mesh
+        d.set_vertices(v.to(device=dev, dtype=d.dtype))  # (differentiable: the gradient returns to m.vertices, wherever it lives)
+        colors = getattr(m, "vertices_colors", None)
+        if colors is not None:
+            c = colors if torch.is_tensor(colors) else torch.as_tensor(np.asarray(colors, dtype=np.float64))
+            d.set_vertices_colors(c.to(device=dev, dtype=d.dtype))
+        self.batched.set_mesh(d)
+        ld = self.light_directional
+        self.batched.light_directional = None if ld is None else (ld if torch.is_tensor(ld) else torch.as_tensor(np.asarray(ld, dtype=np.float64))).to(dev)
+        la = self.light_ambient
+        self.batched.light_ambient = la.to(dev) if torch.is_tensor(la) else la
+        return d, v.device
+
+    def render(self, camera, return_z_buffer=False, backface_culling=True):
+        """-> image [H,W,C] (and z_buffer [H,W]); dr.py:896-983"""
+        d, out_dev = self._sync()
+        image, z = self.batched.render(camera.batched(d.device), return_z_buffer=True, backface_culling=backface_culling)
+        image, z = image[0].to(out_dev), z[0].to(out_dev)
+        return (image, z) if return_z_buffer else image
+
+    def render_depth(self, camera, depth_scale=1.0, backface_culling=True):
+        """-> depth image [H,W,1]: the depth of every vertex rendered as its colour (dr.py:1001-1036)"""
+        d, out_dev = self._sync()
+        return self.batched.render_depth(camera.batched(d.device), depth_scale=depth_scale, backface_culling=backface_culling)[0].to(out_dev)

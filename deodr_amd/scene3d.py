@@ -164,25 +164,30 @@ class LaplacianRigidEnergyDevice:
 
 
 class RenderViewsFunc(torch.autograd.Function):
-    """(ij [n,V,2], colors [n,V,C], shade [n,V]) -> image [n,H,W,C]: the HIP rasterizer with gradients for all three."""
+    """(ij [n,V,2], colors [n,V,C], shade [n,V]) -> image [n,H,W,C]: the HIP rasterizer with gradients for all three.
+
+    ``depths`` [n,V] and ``edgeflags`` [n,T,3] are inputs without gradient (dr.py:1017: the z buffer is not differentiated; the
+    flags select which edges are antialiased).  ALL five per-view arrays are saved: the DeviceScene / workspace are shared by
+    every render of a Scene3DDevice, and when another render has used them since (two cameras, or two vertex sets, in one loss)
+    the adjoint rebuilds this forward's state from its own inputs, not from whatever the scene holds now."""
 
     @staticmethod
-    def forward(ctx, ij, colors, shade, device_scene, rasterizer, sigma):
-        device_scene.set_views(ij=ij.detach(), colors=colors.detach(), shade=shade.detach())
+    def forward(ctx, ij, colors, shade, depths, edgeflags, device_scene, rasterizer, sigma):
+        device_scene.set_views(ij=ij.detach(), colors=colors.detach(), shade=shade.detach(), depths=depths.detach(), edgeflags=edgeflags)
         image, z = rasterizer.render(device_scene, sigma)
         ctx.ds, ctx.r, ctx.sigma, ctx.generation = device_scene, rasterizer, sigma, rasterizer.generation
-        ctx.save_for_backward(ij, colors, shade)
+        ctx.save_for_backward(ij, colors, shade, depths, edgeflags)
         ctx.mark_non_differentiable(z)
         return image, z
 
     @staticmethod
     def backward(ctx, image_b, _z_b):
-        ij, colors, shade = ctx.saved_tensors
+        ij, colors, shade, depths, edgeflags = ctx.saved_tensors
         if ctx.r.generation != ctx.generation:  # another forward used the scene since: restore this one's inputs
-            ctx.ds.set_views(ij=ij.detach(), colors=colors.detach(), shade=shade.detach())
+            ctx.ds.set_views(ij=ij.detach(), colors=colors.detach(), shade=shade.detach(), depths=depths.detach(), edgeflags=edgeflags)
         g = ctx.r.render_backward(ctx.ds, image_b=image_b, generation=ctx.generation, sigma=ctx.sigma)
         ctx.uv_b, ctx.texture_b = g["uv_b"], g["texture_b"]
-        return g["ij_b"].to(ij.dtype), g["colors_b"].to(colors.dtype), g["shade_b"].to(shade.dtype), None, None, None
+        return g["ij_b"].to(ij.dtype), g["colors_b"].to(colors.dtype), g["shade_b"].to(shade.dtype), None, None, None, None, None
 
 
 class DeviceMesh:
@@ -290,9 +295,8 @@ class Scene3DDevice:
         n = camera.n_views
         ds, r = self._rasterizer(n, camera.height, camera.width, int(colors.shape[-1]), textured, backface_culling)
         flags = self.mesh.topology.edge_on_silhouette(ij) if self.sigma > 0 else torch.zeros((n, self.mesh.nb_faces, 3), dtype=torch.uint8, device=ij.device)
-        ds.set_views(depths=depths.detach(), edgeflags=flags)
         self.last = dict(ij=ij, depths=depths, edgeflags=flags, colors=colors, shade=shade)
-        image, z = RenderViewsFunc.apply(ij, colors, shade, ds, r, self.sigma)
+        image, z = RenderViewsFunc.apply(ij, colors, shade, depths.detach(), flags, ds, r, self.sigma)
         return image, z
 
     # ---- the reference's entry points, batched over the camera's views -----------------------------------------------
