@@ -450,6 +450,12 @@ class HipRasterizer:
             else:
                 ib = _on(image_b, ds.device, pd, (n, H, W, Cc), "image_b")
             state = have_forward_state and last_ds is ds and not fused and (generation is None or generation == gen)
+            if not state and not aa and residual_obs is not None:
+                # residual mode forms 2 (image - obs) inside the kernels from the frame of THIS forward; the frame at hand belongs to
+                # another one (a later forward used the workspace, or the last call was a fit step): render again, then the state --
+                # and the frame -- are this scene's
+                image, _z = self.render(ds, sigma, check_overflow=False)
+                state = True
             _check(lib().deodr_hip_render_scene_b(C.byref(sc), _ptr(image), None, _ptr(ib), sigma, int(aa), _ptr(obs_t), None, _ptr(eb),
                                                   _ptr(self.workspace), self.nbytes, int(state), _stream(self.device)))  # fmt: skip
             if not state:

@@ -255,26 +255,25 @@ class Scene3DPytorch:
         m = self.mesh
         assert m is not None, "You need to provide a mesh first."
         if isinstance(m, DeviceMesh):
-            self.batched.set_mesh(m)
-            return m, m.vertices.device
-        v = m.vertices if torch.is_tensor(m.vertices) else torch.as_tensor(np.asarray(m.vertices, dtype=np.float64))
-        dev = _compute_device(v)
-        if self._dev_mesh is None or self._dev_mesh.device != dev:
-            uv, tex = getattr(m, "uv", None), getattr(m, "texture", None)
-            self._dev_mesh = DeviceMesh(np.asarray(m.faces), v.detach(), clockwise=bool(getattr(m, "clockwise", False)), uv=uv,
-                                        faces_uv=getattr(m, "faces_uv", None) if uv is not None else None, texture=tex, device=dev)  # fmt: skip
-        d = self._dev_mesh
-        d.set_vertices(v.to(device=dev, dtype=d.dtype))  # (differentiable: the gradient returns to m.vertices, wherever it lives)
-        colors = getattr(m, "vertices_colors", None)
-        if colors is not None:
-            c = colors if torch.is_tensor(colors) else torch.as_tensor(np.asarray(colors, dtype=np.float64))
-            d.set_vertices_colors(c.to(device=dev, dtype=d.dtype))
+            d, out_dev = m, m.vertices.device
+        else:
+            v = m.vertices if torch.is_tensor(m.vertices) else torch.as_tensor(np.asarray(m.vertices, dtype=np.float64))
+            dev, out_dev = _compute_device(v), v.device
+            if self._dev_mesh is None or self._dev_mesh.device != dev:
+                uv, tex = getattr(m, "uv", None), getattr(m, "texture", None)
+                self._dev_mesh = DeviceMesh(np.asarray(m.faces), v.detach(), clockwise=bool(getattr(m, "clockwise", False)), uv=uv,
+                                            faces_uv=getattr(m, "faces_uv", None) if uv is not None else None, texture=tex, device=dev)  # fmt: skip
+            d = self._dev_mesh
+            d.set_vertices(v.to(device=dev, dtype=d.dtype))  # (differentiable: the gradient returns to m.vertices, wherever it lives)
+            colors = getattr(m, "vertices_colors", None)
+            if colors is not None:
+                c = colors if torch.is_tensor(colors) else torch.as_tensor(np.asarray(colors, dtype=np.float64))
+                d.set_vertices_colors(c.to(device=dev, dtype=d.dtype))
         self.batched.set_mesh(d)
-        ld = self.light_directional
-        self.batched.light_directional = None if ld is None else (ld if torch.is_tensor(ld) else torch.as_tensor(np.asarray(ld, dtype=np.float64))).to(dev)
-        la = self.light_ambient
-        self.batched.light_ambient = la.to(dev) if torch.is_tensor(la) else la
-        return d, v.device
+        ld, la = self.light_directional, self.light_ambient
+        self.batched.light_directional = None if ld is None else (ld if torch.is_tensor(ld) else torch.as_tensor(np.asarray(ld, dtype=np.float64))).to(d.device)
+        self.batched.light_ambient = la.to(d.device) if torch.is_tensor(la) else la
+        return d, out_dev
 
     def render(self, camera, return_z_buffer=False, backface_culling=True):
         """-> image [H,W,C] (and z_buffer [H,W]); dr.py:896-983"""

@@ -127,7 +127,7 @@ class FakeLib:
                 err_buffer[i] = out[2]
         return 0
 
-    def _adjoint(self, sc, a, pd, sigma, antialiase_error, image_b, obs, err_buffer_b):
+    def _adjoint(self, sc, a, pd, sigma, antialiase_error, image_b, obs, err_buffer_b, image=None):
         n = sc.n_views
         for i in range(n):
             s = self._view_scene(sc, a, i)
@@ -136,7 +136,9 @@ class FakeLib:
             if antialiase_error:
                 g = self.repaired.grads(s, sigma, out[0], out[1], None, True, ob, out[2], err_buffer_b[i].astype(np.float64))
             else:
-                seed = 2 * (out[0] - ob) if image_b is None else image_b[i].astype(np.float64)
+                # residual mode: 2 (image - obs) from the frame the CALLER hands over (the library reads that pointer), as the real ABI
+                frame = out[0] if image is None else image[i].astype(np.float64)
+                seed = 2 * (frame - ob) if image_b is None else image_b[i].astype(np.float64)
                 g = self.repaired.grads(s, sigma, out[0], out[1], seed)
             # (where the reference divides by an edge transparency of 0 its gradient is NaN; the library returns finite numbers there)
             g = {k: np.nan_to_num(v) for k, v in g.items()}
@@ -161,7 +163,7 @@ class FakeLib:
             return self._fail("antialiase_error needs obs and err_buffer_b")
         if not antialiase_error and image_b is None and obs is None:
             return self._fail("image_b == NULL (or, for the residual mode, image and obs)")
-        self._adjoint(sc, a, pd, sigma, antialiase_error, image_b, obs, err_buffer_b)
+        self._adjoint(sc, a, pd, sigma, antialiase_error, image_b, obs, err_buffer_b, _view(image, (n, H, W, Cc), pd))
         return 0
 
     def deodr_hip_render_scene_fit(self, sc_ref, image, z_buffer, sigma, obs, clear_gradients, ws, nbytes, stream):

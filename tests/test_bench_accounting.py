@@ -21,13 +21,16 @@ def test_every_accounting_charges_the_survey_bytes():
     want = n * survey_bytes(H, W, C, T, V)
     two_call = bench.algorithmic_bytes(H, W, C, T, V, n, fused=False)
     assert sum(two_call.values()) == want
-    whole_frame = bench.algorithmic_bytes(H, W, C, T, V, n, fused=True)
-    assert sum(whole_frame.values()) == want and whole_frame["raster_bwd_kernel"] == 0
+    whole_frame = bench.algorithmic_bytes(H, W, C, T, V, n, fused=True)  # (no census: every tile counted as non-empty)
+    assert abs(sum(whole_frame.values()) - want) < 1e-6 * want and whole_frame["raster_bwd_kernel"] == 0 and whole_frame["not_moved"] == 0
     for frac in (0.0, 0.385, 1.0):
         by_census = bench.algorithmic_bytes(H, W, C, T, V, n, fused=True, nonempty_frac=frac)
         assert abs(sum(by_census.values()) - want) < 1e-6 * want
         frame = 4 * H * W * (C + 1) * n
-        assert abs(by_census["raster_fwd_kernel"] - 2 * frame * frac) < 1e-6 * frame
+        # a fit step: the forward raster moves both frame terms of the non-empty tiles and 2/3 of the background of the empty ones,
+        # finalize the last third; the adjoint's frame term of the empty tiles is moved by nobody
+        fill_fwd = bench.FILL_W_FWD / (bench.FILL_W_FWD + bench.FILL_W_FIN)
+        assert abs(by_census["raster_fwd_kernel"] - (2 * frame * frac + fill_fwd * frame * (1 - frac))) < 1e-6 * frame
         assert abs(by_census["not_moved"] - frame * (1 - frac)) < 1e-6 * frame
     # the number quoted in DESIGN.md / VERDICT.md for the bench configuration: 345.8 MB per 8-view step
     assert abs(want / 1e6 - 345.8) < 0.1
