@@ -273,7 +273,16 @@ class MeshRGBFitterWithPoseMultiFrame(MeshRGBFitterWithPose):
 
     All views of this process are rendered by ONE batched launch.  Under ``torch.distributed`` (one process per GPU, RCCL) the
     views shard across the ranks (``deodr_amd.distributed.shard_views``): each rank holds the poses of its own views, the shared
-    parameters are replicated, and the only communication per step is one all-reduce of the packed shared gradients + energy."""
+    parameters are replicated, and the only communication per step is one all-reduce of the packed shared gradients + energy.
+
+    Deliberate deviations from the reference's class (its trajectories are therefore NOT those of the unmodified reference; the
+    golden this class is tested on, tests/golden/rgb_multiview_fit.npz, comes from a subclass with the first two repaired -- DESIGN.md
+    section 6, divergence 6): (1) the data term compares the rendered image of frame ``idframe`` with that frame's photograph (the
+    reference indexes ROW ``idframe`` of the image, mesh_fitter.py:538-544); (2) the quaternions are renormalised per view (the
+    reference divides the whole [n, 4] array by its Frobenius norm, :595, which shrinks every rotation step by sqrt(n)); (3) the
+    data gradient is always projected on zero-mean displacements (the reference stops doing so from iteration 500 on, :573);
+    (4) ``update_lights`` / ``update_color`` switch the light and colour updates off (the reference stores the flags and updates
+    anyway, :604-613)."""
 
     # the reference's multi-frame class has its own constants (mesh_fitter.py:391-416): smaller pose steps, more damping, a nearer
     # camera that does not follow translation_init, and a data term weighted by cdata / number of views

@@ -24,6 +24,8 @@ def read_obj(filename):
                 vertices.append([float(x) for x in fields[1:4]])
             elif fields[0] == "f":
                 corners = [int(corner.split("/")[0]) for corner in fields[1:]]
+                if len(corners) != 3:  # (the reference returns an [n, 4] array that its TriMesh then rejects; say so here)
+                    raise ValueError(f"{filename}: face with {len(corners)} corners -- only triangle meshes are supported")
                 faces.append([c - 1 if c > 0 else len(vertices) + c for c in corners])
     return np.array(faces, dtype=np.int64).reshape(-1, 3), np.array(vertices, dtype=np.float64).reshape(-1, 3)
 

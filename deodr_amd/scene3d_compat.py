@@ -116,7 +116,11 @@ class Scene3D:
     """One mesh + a directional and an ambient light, rendered through the device pipeline (dr.py:735-1174).
 
     Same methods and result attributes as the reference; ``scene_2d`` exposes the 2.5-D arrays (and, after a backward, their
-    adjoints) of the last render as NumPy for code that inspects them."""
+    adjoints) of the last render as NumPy for code that inspects them.
+    Caching: the device twin of the mesh (connectivity analysis, uploaded texture and uv) is kept between renders and rebuilt when
+    ``mesh.faces`` / ``mesh.uv`` / ``mesh.texture`` (or the background image) are REPLACED by other objects.  Editing one of those
+    arrays in place is not seen -- rebind it (``mesh.texture = mesh.texture - step``, as the reference's fitters do) or call
+    ``scene.set_mesh(mesh)`` again; vertices, colours and lights are read at every render."""
 
     def __init__(self, sigma=1, perspective_correct=False, integer_pixel_centers=True):
         self.mesh = None
@@ -137,6 +141,7 @@ class Scene3D:
 
     def set_mesh(self, mesh):
         self.mesh = mesh
+        self._dmesh_key, self._dmesh = None, None  # (the device twin is rebuilt at the next render: see "Caching" above)
 
     def set_background_image(self, background_image):
         if self.background_color is not None:
