@@ -314,6 +314,19 @@ class HipRasterizer:
             self._status_event = torch.cuda.Event()
             self._status_event.record()
 
+    def poll_status(self):
+        """For callers that launch this workspace's kernels without going through :meth:`render` & co (a captured HIP graph being
+        replayed): look at the last asynchronous copy of the status block, then queue the next one.  Never waits; raises when a
+        forward since the previous look overflowed the spill pool (the workspace is regrown: capture again) or met invalid indices."""
+        if self._last is None:
+            return
+        self._inspect_poll(self._last[0].c_struct())
+        if self._status_event is None:
+            self._forwards = max(self._forwards, 2)
+            self._status_host.copy_(self._status_words, non_blocking=True)
+            self._status_event = torch.cuda.Event()
+            self._status_event.record()
+
     def status(self, ds):
         """Synchronous check: -> (overflowed, needed_pairs, scene_error_bits)."""
         sc = ds.c_struct()

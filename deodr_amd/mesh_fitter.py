@@ -47,6 +47,59 @@ class _Momentum:
         return x + s
 
 
+class GraphedStep:
+    """``fitter.step_device`` captured once in a HIP graph and replayed: one graph launch per iteration instead of ~240 kernel
+    launches (tools/fit_times.py: an iteration of any of the fitters takes 2.3 - 2.5 ms of host time issuing them, of which the
+    rasterizer's kernels are 0.04 - 0.46 ms).
+
+    A replay re-executes the captured kernels on the captured ADDRESSES, so the optimisation state has to live in fixed storage:
+    the first (eager) call finds out which tensors a step rebinds -- parameters, momentum speeds -- gives each a persistent buffer,
+    and the captured step ends by copying the new values into those buffers.  The tensors a step returns (energy, image, ...) are
+    the graph's output buffers: overwritten by the next replay.  Everything the step reads besides its own state (target images,
+    camera, hyper-parameters) is baked in at capture time: build a new GraphedStep after ``set_image`` or a change of constants."""
+
+    def __init__(self, fitter, warmup=3):
+        self.fitter = fitter
+        self._owners = lambda: [("attr", fitter.__dict__), ("speed", fitter.momentum.speed)]
+        for _ in range(warmup):  # sizes the workspace (spill pool check), creates the momentum speeds, warms the allocator
+            fitter.step_device()
+        before = {(kind, k): v for kind, d in self._owners() for k, v in d.items() if torch.is_tensor(v)}
+        fitter.step_device()
+        self.state = [(kind, k) for kind, d in self._owners() for k, v in d.items() if torch.is_tensor(v) and (kind, k) in before and before[(kind, k)] is not v]
+        self.buffers = {}
+        for kind, k in self.state:
+            d = dict(self._owners())[kind]
+            self.buffers[(kind, k)] = d[k].detach().clone().contiguous()
+            d[k] = self.buffers[(kind, k)]
+        self.graph = torch.cuda.CUDAGraph()
+        side = torch.cuda.Stream(device=fitter.device)
+        side.wait_stream(torch.cuda.current_stream(fitter.device))
+        with torch.cuda.stream(side):
+            self._captured_body()  # once more outside the graph, on the capture stream (allocator pools, lazy initialisations)
+        torch.cuda.current_stream(fitter.device).wait_stream(side)
+        it = fitter.iter
+        with torch.cuda.graph(self.graph):
+            self.outputs = self._captured_body()
+        fitter.iter = it  # (capturing records the step without executing it)
+
+    def _captured_body(self):
+        out = self.fitter.step_device()
+        for kind, k in self.state:  # the step rebound its state to fresh tensors: move the values into the persistent buffers
+            d = dict(self._owners())[kind]
+            self.buffers[(kind, k)].copy_(d[k])
+            d[k] = self.buffers[(kind, k)]
+        return tuple(o.detach() if torch.is_tensor(o) else o for o in out)
+
+    def step_device(self):
+        """one iteration = one graph launch; -> the (static) output tensors of ``fitter.step_device``"""
+        self.graph.replay()
+        self.fitter.iter += 1
+        r = self.fitter.scene._state[2] if self.fitter.scene._state is not None else None
+        if r is not None:
+            r.poll_status()  # (asynchronous: a spill-pool overflow inside a replay surfaces at a later call)
+        return self.outputs
+
+
 class _PoseFitter:
     """deformable vertices + one rigid pose per view, shared machinery of the three fitters"""
 
@@ -234,23 +287,40 @@ class MeshRGBFitterWithPose(_PoseFitter):
         self.light_ambient_leaf = self.light_ambient.detach().requires_grad_(True)
         return [self.mesh_color_leaf, self.light_directional_leaf, self.light_ambient_leaf]
 
-    def render(self):
+    def _pose_scene(self):
         self.mesh.set_vertices(self._transformed(self.vertices_leaf))
         self.scene.light_directional, self.scene.light_ambient = self.light_directional_leaf, self.light_ambient_leaf
         self.mesh.set_vertices_colors(self.mesh_color_leaf[None, :].expand(self.mesh.nb_vertices, -1))
+
+    def render(self):
+        self._pose_scene()
         return self.scene.render(self.camera).to(torch.float64)
 
-    def _data_energy(self, image):
-        diff_image = ((image - self.mesh_image) ** 2).sum(dim=-1)
-        return diff_image.sum(), diff_image
+    data_weight = 1.0  # of sum (image - obs)^2 in the energy
+
+    def _observation(self):
+        """the target image(s) in the rasterizer's pixel dtype, converted once"""
+        if getattr(self, "_obs_key", None) is not self.mesh_image:
+            self._obs_key, self._obs = self.mesh_image, self.mesh_image.to(self.scene.pixel_dtype).contiguous()
+        return self._obs
+
+    def _data_energy(self):
+        """-> (data energy, image [n,H,W,C]).  The data term of the colour fitters is exactly sum (image - obs)^2
+        (mesh_fitter.py:296-318): rendered AND back-propagated by the one-call fit step (Scene3DDevice.render_l2)."""
+        self._pose_scene()
+        loss, image = self.scene.render_l2(self.camera, self._observation())
+        return self.data_weight * loss, image
+
+    def diff_image(self, image):
+        """squared difference per pixel [n,H,W] (what the reference's step returns for display, mesh_fitter.py:313-316)"""
+        return ((image.to(torch.float64) - self.mesh_image) ** 2).sum(dim=-1)
 
     def _reduce_shared(self, grads):
         return grads  # single process, every view local
 
     def step_device(self):
         leaves = self._leaves(self._appearance_leaves())
-        image = self.render()
-        e_data, diff_image = self._data_energy(image)
+        e_data, image = self._data_energy()
         e_rigid, g_rigid = self.rigid_energy.evaluate(self.vertices_leaf.detach())
         g_v, g_q, g_t, g_col, g_dir, g_amb = torch.autograd.grad(e_data, leaves)
         g_v, g_col, g_dir, g_amb, e_data = self._reduce_shared([g_v, g_col, g_dir, g_amb, e_data.detach()])
@@ -261,11 +331,13 @@ class MeshRGBFitterWithPose(_PoseFitter):
             self.light_ambient = m.update("light_ambient", self.light_ambient, g_amb, 0.0001)
         if self.update_color:
             self.mesh_color = m.update("mesh_color", self.mesh_color, g_col, 0.00001)
-        return e_data + e_rigid, image.detach(), diff_image.detach()
+        return e_data + e_rigid, image.detach()
 
     def step(self):
-        energy, image, diff_image = self.step_device()
-        return float(energy.detach()), image[0].cpu().numpy(), diff_image[0].cpu().numpy()
+        """-> (energy, image [H,W,C], squared difference [H,W]) as a float and NumPy arrays, the reference's protocol (synchronises;
+        a loop that never needs them on the host calls step_device -- or a GraphedStep of it -- instead)"""
+        energy, image = self.step_device()
+        return float(energy.detach()), image[0].to(torch.float64).cpu().numpy(), self.diff_image(image)[0].cpu().numpy()
 
 
 class MeshRGBFitterWithPoseMultiFrame(MeshRGBFitterWithPose):
@@ -304,12 +376,10 @@ class MeshRGBFitterWithPoseMultiFrame(MeshRGBFitterWithPose):
         self.camera_center = self.object_center + np.array([0, 0, 6]) * self.object_radius
         self._packed = None
 
-    def _data_energy(self, image):
-        """(cdata / number of views) * sum over THIS rank's views of the squared residual (mesh_fitter.py:533-548; the reference
-        compares row `idframe` of the rendered image with the target there -- a defect, the image of the frame is meant --
-        and is followed as repaired, see tests/golden/make_golden.py::rgb_multiview_fit)"""
-        diff_image = ((image - self.mesh_image) ** 2).sum(dim=-1)
-        return (self.cdata / self.n_views_total) * diff_image.sum(), diff_image
+    # the data term: (cdata / number of views) * sum over THIS rank's views of the squared residual (mesh_fitter.py:533-548; the
+    # reference compares row `idframe` of the rendered image with the target there -- a defect, the image of the frame is meant --
+    # and is followed as repaired, see tests/golden/make_golden.py::rgb_multiview_fit)
+    data_weight = property(lambda self: self.cdata / self.n_views_total)
 
     def set_images(self, mesh_images, focal=None, distortion=None):
         """``mesh_images``: the images of ALL views (every rank keeps only its own)"""
@@ -332,5 +402,5 @@ class MeshRGBFitterWithPoseMultiFrame(MeshRGBFitterWithPose):
         return dd.allreduce_shared_gradients(self._packed, grads, self.group)
 
     def step(self):
-        energy, image, diff_image = self.step_device()
-        return float(energy.detach()), image.cpu().numpy(), diff_image.cpu().numpy()
+        energy, image = self.step_device()
+        return float(energy.detach()), image.to(torch.float64).cpu().numpy(), self.diff_image(image).cpu().numpy()

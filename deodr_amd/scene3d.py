@@ -190,6 +190,27 @@ class RenderViewsFunc(torch.autograd.Function):
         return g["ij_b"].to(ij.dtype), g["colors_b"].to(colors.dtype), g["shade_b"].to(shade.dtype), None, None, None, None, None
 
 
+class RenderViewsL2Func(torch.autograd.Function):
+    """(ij, colors, shade) -> (sum over the views of sum (image - obs)^2, image): ONE ``deodr_hip_render_scene_fit`` call renders and
+    back-propagates the residual (the forward raster knows dL/dimage of a pixel the moment the pixel is resolved), so the backward
+    of this op only scales the gradients the forward left.  What the reference's colour fitters write as render, subtract, square,
+    sum, render_backward (deodr/mesh_fitter.py:296-318, 533-548) -- half the rasterizer time of the two-call path."""
+
+    @staticmethod
+    def forward(ctx, ij, colors, shade, depths, edgeflags, obs, device_scene, rasterizer, sigma):
+        device_scene.set_views(ij=ij.detach(), colors=colors.detach(), shade=shade.detach(), depths=depths.detach(), edgeflags=edgeflags)
+        image, z, g = rasterizer.render_fit(device_scene, obs, sigma, clear_grads=False)
+        ctx.save_for_backward(g["ij_b"].to(ij.dtype), g["colors_b"].to(colors.dtype), g["shade_b"].to(shade.dtype))
+        ctx.uv_b, ctx.texture_b = g["uv_b"], g["texture_b"]
+        ctx.mark_non_differentiable(image)
+        return torch.nn.functional.mse_loss(image.to(torch.float64), obs.to(torch.float64), reduction="sum"), image  # sum (image - obs)^2
+
+    @staticmethod
+    def backward(ctx, loss_b, _image_b):
+        ij_b, colors_b, shade_b = ctx.saved_tensors
+        return loss_b.to(ij_b.dtype) * ij_b, loss_b.to(colors_b.dtype) * colors_b, loss_b.to(shade_b.dtype) * shade_b, None, None, None, None, None, None
+
+
 class DeviceMesh:
     """A coloured (or textured) triangle mesh on the device: topology + per-vertex attributes.
 
@@ -299,7 +320,35 @@ class Scene3DDevice:
         image, z = RenderViewsFunc.apply(ij, colors, shade, depths.detach(), flags, ds, r, self.sigma)
         return image, z
 
+    def _rasterize_l2(self, camera, ij, depths, colors, shade, textured, backface_culling, obs):
+        """-> (sum (image - obs)^2 over all views, image [n,H,W,C]) through the one-call fit step"""
+        if (self.background_image is None) == (self.background_color is None):
+            raise BaseException("You need to provide either a background image or background color")
+        n = camera.n_views
+        ds, r = self._rasterizer(n, camera.height, camera.width, int(colors.shape[-1]), textured, backface_culling)
+        flags = self.mesh.topology.edge_on_silhouette(ij) if self.sigma > 0 else torch.zeros((n, self.mesh.nb_faces, 3), dtype=torch.uint8, device=ij.device)
+        self.last = dict(ij=ij, depths=depths, edgeflags=flags, colors=colors, shade=shade)
+        return RenderViewsL2Func.apply(ij, colors, shade, depths.detach(), flags, obs, ds, r, self.sigma)
+
     # ---- the reference's entry points, batched over the camera's views -----------------------------------------------
+
+    def render_l2(self, camera, obs, backface_culling=True):
+        """-> (sum over views and pixels of (render(camera) - obs)^2 as a differentiable scalar, the rendered images [n,H,W,C]).
+        ``obs`` [n,H,W,C] in the scene's pixel dtype, contiguous (anything else is converted at every call)."""
+        m = self.mesh
+        assert m is not None, "You need to provide a mesh first."
+        ij, depths = camera.project_points(m.vertices)
+        n, V = ij.shape[0], m.nb_vertices
+        obs = obs.to(device=ij.device, dtype=self.pixel_dtype)
+        lum = self.vertices_luminosity(m.vertices)
+        lum = lum[None].expand(n, -1) if lum.dim() == 1 else lum
+        if m.uv is not None:
+            assert m.texture is not None
+            colors = torch.zeros((n, V, int(m.texture.shape[2])), dtype=m.dtype, device=m.device)
+            return self._rasterize_l2(camera, ij, depths, colors, lum, True, backface_culling, obs.expand(n, -1, -1, -1).contiguous())
+        vc = m.vertices_colors if m.vertices_colors.dim() == 3 else m.vertices_colors[None].expand(n, -1, -1)
+        shade = torch.zeros((n, V), dtype=m.dtype, device=m.device)
+        return self._rasterize_l2(camera, ij, depths, vc * lum[..., None], shade, False, backface_culling, obs.expand(n, -1, -1, -1).contiguous())
 
     def render(self, camera, return_z_buffer=False, backface_culling=True):
         """-> image [n,H,W,C] (and z_buffer [n,H,W]); dr.py:896-983"""
