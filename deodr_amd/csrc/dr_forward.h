@@ -1460,8 +1460,8 @@ __global__ __launch_bounds__(64, DR_FWD_WAVES) void raster_fwd_fast_kernel(KPara
 		fill_share_word(p, 2, fi % p.n_views, fi / p.n_views, threadIdx.x & 63);
 		return;
 	}
-	if (FUSED && DR_FUSE_EDGES)
-	{ // (p.fuse_edges is set: the host and the scan kernel follow the same build constant)
+	if (FUSED && DR_FUSE_EDGES && !TEX)
+	{ // (p.fuse_edges is set: the host and the scan kernel follow the same rule -- fit step of an untextured scene)
 		const int G = p.tile_blocks;
 		const long long b = blockIdx.x;
 		const bool chunked = G % (8 * WORK_CHUNK) == 0;
