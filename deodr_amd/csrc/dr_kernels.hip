@@ -45,7 +45,7 @@
 #include <vector>
 
 #include "../../include/deodr_hip.h"
-#include "dr_finalize.h" // <- dr_backward.h <- dr_backward_generic.h <- dr_forward.h <- dr_forward_generic.h <- dr_setup.h <- dr_workspace.h <- dr_prims.h
+#include "dr_fronthalf.h" // <- dr_finalize.h <- dr_backward.h <- dr_backward_generic.h <- dr_forward.h <- dr_forward_generic.h <- dr_setup.h <- dr_workspace.h <- dr_prims.h
 
 using namespace dr;
 
@@ -547,6 +547,82 @@ int deodr_hip_render_scene_fit(const DeodrHipScene *sc, void *image, void *z_buf
 	if (launch_adjoint(sc, p, st, !fused))
 		return 1;
 	return join_side(st, join); // the background fill has been overlapping the adjoint
+}
+
+// ---- front half of a fit iteration (dr_fronthalf.h): plain double arrays on the device, asynchronous on `stream`
+
+int deodr_hip_rigid_transform(const double *vertices, const double *quaternions, const double *translations, double *out, int V, int n, void *stream)
+{
+	if (!vertices || !quaternions || !translations || !out || V <= 0 || n <= 0)
+		return fail("rigid_transform: bad arguments");
+	hipLaunchKernelGGL(rigid_transform_kernel, dim3((V + FH_BLOCK - 1) / FH_BLOCK, n), dim3(FH_BLOCK), 0, (hipStream_t)stream, vertices, quaternions, translations, out, V, n);
+	return check_hip(hipGetLastError(), "rigid_transform launch");
+}
+
+int deodr_hip_rigid_transform_b(const double *vertices, const double *quaternions, const double *out_b, double *vertices_b, double *pose_b, int V, int n,
+								void *stream)
+{ // pose_b [n,7] = (quaternion adjoint 4, translation adjoint 3) per view, overwritten
+	if (!vertices || !quaternions || !out_b || !vertices_b || !pose_b || V <= 0 || n <= 0)
+		return fail("rigid_transform_b: bad arguments");
+	hipStream_t st = (hipStream_t)stream;
+	if (check_hip(hipMemsetAsync(pose_b, 0, sizeof(double) * 7 * (size_t)n, st), "rigid_transform_b clear"))
+		return 1;
+	// (the kernel addresses the two adjoints separately: quaternions first [n,4], then translations [n,3])
+	hipLaunchKernelGGL(rigid_transform_b_kernel, dim3((V + FH_BLOCK - 1) / FH_BLOCK), dim3(FH_BLOCK), 0, st, vertices, quaternions, out_b, vertices_b, pose_b,
+					   pose_b + 4 * (size_t)n, V, n);
+	return check_hip(hipGetLastError(), "rigid_transform_b launch");
+}
+
+int deodr_hip_project_points(const double *points, const double *extrinsic, const double *intrinsic, const double *distortion, double *ij, double *depths,
+							 int V, int n, void *stream)
+{
+	if (!points || !extrinsic || !intrinsic || !ij || !depths || V <= 0 || n <= 0)
+		return fail("project_points: bad arguments");
+	hipLaunchKernelGGL(project_points_kernel, dim3((V + FH_BLOCK - 1) / FH_BLOCK, n), dim3(FH_BLOCK), 0, (hipStream_t)stream, points, extrinsic, intrinsic,
+					   distortion, ij, depths, V, n);
+	return check_hip(hipGetLastError(), "project_points launch");
+}
+
+int deodr_hip_project_points_b(const double *points, const double *extrinsic, const double *intrinsic, const double *distortion, const double *ij_b,
+							   const double *depths_b, double *points_b, int V, int n, void *stream)
+{
+	if (!points || !extrinsic || !intrinsic || !ij_b || !points_b || V <= 0 || n <= 0)
+		return fail("project_points_b: bad arguments");
+	hipLaunchKernelGGL(project_points_b_kernel, dim3((V + FH_BLOCK - 1) / FH_BLOCK, n), dim3(FH_BLOCK), 0, (hipStream_t)stream, points, extrinsic, intrinsic,
+					   distortion, ij_b, depths_b, points_b, V, n);
+	return check_hip(hipGetLastError(), "project_points_b launch");
+}
+
+int deodr_hip_silhouette_flags(const double *ij, const uint32_t *faces, const uint32_t *edge_faces, uint8_t *flags, int T, int V, int n, int clockwise,
+							   void *stream)
+{
+	if (!ij || !faces || !edge_faces || !flags || T <= 0 || V <= 0 || n <= 0)
+		return fail("silhouette_flags: bad arguments");
+	hipLaunchKernelGGL(silhouette_flags_kernel, dim3((T + FH_BLOCK - 1) / FH_BLOCK, n), dim3(FH_BLOCK), 0, (hipStream_t)stream, ij, faces, edge_faces, flags, T, V,
+					   clockwise);
+	return check_hip(hipGetLastError(), "silhouette_flags launch");
+}
+
+int deodr_hip_momentum_update(int n_tensors, double *const *x, double *const *speed, const double *const *grad, const double *const *grad2,
+							  const double *factor, const double *step_max, const int *count, const int *normalize_rows, double inertia, double damping,
+							  void *stream)
+{
+	if (n_tensors <= 0 || n_tensors > MOMENTUM_MAX || !x || !speed || !grad || !factor || !step_max || !count)
+		return fail("momentum_update: bad arguments (at most 8 tensors per call)");
+	MomentumArgs a;
+	memset(&a, 0, sizeof a);
+	int most = 0;
+	for (int k = 0; k < n_tensors; k++)
+	{
+		if (!x[k] || !speed[k] || !grad[k] || count[k] <= 0)
+			return fail("momentum_update: NULL tensor");
+		a.x[k] = x[k], a.speed[k] = speed[k], a.grad[k] = grad[k], a.grad2[k] = grad2 ? grad2[k] : nullptr;
+		a.factor[k] = factor[k], a.step_max[k] = step_max[k], a.count[k] = count[k], a.normalize_rows[k] = normalize_rows ? normalize_rows[k] : 0;
+		most = count[k] > most ? count[k] : most;
+	}
+	a.n = n_tensors, a.inertia = inertia, a.damping = damping;
+	hipLaunchKernelGGL(momentum_update_kernel, dim3((most + FH_BLOCK - 1) / FH_BLOCK, n_tensors), dim3(FH_BLOCK), 0, (hipStream_t)stream, a);
+	return check_hip(hipGetLastError(), "momentum_update launch");
 }
 
 #ifdef DR_WAVE_TRACE

@@ -36,6 +36,26 @@ class _Momentum:
     def __init__(self, inertia, damping):
         self.inertia, self.damping, self.speed = inertia, damping, {}
 
+    def update_all(self, entries):
+        """entries: [(name, x, grad, grad2 | None, factor, step_max | None, normalize_rows)] -> the new x of every entry.  On float64
+        ROCm tensors: ONE kernel for all of them (in place on contiguous copies of x); otherwise the formulas below, entry by entry."""
+        from . import fronthalf
+
+        if all(fronthalf.usable(e[1], e[2]) and (e[3] is None or fronthalf.usable(e[3])) for e in entries) and len(entries) <= 8:
+            rows = []
+            for name, x, grad, grad2, factor, step_max, normalize_rows in entries:
+                if name not in self.speed:
+                    self.speed[name] = torch.zeros_like(x, memory_format=torch.contiguous_format)
+                rows.append((x.contiguous().clone() if not x.is_contiguous() else x.clone(), self.speed[name], grad.contiguous(), None if grad2 is None else grad2.contiguous(),
+                             factor, step_max, normalize_rows))  # fmt: skip
+            fronthalf.momentum_update(rows, self.inertia, self.damping)
+            return [r[0] for r in rows]
+        out = []
+        for name, x, grad, grad2, factor, step_max, normalize_rows in entries:
+            new = self.update(name, x, grad if grad2 is None else grad + grad2, factor, step_max)
+            out.append(new / new.norm(dim=-1, keepdim=True) if normalize_rows else new)
+        return out
+
     def update(self, name, x, grad, factor, step_max=None):
         step = -grad * factor
         if step_max is not None:
@@ -138,8 +158,12 @@ class _PoseFitter:
     def _transformed(self, vertices):
         """centred vertices moved by every pose: [n_poses, V, 3] (the centring is part of the graph: the data gradient comes out
         projected on zero-mean displacements, as the reference does by hand, mesh_fitter.py:140, 319)"""
+        from . import fronthalf
+
         q = self.transform_quaternion_leaf / self.transform_quaternion_leaf.norm(dim=-1, keepdim=True)
         centred = vertices - vertices.mean(dim=0, keepdim=True)
+        if fronthalf.usable(centred, q, self.transform_translation_leaf):  # one kernel (two with its adjoint) instead of ~12 + ~25
+            return fronthalf.RigidTransformFunc.apply(centred, q, self.transform_translation_leaf)
         return qrot(q, centred[None].expand(q.shape[0], -1, -1)) + self.transform_translation_leaf[:, None, :]
 
     def _leaves(self, extra=()):
@@ -149,13 +173,16 @@ class _PoseFitter:
         self.transform_translation_leaf = self.transform_translation.detach().requires_grad_(True)
         return [self.vertices_leaf, self.transform_quaternion_leaf, self.transform_translation_leaf] + list(extra)
 
-    def _update_pose_and_shape(self, g_vertices, g_quaternion, g_translation, grad_rigidity, step_max):
-        m = self.momentum
-        self.vertices = m.update("vertices", self.vertices, g_vertices + grad_rigidity, self.step_factor_vertices, step_max[0])
-        q = m.update("quaternion", self.transform_quaternion, g_quaternion, self.step_factor_quaternion, step_max[1])
-        self.transform_quaternion = q / q.norm(dim=-1, keepdim=True)
-        self.transform_translation = m.update("translation", self.transform_translation, g_translation, self.step_factor_translation, step_max[2])
+    def _update_pose_and_shape(self, g_vertices, g_quaternion, g_translation, grad_rigidity, step_max, extra=()):
+        entries = [
+            ("vertices", self.vertices, g_vertices, grad_rigidity, self.step_factor_vertices, step_max[0], 0),
+            ("quaternion", self.transform_quaternion, g_quaternion, None, self.step_factor_quaternion, step_max[1], 4),  # renormalised per view
+            ("translation", self.transform_translation, g_translation, None, self.step_factor_translation, step_max[2], 0),
+        ] + list(extra)
+        new = self.momentum.update_all(entries)
+        self.vertices, self.transform_quaternion, self.transform_translation = new[:3]
         self.iter += 1
+        return new[3:]
 
 
 class MeshDepthFitter(_PoseFitter):
@@ -324,13 +351,16 @@ class MeshRGBFitterWithPose(_PoseFitter):
         e_rigid, g_rigid = self.rigid_energy.evaluate(self.vertices_leaf.detach())
         g_v, g_q, g_t, g_col, g_dir, g_amb = torch.autograd.grad(e_data, leaves)
         g_v, g_col, g_dir, g_amb, e_data = self._reduce_shared([g_v, g_col, g_dir, g_amb, e_data.detach()])
-        self._update_pose_and_shape(g_v, g_q, g_t, g_rigid, (0.5, 0.05, 0.1))
-        m = self.momentum
+        extra, names = [], []
         if self.update_lights:
-            self.light_directional = m.update("light_directional", self.light_directional, g_dir, 0.0001)
-            self.light_ambient = m.update("light_ambient", self.light_ambient, g_amb, 0.0001)
+            extra += [("light_directional", self.light_directional, g_dir, None, 0.0001, None, 0),
+                      ("light_ambient", self.light_ambient.reshape(1), g_amb.reshape(1), None, 0.0001, None, 0)]  # fmt: skip
+            names += ["light_directional", "light_ambient"]
         if self.update_color:
-            self.mesh_color = m.update("mesh_color", self.mesh_color, g_col, 0.00001)
+            extra.append(("mesh_color", self.mesh_color, g_col, None, 0.00001, None, 0))
+            names.append("mesh_color")
+        for name, value in zip(names, self._update_pose_and_shape(g_v, g_q, g_t, g_rigid, (0.5, 0.05, 0.1), extra)):
+            setattr(self, name, value.reshape(()) if name == "light_ambient" else value)
         return e_data + e_rigid, image.detach()
 
     def step(self):

@@ -38,7 +38,8 @@ class DeviceCamera:
         self.distortion = None
         if distortion is not None:
             d = _t(distortion, self.device, dtype)
-            self.distortion = (d[None] if d.dim() == 1 else d).expand(self.n_views, 5)
+            self.distortion = (d[None] if d.dim() == 1 else d).expand(self.n_views, 5).contiguous()
+        self.extrinsic, self.intrinsic = self.extrinsic.contiguous(), self.intrinsic.contiguous()
 
     @classmethod
     def stack(cls, cameras, device="cuda", dtype=torch.float64):
@@ -58,6 +59,12 @@ class DeviceCamera:
 
     def project_points(self, points_3d):
         """-> (image coordinates [n,V,2] with x = column first, depths [n,V]); differentiable (dr.py:341-395)."""
+        from . import fronthalf
+
+        if fronthalf.usable(points_3d, self.extrinsic, self.intrinsic) and (self.distortion is None or fronthalf.usable(self.distortion)):
+            # one kernel (two with its adjoint) instead of ~15 + ~25 torch kernels
+            p = points_3d if points_3d.dim() == 3 else points_3d[None].expand(self.n_views, -1, -1)
+            return fronthalf.ProjectPointsFunc.apply(p, self.extrinsic, self.intrinsic, self.distortion)
         pc = self.world_to_camera(points_3d)
         depths = pc[..., 2]
         xy = pc[..., :2] / depths[..., None]
@@ -96,6 +103,18 @@ class MeshTopology:
         self.is_closed = bool(self.is_manifold and np.all(counts == 2))
         self.faces = torch.as_tensor(f, device=self.device)
         self.face_edge = torch.as_tensor(edge_id.reshape(3, -1).T.copy(), device=self.device)  # [T,3]
+        # for the fused silhouette kernel (manifold meshes): the face across every edge slot, 0xffffffff on a boundary
+        self._edge_faces = None
+        if self.is_manifold and self.nb_faces:
+            slot_face = np.tile(np.arange(self.nb_faces), 3)  # face of slot-major entry i of `e`
+            order = np.argsort(edge_id, kind="stable")
+            sorted_edge, sorted_face = edge_id[order], slot_face[order]
+            other = np.full(3 * self.nb_faces, 0xFFFFFFFF, dtype=np.int64)
+            same = sorted_edge[1:] == sorted_edge[:-1]  # (at most two slots per edge)
+            other[order[:-1][same]] = sorted_face[1:][same]
+            other[order[1:][same]] = sorted_face[:-1][same]
+            self._edge_faces = torch.as_tensor(other.reshape(3, -1).T.astype(np.uint32).view(np.int32).copy(), device=self.device)
+            self._faces_u32 = torch.as_tensor(f.astype(np.uint32).view(np.int32), device=self.device).contiguous()
         # graph Laplacian over "shares a face" adjacency, and M = L^T L as a COO list (dr: laplacian_rigid_energy.py:18-22)
         a = np.zeros((0, 2), dtype=np.int64)
         if self.nb_faces:
@@ -131,6 +150,10 @@ class MeshTopology:
     def edge_on_silhouette(self, ij):
         """[..., V, 2] image coordinates -> uint8 [..., T, 3]: the edge has exactly one front-facing incident face in the image
         (triangulated_mesh.py:153-166).  No gradient (the flags select which edges are antialiased)."""
+        from . import fronthalf
+
+        if self._edge_faces is not None and ij.dim() == 3 and fronthalf.usable(ij):
+            return fronthalf.silhouette_flags(ij, self._faces_u32, self._edge_faces, self.clockwise)  # one kernel instead of eight
         with torch.no_grad():
             tri = ij[..., self.faces, :]
             u, v = tri[..., 1, :] - tri[..., 0, :], tri[..., 2, :] - tri[..., 0, :]

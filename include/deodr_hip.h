@@ -114,6 +114,38 @@ int deodr_hip_render_scene_b(const DeodrHipScene *scene, const void *image, cons
 int deodr_hip_render_scene_fit(const DeodrHipScene *scene, void *image, void *z_buffer, double sigma, const void *obs,
 							   int clear_gradients, void *workspace, size_t workspace_bytes, void *stream);
 
+/* ---- Front half of a fit iteration: the O(V) algebra between the parameters of a fitter and the 2.5-D
+ * scene, and its adjoint, as kernels -- as torch ops one iteration is ~240 launches, most of them this algebra.  Plain double
+ * arrays on the device, contiguous, asynchronous on `stream`; n = number of views (poses / cameras), V vertices, T triangles.
+ *
+ * deodr_hip_rigid_transform     out[b][v] = qrot(quaternions[b], vertices[v]) + translations[b]   (q = (x, y, z, w), unit;
+ *                               deodr/tools.py:8-22, deodr/mesh_fitter.py:139-151)
+ * deodr_hip_rigid_transform_b   its adjoint (deodr/tools.py:25-35): vertices_b [V,3] = sum over the views; pose_b [n*4 + n*3] = the
+ *                               quaternion adjoints of all views, then the translation adjoints (both overwritten)
+ * deodr_hip_project_points      Camera.project_points (deodr/differentiable_renderer.py:341-395): points [n,V,3], extrinsic [n,3,4],
+ *                               intrinsic [n,3,3], distortion [n,5] (k1, k2, p1, p2, k3) or NULL -> ij [n,V,2] (x = column first),
+ *                               depths [n,V]
+ * deodr_hip_project_points_b    Camera.project_points_backward (dr.py:397-438): ij_b, depths_b (or NULL) -> points_b [n,V,3]
+ * deodr_hip_silhouette_flags    TriMeshAdjacencies.edge_on_silhouette (deodr/triangulated_mesh.py:153-166) for n views: flags
+ *                               [n,T,3] = 1 where exactly one of the faces on edge e of face f is front-facing in the image;
+ *                               edge_faces [T,3] = the face across edge (v_e, v_e+1) of face f, 0xffffffff on a boundary
+ * deodr_hip_momentum_update     s = (1 - damping)(inertia s + (1 - inertia) clamp(-factor (grad + grad2), +-step_max)); x += s
+ *                               (deodr/mesh_fitter.py:153-190) for up to 8 parameter tensors in one launch; step_max <= 0: no clamp;
+ *                               normalize_rows[k] = r > 0: x[k] is [count/r, r] and every row is renormalised afterwards (the
+ *                               quaternions, mesh_fitter.py:176; per view: see DESIGN.md section 6, divergence 6) */
+int deodr_hip_rigid_transform(const double *vertices, const double *quaternions, const double *translations, double *out, int V, int n, void *stream);
+int deodr_hip_rigid_transform_b(const double *vertices, const double *quaternions, const double *out_b, double *vertices_b, double *pose_b, int V, int n,
+								void *stream);
+int deodr_hip_project_points(const double *points, const double *extrinsic, const double *intrinsic, const double *distortion, double *ij, double *depths,
+							 int V, int n, void *stream);
+int deodr_hip_project_points_b(const double *points, const double *extrinsic, const double *intrinsic, const double *distortion, const double *ij_b,
+							   const double *depths_b, double *points_b, int V, int n, void *stream);
+int deodr_hip_silhouette_flags(const double *ij, const uint32_t *faces, const uint32_t *edge_faces, uint8_t *flags, int T, int V, int n, int clockwise,
+							   void *stream);
+int deodr_hip_momentum_update(int n_tensors, double *const *x, double *const *speed, const double *const *grad, const double *const *grad2,
+							  const double *factor, const double *step_max, const int *count, const int *normalize_rows, double inertia, double damping,
+							  void *stream);
+
 /* Bits of the sticky scene-error word: the index checks of the reference's checkSceneValid
  * (DifferentiableRenderer.h:2700-2712: `faces` entries < nb_vertices, `faces_uv` entries < nb_uv; plus the null-texture
  * check of H.h:2687-2694 that needs per-triangle data) are made by the set-up kernel where it reads the indices -- a
@@ -162,7 +194,7 @@ const char *deodr_hip_last_error(void);
 
 /* ABI version of this header; bumped on any incompatible change. */
 int deodr_hip_abi_version(void);
-#define DEODR_HIP_ABI_VERSION 3
+#define DEODR_HIP_ABI_VERSION 4
 
 #ifdef __cplusplus
 }

@@ -275,3 +275,70 @@ def test_graphed_fit_steps_follow_the_reference_curves():
     e_graph = [float(graphed.step_device()[0]) for _ in range(7)]
     assert np.abs(np.array(e_graph) - np.array(e_eager[5:])).max() <= 1e-6 * e_eager[0]
     assert np.abs(np.array(e_eager[:10]) - r["energies"][:10]).max() <= 1e-6 * r["energies"][0]
+
+
+def test_fused_front_half_kernels_equal_the_torch_formulas(monkeypatch):
+    """rigid transform, projection (+ distortion), silhouette flags, momentum update: the kernels of dr_fronthalf.h (values and
+    adjoints) against the torch formulas of scene3d.py / mesh_fitter.py they replace on float64 ROCm tensors"""
+    from deodr_amd import fronthalf
+    from deodr_amd.mesh_fitter import _Momentum, qrot
+    from deodr_amd.scene3d import DeviceCamera, MeshTopology
+
+    rs = np.random.RandomState(0)
+    vertices, faces = hand()
+    n, V = 3, len(vertices)
+    dev = "cuda"
+    # ---- rigid transform
+    vc = torch.tensor(vertices - vertices.mean(axis=0), device=dev, requires_grad=True)
+    q = torch.tensor(rs.randn(n, 4), device=dev)
+    q = (q / q.norm(dim=-1, keepdim=True)).requires_grad_(True)
+    t = torch.tensor(rs.randn(n, 3), device=dev, requires_grad=True)
+    w = torch.tensor(rs.randn(n, V, 3), device=dev)
+    out = fronthalf.RigidTransformFunc.apply(vc, q, t)
+    ref = qrot(q, vc[None].expand(n, -1, -1)) + t[:, None, :]
+    assert rel(out.detach().cpu(), ref.detach().cpu()) < 1e-14
+    g = torch.autograd.grad((out * w).sum(), [vc, q, t])
+    g_ref = torch.autograd.grad((ref * w).sum(), [vc, q, t])
+    for a, b in zip(g, g_ref):
+        assert rel(a.cpu(), b.cpu()) < 1e-12
+    # ---- projection with distortion, against the torch path of the same class
+    rot = np.array([[1.0, 0, 0], [0, -1, 0], [0, 0, -1]])
+    ext = np.stack([np.column_stack((rot, -rot.T.dot(vertices.mean(axis=0) + np.array([0.3 * i, 0, 8.0 + i]) * np.std(vertices)))) for i in range(n)])
+    K = np.stack([np.array([[250.0 + 10 * i, 0.3, 64], [0, 240.0, 48 + i], [0, 0, 1]]) for i in range(n)])
+    dist = np.stack([np.array([0.1, -0.02, 0.003, -0.004, 0.01]) * (i + 1) for i in range(n)])
+    for distortion in (None, dist):
+        cam = DeviceCamera(ext, K, 96, 128, distortion, dev)
+        pts = torch.tensor(vertices[None] + 0.01 * rs.randn(n, V, 3), device=dev, requires_grad=True)
+        wi, wd = torch.tensor(rs.randn(n, V, 2), device=dev), torch.tensor(rs.randn(n, V), device=dev)
+        ij, depths = cam.project_points(pts)  # fused
+        (g,) = torch.autograd.grad((ij * wi).sum() + (depths * wd).sum(), [pts])
+        with monkeypatch.context() as m:
+            m.setattr(fronthalf, "usable", lambda *a: False)
+            ij_r, depths_r = cam.project_points(pts)  # torch ops
+            (g_r,) = torch.autograd.grad((ij_r * wi).sum() + (depths_r * wd).sum(), [pts])
+        assert rel(ij.detach().cpu(), ij_r.detach().cpu()) < 1e-13 and rel(depths.detach().cpu(), depths_r.detach().cpu()) < 1e-14
+        assert rel(g.cpu(), g_r.cpu()) < 1e-11
+    # ---- silhouette flags (closed sphere, open hand mesh with a boundary at the wrist)
+    for verts, fcs in ((vertices, faces), scenes.bumpy_sphere(30, 24)):
+        topo = MeshTopology(fcs, len(verts), clockwise=False, device=dev)
+        cams = DeviceCamera(ext, K, 96, 128, None, dev)
+        ij, _ = cams.project_points(torch.tensor(np.asarray(verts, dtype=np.float64) * (1.0 if len(verts) == V else 0.2) + vertices.mean(axis=0), device=dev))
+        fused = topo.edge_on_silhouette(ij)
+        with monkeypatch.context() as m:
+            m.setattr(fronthalf, "usable", lambda *a: False)
+            plain = topo.edge_on_silhouette(ij)
+        assert fused.dtype == torch.uint8 and torch.equal(fused, plain) and int(fused.sum()) > 0
+    # ---- momentum update (clamp, second gradient, per-row renormalisation)
+    mom_a, mom_b = _Momentum(0.96, 0.05), _Momentum(0.96, 0.05)
+    x = [torch.tensor(rs.randn(V, 3), device=dev), torch.tensor(rs.randn(n, 4), device=dev), torch.tensor(rs.randn(1), device=dev)]
+    for step in range(3):
+        grads = [torch.tensor(rs.randn(*t_.shape) * 1e3, device=dev) for t_ in x]
+        g2 = torch.tensor(rs.randn(V, 3), device=dev)
+        entries = [("v", x[0], grads[0], g2, 0.0005, 0.5, 0), ("q", x[1], grads[1], None, 0.00006, 0.1, 4), ("a", x[2], grads[2], None, 0.0001, None, 0)]
+        new = mom_a.update_all(entries)
+        with monkeypatch.context() as m:
+            m.setattr(fronthalf, "usable", lambda *a: False)
+            new_r = mom_b.update_all([(nm, xr, gr, g2r, f, sm, rows) for (nm, _x, gr, g2r, f, sm, rows), xr in zip(entries, x)])
+        for a, b in zip(new, new_r):
+            assert rel(a.cpu(), b.cpu()) < 1e-14
+        x = new

@@ -659,7 +659,9 @@ def test_dropin_scene3d_render_deferred():
         ref = d["buf_" + k]
         assert v.shape == ref.shape, k
         assert np.abs(v - ref).max() <= 1e-9 * max(1.0, np.abs(ref).max()), k
-    assert np.array_equal(buffers["face_id"], d["buf_face_id"])  # flat per triangle: exact
+    # flat per triangle: the same owner at every pixel (the values carry the rounding of the plane coefficients, which depends on the
+    # last bit of the projected vertices: the fused projection kernel and the reference's NumPy do not round identically)
+    assert np.array_equal(np.round(buffers["face_id"]), np.round(d["buf_face_id"]))
 
 
 @pytest.mark.gpu
