@@ -1,0 +1,424 @@
+// deodr_amd/csrc/dr_fititer.h -- part of the single translation unit dr_kernels.hip (device code, gfx950 / wave64).
+// One iteration of the reference's fitters (deodr/mesh_fitter.py:108-190, 287-376, 529-632) WITHOUT an autograd graph: the chain
+//
+//   fit_pose_project_kernel   centre the vertices, pose them with every view's (renormalised) quaternion + translation, project them
+//                             with every view's camera                                       -> posed, ij, depths
+//   vertex_shade_kernel       vertex normals (normalised sum of the unit normals of the faces around a vertex,
+//                             deodr/triangulated_mesh.py:113-151), luminosity max(0, -n.l) + ambient (dr.py:814-822), colour * luminosity
+//   ... silhouette flags, the rasterizer's fit step (image, loss gradient w.r.t. ij and colours) ...
+//   vertex_shade_b1/b2        adjoint of the shading: b1 per vertex (light / ambient / colour sums, adjoint of the accumulated normal),
+//                             b2 gathers the adjoint of the posed vertices over the faces around each vertex
+//   fit_pose_project_b        adjoint of projection and pose: vertices_b (summed over the views, fixed order), its column mean (the data
+//                             gradient is projected on zero-mean displacements, mesh_fitter.py:140), pose_b of every view
+//   rigid_energy_kernel       0.5 c d^T (L^T L) d and its gradient over a CSR of L^T L (deodr/laplacian_rigid_energy.py:15-41)
+//   momentum_update_kernel    (dr_fronthalf.h) all parameters, in place
+//
+// All sums over vertices are DETERMINISTIC: per-workgroup partials in a fixed order, added up by the last workgroup to arrive
+// (grid_sum below) -- the torch formulation of the same chain (deodr_amd/scene3d.py, mesh_fitter.py) is what these are tested against.
+// The gathers use a vertex -> incident (face, corner) CSR built once per topology (MeshTopology), no atomics.
+#pragma once
+
+#include "dr_fronthalf.h"
+
+namespace
+{
+
+__device__ __forceinline__ Vec3 load3(const double *p) { return {p[0], p[1], p[2]}; }
+__device__ __forceinline__ Vec3 sub3(const Vec3 &a, const Vec3 &b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+__device__ __forceinline__ void store3(double *p, const Vec3 &a) { p[0] = a.x, p[1] = a.y, p[2] = a.z; }
+
+// q = (x, y, z, w): p + 2 (w (u x p) + u x (u x p))   (deodr/tools.py:8-22)
+__device__ __forceinline__ Vec3 qrot_point(const Vec3 &u, double w, const Vec3 &p)
+{
+	const Vec3 a = cross3(u, p), bb = cross3(u, a);
+	return {p.x + 2 * (w * a.x + bb.x), p.y + 2 * (w * a.y + bb.y), p.z + 2 * (w * a.z + bb.z)};
+}
+
+__device__ __forceinline__ void project_point(const CameraRow &c, const Vec3 &p, double &i, double &j, double &depth)
+{
+	const double cx = c.E[0] * p.x + c.E[1] * p.y + c.E[2] * p.z + c.E[3], cy = c.E[4] * p.x + c.E[5] * p.y + c.E[6] * p.z + c.E[7],
+				 cz = c.E[8] * p.x + c.E[9] * p.y + c.E[10] * p.z + c.E[11];
+	double x = cx / cz, y = cy / cz;
+	if (c.distort)
+	{
+		const double k1 = c.d[0], k2 = c.d[1], p1 = c.d[2], p2 = c.d[3], k3 = c.d[4];
+		const double x2 = x * x, y2 = y * y, r2 = x2 + y2, r4 = r2 * r2;
+		const double radial = 1 + k1 * r2 + k2 * r4 + k3 * (r2 * r4);
+		const double xd = x * radial + (2 * p1 * x * y + p2 * (r2 + 2 * x2)), yd = y * radial + (p1 * (r2 + 2 * y2) + 2 * p2 * x * y);
+		x = xd, y = yd;
+	}
+	i = c.K[0] * x + c.K[1] * y + c.K[2];
+	j = c.K[3] * x + c.K[4] * y + c.K[5];
+	depth = cz;
+}
+
+__device__ __forceinline__ Vec3 project_point_b(const CameraRow &c, const Vec3 &p, double g0, double g1, double gd)
+{ // (the same lines as project_points_b_kernel)
+	const double cx = c.E[0] * p.x + c.E[1] * p.y + c.E[2] * p.z + c.E[3], cy = c.E[4] * p.x + c.E[5] * p.y + c.E[6] * p.z + c.E[7],
+				 cz = c.E[8] * p.x + c.E[9] * p.y + c.E[10] * p.z + c.E[11];
+	const double x = cx / cz, y = cy / cz;
+	const double xd_b = c.K[0] * g0 + c.K[3] * g1, yd_b = c.K[1] * g0 + c.K[4] * g1;
+	double x_b = xd_b, y_b = yd_b;
+	if (c.distort)
+	{
+		const double k1 = c.d[0], k2 = c.d[1], p1 = c.d[2], p2 = c.d[3], k3 = c.d[4];
+		const double r2 = x * x + y * y, r4 = r2 * r2;
+		const double radial = 1 + k1 * r2 + k2 * r4 + k3 * (r2 * r4);
+		const double radial_b = x * xd_b + y * yd_b;
+		x_b = radial * xd_b + 2 * p1 * y * xd_b + 4 * p2 * x * xd_b + 2 * p2 * y * yd_b;
+		y_b = radial * yd_b + 2 * p1 * x * xd_b + 4 * p1 * y * yd_b + 2 * p2 * x * yd_b;
+		const double r2_b = p2 * xd_b + p1 * yd_b + radial_b * (k1 + 2 * k2 * r2 + 3 * k3 * r4);
+		x_b += 2 * x * r2_b;
+		y_b += 2 * y * r2_b;
+	}
+	const double cx_b = x_b / cz, cy_b = y_b / cz, cz_b = gd - (x * x_b + y * y_b) / cz;
+	return {c.E[0] * cx_b + c.E[4] * cy_b + c.E[8] * cz_b, c.E[1] * cx_b + c.E[5] * cy_b + c.E[9] * cz_b, c.E[2] * cx_b + c.E[6] * cy_b + c.E[10] * cz_b};
+}
+
+constexpr int FIT_MAX_VIEWS = 64; // views (poses) of one fit_pose_project_b call
+
+struct UnitQuaternion
+{
+	Vec3 u;
+	double w, norm;
+};
+__device__ __forceinline__ UnitQuaternion load_unit_quaternion(const double *q, int b)
+{
+	const double x = q[4 * b], y = q[4 * b + 1], z = q[4 * b + 2], w = q[4 * b + 3];
+	const double norm = sqrt(x * x + y * y + z * z + w * w);
+	return {{x / norm, y / norm, z / norm}, w / norm, norm};
+}
+
+// ---- forward: one thread per vertex walks the views.  vertices [V,3] are centred IN PLACE when `mean` is given (the reference
+// re-centres its vertices at the start of every step, mesh_fitter.py:131); quaternions are the raw parameters (normalised here)
+__global__ __launch_bounds__(FH_BLOCK) void fit_pose_project_kernel(double *vertices, const double *mean, const double *q, const double *t,
+																	 const double *extrinsic, const double *intrinsic, const double *distortion, double *posed,
+																	 double *ij, double *depths, int V, int n)
+{
+	const int v = blockIdx.x * FH_BLOCK + threadIdx.x;
+	if (v >= V)
+		return;
+	Vec3 c = load3(vertices + 3 * v);
+	if (mean)
+	{
+		c = sub3(c, load3(mean));
+		store3(vertices + 3 * v, c);
+	}
+	for (int b = 0; b < n; b++)
+	{
+		const UnitQuaternion uq = load_unit_quaternion(q, b);
+		const Vec3 p = add3(qrot_point(uq.u, uq.w, c), load3(t + 3 * b));
+		const size_t at = (size_t)b * V + v;
+		store3(posed + 3 * at, p);
+		const CameraRow cam = load_camera(extrinsic, intrinsic, distortion, b);
+		project_point(cam, p, ij[2 * at], ij[2 * at + 1], depths[at]);
+	}
+}
+
+// ---- adjoint.  posed_b (may be NULL): what the shading back-propagated to the posed vertices; ij_b, depths_b (may be NULL): the
+// rasterizer's.  -> vertices_b [V,3] (sum over the views), out[0..3) = column mean of vertices_b, then pose_b: quaternion adjoints
+// [n,4] (w.r.t. the RAW quaternions: through the normalisation) and translation adjoints [n,3].  partials: (7 n + 3) doubles per
+// workgroup.
+__global__ __launch_bounds__(FH_BLOCK) void fit_pose_project_b_kernel(const double *vertices, const double *q, const double *posed, const double *extrinsic,
+																	   const double *intrinsic, const double *distortion, const double *posed_b, const double *ij_b,
+																	   const double *depths_b, double *vertices_b, double *out, double *partials,
+																	   unsigned *counter, int V, int n)
+{
+	__shared__ double s_wave[FH_BLOCK / 64][7 * FIT_MAX_VIEWS + 3];
+	__shared__ double s_quat[FIT_MAX_VIEWS][4];
+	__shared__ int s_last;
+	const int v = blockIdx.x * FH_BLOCK + threadIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	const bool on = v < V;
+	const int K = 7 * n + 3;
+	double *mine = partials + (size_t)blockIdx.x * K;
+	const Vec3 c = on ? load3(vertices + 3 * v) : Vec3{0, 0, 0};
+	Vec3 acc = {0, 0, 0};
+	for (int b = 0; b < n; b++)
+	{
+		const UnitQuaternion uq = load_unit_quaternion(q, b);
+		Vec3 g = {0, 0, 0};
+		if (on)
+		{
+			const size_t at = (size_t)b * V + v;
+			const CameraRow cam = load_camera(extrinsic, intrinsic, distortion, b);
+			g = project_point_b(cam, load3(posed + 3 * at), ij_b[2 * at], ij_b[2 * at + 1], depths_b ? depths_b[at] : 0.0);
+			if (posed_b)
+				g = add3(g, load3(posed_b + 3 * at));
+		}
+		// r = c + 2 w a + 2 bb, a = u x c, bb = u x a   (deodr/tools.py:25-35)
+		const Vec3 &u = uq.u;
+		const Vec3 a = cross3(u, c);
+		const double w_b = 2 * dot3(g, a);
+		const Vec3 bb_b = scale3(2, g);
+		const Vec3 a_b = add3(scale3(2 * uq.w, g), cross3(bb_b, u));
+		const Vec3 u_b = add3(cross3(a, bb_b), cross3(c, a_b));
+		acc = add3(acc, add3(g, cross3(a_b, u)));
+		const double sums[7] = {u_b.x, u_b.y, u_b.z, w_b, g.x, g.y, g.z};
+#pragma unroll
+		for (int i = 0; i < 7; i++)
+		{
+			const double s = wave_sum(sums[i]); // (every lane takes part: lanes beyond V hold zeros)
+			if (lane == 0)
+				s_wave[wave][7 * b + i] = s;
+		}
+	}
+	if (on)
+		store3(vertices_b + 3 * v, acc);
+	{
+		const double sums[3] = {acc.x, acc.y, acc.z};
+#pragma unroll
+		for (int i = 0; i < 3; i++)
+		{
+			const double s = wave_sum(sums[i]);
+			if (lane == 0)
+				s_wave[wave][7 * n + i] = s;
+		}
+	}
+	__syncthreads();
+	for (int k = threadIdx.x; k < K; k += FH_BLOCK)
+	{
+		double s = 0;
+		for (int w = 0; w < FH_BLOCK / 64; w++)
+			s += s_wave[w][k];
+		mine[k] = s;
+	}
+	__threadfence();
+	__syncthreads();
+	if (threadIdx.x == 0)
+		s_last = atomicAdd(counter, 1u) == gridDim.x - 1;
+	__syncthreads();
+	if (!s_last)
+		return;
+	__threadfence();
+	double *pose_b = out + 3; // [n,4] then [n,3]
+	// wavefront w adds up the outputs w, w + 4, ...: its lanes share the workgroups' partials (lane l: l, l + 64, ...), then a DPP tree
+	for (int k = wave; k < K; k += FH_BLOCK / 64)
+	{
+		double s = 0;
+		for (unsigned blk = lane; blk < gridDim.x; blk += 64)
+			s += partials[(size_t)blk * K + k];
+		s = wave_sum(s);
+		if (lane != 0)
+			continue;
+		if (k >= 7 * n)
+			out[k - 7 * n] = s / V;
+		else if (k % 7 >= 4)
+			pose_b[4 * n + 3 * (k / 7) + (k % 7 - 4)] = s;
+		else
+			s_quat[k / 7][k % 7] = s; // (the quaternion needs its four sums together: below)
+	}
+	if (threadIdx.x == 0)
+		atomicExch(counter, 0u);
+	__syncthreads();
+	for (int b = threadIdx.x; b < n; b += FH_BLOCK)
+	{ // q = raw / |raw|:  raw_b = (q_b - q (q . q_b)) / |raw|
+		const UnitQuaternion uq = load_unit_quaternion(q, b);
+		const double g[4] = {s_quat[b][0], s_quat[b][1], s_quat[b][2], s_quat[b][3]};
+		const double qq[4] = {uq.u.x, uq.u.y, uq.u.z, uq.w};
+		const double along = g[0] * qq[0] + g[1] * qq[1] + g[2] * qq[2] + g[3] * qq[3];
+		for (int i = 0; i < 4; i++)
+			pose_b[4 * b + i] = (g[i] - qq[i] * along) / uq.norm;
+	}
+}
+
+// ---- shading.  vf_offsets [V+1], vf_corners [3T]: for every vertex the (3 face + corner) slots it occupies (static per mesh)
+struct FaceNormal
+{
+	Vec3 e1, e2, unit; // edges from corner 0, n / |n|
+	double len;
+	uint32_t i0, i1, i2;
+};
+__device__ __forceinline__ FaceNormal face_normal(const double *P, const uint32_t *faces, uint32_t f)
+{
+	FaceNormal r;
+	r.i0 = faces[3 * f], r.i1 = faces[3 * f + 1], r.i2 = faces[3 * f + 2];
+	const Vec3 p0 = load3(P + 3 * (size_t)r.i0);
+	r.e1 = sub3(load3(P + 3 * (size_t)r.i1), p0), r.e2 = sub3(load3(P + 3 * (size_t)r.i2), p0);
+	const Vec3 nn = cross3(r.e1, r.e2);
+	r.len = sqrt(dot3(nn, nn));
+	r.unit = {nn.x / r.len, nn.y / r.len, nn.z / r.len};
+	return r;
+}
+
+struct ShadeArgs
+{
+	const double *posed;	   // [n,V,3]
+	const uint32_t *faces;	   // [T,3]
+	const uint32_t *vf_offsets; // [V+1]
+	const uint32_t *vf_corners; // [3T]
+	const double *light;	   // [3] directional light
+	const double *ambient;	   // [1]
+	const double *color;	   // [C] one colour for the whole mesh, or NULL (luminosity only)
+	int C, V, n;
+	double sign; // -1: clockwise faces
+};
+
+// The gathers below give every list (the faces around a vertex, a row of L^T L) to GATHER_LANES adjacent lanes: one list entry is a
+// chain of dependent loads (slot -> vertex ids -> positions, ~1 us each on an idle chip), and a list of 6 - 20 entries walked by one
+// lane IS the kernel's duration (measured: 15 - 20 us per kernel, one lane per list).  Lane s takes the entries s, s + GATHER_LANES, ...
+// in order; the lanes' sums meet in a butterfly -- an order fixed by the list alone.
+constexpr int GATHER_LANES = 8;
+__device__ __forceinline__ double lanes_sum(double v)
+{ // all lanes of the wavefront call it; -> the sum over each group of GATHER_LANES adjacent lanes, in every lane of the group
+	v += __shfl_xor(v, 1);
+	v += __shfl_xor(v, 2);
+	v += __shfl_xor(v, 4);
+	return v;
+}
+__device__ __forceinline__ Vec3 lanes_sum3(const Vec3 &a) { return {lanes_sum(a.x), lanes_sum(a.y), lanes_sum(a.z)}; }
+
+// sign * sum of the unit normals of the faces around vertex v (`on` false: an empty list); in every lane of the group
+__device__ __forceinline__ Vec3 accumulated_normal(const ShadeArgs &a, const double *P, int v, int sub, bool on)
+{
+	Vec3 acc = {0, 0, 0};
+	const uint32_t begin = on ? a.vf_offsets[v] : 0, end = on ? a.vf_offsets[v + 1] : 0;
+	for (uint32_t k = begin + sub; k < end; k += GATHER_LANES)
+		acc = add3(acc, face_normal(P, a.faces, a.vf_corners[k] / 3).unit);
+	return scale3(a.sign, lanes_sum3(acc));
+}
+
+// grid: (V GATHER_LANES / FH_BLOCK, n)
+__global__ __launch_bounds__(FH_BLOCK) void vertex_shade_kernel(ShadeArgs a, double *lum_out, double *colors_out)
+{
+	const int t = blockIdx.x * FH_BLOCK + threadIdx.x, v = t / GATHER_LANES, sub = t % GATHER_LANES, b = blockIdx.y;
+	const bool on = v < a.V;
+	const Vec3 acc = accumulated_normal(a, a.posed + (size_t)b * a.V * 3, v, sub, on);
+	if (!on || sub != 0)
+		return;
+	const double len = sqrt(dot3(acc, acc));
+	const Vec3 N = {acc.x / len, acc.y / len, acc.z / len};
+	const double d = -dot3(N, load3(a.light));
+	const double lum = (d > 0 ? d : 0.0) + a.ambient[0];
+	const size_t at = (size_t)b * a.V + v;
+	if (lum_out)
+		lum_out[at] = lum;
+	if (colors_out)
+		for (int c = 0; c < a.C; c++)
+			colors_out[at * a.C + c] = a.color[c] * lum;
+}
+
+// b1: per (view, vertex), a 1-D grid over n V GATHER_LANES threads.  -> acc_b [n,V,3] (adjoint of the accumulated, not yet normalised,
+// normal), out[0..3) light_b, out[3] ambient_b, out[4..4+C) color_b  (C <= 3)
+__global__ __launch_bounds__(FH_BLOCK) void vertex_shade_b1_kernel(ShadeArgs a, const double *lum_b_in, const double *colors_b, double *acc_b, double *out,
+																	double *partials, unsigned *counter)
+{
+	const long long t = (long long)blockIdx.x * FH_BLOCK + threadIdx.x, at = t / GATHER_LANES;
+	const int sub = (int)(t % GATHER_LANES);
+	const bool on = at < (long long)a.n * a.V;
+	const int b = on ? (int)(at / a.V) : 0, v = on ? (int)(at % a.V) : 0;
+	const Vec3 acc = accumulated_normal(a, a.posed + (size_t)b * a.V * 3, v, sub, on);
+	double sums[7] = {0, 0, 0, 0, 0, 0, 0};
+	if (on && sub == 0)
+	{
+		const double len = sqrt(dot3(acc, acc));
+		const Vec3 N = {acc.x / len, acc.y / len, acc.z / len}, L = load3(a.light);
+		const double d = -dot3(N, L);
+		const double lum = (d > 0 ? d : 0.0) + a.ambient[0];
+		double lum_b = lum_b_in ? lum_b_in[at] : 0.0;
+		if (colors_b)
+			for (int c = 0; c < a.C; c++)
+			{
+				const double g = colors_b[at * a.C + c];
+				lum_b += g * a.color[c];
+				sums[4 + c] = g * lum;
+			}
+		const double d_b = d > 0 ? lum_b : 0.0;
+		sums[0] = -N.x * d_b, sums[1] = -N.y * d_b, sums[2] = -N.z * d_b, sums[3] = lum_b;
+		const Vec3 N_b = scale3(-d_b, L);
+		const double along = dot3(N, N_b);
+		store3(acc_b + 3 * at, {(N_b.x - N.x * along) / len, (N_b.y - N.y * along) / len, (N_b.z - N.z * along) / len});
+	}
+	double total[7];
+	if (grid_sum<7>(sums, partials, counter, total) && threadIdx.x < 4 + a.C)
+		out[threadIdx.x] = total[threadIdx.x];
+}
+
+// b2: posed_b[b][v] = sum over the faces around v of the adjoint of that face's corner (a gather: every element written once);
+// grid: (V GATHER_LANES / FH_BLOCK, n)
+__global__ __launch_bounds__(FH_BLOCK) void vertex_shade_b2_kernel(ShadeArgs a, const double *acc_b, double *posed_b)
+{
+	const int t = blockIdx.x * FH_BLOCK + threadIdx.x, v = t / GATHER_LANES, sub = t % GATHER_LANES, b = blockIdx.y;
+	const bool on = v < a.V;
+	const double *P = a.posed + (size_t)b * a.V * 3, *A = acc_b + (size_t)b * a.V * 3;
+	Vec3 g = {0, 0, 0};
+	const uint32_t begin = on ? a.vf_offsets[v] : 0, end = on ? a.vf_offsets[v + 1] : 0;
+	for (uint32_t k = begin + sub; k < end; k += GATHER_LANES)
+	{
+		const uint32_t slot = a.vf_corners[k], f = slot / 3, corner = slot % 3;
+		const FaceNormal fn = face_normal(P, a.faces, f);
+		const Vec3 unit_b = scale3(a.sign, add3(add3(load3(A + 3 * (size_t)fn.i0), load3(A + 3 * (size_t)fn.i1)), load3(A + 3 * (size_t)fn.i2)));
+		const double along = dot3(fn.unit, unit_b);
+		const Vec3 n_b = {(unit_b.x - fn.unit.x * along) / fn.len, (unit_b.y - fn.unit.y * along) / fn.len, (unit_b.z - fn.unit.z * along) / fn.len};
+		const Vec3 e1_b = cross3(fn.e2, n_b), e2_b = cross3(n_b, fn.e1); // n = e1 x e2
+		g = add3(g, corner == 0 ? scale3(-1, add3(e1_b, e2_b)) : corner == 1 ? e1_b : e2_b);
+	}
+	g = lanes_sum3(g);
+	if (on && sub == 0)
+		store3(posed_b + ((size_t)b * a.V + v) * 3, g);
+}
+
+// ---- rigid energy over a CSR of M = L^T L: grad = c M (x - ref), energy[0] = 0.5 (x - ref) . grad; with a data term at hand,
+// energy[1] = data_weight * data_energy[0] + energy[0] (what a fitter's step reports, mesh_fitter.py:147).  grid: V GATHER_LANES / FH_BLOCK
+__global__ __launch_bounds__(FH_BLOCK) void rigid_energy_kernel(const double *x, const double *ref, const uint32_t *offsets, const uint32_t *cols,
+																 const double *vals, double cregu, double *grad, double *energy, const double *data_energy,
+																 double data_weight, double *partials, unsigned *counter, int V)
+{
+	const int t = blockIdx.x * FH_BLOCK + threadIdx.x, v = t / GATHER_LANES, sub = t % GATHER_LANES;
+	const bool on = v < V;
+	Vec3 g = {0, 0, 0};
+	const uint32_t begin = on ? offsets[v] : 0, end = on ? offsets[v + 1] : 0;
+	for (uint32_t k = begin + sub; k < end; k += GATHER_LANES)
+	{
+		const size_t j = cols[k];
+		g = add3(g, scale3(vals[k], sub3(load3(x + 3 * j), load3(ref + 3 * j))));
+	}
+	g = scale3(cregu, lanes_sum3(g));
+	double e[1] = {0};
+	if (on && sub == 0)
+	{
+		store3(grad + 3 * (size_t)v, g);
+		e[0] = 0.5 * dot3(sub3(load3(x + 3 * (size_t)v), load3(ref + 3 * (size_t)v)), g);
+	}
+	double total[1];
+	if (grid_sum<1>(e, partials, counter, total) && threadIdx.x == 0)
+	{
+		energy[0] = total[0];
+		if (data_energy)
+			energy[1] = data_weight * data_energy[0] + total[0];
+	}
+}
+
+// ---- sum (image - obs)^2 over a frame batch in the pixel type PixT, accumulated in double: the data energy of the colour fitters
+// (mesh_fitter.py:296-318); the rasterizer's fit step back-propagates exactly this residual.  One partial per workgroup, fixed order.
+constexpr int L2_BLOCKS = 2048;
+template <class PixT>
+__global__ __launch_bounds__(FH_BLOCK) void l2_loss_kernel(const PixT *image, const PixT *obs, size_t count, double *out, double *partials, unsigned *counter)
+{
+	constexpr int W = 32 / sizeof(PixT); // 32 bytes of each array per thread and round
+	struct alignas(32) Chunk
+	{
+		PixT v[W];
+	};
+	double s[1] = {0};
+	const size_t chunks = count / W;
+	for (size_t i = (size_t)blockIdx.x * FH_BLOCK + threadIdx.x; i < chunks; i += (size_t)gridDim.x * FH_BLOCK)
+	{
+		const Chunk a = ((const Chunk *)image)[i], b = ((const Chunk *)obs)[i];
+#pragma unroll
+		for (int j = 0; j < W; j++)
+		{
+			const double r = (double)a.v[j] - (double)b.v[j];
+			s[0] += r * r;
+		}
+	}
+	if (blockIdx.x == 0 && threadIdx.x < count - chunks * W)
+	{
+		const double r = (double)image[chunks * W + threadIdx.x] - (double)obs[chunks * W + threadIdx.x];
+		s[0] += r * r;
+	}
+	double total[1];
+	if (grid_sum<1>(s, partials, counter, total) && threadIdx.x == 0)
+		out[0] = total[0];
+}
+
+} // namespace

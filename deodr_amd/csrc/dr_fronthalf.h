@@ -32,6 +32,71 @@ __device__ __forceinline__ double dot3(const Vec3 &a, const Vec3 &b) { return a.
 
 constexpr int FH_BLOCK = 256;
 
+// ---- grid-wide sums without atomics on the values.  Every thread of every workgroup of a launch whose blockIdx.x runs over the
+// reduced range brings K values; `partials` holds K doubles per workgroup, `counter` one word that is zero between launches (the last
+// workgroup to arrive resets it).  -> true in ALL threads of the last workgroup, whose total[] then holds the sums (in workgroup order).
+// Deterministic grid-wide sums without atomics on the values.  Every thread of every workgroup of a launch (blockIdx.x over the reduced
+// range) brings K values; `partials` holds K doubles per workgroup, `counter` one word that is zero between launches (the last
+// workgroup to arrive resets it).  -> true in ALL threads of the last workgroup, whose total[] then holds the sums: the partial of
+// workgroup i is added by thread i mod FH_BLOCK in the order i, i + FH_BLOCK, ...; then the lanes of a wavefront (DPP tree), then
+// the wavefronts in order -- fixed by the launch geometry alone.
+template <int K>
+__device__ __forceinline__ bool grid_sum(const double (&v)[K], double *partials, unsigned *counter, double (&total)[K])
+{
+	__shared__ double s_wave[FH_BLOCK / 64][K];
+	__shared__ int s_last;
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+	for (int k = 0; k < K; k++)
+	{
+		const double s = wave_sum(v[k]);
+		if (lane == 0)
+			s_wave[wave][k] = s;
+	}
+	__syncthreads();
+	if (threadIdx.x < K)
+	{
+		double s = 0;
+		for (int w = 0; w < FH_BLOCK / 64; w++)
+			s += s_wave[w][threadIdx.x];
+		partials[(size_t)blockIdx.x * K + threadIdx.x] = s;
+		__threadfence(); // release: the partial is visible to the device before this workgroup takes its ticket
+	}
+	__syncthreads();
+	if (threadIdx.x == 0)
+		s_last = atomicAdd(counter, 1u) == gridDim.x - 1;
+	__syncthreads();
+	if (!s_last)
+		return false;
+	__threadfence(); // acquire: the loads below see every workgroup's partial
+	double mine[K];
+#pragma unroll
+	for (int k = 0; k < K; k++)
+		mine[k] = 0;
+	for (unsigned i = threadIdx.x; i < gridDim.x; i += FH_BLOCK)
+#pragma unroll
+		for (int k = 0; k < K; k++)
+			mine[k] += partials[(size_t)i * K + k];
+#pragma unroll
+	for (int k = 0; k < K; k++)
+	{
+		const double s = wave_sum(mine[k]);
+		if (lane == 0)
+			s_wave[wave][k] = s; // (every thread is past its reads of s_wave: the barriers above)
+	}
+	__syncthreads();
+#pragma unroll
+	for (int k = 0; k < K; k++)
+	{
+		total[k] = 0;
+		for (int w = 0; w < FH_BLOCK / 64; w++)
+			total[k] += s_wave[w][k];
+	}
+	if (threadIdx.x == 0)
+		atomicExch(counter, 0u);
+	return true;
+}
+
 // ---- rigid transform: out[b][v] = qrot(q[b], v[v]) + t[b]   (q = (x, y, z, w), unit)
 __global__ __launch_bounds__(FH_BLOCK) void rigid_transform_kernel(const double *vc, const double *q, const double *t, double *out, int V, int n)
 {
@@ -201,22 +266,37 @@ __global__ __launch_bounds__(FH_BLOCK) void silhouette_flags_kernel(const double
 	}
 }
 
-// ---- momentum update of up to MOMENTUM_MAX parameter tensors in one launch
+// ---- momentum update of up to MOMENTUM_MAX parameter tensors in one launch, IN PLACE
 constexpr int MOMENTUM_MAX = 8;
 struct MomentumArgs
 {
 	double *x[MOMENTUM_MAX], *speed[MOMENTUM_MAX];
-	const double *grad[MOMENTUM_MAX], *grad2[MOMENTUM_MAX]; // grad2: optional second gradient added to the first (rigid energy)
-	double factor[MOMENTUM_MAX], step_max[MOMENTUM_MAX];		// step_max <= 0: no clamp
-	int count[MOMENTUM_MAX], normalize_rows[MOMENTUM_MAX];	// normalize_rows = row length: rows of x renormalised afterwards (quaternions)
+	const double *grad[MOMENTUM_MAX], *grad2[MOMENTUM_MAX]; // the step follows -(grad_scale (grad - grad_mean) + grad2): grad2 = the rigid energy's
+	const double *grad_mean[MOMENTUM_MAX];					// optional [3]: subtracted from every row of a [count/3, 3] gradient (zero-mean projection)
+	double *mean_out[MOMENTUM_MAX];							// optional [3]: column mean of the updated [count/3, 3] tensor (next step's centring)
+	double grad_scale[MOMENTUM_MAX], factor[MOMENTUM_MAX], step_max[MOMENTUM_MAX]; // step_max <= 0: no clamp
+	int count[MOMENTUM_MAX], normalize_rows[MOMENTUM_MAX]; // normalize_rows = row length: rows of x renormalised afterwards (quaternions)
 	int n;
 	double inertia, damping;
+	double *partials; // 3 doubles per workgroup and tensor (mean_out)
+	unsigned *counters; // one word per tensor
 };
+__device__ __forceinline__ double momentum_step(const MomentumArgs &a, int k, int at, int column)
+{
+	double g = a.grad[k][at];
+	if (a.grad_mean[k])
+		g -= a.grad_mean[k][column];
+	g = g * a.grad_scale[k] + (a.grad2[k] ? a.grad2[k][at] : 0.0);
+	double step = -g * a.factor[k];
+	if (a.step_max[k] > 0)
+		step = fmin(fmax(step, -a.step_max[k]), a.step_max[k]);
+	const double s = (1 - a.damping) * (a.speed[k][at] * a.inertia + (1 - a.inertia) * step);
+	a.speed[k][at] = s;
+	return s;
+}
 __global__ __launch_bounds__(FH_BLOCK) void momentum_update_kernel(MomentumArgs a)
 {
 	const int k = blockIdx.y;
-	if (k >= a.n)
-		return;
 	const int i = blockIdx.x * FH_BLOCK + threadIdx.x;
 	const int rows = a.normalize_rows[k];
 	if (rows > 0)
@@ -228,12 +308,7 @@ __global__ __launch_bounds__(FH_BLOCK) void momentum_update_kernel(MomentumArgs 
 		for (int j = 0; j < rows; j++)
 		{
 			const int at = i * rows + j;
-			double step = -(a.grad[k][at] + (a.grad2[k] ? a.grad2[k][at] : 0.0)) * a.factor[k];
-			if (a.step_max[k] > 0)
-				step = fmin(fmax(step, -a.step_max[k]), a.step_max[k]);
-			const double s = (1 - a.damping) * (a.speed[k][at] * a.inertia + (1 - a.inertia) * step);
-			a.speed[k][at] = s;
-			const double xn = a.x[k][at] + s;
+			const double xn = a.x[k][at] + momentum_step(a, k, at, 0);
 			a.x[k][at] = xn;
 			norm2 += xn * xn;
 		}
@@ -242,14 +317,18 @@ __global__ __launch_bounds__(FH_BLOCK) void momentum_update_kernel(MomentumArgs 
 			a.x[k][i * rows + j] *= inv;
 		return;
 	}
-	if (i >= a.count[k])
-		return;
-	double step = -(a.grad[k][i] + (a.grad2[k] ? a.grad2[k][i] : 0.0)) * a.factor[k];
-	if (a.step_max[k] > 0)
-		step = fmin(fmax(step, -a.step_max[k]), a.step_max[k]);
-	const double s = (1 - a.damping) * (a.speed[k][i] * a.inertia + (1 - a.inertia) * step);
-	a.speed[k][i] = s;
-	a.x[k][i] += s;
+	double col[3] = {0, 0, 0};
+	if (i < a.count[k])
+	{
+		const double xn = a.x[k][i] + momentum_step(a, k, i, i % 3);
+		a.x[k][i] = xn;
+		col[i % 3] = xn;
+	}
+	if (!a.mean_out[k])
+		return; // (uniform per workgroup row)
+	double total[3];
+	if (grid_sum<3>(col, a.partials + (size_t)k * gridDim.x * 3, a.counters + k, total) && threadIdx.x < 3)
+		a.mean_out[k][threadIdx.x] = total[threadIdx.x] / (a.count[k] / 3);
 }
 
 } // namespace

@@ -45,7 +45,7 @@
 #include <vector>
 
 #include "../../include/deodr_hip.h"
-#include "dr_fronthalf.h" // <- dr_finalize.h <- dr_backward.h <- dr_backward_generic.h <- dr_forward.h <- dr_forward_generic.h <- dr_setup.h <- dr_workspace.h <- dr_prims.h
+#include "dr_fititer.h" // <- dr_finalize.h <- dr_backward.h <- dr_backward_generic.h <- dr_forward.h <- dr_forward_generic.h <- dr_setup.h <- dr_workspace.h <- dr_prims.h
 
 using namespace dr;
 
@@ -603,8 +603,37 @@ int deodr_hip_silhouette_flags(const double *ij, const uint32_t *faces, const ui
 	return check_hip(hipGetLastError(), "silhouette_flags launch");
 }
 
+// scratch of the fit-iteration kernels: 16 counter words (zero between launches: allocate zero-filled once), then doubles
+static size_t fh_blocks(long long count) { return (size_t)((count + FH_BLOCK - 1) / FH_BLOCK); }
+static size_t fit_scratch_need_pose_b(int V, int n) { return 64 + 8 * fh_blocks(V) * (size_t)(7 * n + 3); }
+static size_t fit_scratch_need_shade_b(int V, int n) { return 64 + 8 * (3 * (size_t)n * V + 7 * fh_blocks((long long)n * V * GATHER_LANES)); }
+static size_t fit_scratch_need_rigid(int V) { return 64 + 8 * fh_blocks((long long)V * GATHER_LANES); }
+static size_t fit_scratch_need_l2(void) { return 64 + 8 * (size_t)L2_BLOCKS; }
+static size_t fit_scratch_need_momentum(int most) { return 64 + 8 * (size_t)MOMENTUM_MAX * 3 * fh_blocks(most); }
+enum FitCounter
+{
+	FC_POSE_B = 0,
+	FC_SHADE_B = 1,
+	FC_RIGID = 2,
+	FC_L2 = 3,
+	FC_MOMENTUM = 4 // ... + MOMENTUM_MAX
+};
+
+size_t deodr_hip_fit_scratch_bytes(int V, int n)
+{
+	if (V <= 0 || n <= 0)
+		return 0;
+	size_t need = fit_scratch_need_pose_b(V, n);
+	const size_t others[4] = {fit_scratch_need_shade_b(V, n), fit_scratch_need_rigid(V), fit_scratch_need_momentum(3 * V > 7 * n ? 3 * V : 7 * n),
+							  fit_scratch_need_l2()};
+	for (size_t o : others)
+		need = o > need ? o : need;
+	return need;
+}
+
 int deodr_hip_momentum_update(int n_tensors, double *const *x, double *const *speed, const double *const *grad, const double *const *grad2,
 							  const double *factor, const double *step_max, const int *count, const int *normalize_rows, double inertia, double damping,
+							  const double *grad_scale, const double *const *grad_mean, double *const *mean_out, void *scratch, size_t scratch_bytes,
 							  void *stream)
 {
 	if (n_tensors <= 0 || n_tensors > MOMENTUM_MAX || !x || !speed || !grad || !factor || !step_max || !count)
@@ -612,17 +641,127 @@ int deodr_hip_momentum_update(int n_tensors, double *const *x, double *const *sp
 	MomentumArgs a;
 	memset(&a, 0, sizeof a);
 	int most = 0;
+	bool means = false;
 	for (int k = 0; k < n_tensors; k++)
 	{
 		if (!x[k] || !speed[k] || !grad[k] || count[k] <= 0)
 			return fail("momentum_update: NULL tensor");
 		a.x[k] = x[k], a.speed[k] = speed[k], a.grad[k] = grad[k], a.grad2[k] = grad2 ? grad2[k] : nullptr;
 		a.factor[k] = factor[k], a.step_max[k] = step_max[k], a.count[k] = count[k], a.normalize_rows[k] = normalize_rows ? normalize_rows[k] : 0;
+		a.grad_scale[k] = grad_scale ? grad_scale[k] : 1.0;
+		a.grad_mean[k] = grad_mean ? grad_mean[k] : nullptr;
+		a.mean_out[k] = mean_out ? mean_out[k] : nullptr;
+		if ((a.grad_mean[k] || a.mean_out[k]) && (count[k] % 3 || a.normalize_rows[k]))
+			return fail("momentum_update: grad_mean / mean_out are for [count/3, 3] tensors without row normalisation");
+		means = means || a.mean_out[k];
 		most = count[k] > most ? count[k] : most;
 	}
+	if (means && (!scratch || scratch_bytes < fit_scratch_need_momentum(most)))
+		return fail("momentum_update: mean_out needs the fit scratch (deodr_hip_fit_scratch_bytes)");
 	a.n = n_tensors, a.inertia = inertia, a.damping = damping;
+	a.counters = scratch ? (unsigned *)scratch + FC_MOMENTUM : nullptr;
+	a.partials = scratch ? (double *)((char *)scratch + 64) : nullptr;
 	hipLaunchKernelGGL(momentum_update_kernel, dim3((most + FH_BLOCK - 1) / FH_BLOCK, n_tensors), dim3(FH_BLOCK), 0, (hipStream_t)stream, a);
 	return check_hip(hipGetLastError(), "momentum_update launch");
+}
+
+int deodr_hip_fit_pose_project(double *vertices, const double *vertices_mean, const double *quaternions, const double *translations, const double *extrinsic,
+							   const double *intrinsic, const double *distortion, double *posed, double *ij, double *depths, int V, int n, void *stream)
+{
+	if (!vertices || !quaternions || !translations || !extrinsic || !intrinsic || !posed || !ij || !depths || V <= 0 || n <= 0)
+		return fail("fit_pose_project: bad arguments");
+	hipLaunchKernelGGL(fit_pose_project_kernel, dim3(fh_blocks(V)), dim3(FH_BLOCK), 0, (hipStream_t)stream, vertices, vertices_mean, quaternions, translations,
+					   extrinsic, intrinsic, distortion, posed, ij, depths, V, n);
+	return check_hip(hipGetLastError(), "fit_pose_project launch");
+}
+
+int deodr_hip_fit_pose_project_b(const double *vertices, const double *quaternions, const double *posed, const double *extrinsic, const double *intrinsic,
+								 const double *distortion, const double *posed_b, const double *ij_b, const double *depths_b, double *vertices_b, double *out,
+								 void *scratch, size_t scratch_bytes, int V, int n, void *stream)
+{
+	if (!vertices || !quaternions || !posed || !extrinsic || !intrinsic || !ij_b || !vertices_b || !out || V <= 0 || n <= 0)
+		return fail("fit_pose_project_b: bad arguments");
+	if (n > FIT_MAX_VIEWS)
+		return fail("fit_pose_project_b: at most 64 views per call");
+	if (!scratch || scratch_bytes < fit_scratch_need_pose_b(V, n))
+		return fail("fit_pose_project_b: scratch too small (deodr_hip_fit_scratch_bytes)");
+	hipLaunchKernelGGL(fit_pose_project_b_kernel, dim3(fh_blocks(V)), dim3(FH_BLOCK), 0, (hipStream_t)stream, vertices, quaternions, posed, extrinsic, intrinsic,
+					   distortion, posed_b, ij_b, depths_b, vertices_b, out, (double *)((char *)scratch + 64), (unsigned *)scratch + FC_POSE_B, V, n);
+	return check_hip(hipGetLastError(), "fit_pose_project_b launch");
+}
+
+static int shade_args(ShadeArgs &a, const double *posed, const uint32_t *faces, const uint32_t *vf_offsets, const uint32_t *vf_corners, const double *light,
+					  const double *ambient, const double *color, int C, int V, int n, int clockwise)
+{
+	if (!posed || !faces || !vf_offsets || !vf_corners || !light || !ambient || V <= 0 || n <= 0 || (color && (C < 1 || C > 3)))
+		return fail("vertex_shade: bad arguments (one colour of 1 - 3 channels, or none)");
+	a = ShadeArgs{posed, faces, vf_offsets, vf_corners, light, ambient, color, color ? C : 0, V, n, clockwise ? -1.0 : 1.0};
+	return 0;
+}
+
+int deodr_hip_vertex_shade(const double *posed, const uint32_t *faces, const uint32_t *vf_offsets, const uint32_t *vf_corners, const double *light,
+						   const double *ambient, const double *color, int C, double *luminosity, double *colors, int V, int n, int clockwise, void *stream)
+{
+	ShadeArgs a;
+	if (shade_args(a, posed, faces, vf_offsets, vf_corners, light, ambient, color, C, V, n, clockwise))
+		return 1;
+	if ((!luminosity && !colors) || (colors && !color))
+		return fail("vertex_shade: nothing to write, or colours asked for without a colour");
+	hipLaunchKernelGGL(vertex_shade_kernel, dim3(fh_blocks((long long)V * GATHER_LANES), n), dim3(FH_BLOCK), 0, (hipStream_t)stream, a, luminosity, colors);
+	return check_hip(hipGetLastError(), "vertex_shade launch");
+}
+
+int deodr_hip_vertex_shade_b(const double *posed, const uint32_t *faces, const uint32_t *vf_offsets, const uint32_t *vf_corners, const double *light,
+							 const double *ambient, const double *color, int C, const double *luminosity_b, const double *colors_b, double *posed_b, double *out,
+							 void *scratch, size_t scratch_bytes, int V, int n, int clockwise, void *stream)
+{
+	ShadeArgs a;
+	if (shade_args(a, posed, faces, vf_offsets, vf_corners, light, ambient, color, C, V, n, clockwise))
+		return 1;
+	if ((!luminosity_b && !colors_b) || (colors_b && !color) || !posed_b || !out)
+		return fail("vertex_shade_b: bad arguments");
+	if (!scratch || scratch_bytes < fit_scratch_need_shade_b(V, n))
+		return fail("vertex_shade_b: scratch too small (deodr_hip_fit_scratch_bytes)");
+	hipStream_t st = (hipStream_t)stream;
+	double *acc_b = (double *)((char *)scratch + 64), *partials = acc_b + 3 * (size_t)n * V;
+	hipLaunchKernelGGL(vertex_shade_b1_kernel, dim3(fh_blocks((long long)n * V * GATHER_LANES)), dim3(FH_BLOCK), 0, st, a, luminosity_b, colors_b, acc_b, out, partials,
+					   (unsigned *)scratch + FC_SHADE_B);
+	hipLaunchKernelGGL(vertex_shade_b2_kernel, dim3(fh_blocks((long long)V * GATHER_LANES), n), dim3(FH_BLOCK), 0, st, a, (const double *)acc_b, posed_b);
+	return check_hip(hipGetLastError(), "vertex_shade_b launch");
+}
+
+int deodr_hip_rigid_energy(const double *vertices, const double *vertices_ref, const uint32_t *m_offsets, const uint32_t *m_cols, const double *m_vals,
+						   double cregu, double *gradient, double *energy, const double *data_energy, double data_weight, void *scratch, size_t scratch_bytes,
+						   int V, void *stream)
+{
+	if (!vertices || !vertices_ref || !m_offsets || !m_cols || !m_vals || !gradient || !energy || V <= 0)
+		return fail("rigid_energy: bad arguments");
+	if (!scratch || scratch_bytes < fit_scratch_need_rigid(V))
+		return fail("rigid_energy: scratch too small (deodr_hip_fit_scratch_bytes)");
+	hipLaunchKernelGGL(rigid_energy_kernel, dim3(fh_blocks((long long)V * GATHER_LANES)), dim3(FH_BLOCK), 0, (hipStream_t)stream, vertices, vertices_ref, m_offsets, m_cols, m_vals, cregu,
+					   gradient, energy, data_energy, data_weight, (double *)((char *)scratch + 64), (unsigned *)scratch + FC_RIGID, V);
+	return check_hip(hipGetLastError(), "rigid_energy launch");
+}
+
+int deodr_hip_l2_loss(const void *image, const void *obs, int pixel_dtype, size_t count, double *out, void *scratch, size_t scratch_bytes, void *stream)
+{
+	if (!image || !obs || !out || count == 0 || (pixel_dtype != DEODR_HIP_F32 && pixel_dtype != DEODR_HIP_F64))
+		return fail("l2_loss: bad arguments");
+	if (!scratch || scratch_bytes < fit_scratch_need_l2())
+		return fail("l2_loss: scratch too small (deodr_hip_fit_scratch_bytes)");
+	if (((uintptr_t)image | (uintptr_t)obs) & 31)
+		return fail("l2_loss: image and obs must be 32-byte aligned");
+	const size_t want = (count + FH_BLOCK * 8 - 1) / (FH_BLOCK * 8);
+	const dim3 grid((unsigned)(want < (size_t)L2_BLOCKS ? want : (size_t)L2_BLOCKS));
+	double *partials = (double *)((char *)scratch + 64);
+	unsigned *counter = (unsigned *)scratch + FC_L2;
+	if (pixel_dtype == DEODR_HIP_F64)
+		hipLaunchKernelGGL(l2_loss_kernel<double>, grid, dim3(FH_BLOCK), 0, (hipStream_t)stream, (const double *)image, (const double *)obs, count, out, partials,
+						   counter);
+	else
+		hipLaunchKernelGGL(l2_loss_kernel<float>, grid, dim3(FH_BLOCK), 0, (hipStream_t)stream, (const float *)image, (const float *)obs, count, out, partials,
+						   counter);
+	return check_hip(hipGetLastError(), "l2_loss launch");
 }
 
 #ifdef DR_WAVE_TRACE

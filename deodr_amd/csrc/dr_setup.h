@@ -95,7 +95,6 @@ constexpr int PRIM_BLOCK = DR_PRIM_BLOCK;
 #ifndef DR_PRIM_WAVES
 #define DR_PRIM_WAVES 3 // waves per SIMD the per-primitive kernels are compiled for (4: spills, same time)
 #endif
-constexpr int COOP_BLOCKS = 8; // 3 x 3-tile blocks of a bounding box one thread bins by itself
 
 __host__ __device__ inline int prim_tri_blocks(int T) { return (T + PRIM_BLOCK - 1) / PRIM_BLOCK; }
 __host__ __device__ inline int prim_blocks(int T) { return prim_tri_blocks(T) + (3 * T + PRIM_BLOCK - 1) / PRIM_BLOCK; }
@@ -260,40 +259,72 @@ __global__ __launch_bounds__(PRIM_BLOCK, DR_PRIM_WAVES) void setup_bin_kernel(KP
 	// Records are built in registers and leave with one 128-byte store: the binning below reads the local copy (reading a
 	// record back from HBM right after writing it costs a full memory round trip per field), a culled triangle only gets its two
 	// flags written, an edge slot that is not a silhouette edge nothing at all.
-	// A primitive whose bounding box needs more than COOP_BLOCKS blocks of 3 x 3 tiles is not binned by its own thread
-	// (hundreds of dependent atomic round trips in one lane: 0.3 ms of set-up for a 1 000-triangle mesh filling a 1024^2
-	// frame) but handed to the whole wavefront below: its half-planes and box are kept here.  Smaller ones stay with their
-	// thread (all threads at once beat the wavefront working through its large primitives one after the other).
+	// A thread bins the first 3 x 3 block of tiles of its primitive itself (for the usual small triangle: all of it).  The other
+	// blocks of all the primitives of the wavefront are dealt out evenly over its 64 lanes, nine slot requests per lane and round:
+	// a lane working through a wide bounding box alone is a chain of dependent atomic round trips of ~2.5 us each -- the hand mesh
+	// at 1024^2 (1 048 triangles of 33 tiles on average, 17 wavefronts on the whole chip) spent 68 us of set-up that way, up to 8
+	// rounds per lane plus the wavefront walking its 9 largest boxes one after the other.
 	const int lane = threadIdx.x & 63;
-	// ---- the large primitives of this wavefront, one after the other, 64 tiles of the bounding box at a time
-	auto bin_large = [&](bool big, const double *hp, int btx0, int bty0, int bntx, int bnty, int bprim) {
-		unsigned long long todo = __ballot(big);
-		while (todo)
+	auto bin_rest = [&](int extra, bool first_done, const double *hp, int btx0, int bty0, int bntx, int bnty, int bprim) {
+		if (__ballot(extra > 0) == 0)
+			return;
+		int incl = extra; // inclusive scan over the lanes
+#pragma unroll
+		for (int d = 1; d < 64; d <<= 1)
 		{
-			const int src = __ffsll((long long)todo) - 1;
-			todo &= todo - 1;
+			const int up = __shfl_up(incl, d, 64);
+			incl += lane >= d ? up : 0;
+		}
+		const int total = __shfl(incl, 63, 64);
+		for (int base = 0; base < total; base += 64)
+		{
+			const int item = base + lane;
+			int owner = 0; // first lane whose inclusive count exceeds item (lanes past the end: any lane, nothing is written)
+#pragma unroll
+			for (int step = 32; step; step >>= 1)
+				owner += __shfl(incl, owner + step - 1, 64) <= item ? step : 0;
+			owner = owner > 63 ? 63 : owner;
+			const int before = __shfl(incl - extra, owner, 64);
+			const bool valid = item < total;
 			double q[12];
 #pragma unroll
 			for (int i = 0; i < 12; i++)
-				q[i] = __shfl(hp[i], src, 64);
-			const int tx0 = __shfl(btx0, src, 64), ty0 = __shfl(bty0, src, 64), ntx = __shfl(bntx, src, 64), nty = __shfl(bnty, src, 64);
-			const uint32_t prim = (uint32_t)__shfl(bprim, src, 64);
-			for (int t = lane; t < ntx * nty; t += 64)
+				q[i] = (tri_block && i >= 9) ? 0.0 : __shfl(hp[i], owner, 64);
+			const int tx0 = __shfl(btx0, owner, 64), ty0 = __shfl(bty0, owner, 64), ntx = __shfl(bntx, owner, 64), nty = __shfl(bnty, owner, 64);
+			const uint32_t prim = (uint32_t)__shfl(bprim, owner, 64);
+			if (!valid)
+				continue;
+			const int nbx = (ntx + 2) / 3, blk = item - before + (first_done ? 1 : 0);
+			const int bx = (blk % nbx) * 3, by = (blk / nbx) * 3;
+			const int keep_dx = (tri_block && !p.strict) ? ntx - 1 : -1; // (non-strict fill rule: see the first block below)
+			const uint32_t outside = tri_block ? tiles3x3_outside_halfplanes<3>(q, tx0 + bx, ty0 + by) : tiles3x3_outside_halfplanes<4>(q, tx0 + bx, ty0 + by);
+			uint32_t *cnt = tri_block ? w.tri_cnt : w.edge_cnt;
+			uint32_t got[9];
+			bool use[9];
+#pragma unroll
+			for (int c = 0; c < 9; c++)
 			{
-				const int tx = tx0 + t % ntx, ty = ty0 + t / ntx, tile = ty * p.L.tiles_x + tx;
-				if (tri_block)
-				{
-					if (!tile_outside_halfplanes<3>(q, tx, ty) || (!p.strict && tx == tx0 + ntx - 1))
-						push_tile(w.tri_cnt, w.tri_list, K_TRI, w.tri_pool, p.L.tri_pool_cap, &w.hdr->tri_spill[cur], tile, prim);
-				}
-				else if (!tile_outside_halfplanes<4>(q, tx, ty))
-					push_tile(w.edge_cnt, w.edge_list, K_EDGE, w.edge_pool, p.L.edge_pool_cap, &w.hdr->edge_spill[cur], tile, prim);
+				const int dx = bx + c % 3, dy = by + c / 3;
+				use[c] = dx < ntx && dy < nty && (!((outside >> c) & 1u) || dx == keep_dx);
+				got[c] = 0;
+				if (use[c])
+					got[c] = atomicAdd(&cnt[(ty0 + dy) * p.L.tiles_x + tx0 + dx], 1u);
 			}
+#pragma unroll
+			for (int c = 0; c < 9; c++)
+				if (use[c])
+				{
+					const int tile = (ty0 + by + c / 3) * p.L.tiles_x + tx0 + bx + c % 3;
+					if (tri_block)
+						place_in_tile(w.tri_list, K_TRI, w.tri_pool, p.L.tri_pool_cap, &w.hdr->tri_spill[cur], tile, prim, got[c]);
+					else
+						place_in_tile(w.edge_list, K_EDGE, w.edge_pool, p.L.edge_pool_cap, &w.hdr->edge_spill[cur], tile, prim, got[c]);
+				}
 		}
 	};
 	if (tri_block)
 	{
-		bool big = false;
+		int extra = 0;
 		double hp[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 		int btx0 = 0, bty0 = 0, bntx = 0, bnty = 0, bprim = 0;
 		do
@@ -322,7 +353,6 @@ __global__ __launch_bounds__(PRIM_BLOCK, DR_PRIM_WAVES) void setup_bin_kernel(KP
 			const bool on_screen = !(x0 > x1 || y0 > y1 || (DR_ABLATE & 2048));
 			const double eq[9] = {rec.eq[0][0], rec.eq[0][1], rec.eq[0][2], rec.eq[1][0], rec.eq[1][1], rec.eq[1][2], rec.eq[2][0], rec.eq[2][1], rec.eq[2][2]};
 			const int tx0 = x0 / TILE, ty0 = y0 / TILE, ntx = x1 / TILE - tx0 + 1, nty = y1 / TILE - ty0 + 1;
-			const bool large = on_screen && ((ntx + 2) / 3) * ((nty + 2) / 3) > COOP_BLOCKS;
 			// Non-strict fill rule: get_xrange's ceil_div clamps the left end of a row to x_max (H.h:895), so a row whose span lies
 			// wholly between x_max and the rightmost vertex -- or beyond the right border of the frame -- still draws the pixel of
 			// column x_max although that pixel is outside the left edge.  tri_half_span reproduces it; the half-plane test must
@@ -336,7 +366,7 @@ __global__ __launch_bounds__(PRIM_BLOCK, DR_PRIM_WAVES) void setup_bin_kernel(KP
 #pragma unroll
 			for (int q = 0; q < 9; q++)
 				use0[q] = false, slot0[q] = 0;
-			if (on_screen && !large)
+			if (on_screen)
 			{
 				const uint32_t outside = tiles3x3_outside_halfplanes<3>(eq, tx0, ty0);
 #pragma unroll
@@ -356,15 +386,6 @@ __global__ __launch_bounds__(PRIM_BLOCK, DR_PRIM_WAVES) void setup_bin_kernel(KP
 				out = rec;
 			if (!on_screen)
 				break;
-			if (large)
-			{
-				big = true;
-#pragma unroll
-				for (int i = 0; i < 9; i++)
-					hp[i] = eq[i];
-				btx0 = tx0, bty0 = ty0, bntx = ntx, bnty = nty, bprim = k;
-				break;
-			}
 			DR_WAVE_PHASE_T(3); // record stored
 #pragma unroll
 			for (int q = 0; q < 9; q++)
@@ -373,33 +394,14 @@ __global__ __launch_bounds__(PRIM_BLOCK, DR_PRIM_WAVES) void setup_bin_kernel(KP
 					const int tile = (ty0 + q / 3) * p.L.tiles_x + tx0 + q % 3;
 					place_in_tile(w.tri_list, K_TRI, w.tri_pool, p.L.tri_pool_cap, &w.hdr->tri_spill[cur], tile, (uint32_t)k, slot0[q]);
 				}
-			// the other 3 x 3 blocks of a wider box, the slot requests of a block all in flight together
-			for (int by = 0; by < nty; by += 3)
-				for (int bx = by == 0 ? 3 : 0; bx < ntx; bx += 3)
-				{
-					uint32_t slot[9];
-					bool use[9];
-					const uint32_t outside = tiles3x3_outside_halfplanes<3>(eq, tx0 + bx, ty0 + by);
+			extra = ((ntx + 2) / 3) * ((nty + 2) / 3) - 1; // the other 3 x 3 blocks of a wider box: shared out below
 #pragma unroll
-					for (int q = 0; q < 9; q++)
-					{
-						const int dx = bx + q % 3, dy = by + q / 3;
-						use[q] = dx < ntx && dy < nty && (!((outside >> q) & 1u) || dx == keep_dx);
-						slot[q] = 0;
-						if (use[q])
-							slot[q] = atomicAdd(&w.tri_cnt[(ty0 + dy) * p.L.tiles_x + tx0 + dx], 1u);
-					}
-#pragma unroll
-					for (int q = 0; q < 9; q++)
-						if (use[q])
-						{
-							const int tile = (ty0 + by + q / 3) * p.L.tiles_x + tx0 + bx + q % 3;
-							place_in_tile(w.tri_list, K_TRI, w.tri_pool, p.L.tri_pool_cap, &w.hdr->tri_spill[cur], tile, (uint32_t)k, slot[q]);
-						}
-				}
+			for (int i = 0; i < 9; i++)
+				hp[i] = eq[i];
+			btx0 = tx0, bty0 = ty0, bntx = ntx, bnty = nty, bprim = k;
 		} while (false);
 		DR_WAVE_PHASE_T(4);
-		bin_large(big, hp, btx0, bty0, bntx, bnty, bprim);
+		bin_rest(extra, true, hp, btx0, bty0, bntx, bnty, bprim);
 		return;
 	}
 	// nothing is written for the ~97 % of slots that are not silhouette edges: records are only reached through the
@@ -407,7 +409,7 @@ __global__ __launch_bounds__(PRIM_BLOCK, DR_PRIM_WAVES) void setup_bin_kernel(KP
 	const int slot = compact_flagged_slots(p, s.edgeflags, pw.index);
 	DR_WAVE_PHASE(1); // flags compacted
 	{
-		bool big = false;
+		int extra = 0;
 		double hp[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 		int btx0 = 0, bty0 = 0, bntx = 0, bnty = 0, bprim = 0;
 		do
@@ -442,41 +444,14 @@ __global__ __launch_bounds__(PRIM_BLOCK, DR_PRIM_WAVES) void setup_bin_kernel(KP
 			const double band[12] = {e.x2b[0], e.x2b[1], e.x2b[2], e.x2b[3], e.x2b[4], e.x2b[5], e.x2t[0], e.x2t[1], e.x2t[2],
 									 -e.x2t[0], -e.x2t[1], 1 - e.x2t[2]}; // the four half-planes of the band, H.h:1418-1435
 			const int tx0 = e.x_begin / TILE, ty0 = e.y_begin / TILE, ntx = e.x_end / TILE - tx0 + 1, nty = e.y_end / TILE - ty0 + 1;
-			if (((ntx + 2) / 3) * ((nty + 2) / 3) > COOP_BLOCKS)
-			{
-				big = true;
+			extra = ((ntx + 2) / 3) * ((nty + 2) / 3); // all its 3 x 3 blocks: shared out below
 #pragma unroll
-				for (int i = 0; i < 12; i++)
-					hp[i] = band[i];
-				btx0 = tx0, bty0 = ty0, bntx = ntx, bnty = nty, bprim = slot;
-				break;
-			}
-			for (int by = 0; by < nty; by += 3)
-				for (int bx = 0; bx < ntx; bx += 3)
-				{
-					uint32_t got[9];
-					bool use[9];
-					const uint32_t outside = tiles3x3_outside_halfplanes<4>(band, tx0 + bx, ty0 + by);
-#pragma unroll
-					for (int q = 0; q < 9; q++)
-					{
-						const int dx = bx + q % 3, dy = by + q / 3;
-						use[q] = dx < ntx && dy < nty && !((outside >> q) & 1u);
-						got[q] = 1;
-						if (use[q])
-							got[q] = atomicAdd(&w.edge_cnt[(ty0 + dy) * p.L.tiles_x + tx0 + dx], 1u);
-					}
-#pragma unroll
-					for (int q = 0; q < 9; q++)
-						if (use[q])
-						{
-							const int tile = (ty0 + by + q / 3) * p.L.tiles_x + tx0 + bx + q % 3;
-							place_in_tile(w.edge_list, K_EDGE, w.edge_pool, p.L.edge_pool_cap, &w.hdr->edge_spill[cur], tile, (uint32_t)slot, got[q]);
-						}
-				}
+			for (int i = 0; i < 12; i++)
+				hp[i] = band[i];
+			btx0 = tx0, bty0 = ty0, bntx = ntx, bnty = nty, bprim = slot;
 		} while (false);
-		DR_WAVE_PHASE(5); // own binning done
-		bin_large(big, hp, btx0, bty0, bntx, bnty, bprim);
+		DR_WAVE_PHASE(5); // record done
+		bin_rest(extra, false, hp, btx0, bty0, bntx, bnty, bprim);
 	}
 }
 

@@ -32,8 +32,16 @@ def _lib():
         L.deodr_hip_project_points.argtypes = [vp] * 6 + [i, i, vp]
         L.deodr_hip_project_points_b.argtypes = [vp] * 7 + [i, i, vp]
         L.deodr_hip_silhouette_flags.argtypes = [vp, vp, vp, vp, i, i, i, i, vp]
-        L.deodr_hip_momentum_update.argtypes = [i, vp, vp, vp, vp, vp, vp, vp, vp, d, d, vp]
-        for f in ("rigid_transform", "rigid_transform_b", "project_points", "project_points_b", "silhouette_flags", "momentum_update"):
+        L.deodr_hip_momentum_update.argtypes = [i, vp, vp, vp, vp, vp, vp, vp, vp, d, d, vp, vp, vp, vp, C.c_size_t, vp]
+        L.deodr_hip_fit_scratch_bytes.argtypes, L.deodr_hip_fit_scratch_bytes.restype = [i, i], C.c_size_t
+        L.deodr_hip_fit_pose_project.argtypes = [vp] * 10 + [i, i, vp]
+        L.deodr_hip_fit_pose_project_b.argtypes = [vp] * 12 + [C.c_size_t, i, i, vp]
+        L.deodr_hip_vertex_shade.argtypes = [vp] * 7 + [i, vp, vp, i, i, i, vp]
+        L.deodr_hip_vertex_shade_b.argtypes = [vp] * 7 + [i, vp, vp, vp, vp, vp, C.c_size_t, i, i, i, vp]
+        L.deodr_hip_rigid_energy.argtypes = [vp] * 5 + [d, vp, vp, vp, d, vp, C.c_size_t, i, vp]
+        L.deodr_hip_l2_loss.argtypes = [vp, vp, i, C.c_size_t, vp, vp, C.c_size_t, vp]
+        for f in ("rigid_transform", "rigid_transform_b", "project_points", "project_points_b", "silhouette_flags", "momentum_update", "fit_pose_project",
+                  "fit_pose_project_b", "vertex_shade", "vertex_shade_b", "rigid_energy", "l2_loss"):  # fmt: skip
             getattr(L, "deodr_hip_" + f).restype = i
         _bound = True
     return L
@@ -93,29 +101,143 @@ class ProjectPointsFunc(torch.autograd.Function):
         return pts_b, None, None, None
 
 
-def silhouette_flags(ij, faces_u32, edge_faces_u32, clockwise):
+def silhouette_flags(ij, faces_u32, edge_faces_u32, clockwise, out=None):
     """ij [n,V,2] -> uint8 [n,T,3] (TriMeshAdjacencies.edge_on_silhouette, deodr/triangulated_mesh.py:153-166); no gradient"""
     ij = ij.detach().contiguous()
     n, V, T = ij.shape[0], ij.shape[1], faces_u32.shape[0]
-    flags = torch.empty((n, T, 3), dtype=torch.uint8, device=ij.device)
+    flags = torch.empty((n, T, 3), dtype=torch.uint8, device=ij.device) if out is None else out
     with torch.cuda.device(ij.device):
         _check(_lib().deodr_hip_silhouette_flags(_p(ij), _p(faces_u32), _p(edge_faces_u32), _p(flags), T, V, n, int(bool(clockwise)), _stream(ij.device)))
     return flags
 
 
-def momentum_update(entries, inertia, damping):
-    """entries: [(x, speed, grad, grad2 | None, factor, step_max | None, normalize_rows)]; x and speed are updated IN PLACE
-    (deodr/mesh_fitter.py:153-190: s = (1 - damping)(inertia s + (1 - inertia) clamp(-factor (grad + grad2))), x += s)"""
+def momentum_update(entries, inertia, damping, scratch=None):
+    """entries: [(x, speed, grad, grad2 | None, factor, step_max | None, normalize_rows[, grad_scale, grad_mean | None, mean_out | None])];
+    x and speed are updated IN PLACE: s = (1 - damping)(inertia s + (1 - inertia) clamp(-factor (grad_scale (grad - grad_mean) + grad2))),
+    x += s (deodr/mesh_fitter.py:153-190); mean_out [3] receives the column mean of the updated [.,3] tensor (needs ``scratch``)"""
     k = len(entries)
     assert 0 < k <= 8
+    entries = [tuple(e) + (1.0, None, None)[len(e) - 7 :] for e in entries]
     ptrs = lambda j: (C.c_void_p * k)(*[None if e[j] is None else e[j].data_ptr() for e in entries])
     factor = (C.c_double * k)(*[float(e[4]) for e in entries])
     step_max = (C.c_double * k)(*[0.0 if e[5] is None else float(e[5]) for e in entries])
     count = (C.c_int * k)(*[int(e[0].numel()) for e in entries])
     rows = (C.c_int * k)(*[int(e[6]) for e in entries])
+    scale = (C.c_double * k)(*[float(e[7]) for e in entries])
     dev = entries[0][0].device
     for e in entries:
         assert e[0].is_contiguous() and e[1].is_contiguous() and e[2].is_contiguous() and (e[3] is None or e[3].is_contiguous())
     with torch.cuda.device(dev):
-        _check(_lib().deodr_hip_momentum_update(k, ptrs(0), ptrs(1), ptrs(2), ptrs(3), factor, step_max, count, rows, float(inertia), float(damping),
-                                                _stream(dev)))  # fmt: skip
+        _check(_lib().deodr_hip_momentum_update(k, ptrs(0), ptrs(1), ptrs(2), ptrs(3), factor, step_max, count, rows, float(inertia), float(damping), scale,
+                                                ptrs(8), ptrs(9), _p(scratch), 0 if scratch is None else scratch.numel(), _stream(dev)))  # fmt: skip
+
+
+# ---- one fit iteration without an autograd graph (deodr_amd/csrc/dr_fititer.h) ----------------------------------------------------
+
+
+def fit_scratch(V, n, device):
+    """zero-filled scratch of the kernels below (their counter words stay zero between launches)"""
+    return torch.zeros(int(_lib().deodr_hip_fit_scratch_bytes(int(V), int(n))), dtype=torch.uint8, device=device)
+
+
+def _topology_scratch(topology, n):
+    """one scratch per (topology, number of views), for the autograd wrappers (the kernels of one stream run one after the other)"""
+    cache = topology.__dict__.setdefault("_fit_scratch", {})
+    if n not in cache:
+        cache[n] = fit_scratch(topology.nb_vertices, n, topology.device)
+    return cache[n]
+
+
+def fit_pose_project(vertices, vertices_mean, quaternions, translations, camera, posed, ij, depths):
+    """centre ``vertices`` [V,3] in place (when a mean [3] is given), pose them with every view's quaternion (normalised inside) and
+    translation, project them with every view's camera -> posed [n,V,3], ij [n,V,2], depths [n,V] (all written)"""
+    n, V = posed.shape[0], posed.shape[1]
+    with torch.cuda.device(posed.device):
+        _check(_lib().deodr_hip_fit_pose_project(_p(vertices), _p(vertices_mean), _p(quaternions), _p(translations), _p(camera.extrinsic), _p(camera.intrinsic),
+                                                 _p(camera.distortion), _p(posed), _p(ij), _p(depths), V, n, _stream(posed.device)))  # fmt: skip
+
+
+def fit_pose_project_b(vertices, quaternions, posed, camera, posed_b, ij_b, depths_b, vertices_b, out, scratch):
+    """adjoint of :func:`fit_pose_project`: -> vertices_b [V,3]; out [3 + 7n] = mean of vertices_b over the vertices, quaternion adjoints
+    [n,4] (raw quaternions), translation adjoints [n,3]"""
+    n, V = posed.shape[0], posed.shape[1]
+    with torch.cuda.device(posed.device):
+        _check(_lib().deodr_hip_fit_pose_project_b(_p(vertices), _p(quaternions), _p(posed), _p(camera.extrinsic), _p(camera.intrinsic), _p(camera.distortion),
+                                                   _p(posed_b), _p(ij_b), _p(depths_b), _p(vertices_b), _p(out), _p(scratch), scratch.numel(), V, n,
+                                                   _stream(posed.device)))  # fmt: skip
+
+
+def vertex_shade(posed, topology, light, ambient, color=None, luminosity=None, colors=None):
+    """luminosity [n,V] = max(0, -normal . light) + ambient and / or colors [n,V,C] = color [C] * luminosity (written)"""
+    n, V = posed.shape[0], posed.shape[1]
+    with torch.cuda.device(posed.device):
+        _check(_lib().deodr_hip_vertex_shade(_p(posed), _p(topology._faces_u32), _p(topology._vf_offsets), _p(topology._vf_corners), _p(light), _p(ambient),
+                                             _p(color), 0 if color is None else color.numel(), _p(luminosity), _p(colors), V, n, int(topology.clockwise),
+                                             _stream(posed.device)))  # fmt: skip
+
+
+def vertex_shade_b(posed, topology, light, ambient, color, luminosity_b, colors_b, posed_b, out, scratch):
+    """adjoint of :func:`vertex_shade`: -> posed_b [n,V,3] (written), out [4 + C] = light_b, ambient_b, color_b"""
+    n, V = posed.shape[0], posed.shape[1]
+    with torch.cuda.device(posed.device):
+        _check(_lib().deodr_hip_vertex_shade_b(_p(posed), _p(topology._faces_u32), _p(topology._vf_offsets), _p(topology._vf_corners), _p(light), _p(ambient),
+                                               _p(color), 0 if color is None else color.numel(), _p(luminosity_b), _p(colors_b), _p(posed_b), _p(out), _p(scratch),
+                                               scratch.numel(), V, n, int(topology.clockwise), _stream(posed.device)))  # fmt: skip
+
+
+def rigid_energy(vertices, vertices_ref, topology, cregu, gradient, energy, scratch, data_energy=None, data_weight=1.0):
+    """energy[0] = 0.5 c d^T (L^T L) d, gradient [V,3] = c (L^T L) d, d = vertices - vertices_ref (both written); with ``data_energy`` [1]
+    also energy[1] = data_weight * data_energy[0] + energy[0]"""
+    off, cols, vals = topology._m_csr
+    with torch.cuda.device(vertices.device):
+        _check(_lib().deodr_hip_rigid_energy(_p(vertices), _p(vertices_ref), _p(off), _p(cols), _p(vals), float(cregu), _p(gradient), _p(energy), _p(data_energy),
+                                             float(data_weight), _p(scratch), scratch.numel(), vertices.shape[0], _stream(vertices.device)))  # fmt: skip
+
+
+def l2_loss(image, obs, out, scratch):
+    """out[0] = sum (image - obs)^2, image and obs contiguous tensors of one pixel dtype (float32 / float64) and one shape"""
+    assert image.dtype == obs.dtype and image.shape == obs.shape and image.is_contiguous() and obs.is_contiguous()
+    with torch.cuda.device(image.device):
+        _check(_lib().deodr_hip_l2_loss(_p(image), _p(obs), 1 if image.dtype == torch.float64 else 0, image.numel(), _p(out), _p(scratch), scratch.numel(),
+                                        _stream(image.device)))  # fmt: skip
+
+
+class VertexLuminosityFunc(torch.autograd.Function):
+    """(posed [n,V,3], light [3], ambient []) -> luminosity [n,V]: vertex normals + max(0, -n.l) + ambient in one kernel, two for the adjoint
+    (deodr/triangulated_mesh.py:113-151, deodr/differentiable_renderer.py:814-822)"""
+
+    @staticmethod
+    def forward(ctx, posed, light, ambient, topology):
+        posed, light, ambient = posed.contiguous(), light.contiguous(), ambient.contiguous()
+        lum = torch.empty(posed.shape[:2], dtype=torch.float64, device=posed.device)
+        vertex_shade(posed, topology, light, ambient, luminosity=lum)
+        ctx.save_for_backward(posed, light, ambient)
+        ctx.topology = topology
+        return lum
+
+    @staticmethod
+    def backward(ctx, lum_b):
+        posed, light, ambient = ctx.saved_tensors
+        posed_b = torch.empty_like(posed)
+        out = torch.empty(4, dtype=torch.float64, device=posed.device)
+        vertex_shade_b(posed, ctx.topology, light, ambient, None, lum_b.contiguous(), None, posed_b, out, _topology_scratch(ctx.topology, posed.shape[0]))
+        return posed_b, out[:3], out[3].reshape(ambient.shape), None
+
+
+class RigidEnergyFunc(torch.autograd.Function):
+    """vertices [V,3] -> (energy, gradient [V,3]) of the as-rigid-as-possible energy (deodr/laplacian_rigid_energy.py:15-41) in one kernel;
+    the energy is differentiable (its adjoint is the gradient the same launch produced)"""
+
+    @staticmethod
+    def forward(ctx, vertices, vertices_ref, topology, cregu):
+        v = vertices.contiguous()
+        grad, energy = torch.empty_like(v), torch.empty(1, dtype=torch.float64, device=v.device)
+        rigid_energy(v, vertices_ref, topology, cregu, grad, energy, _topology_scratch(topology, 1))
+        ctx.save_for_backward(grad)
+        ctx.mark_non_differentiable(grad)
+        return energy[0], grad
+
+    @staticmethod
+    def backward(ctx, energy_b, _grad_b):
+        (grad,) = ctx.saved_tensors
+        return energy_b * grad, None, None, None

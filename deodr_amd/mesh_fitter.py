@@ -13,6 +13,7 @@ import numpy as np
 import torch
 
 from . import distributed as dd
+from .fronthalf import usable as fronthalf_usable
 from .scene3d import DeviceCamera, DeviceMesh, LaplacianRigidEnergyDevice, Scene3DDevice
 
 
@@ -120,8 +121,60 @@ class GraphedStep:
         return self.outputs
 
 
+class _DirectIteration:
+    """Buffers of a fitter iteration that runs as a FIXED KERNEL SEQUENCE (deodr_amd/csrc/dr_fititer.h) instead of an autograd graph:
+    pose + projection, shading, silhouette flags, the rasterizer's fit step, the three adjoint kernels, the rigid energy and one momentum
+    update of all parameters in place -- about a dozen launches, all sums deterministic.  (As torch ops, even with the fused front-half
+    Functions, the colour fitter's iteration is ~155 launches of ~4 us: tools/fit_kernels.sh.)
+
+    Layout of ``flat``: [light_b 3 | ambient_b 1 | colour_b C | data energy 1 | vertices_b 3V | mean of vertices_b 3 || quaternion_b 4n |
+    translation_b 3n]: everything before the bar is shared by the views and is what ONE all-reduce sums over the ranks of a multi-GPU fit
+    (no packing copies); the pose adjoints after it stay local."""
+
+    def __init__(self, fitter, nb_colors, shaded):
+        from . import fronthalf
+
+        f, topo, cam = fitter, fitter.mesh.topology, fitter.camera
+        n, V, T, dev, C = cam.n_views, topo.nb_vertices, topo.nb_faces, fitter.device, nb_colors
+        z = lambda *shape: torch.zeros(shape, dtype=torch.float64, device=dev)
+        self.posed, self.ij, self.depths, self.colors, self.shade = z(n, V, 3), z(n, V, 2), z(n, V), z(n, V, C), z(n, V)
+        self.flags = torch.zeros((n, T, 3), dtype=torch.uint8, device=dev)
+        self.posed_b = z(n, V, 3) if shaded else None
+        self.scratch = fronthalf.fit_scratch(V, n, dev)
+        self.flat = z(5 + C + 3 * V + 3 + 7 * n)
+        self.shade_out, self.e_data = self.flat[: 4 + C], self.flat[4 + C : 5 + C]
+        self.vertices_b = self.flat[5 + C : 5 + C + 3 * V].view(V, 3)
+        self.pose_out = self.flat[5 + C + 3 * V :]  # mean of vertices_b [3], quaternion adjoints [n,4], translation adjoints [n,3]
+        self.shared = self.flat[: 5 + C + 3 * V + 3]
+        self.g_rigid, self.energy, self.vmean = z(V, 3), z(2), z(3)  # energy: rigid, data_weight * data + rigid
+        sc = f.scene
+        if (sc.background_image is None) == (sc.background_color is None):
+            raise BaseException("You need to provide either a background image or background color")
+        self.ds, self.rasterizer = sc._rasterizer(n, cam.height, cam.width, C, False, True)
+        self.ds.set_views(ij=self.ij, depths=self.depths, colors=self.colors, shade=self.shade, edgeflags=self.flags)  # (used as they are)
+        assert self.ds.ij.data_ptr() == self.ij.data_ptr() and self.ds.colors.data_ptr() == self.colors.data_ptr()
+        sizes = [("ij_b", (n, V, 2)), ("colors_b", (n, V, C)), ("shade_b", (n, V)), ("uv_b", tuple(self.ds.uv.shape))]
+        self.grads_flat = z(sum(int(np.prod(shape)) for _, shape in sizes))  # one buffer: one fill clears all of them
+        self.grads, at = {"texture_b": None}, 0
+        for name, shape in sizes:
+            self.grads[name] = self.grads_flat[at : at + int(np.prod(shape))].view(shape)
+            at += int(np.prod(shape))
+        pd = sc.pixel_dtype
+        self.image, self.z = torch.empty((n, cam.height, cam.width, C), dtype=pd, device=dev), torch.empty((n, cam.height, cam.width), dtype=pd, device=dev)
+        self.bound = None
+
+    def sync(self, fitter):
+        """the kernels keep the column mean of the vertices up to date themselves; recompute it when the fitter's tensors were replaced"""
+        now = (fitter.vertices, fitter.transform_quaternion, fitter.transform_translation)
+        if self.bound is None or any(a is not b for a, b in zip(now, self.bound)):
+            self.vmean.copy_(fitter.vertices.mean(dim=0))
+            self.bound = now
+
+
 class _PoseFitter:
     """deformable vertices + one rigid pose per view, shared machinery of the three fitters"""
+
+    direct = True  # run an iteration as the fixed kernel sequence of _DirectIteration when the tensors allow it (False: always autograd)
 
     step_factor_vertices, step_factor_quaternion, step_factor_translation = 0.0005, 0.00006, 0.00005
 
@@ -147,6 +200,7 @@ class _PoseFitter:
         self.transform_translation = self.transform_translation_init.clone()
         self.momentum = _Momentum(self.inertia, self.damping)
         self.iter = 0
+        self._direct_state = None
 
     def _camera(self, height, width, focal, distortion, camera_center):
         focal = 2 * width if focal is None else focal
@@ -184,6 +238,63 @@ class _PoseFitter:
         self.iter += 1
         return new[3:]
 
+    # ---- the iteration as a fixed kernel sequence (float64 ROCm tensors, manifold mesh) ------------------------------------------
+
+    def _direct_iteration(self, nb_colors, shaded):
+        """-> the _DirectIteration of this fitter, or None when an iteration has to go through autograd (CPU tensors: the CPU suite;
+        a non-manifold mesh: no static table for the silhouette flags; ``direct = False``)"""
+        from . import fronthalf
+
+        topo = self.mesh.topology
+        params = (self.vertices, self.transform_quaternion, self.transform_translation)
+        if not (self.direct and fronthalf.usable(*params) and all(p.is_contiguous() for p in params) and topo._edge_faces is not None):
+            return None
+        key = (id(self.camera), nb_colors, shaded, self.scene.pixel_dtype, id(self.scene.background_color), id(self.scene.background_image))
+        if self._direct_state is None or self._direct_state[0] != key:
+            self._direct_state = (key, _DirectIteration(self, nb_colors, shaded))
+        d = self._direct_state[1]
+        d.sync(self)
+        return d
+
+    def _direct_forward(self, d):
+        """parameters -> posed vertices, image coordinates, depths, silhouette flags (in the rasterizer's own arrays)"""
+        from . import fronthalf
+
+        topo = self.mesh.topology
+        d.ds.set_views(ij=d.ij, depths=d.depths, colors=d.colors, shade=d.shade, edgeflags=d.flags)  # (no copies; another render may have rebound them)
+        fronthalf.fit_pose_project(self.vertices, d.vmean, self.transform_quaternion, self.transform_translation, self.camera, d.posed, d.ij, d.depths)
+        if self.scene.sigma > 0:
+            fronthalf.silhouette_flags(d.ij, topo._faces_u32, topo._edge_faces, topo.clockwise, out=d.flags)
+
+    def _direct_backward_and_update(self, d, depths_b, step_max, data_weight, extra=()):
+        """adjoint of pose + projection, rigid energy, (all-reduce of the shared block,) momentum update of every parameter in place"""
+        from . import fronthalf
+
+        n = d.posed.shape[0]
+        fronthalf.fit_pose_project_b(self.vertices, self.transform_quaternion, d.posed, self.camera, d.posed_b, d.grads["ij_b"], depths_b, d.vertices_b,
+                                     d.pose_out, d.scratch)  # fmt: skip
+        self._allreduce_shared(d.shared)
+        fronthalf.rigid_energy(self.vertices, self.rigid_energy.vertices_ref, self.mesh.topology, self.cregu, d.g_rigid, d.energy, d.scratch, d.e_data,
+                               data_weight)  # fmt: skip
+        def speed(name, x):
+            if name not in self.momentum.speed:
+                self.momentum.speed[name] = torch.zeros_like(x)
+            return self.momentum.speed[name]
+
+        entries = [
+            (self.vertices, speed("vertices", self.vertices), d.vertices_b, d.g_rigid, self.step_factor_vertices, step_max[0], 0, data_weight, d.pose_out[:3], d.vmean),
+            (self.transform_quaternion, speed("quaternion", self.transform_quaternion), d.pose_out[3 : 3 + 4 * n], None, self.step_factor_quaternion,
+             step_max[1], 4, data_weight, None, None),
+            (self.transform_translation, speed("translation", self.transform_translation), d.pose_out[3 + 4 * n :], None, self.step_factor_translation,
+             step_max[2], 0, data_weight, None, None),
+        ] + [(x, speed(name, x), g, None, factor, None, 0, data_weight, None, None) for name, x, g, factor in extra]  # fmt: skip
+        fronthalf.momentum_update(entries, self.inertia, self.damping, scratch=d.scratch)
+        self.iter += 1
+        return d.energy[1]
+
+    def _allreduce_shared(self, shared):
+        pass  # single process, every view local
+
 
 class MeshDepthFitter(_PoseFitter):
     """Fit a deformable mesh to a depth image (reference deodr/mesh_fitter.py:20-196)."""
@@ -215,7 +326,25 @@ class MeshDepthFitter(_PoseFitter):
         e_rigid, g_rigid = self.rigid_energy.evaluate(self.vertices_leaf.detach())
         return diff_image.sum(), e_rigid, g_rigid, depth[:, :, 0], diff_image
 
+    def _step_direct(self, d):
+        self._direct_forward(d)
+        torch.mul(d.depths[..., None], self.depthScale, out=d.colors)  # the depth of a vertex is its colour (dr.py:1001-1036)
+        image, _z = d.rasterizer.render(d.ds, self.scene.sigma, out=(d.image, d.z))
+        depth = image.clamp(0, self.max_depth).to(torch.float64)  # [1,H,W,1]
+        residual = depth - self.mesh_image[None, :, :, None]
+        diff_image = (residual * residual)[0, :, :, 0]
+        torch.sum(diff_image, dim=(0, 1), out=d.e_data[0])
+        image_b = (2 * residual * ((image >= 0) & (image <= self.max_depth))).to(image.dtype)  # (clamp passes the gradient on [0, max_depth])
+        d.grads_flat.zero_()
+        d.rasterizer.render_backward(d.ds, image_b=image_b, grads=d.grads)
+        depths_b = d.grads["colors_b"][..., 0] * self.depthScale
+        energy = self._direct_backward_and_update(d, depths_b, (1, 0.1, 0.1), 1.0)
+        return energy, depth[0, :, :, 0], diff_image
+
     def step_device(self):
+        d = self._direct_iteration(1, False)
+        if d is not None:
+            return self._step_direct(d)
         leaves = self._leaves()
         e_data, e_rigid, g_rigid, depth, diff_image = self.energy()
         g_v, g_q, g_t = torch.autograd.grad(e_data, leaves)
@@ -320,8 +449,10 @@ class MeshRGBFitterWithPose(_PoseFitter):
         self.mesh.set_vertices_colors(self.mesh_color_leaf[None, :].expand(self.mesh.nb_vertices, -1))
 
     def render(self):
+        """the image(s) of the current parameters [n,H,W,C] (mesh_fitter.py:270-285)"""
+        self._leaves(self._appearance_leaves())
         self._pose_scene()
-        return self.scene.render(self.camera).to(torch.float64)
+        return self.scene.render(self.camera).to(torch.float64).detach()
 
     data_weight = 1.0  # of sum (image - obs)^2 in the energy
 
@@ -345,7 +476,29 @@ class MeshRGBFitterWithPose(_PoseFitter):
     def _reduce_shared(self, grads):
         return grads  # single process, every view local
 
+    def _step_direct(self, d):
+        from . import fronthalf
+
+        topo = self.mesh.topology
+        self._direct_forward(d)
+        fronthalf.vertex_shade(d.posed, topo, self.light_directional, self.light_ambient, self.mesh_color, colors=d.colors)
+        obs = self._observation()
+        image, _z, _g = d.rasterizer.render_fit(d.ds, obs, self.scene.sigma, grads=d.grads, out=(d.image, d.z), clear_grads=True)
+        fronthalf.l2_loss(image, obs, d.e_data, d.scratch)
+        fronthalf.vertex_shade_b(d.posed, topo, self.light_directional, self.light_ambient, self.mesh_color, None, d.grads["colors_b"], d.posed_b, d.shade_out,
+                                 d.scratch)  # fmt: skip
+        extra = []
+        if self.update_lights:
+            extra += [("light_directional", self.light_directional, d.shade_out[:3], 0.0001), ("light_ambient", self.light_ambient, d.shade_out[3:4], 0.0001)]
+        if self.update_color:
+            extra.append(("mesh_color", self.mesh_color, d.shade_out[4:], 0.00001))
+        energy = self._direct_backward_and_update(d, None, (0.5, 0.05, 0.1), self.data_weight, extra)
+        return energy, image
+
     def step_device(self):
+        d = None if self.light_directional is None else self._direct_iteration(int(self.mesh_color.numel()), True)
+        if d is not None and fronthalf_usable(self.mesh_color, self.light_directional, self.light_ambient):
+            return self._step_direct(d)
         leaves = self._leaves(self._appearance_leaves())
         e_data, image = self._data_energy()
         e_rigid, g_rigid = self.rigid_energy.evaluate(self.vertices_leaf.detach())
@@ -430,6 +583,12 @@ class MeshRGBFitterWithPoseMultiFrame(MeshRGBFitterWithPose):
         if self._packed is None:
             self._packed = dd.PackedGradients([g.shape for g in grads], dtype=torch.float64, device=self.device)
         return dd.allreduce_shared_gradients(self._packed, grads, self.group)
+
+    def _allreduce_shared(self, shared):
+        if self.world > 1:
+            import torch.distributed as dist
+
+            dist.all_reduce(shared, op=dist.ReduceOp.SUM, group=self.group)  # (the shared gradients are contiguous by construction)
 
     def step(self):
         energy, image = self.step_device()

@@ -125,6 +125,16 @@ class MeshTopology:
         adj = sp.coo_matrix((np.ones(len(a)), (a[:, 0], a[:, 1])), shape=(self.nb_vertices, self.nb_vertices)).tocsr()
         lap = sp.diags(np.asarray(adj.sum(axis=1)).ravel()) - adj
         m = (lap.T @ lap).tocoo()
+        u32 = lambda a: torch.as_tensor(np.ascontiguousarray(a).astype(np.uint32).view(np.int32), device=self.device)
+        mc = m.tocsr()
+        mc.sort_indices()
+        self._m_csr = (u32(mc.indptr), u32(mc.indices), torch.as_tensor(mc.data.astype(np.float64), device=self.device))  # rows of L^T L
+        # vertex -> the slots 3 f + corner it occupies in `faces` (the gathers of the shading adjoint, no atomics)
+        corner_vertex = f.reshape(-1)
+        self._vf_corners = u32(np.argsort(corner_vertex, kind="stable"))
+        self._vf_offsets = u32(np.concatenate(([0], np.cumsum(np.bincount(corner_vertex, minlength=self.nb_vertices)))))
+        if self._edge_faces is None and self.nb_faces:
+            self._faces_u32 = u32(f)
         self._m_rows = torch.as_tensor(m.row.astype(np.int64), device=self.device)
         self._m_cols = torch.as_tensor(m.col.astype(np.int64), device=self.device)
         self._m_vals = torch.as_tensor(m.data.astype(np.float64), device=self.device)
@@ -181,6 +191,10 @@ class LaplacianRigidEnergyDevice:
 
     def evaluate(self, vertices):
         """-> (energy, gradient [V,3]); the energy is differentiable too (autograd sees plain tensor ops)"""
+        from . import fronthalf
+
+        if fronthalf.usable(vertices, self.vertices_ref) and vertices.dim() == 2:
+            return fronthalf.RigidEnergyFunc.apply(vertices, self.vertices_ref, self.topology, self.cregu)  # one kernel, deterministic
         diff = vertices - self.vertices_ref
         grad = self.cregu * self.topology.laplacian_quadratic(diff)
         return 0.5 * (diff * grad).sum(), grad
@@ -306,8 +320,15 @@ class Scene3DDevice:
         amb = self.light_ambient
         if self.light_directional is None:
             return torch.zeros(vertices.shape[:-1], dtype=vertices.dtype, device=vertices.device) + amb
+        from . import fronthalf
+
+        light = self.light_directional
+        if fronthalf.usable(vertices, light) and self.mesh.nb_faces and (not torch.is_tensor(amb) or fronthalf.usable(amb)):
+            amb = amb if torch.is_tensor(amb) else torch.full((), float(amb), dtype=torch.float64, device=vertices.device)
+            lum = fronthalf.VertexLuminosityFunc.apply(vertices if vertices.dim() == 3 else vertices[None], light, amb, self.mesh.topology)  # 1 kernel
+            return lum if vertices.dim() == 3 else lum[0]
         normals = self.mesh.topology.vertex_normals(vertices)
-        return torch.relu(-(normals * self.light_directional).sum(-1)) + amb
+        return torch.relu(-(normals * light).sum(-1)) + amb
 
     def _rasterizer(self, n_views, height, width, nb_colors, textured, backface_culling):
         m = self.mesh

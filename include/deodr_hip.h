@@ -144,7 +144,50 @@ int deodr_hip_silhouette_flags(const double *ij, const uint32_t *faces, const ui
 							   void *stream);
 int deodr_hip_momentum_update(int n_tensors, double *const *x, double *const *speed, const double *const *grad, const double *const *grad2,
 							  const double *factor, const double *step_max, const int *count, const int *normalize_rows, double inertia, double damping,
+							  const double *grad_scale, const double *const *grad_mean, double *const *mean_out, void *scratch, size_t scratch_bytes,
 							  void *stream);
+
+/* ---- One fit iteration without an autograd graph (deodr/mesh_fitter.py:108-190, 287-376, 529-632): the chain parameters -> posed and
+ * projected vertices -> shading -> [silhouette flags, deodr_hip_render_scene_fit] -> adjoints -> rigid energy -> momentum update, about
+ * twelve launches.  Every sum over vertices is deterministic (per-workgroup partials added up in a fixed order by the last workgroup
+ * to arrive), every gather runs over a static vertex -> (face, corner) table: no atomics on values.  `scratch`: device memory of
+ * deodr_hip_fit_scratch_bytes(V, n) bytes, ZERO-FILLED ONCE by the caller (the kernels leave its counter words zero), shared by all
+ * these calls on one stream.
+ *
+ * deodr_hip_fit_pose_project     vertices [V,3] (centred IN PLACE by vertices_mean [3] when not NULL, mesh_fitter.py:131), raw
+ *                                quaternions [n,4] (normalised inside), translations [n,3], cameras as in deodr_hip_project_points
+ *                                -> posed [n,V,3], ij [n,V,2], depths [n,V]
+ * deodr_hip_fit_pose_project_b   posed_b [n,V,3] (or NULL), ij_b, depths_b (or NULL) -> vertices_b [V,3] summed over the views;
+ *                                out [3 + 7 n] = column mean of vertices_b (the data gradient is projected on zero-mean displacements,
+ *                                mesh_fitter.py:140, 319), quaternion adjoints [n,4] w.r.t. the RAW quaternions, translation adjoints [n,3]
+ * deodr_hip_vertex_shade         posed [n,V,3] -> luminosity [n,V] = max(0, -normal . light) + ambient (dr.py:814-822) with the vertex
+ *                                normals of triangulated_mesh.py:113-151, and/or colors [n,V,C] = color [C] * luminosity (C <= 3).
+ *                                vf_offsets [V+1], vf_corners [3T]: for every vertex the slots 3 f + corner it occupies in `faces`
+ * deodr_hip_vertex_shade_b       luminosity_b and/or colors_b -> posed_b [n,V,3] (overwritten); out [4 + C] = light_b [3], ambient_b,
+ *                                color_b [C]
+ * deodr_hip_rigid_energy         energy[0] = 0.5 c d^T (L^T L) d, d = vertices - vertices_ref, and its gradient c (L^T L) d [V,3]
+ *                                (deodr/laplacian_rigid_energy.py:15-41); L^T L as CSR rows m_offsets [V+1], m_cols, m_vals.  With
+ *                                data_energy [1] != NULL also energy[1] = data_weight * data_energy[0] + energy[0], the energy a
+ *                                fitter's step reports (mesh_fitter.py:147)
+ * deodr_hip_l2_loss              out[0] = sum (image - obs)^2 over `count` values of the pixel type (DEODR_HIP_F32 / _F64), accumulated in
+ *                                double: the data energy whose gradient deodr_hip_render_scene_fit back-propagates (mesh_fitter.py:296-318)
+ * deodr_hip_momentum_update      (above) grad_scale[k]: weight of grad (not of grad2); grad_mean[k] [3] or NULL: subtracted from every
+ *                                row of a [count/3, 3] gradient; mean_out[k] [3] or NULL: column mean of the updated tensor */
+size_t deodr_hip_fit_scratch_bytes(int V, int n);
+int deodr_hip_fit_pose_project(double *vertices, const double *vertices_mean, const double *quaternions, const double *translations, const double *extrinsic,
+							   const double *intrinsic, const double *distortion, double *posed, double *ij, double *depths, int V, int n, void *stream);
+int deodr_hip_fit_pose_project_b(const double *vertices, const double *quaternions, const double *posed, const double *extrinsic, const double *intrinsic,
+								 const double *distortion, const double *posed_b, const double *ij_b, const double *depths_b, double *vertices_b, double *out,
+								 void *scratch, size_t scratch_bytes, int V, int n, void *stream);
+int deodr_hip_vertex_shade(const double *posed, const uint32_t *faces, const uint32_t *vf_offsets, const uint32_t *vf_corners, const double *light,
+						   const double *ambient, const double *color, int C, double *luminosity, double *colors, int V, int n, int clockwise, void *stream);
+int deodr_hip_vertex_shade_b(const double *posed, const uint32_t *faces, const uint32_t *vf_offsets, const uint32_t *vf_corners, const double *light,
+							 const double *ambient, const double *color, int C, const double *luminosity_b, const double *colors_b, double *posed_b, double *out,
+							 void *scratch, size_t scratch_bytes, int V, int n, int clockwise, void *stream);
+int deodr_hip_rigid_energy(const double *vertices, const double *vertices_ref, const uint32_t *m_offsets, const uint32_t *m_cols, const double *m_vals,
+						   double cregu, double *gradient, double *energy, const double *data_energy, double data_weight, void *scratch, size_t scratch_bytes,
+						   int V, void *stream);
+int deodr_hip_l2_loss(const void *image, const void *obs, int pixel_dtype, size_t count, double *out, void *scratch, size_t scratch_bytes, void *stream);
 
 /* Bits of the sticky scene-error word: the index checks of the reference's checkSceneValid
  * (DifferentiableRenderer.h:2700-2712: `faces` entries < nb_vertices, `faces_uv` entries < nb_uv; plus the null-texture
@@ -194,7 +237,7 @@ const char *deodr_hip_last_error(void);
 
 /* ABI version of this header; bumped on any incompatible change. */
 int deodr_hip_abi_version(void);
-#define DEODR_HIP_ABI_VERSION 4
+#define DEODR_HIP_ABI_VERSION 5
 
 #ifdef __cplusplus
 }

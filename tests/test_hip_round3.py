@@ -342,3 +342,118 @@ def test_fused_front_half_kernels_equal_the_torch_formulas(monkeypatch):
         for a, b in zip(new, new_r):
             assert rel(a.cpu(), b.cpu()) < 1e-14
         x = new
+
+
+def test_fit_iteration_kernels_equal_the_torch_formulas(monkeypatch):
+    """vertex normals + luminosity and the rigid energy as kernels (dr_fititer.h), values and adjoints, against the torch formulas of
+    scene3d.py they replace on float64 ROCm tensors; bit-reproducible run to run (no atomics on values)"""
+    from deodr_amd import fronthalf
+    from deodr_amd.scene3d import DeviceMesh, LaplacianRigidEnergyDevice, Scene3DDevice
+
+    rs = np.random.RandomState(1)
+    vertices, faces = hand()
+    n, V = 3, len(vertices)
+    dev = "cuda"
+    for clockwise in (False, True):
+        mesh = DeviceMesh(faces, vertices, clockwise=clockwise, colors=np.zeros((V, 3)), device=dev)
+        scene = Scene3DDevice()
+        scene.set_mesh(mesh)
+        light = torch.tensor([0.3, -0.5, 0.6], device=dev, dtype=torch.float64, requires_grad=True)
+        amb = torch.tensor(0.25, device=dev, dtype=torch.float64, requires_grad=True)
+        scene.light_directional, scene.light_ambient = light, amb
+        posed = torch.tensor(vertices[None] + 0.02 * rs.randn(n, V, 3), device=dev, requires_grad=True)
+        w = torch.tensor(rs.randn(n, V), device=dev)
+        lum = scene.vertices_luminosity(posed)  # kernel
+        assert type(lum.grad_fn).__name__.startswith("VertexLuminosityFunc")
+        g = torch.autograd.grad((lum * w).sum(), [posed, light, amb])
+        g2 = torch.autograd.grad((scene.vertices_luminosity(posed) * w).sum(), [posed, light, amb])
+        with monkeypatch.context() as m:
+            m.setattr(fronthalf, "usable", lambda *a: False)
+            lum_r = scene.vertices_luminosity(posed)  # torch ops
+            g_r = torch.autograd.grad((lum_r * w).sum(), [posed, light, amb])
+        assert rel(lum.detach().cpu(), lum_r.detach().cpu()) < 1e-13
+        assert float((lum.detach() > amb.detach()).double().mean()) > 0.2  # (lit and unlit vertices both present)
+        for a, b, c in zip(g, g_r, g2):
+            assert rel(a.cpu(), b.cpu()) < 1e-11
+            assert torch.equal(a, c)  # deterministic
+        # a single posed mesh [V,3] goes the same way
+        assert rel(scene.vertices_luminosity(posed[0]).detach().cpu(), lum_r[0].detach().cpu()) < 1e-13
+    # ---- rigid energy
+    mesh = DeviceMesh(faces, vertices, device=dev)
+    energy = LaplacianRigidEnergyDevice(mesh.topology, vertices, 1000.0)
+    x = torch.tensor(vertices + 0.01 * rs.randn(V, 3), device=dev, requires_grad=True)
+    e, grad = energy.evaluate(x)
+    (ge,) = torch.autograd.grad(e, [x])
+    with monkeypatch.context() as m:
+        m.setattr(fronthalf, "usable", lambda *a: False)
+        e_r, grad_r = energy.evaluate(x)
+        (ge_r,) = torch.autograd.grad(e_r, [x])
+    assert abs(float(e) - float(e_r)) <= 1e-12 * abs(float(e_r)) and rel(grad.cpu(), grad_r.detach().cpu()) < 1e-12 and rel(ge.cpu(), ge_r.cpu()) < 1e-12
+    assert torch.equal(energy.evaluate(x)[0], e.detach()) or float(energy.evaluate(x)[0]) == float(e)
+
+
+def test_direct_fit_iteration_equals_the_autograd_iteration():
+    """The fitters' iteration as a fixed kernel sequence (_DirectIteration, the default on float64 ROCm tensors) against the same
+    iteration through autograd (``direct = False``): energies and every parameter, step by step, for the three fitters (the multi-frame
+    one with its per-view poses and the shared block of gradients)"""
+    from deodr_amd.mesh_fitter import MeshDepthFitter, MeshRGBFitterWithPose, MeshRGBFitterWithPoseMultiFrame
+
+    vertices, faces = hand()
+    d = fixture("depth_hand_fit.npz")
+    depth = d["depth_raw_f32"].astype(np.float64)
+    depth[depth == 0] = float(d["max_depth"])
+    r = fixture("rgb_hand_fit.npz")
+    rs = np.random.RandomState(2)
+
+    def depth_fitter():
+        f = MeshDepthFitter(vertices, faces, d["euler_init"], d["translation_init"], cregu=1000)
+        f.set_image(depth / float(d["max_depth"]), focal=241, distortion=d["distortion"])
+        f.set_max_depth(1)
+        f.set_depth_scale(float(d["depth_scale"]))
+        return f, ("vertices", "transform_quaternion", "transform_translation")
+
+    def rgb_fitter():
+        f = MeshRGBFitterWithPose(r["vertices_centered"], faces, np.zeros(3), r["translation_init"], r["default_color"], r["default_light_directional"],
+                                  float(r["default_light_ambient"]), cregu=1000)  # fmt: skip
+        f.set_image(r["image_u8"].astype(np.float64) / 255)
+        f.set_background_color(r["background_color"])
+        return f, ("vertices", "transform_quaternion", "transform_translation", "mesh_color", "light_directional", "light_ambient")
+
+    images = [np.clip(r["image_u8"].astype(np.float64) / 255 + 0.05 * rs.randn(*r["image_u8"].shape), 0, 1) for _ in range(3)]
+
+    def multi_fitter():
+        eul = np.stack([np.array([0, a, 0]) for a in (-0.2, 0.0, 0.2)])
+        f = MeshRGBFitterWithPoseMultiFrame(r["vertices_centered"], faces, eul, np.tile(r["translation_init"], (3, 1)), r["default_color"],
+                                            r["default_light_directional"], float(r["default_light_ambient"]), cregu=2000)  # fmt: skip
+        f.set_images(images)
+        f.set_background_color(r["background_color"])
+        return f, ("vertices", "transform_quaternion", "transform_translation", "mesh_color", "light_directional", "light_ambient")
+
+    for build in (depth_fitter, rgb_fitter, multi_fitter):
+        (a, names), (b, _) = build(), build()
+        b.direct = False
+        for step in range(6):
+            out_a, out_b = a.step_device(), b.step_device()
+            assert a._direct_state is not None and b._direct_state is None
+            ea, eb = float(out_a[0]), float(out_b[0])
+            assert abs(ea - eb) <= 1e-9 * abs(eb), (build.__name__, step, ea, eb)
+            assert rel(out_a[1].to(torch.float64).cpu(), out_b[1].to(torch.float64).cpu()) < 1e-9
+            for name in names:
+                pa, pb = getattr(a, name).detach().cpu(), getattr(b, name).detach().cpu()
+                assert rel(pa, pb) < 1e-9, (build.__name__, step, name)
+        assert a.iter == b.iter == 6
+
+
+def test_l2_loss_kernel():
+    """sum (image - obs)^2 of a frame batch in either pixel type, accumulated in double, deterministic"""
+    from deodr_amd import fronthalf
+
+    g = torch.Generator(device="cuda").manual_seed(0)
+    scratch = fronthalf.fit_scratch(100, 1, "cuda")
+    for dtype, shape in ((torch.float64, (2, 301, 517, 3)), (torch.float32, (8, 1024, 1024, 3)), (torch.float32, (1, 7, 5, 1))):
+        a, b = torch.rand(shape, dtype=dtype, device="cuda", generator=g), torch.rand(shape, dtype=dtype, device="cuda", generator=g)
+        out, again = torch.zeros(1, dtype=torch.float64, device="cuda"), torch.zeros(1, dtype=torch.float64, device="cuda")
+        fronthalf.l2_loss(a, b, out, scratch)
+        fronthalf.l2_loss(a, b, again, scratch)
+        ref = float(((a.double() - b.double()) ** 2).sum())
+        assert abs(float(out) - ref) <= 1e-12 * ref and float(out) == float(again)

@@ -36,19 +36,36 @@ def build(name):
         f.set_max_depth(1)
         f.set_depth_scale(float(d["depth_scale"]))
         return f, 1, 200 * 200
-    rs = np.random.RandomState(0)
     v0 = vertices - vertices.mean(axis=0)
     n = 1 if name == "rgb" else 8
-    img = [np.clip(0.5 + 0.2 * rs.randn(1024, 1024, 3), 0, 1) for _ in range(n)]  # (what is timed does not depend on the picture)
-    if name == "rgb":
-        f = MeshRGBFitterWithPose(v0, faces, np.zeros(3), np.zeros(3), np.array([0.8, 0.6, 0.5]), np.array([0.1, 0.5, 0.4]), 0.6, cregu=1000, pixel_dtype=pixel_dtype)
-        f.set_image(img[0])
-    else:
-        eul = np.stack([np.array([0, a, 0]) for a in np.linspace(-0.5, 0.5, 8)])
-        f = MeshRGBFitterWithPoseMultiFrame(v0, faces, eul, np.zeros((8, 3)), np.array([0.8, 0.6, 0.5]), np.array([0.1, 0.5, 0.4]), 0.6, cregu=2000, pixel_dtype=pixel_dtype)
-        f.set_images(img)
-    f.set_background_color(np.array([0.5, 0.6, 0.7]))
+    color, light, ambient, bg = np.array([0.8, 0.6, 0.5]), np.array([0.1, 0.5, 0.4]), 0.6, np.array([0.5, 0.6, 0.7])
+    eul = np.stack([np.array([0, a, 0]) for a in (np.linspace(-0.5, 0.5, 8) if n > 1 else [0.0])])
+
+    def make(euler, color):
+        if name == "rgb":
+            f = MeshRGBFitterWithPose(v0, faces, euler[0], np.zeros(3), color, light, ambient, cregu=1000, pixel_dtype=pixel_dtype)
+            f.set_image(np.zeros((1024, 1024, 3)))
+        else:
+            f = MeshRGBFitterWithPoseMultiFrame(v0, faces, euler, np.zeros((8, 3)), color, light, ambient, cregu=2000, pixel_dtype=pixel_dtype)
+            f.set_images([np.zeros((1024, 1024, 3))] * 8)
+        f.set_background_color(bg)
+        return f
+
+    # the target: the same mesh a little further round and of another colour, rendered by the fitter's own scene (a fit that converges:
+    # with a noise image as the target the mesh blows up over the timed iterations and the rasterizer's share with it)
+    target = make(eul + np.array([0.04, 0.06, -0.03]), np.array([0.7, 0.65, 0.55])).render().detach().cpu().numpy()
+    f = make(eul, color)
+    f.set_image(target[0]) if name == "rgb" else f.set_images(list(target))
     return f, n, n * 1024 * 1024
+
+
+def timed(run, count):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(count):
+        run()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / count
 
 
 for name in which:
@@ -61,40 +78,31 @@ for name in which:
             g.step_device()
         torch.cuda.synchronize()
         continue
+    # every measurement on a FRESH fitter over the same iterations (5 .. 5 + steps), so that the scene is the same in all of them
     for _ in range(5):
         f.step_device()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        f.step_device()  # energies stay on the device: nothing synchronises inside the loop
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / steps
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        f.step()  # the reference's protocol: float energy + NumPy images every step
-    torch.cuda.synchronize()
-    dt_host = (time.perf_counter() - t0) / steps
+    dt = timed(f.step_device, steps)  # energies stay on the device: nothing synchronises inside the loop
+    f, n, px = build(name)
+    for _ in range(5):
+        f.step_device()
+    dt_host = timed(f.step, steps)  # the reference's protocol: float energy + NumPy images every step
     from deodr_amd.mesh_fitter import GraphedStep
     dt_graph = float("nan")
     try:
-        g = GraphedStep(f)
-        for _ in range(3):
-            g.step_device()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            g.step_device()
-        torch.cuda.synchronize()
-        dt_graph = (time.perf_counter() - t0) / steps
+        g = GraphedStep(build(name)[0], warmup=3)  # (iterations 0 .. 4)
+        dt_graph = timed(g.step_device, steps)
     except Exception as e:
         print(f"{name}: graph capture failed: {e!r}")
+    f, n, px = build(name)
+    for _ in range(5):
+        f.step_device()
     hr.lib().deodr_hip_profile_enable(1)
-    for _ in range(8):
+    for _ in range(steps):
         f.step_device()
     torch.cuda.synchronize()
     hr.lib().deodr_hip_profile_enable(0)
     ms, ln = (ctypes.c_double * 4)(), (ctypes.c_ulonglong * 4)()
     hr.lib().deodr_hip_profile_read(ms, ln)
-    raster = sum(ms[i] for i in range(4)) / 8
+    raster = sum(ms[i] for i in range(4)) / steps
     print(f"{name}: {n} view(s), {px} pixels: step_device {dt*1e3:.3f} ms, step (float energy + NumPy images) {dt_host*1e3:.3f} ms, ONE HIP-GRAPH REPLAY per step {dt_graph*1e3:.3f} ms; rasterizer kernels "
-          f"{raster:.3f} ms per step = {100*raster/(dt*1e3):.0f} % of step_device; launches of the library per step: {sum(ln[i] for i in range(4))/8:.1f}")
+          f"{raster:.3f} ms per step: the graphed iteration is {dt_graph*1e3/raster:.2f} x the rasterizer; launches of the library's rasterizer per step: {sum(ln[i] for i in range(4))/steps:.1f}")
