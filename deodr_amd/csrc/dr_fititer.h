@@ -93,7 +93,7 @@ __device__ __forceinline__ UnitQuaternion load_unit_quaternion(const double *q, 
 // re-centres its vertices at the start of every step, mesh_fitter.py:131); quaternions are the raw parameters (normalised here)
 __global__ __launch_bounds__(FH_BLOCK) void fit_pose_project_kernel(double *vertices, const double *mean, const double *q, const double *t,
 																	 const double *extrinsic, const double *intrinsic, const double *distortion, double *posed,
-																	 double *ij, double *depths, int V, int n)
+																	 double *ij, double *depths, double *depth_colors, double depth_scale, int V, int n)
 {
 	const int v = blockIdx.x * FH_BLOCK + threadIdx.x;
 	if (v >= V)
@@ -112,6 +112,8 @@ __global__ __launch_bounds__(FH_BLOCK) void fit_pose_project_kernel(double *vert
 		store3(posed + 3 * at, p);
 		const CameraRow cam = load_camera(extrinsic, intrinsic, distortion, b);
 		project_point(cam, p, ij[2 * at], ij[2 * at + 1], depths[at]);
+		if (depth_colors) // a depth image is rendered with the scaled depth of a vertex as its one-channel colour (dr.py:1001-1036)
+			depth_colors[at] = depths[at] * depth_scale;
 	}
 }
 
@@ -121,8 +123,8 @@ __global__ __launch_bounds__(FH_BLOCK) void fit_pose_project_kernel(double *vert
 // workgroup.
 __global__ __launch_bounds__(FH_BLOCK) void fit_pose_project_b_kernel(const double *vertices, const double *q, const double *posed, const double *extrinsic,
 																	   const double *intrinsic, const double *distortion, const double *posed_b, const double *ij_b,
-																	   const double *depths_b, double *vertices_b, double *out, double *partials,
-																	   unsigned *counter, int V, int n)
+																	   const double *depths_b, double depths_b_scale, double *vertices_b, double *out,
+																	   double *partials, unsigned *counter, int V, int n)
 {
 	__shared__ double s_wave[FH_BLOCK / 64][7 * FIT_MAX_VIEWS + 3];
 	__shared__ double s_quat[FIT_MAX_VIEWS][4];
@@ -141,7 +143,7 @@ __global__ __launch_bounds__(FH_BLOCK) void fit_pose_project_b_kernel(const doub
 		{
 			const size_t at = (size_t)b * V + v;
 			const CameraRow cam = load_camera(extrinsic, intrinsic, distortion, b);
-			g = project_point_b(cam, load3(posed + 3 * at), ij_b[2 * at], ij_b[2 * at + 1], depths_b ? depths_b[at] : 0.0);
+			g = project_point_b(cam, load3(posed + 3 * at), ij_b[2 * at], ij_b[2 * at + 1], depths_b ? depths_b[at] * depths_b_scale : 0.0);
 			if (posed_b)
 				g = add3(g, load3(posed_b + 3 * at));
 		}
@@ -390,26 +392,37 @@ __global__ __launch_bounds__(FH_BLOCK) void rigid_energy_kernel(const double *x,
 
 // ---- sum (image - obs)^2 over a frame batch in the pixel type PixT, accumulated in double: the data energy of the colour fitters
 // (mesh_fitter.py:296-318); the rasterizer's fit step back-propagates exactly this residual.  One partial per workgroup, fixed order.
-constexpr int L2_BLOCKS = 2048;
+constexpr int L2_BLOCKS = 256; // (every workgroup ends with a ticket on ONE counter word: ~30 ns each, one after the other -- 2 048
+								// workgroups measured 64 us for a 50 MB frame, 1 024 workgroups 32 us, 512 workgroups 27 us)
+constexpr int L2_ROUND = 4;	   // chunks of 32 bytes per array a thread has in flight
 template <class PixT>
 __global__ __launch_bounds__(FH_BLOCK) void l2_loss_kernel(const PixT *image, const PixT *obs, size_t count, double *out, double *partials, unsigned *counter)
 {
-	constexpr int W = 32 / sizeof(PixT); // 32 bytes of each array per thread and round
+	constexpr int W = 32 / sizeof(PixT);
 	struct alignas(32) Chunk
 	{
 		PixT v[W];
 	};
 	double s[1] = {0};
-	const size_t chunks = count / W;
-	for (size_t i = (size_t)blockIdx.x * FH_BLOCK + threadIdx.x; i < chunks; i += (size_t)gridDim.x * FH_BLOCK)
+	const size_t chunks = count / W, stride = (size_t)gridDim.x * FH_BLOCK;
+	for (size_t i = (size_t)blockIdx.x * FH_BLOCK + threadIdx.x; i < chunks; i += L2_ROUND * stride)
 	{
-		const Chunk a = ((const Chunk *)image)[i], b = ((const Chunk *)obs)[i];
+		Chunk a[L2_ROUND], b[L2_ROUND];
 #pragma unroll
-		for (int j = 0; j < W; j++)
+		for (int u = 0; u < L2_ROUND; u++)
 		{
-			const double r = (double)a.v[j] - (double)b.v[j];
-			s[0] += r * r;
+			const size_t at = i + u * stride < chunks ? i + u * stride : i;
+			a[u] = ((const Chunk *)image)[at], b[u] = ((const Chunk *)obs)[at];
 		}
+#pragma unroll
+		for (int u = 0; u < L2_ROUND; u++)
+			if (i + u * stride < chunks)
+#pragma unroll
+				for (int j = 0; j < W; j++)
+				{
+					const double r = (double)a[u].v[j] - (double)b[u].v[j];
+					s[0] += r * r;
+				}
 	}
 	if (blockIdx.x == 0 && threadIdx.x < count - chunks * W)
 	{
@@ -419,6 +432,28 @@ __global__ __launch_bounds__(FH_BLOCK) void l2_loss_kernel(const PixT *image, co
 	double total[1];
 	if (grid_sum<1>(s, partials, counter, total) && threadIdx.x == 0)
 		out[0] = total[0];
+}
+
+// ---- the data term of the depth fitter (deodr/mesh_fitter.py:108-123): depth = clamp(image, 0, max_depth), diff = (depth - obs)^2,
+// loss = sum diff, image_b = d loss / d image = 2 (depth - obs) where the clamp passes (0 <= image <= max_depth), else 0
+template <class PixT>
+__global__ __launch_bounds__(FH_BLOCK) void depth_residual_kernel(const PixT *image, const double *obs, double max_depth, size_t count, double *depth, double *diff,
+																   PixT *image_b, double *loss, double *partials, unsigned *counter)
+{
+	double s[1] = {0};
+	for (size_t i = (size_t)blockIdx.x * FH_BLOCK + threadIdx.x; i < count; i += (size_t)gridDim.x * FH_BLOCK)
+	{
+		const double v = (double)image[i];
+		const double d = v < 0 ? 0.0 : v > max_depth ? max_depth : v;
+		const double r = d - obs[i];
+		depth[i] = d;
+		diff[i] = r * r;
+		image_b[i] = (PixT)((v >= 0 && v <= max_depth) ? 2 * r : 0.0);
+		s[0] += r * r;
+	}
+	double total[1];
+	if (grid_sum<1>(s, partials, counter, total) && threadIdx.x == 0)
+		loss[0] = total[0];
 }
 
 } // namespace

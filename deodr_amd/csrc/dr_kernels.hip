@@ -666,18 +666,19 @@ int deodr_hip_momentum_update(int n_tensors, double *const *x, double *const *sp
 }
 
 int deodr_hip_fit_pose_project(double *vertices, const double *vertices_mean, const double *quaternions, const double *translations, const double *extrinsic,
-							   const double *intrinsic, const double *distortion, double *posed, double *ij, double *depths, int V, int n, void *stream)
+							   const double *intrinsic, const double *distortion, double *posed, double *ij, double *depths, double *depth_colors,
+							   double depth_scale, int V, int n, void *stream)
 {
 	if (!vertices || !quaternions || !translations || !extrinsic || !intrinsic || !posed || !ij || !depths || V <= 0 || n <= 0)
 		return fail("fit_pose_project: bad arguments");
 	hipLaunchKernelGGL(fit_pose_project_kernel, dim3(fh_blocks(V)), dim3(FH_BLOCK), 0, (hipStream_t)stream, vertices, vertices_mean, quaternions, translations,
-					   extrinsic, intrinsic, distortion, posed, ij, depths, V, n);
+					   extrinsic, intrinsic, distortion, posed, ij, depths, depth_colors, depth_scale, V, n);
 	return check_hip(hipGetLastError(), "fit_pose_project launch");
 }
 
 int deodr_hip_fit_pose_project_b(const double *vertices, const double *quaternions, const double *posed, const double *extrinsic, const double *intrinsic,
-								 const double *distortion, const double *posed_b, const double *ij_b, const double *depths_b, double *vertices_b, double *out,
-								 void *scratch, size_t scratch_bytes, int V, int n, void *stream)
+								 const double *distortion, const double *posed_b, const double *ij_b, const double *depths_b, double depths_b_scale,
+								 double *vertices_b, double *out, void *scratch, size_t scratch_bytes, int V, int n, void *stream)
 {
 	if (!vertices || !quaternions || !posed || !extrinsic || !intrinsic || !ij_b || !vertices_b || !out || V <= 0 || n <= 0)
 		return fail("fit_pose_project_b: bad arguments");
@@ -686,7 +687,7 @@ int deodr_hip_fit_pose_project_b(const double *vertices, const double *quaternio
 	if (!scratch || scratch_bytes < fit_scratch_need_pose_b(V, n))
 		return fail("fit_pose_project_b: scratch too small (deodr_hip_fit_scratch_bytes)");
 	hipLaunchKernelGGL(fit_pose_project_b_kernel, dim3(fh_blocks(V)), dim3(FH_BLOCK), 0, (hipStream_t)stream, vertices, quaternions, posed, extrinsic, intrinsic,
-					   distortion, posed_b, ij_b, depths_b, vertices_b, out, (double *)((char *)scratch + 64), (unsigned *)scratch + FC_POSE_B, V, n);
+					   distortion, posed_b, ij_b, depths_b, depths_b_scale, vertices_b, out, (double *)((char *)scratch + 64), (unsigned *)scratch + FC_POSE_B, V, n);
 	return check_hip(hipGetLastError(), "fit_pose_project_b launch");
 }
 
@@ -751,7 +752,7 @@ int deodr_hip_l2_loss(const void *image, const void *obs, int pixel_dtype, size_
 		return fail("l2_loss: scratch too small (deodr_hip_fit_scratch_bytes)");
 	if (((uintptr_t)image | (uintptr_t)obs) & 31)
 		return fail("l2_loss: image and obs must be 32-byte aligned");
-	const size_t want = (count + FH_BLOCK * 8 - 1) / (FH_BLOCK * 8);
+	const size_t want = (count + FH_BLOCK * 32 - 1) / (FH_BLOCK * 32);
 	const dim3 grid((unsigned)(want < (size_t)L2_BLOCKS ? want : (size_t)L2_BLOCKS));
 	double *partials = (double *)((char *)scratch + 64);
 	unsigned *counter = (unsigned *)scratch + FC_L2;
@@ -762,6 +763,26 @@ int deodr_hip_l2_loss(const void *image, const void *obs, int pixel_dtype, size_
 		hipLaunchKernelGGL(l2_loss_kernel<float>, grid, dim3(FH_BLOCK), 0, (hipStream_t)stream, (const float *)image, (const float *)obs, count, out, partials,
 						   counter);
 	return check_hip(hipGetLastError(), "l2_loss launch");
+}
+
+int deodr_hip_depth_residual(const void *image, int pixel_dtype, const double *obs, double max_depth, size_t count, double *depth, double *diff, void *image_b,
+							 double *loss, void *scratch, size_t scratch_bytes, void *stream)
+{
+	if (!image || !obs || !depth || !diff || !image_b || !loss || count == 0 || (pixel_dtype != DEODR_HIP_F32 && pixel_dtype != DEODR_HIP_F64))
+		return fail("depth_residual: bad arguments");
+	if (!scratch || scratch_bytes < fit_scratch_need_l2())
+		return fail("depth_residual: scratch too small (deodr_hip_fit_scratch_bytes)");
+	const size_t want = (count + FH_BLOCK * 4 - 1) / (FH_BLOCK * 4);
+	const dim3 grid((unsigned)(want < (size_t)L2_BLOCKS ? want : (size_t)L2_BLOCKS));
+	double *partials = (double *)((char *)scratch + 64);
+	unsigned *counter = (unsigned *)scratch + FC_L2;
+	if (pixel_dtype == DEODR_HIP_F64)
+		hipLaunchKernelGGL(depth_residual_kernel<double>, grid, dim3(FH_BLOCK), 0, (hipStream_t)stream, (const double *)image, obs, max_depth, count, depth, diff,
+						   (double *)image_b, loss, partials, counter);
+	else
+		hipLaunchKernelGGL(depth_residual_kernel<float>, grid, dim3(FH_BLOCK), 0, (hipStream_t)stream, (const float *)image, obs, max_depth, count, depth, diff,
+						   (float *)image_b, loss, partials, counter);
+	return check_hip(hipGetLastError(), "depth_residual launch");
 }
 
 #ifdef DR_WAVE_TRACE

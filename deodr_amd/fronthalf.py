@@ -34,14 +34,15 @@ def _lib():
         L.deodr_hip_silhouette_flags.argtypes = [vp, vp, vp, vp, i, i, i, i, vp]
         L.deodr_hip_momentum_update.argtypes = [i, vp, vp, vp, vp, vp, vp, vp, vp, d, d, vp, vp, vp, vp, C.c_size_t, vp]
         L.deodr_hip_fit_scratch_bytes.argtypes, L.deodr_hip_fit_scratch_bytes.restype = [i, i], C.c_size_t
-        L.deodr_hip_fit_pose_project.argtypes = [vp] * 10 + [i, i, vp]
-        L.deodr_hip_fit_pose_project_b.argtypes = [vp] * 12 + [C.c_size_t, i, i, vp]
+        L.deodr_hip_fit_pose_project.argtypes = [vp] * 11 + [d, i, i, vp]
+        L.deodr_hip_fit_pose_project_b.argtypes = [vp] * 9 + [d, vp, vp, vp, C.c_size_t, i, i, vp]
         L.deodr_hip_vertex_shade.argtypes = [vp] * 7 + [i, vp, vp, i, i, i, vp]
         L.deodr_hip_vertex_shade_b.argtypes = [vp] * 7 + [i, vp, vp, vp, vp, vp, C.c_size_t, i, i, i, vp]
         L.deodr_hip_rigid_energy.argtypes = [vp] * 5 + [d, vp, vp, vp, d, vp, C.c_size_t, i, vp]
         L.deodr_hip_l2_loss.argtypes = [vp, vp, i, C.c_size_t, vp, vp, C.c_size_t, vp]
+        L.deodr_hip_depth_residual.argtypes = [vp, i, vp, d, C.c_size_t, vp, vp, vp, vp, vp, C.c_size_t, vp]
         for f in ("rigid_transform", "rigid_transform_b", "project_points", "project_points_b", "silhouette_flags", "momentum_update", "fit_pose_project",
-                  "fit_pose_project_b", "vertex_shade", "vertex_shade_b", "rigid_energy", "l2_loss"):  # fmt: skip
+                  "fit_pose_project_b", "vertex_shade", "vertex_shade_b", "rigid_energy", "l2_loss", "depth_residual"):  # fmt: skip
             getattr(L, "deodr_hip_" + f).restype = i
         _bound = True
     return L
@@ -148,22 +149,22 @@ def _topology_scratch(topology, n):
     return cache[n]
 
 
-def fit_pose_project(vertices, vertices_mean, quaternions, translations, camera, posed, ij, depths):
+def fit_pose_project(vertices, vertices_mean, quaternions, translations, camera, posed, ij, depths, depth_colors=None, depth_scale=1.0):
     """centre ``vertices`` [V,3] in place (when a mean [3] is given), pose them with every view's quaternion (normalised inside) and
     translation, project them with every view's camera -> posed [n,V,3], ij [n,V,2], depths [n,V] (all written)"""
     n, V = posed.shape[0], posed.shape[1]
     with torch.cuda.device(posed.device):
         _check(_lib().deodr_hip_fit_pose_project(_p(vertices), _p(vertices_mean), _p(quaternions), _p(translations), _p(camera.extrinsic), _p(camera.intrinsic),
-                                                 _p(camera.distortion), _p(posed), _p(ij), _p(depths), V, n, _stream(posed.device)))  # fmt: skip
+                                                 _p(camera.distortion), _p(posed), _p(ij), _p(depths), _p(depth_colors), float(depth_scale), V, n, _stream(posed.device)))  # fmt: skip
 
 
-def fit_pose_project_b(vertices, quaternions, posed, camera, posed_b, ij_b, depths_b, vertices_b, out, scratch):
+def fit_pose_project_b(vertices, quaternions, posed, camera, posed_b, ij_b, depths_b, vertices_b, out, scratch, depths_b_scale=1.0):
     """adjoint of :func:`fit_pose_project`: -> vertices_b [V,3]; out [3 + 7n] = mean of vertices_b over the vertices, quaternion adjoints
     [n,4] (raw quaternions), translation adjoints [n,3]"""
     n, V = posed.shape[0], posed.shape[1]
     with torch.cuda.device(posed.device):
         _check(_lib().deodr_hip_fit_pose_project_b(_p(vertices), _p(quaternions), _p(posed), _p(camera.extrinsic), _p(camera.intrinsic), _p(camera.distortion),
-                                                   _p(posed_b), _p(ij_b), _p(depths_b), _p(vertices_b), _p(out), _p(scratch), scratch.numel(), V, n,
+                                                   _p(posed_b), _p(ij_b), _p(depths_b), float(depths_b_scale), _p(vertices_b), _p(out), _p(scratch), scratch.numel(), V, n,
                                                    _stream(posed.device)))  # fmt: skip
 
 
@@ -200,6 +201,16 @@ def l2_loss(image, obs, out, scratch):
     with torch.cuda.device(image.device):
         _check(_lib().deodr_hip_l2_loss(_p(image), _p(obs), 1 if image.dtype == torch.float64 else 0, image.numel(), _p(out), _p(scratch), scratch.numel(),
                                         _stream(image.device)))  # fmt: skip
+
+
+def depth_residual(image, obs, max_depth, depth, diff, image_b, loss, scratch):
+    """the depth fitter's data term in one kernel: depth = clamp(image, 0, max_depth), diff = (depth - obs)^2 (both float64, written),
+    image_b = d sum(diff) / d image in the pixel dtype, loss[0] = sum diff (deodr/mesh_fitter.py:108-123)"""
+    assert obs.dtype == torch.float64 and depth.dtype == torch.float64 and diff.dtype == torch.float64 and image_b.dtype == image.dtype
+    assert all(t.is_contiguous() and t.numel() == image.numel() for t in (image, obs, depth, diff, image_b))
+    with torch.cuda.device(image.device):
+        _check(_lib().deodr_hip_depth_residual(_p(image), 1 if image.dtype == torch.float64 else 0, _p(obs), float(max_depth), image.numel(), _p(depth), _p(diff),
+                                               _p(image_b), _p(loss), _p(scratch), scratch.numel(), _stream(image.device)))  # fmt: skip
 
 
 class VertexLuminosityFunc(torch.autograd.Function):

@@ -161,7 +161,7 @@ class _DirectIteration:
             at += int(np.prod(shape))
         pd = sc.pixel_dtype
         self.image, self.z = torch.empty((n, cam.height, cam.width, C), dtype=pd, device=dev), torch.empty((n, cam.height, cam.width), dtype=pd, device=dev)
-        self.bound = None
+        self.bound = self.depth = self.diff = self.image_b = None
 
     def sync(self, fitter):
         """the kernels keep the column mean of the vertices up to date themselves; recompute it when the fitter's tensors were replaced"""
@@ -256,23 +256,24 @@ class _PoseFitter:
         d.sync(self)
         return d
 
-    def _direct_forward(self, d):
+    def _direct_forward(self, d, depth_colors=None, depth_scale=1.0):
         """parameters -> posed vertices, image coordinates, depths, silhouette flags (in the rasterizer's own arrays)"""
         from . import fronthalf
 
         topo = self.mesh.topology
         d.ds.set_views(ij=d.ij, depths=d.depths, colors=d.colors, shade=d.shade, edgeflags=d.flags)  # (no copies; another render may have rebound them)
-        fronthalf.fit_pose_project(self.vertices, d.vmean, self.transform_quaternion, self.transform_translation, self.camera, d.posed, d.ij, d.depths)
+        fronthalf.fit_pose_project(self.vertices, d.vmean, self.transform_quaternion, self.transform_translation, self.camera, d.posed, d.ij, d.depths,
+                                   depth_colors, depth_scale)  # fmt: skip
         if self.scene.sigma > 0:
             fronthalf.silhouette_flags(d.ij, topo._faces_u32, topo._edge_faces, topo.clockwise, out=d.flags)
 
-    def _direct_backward_and_update(self, d, depths_b, step_max, data_weight, extra=()):
+    def _direct_backward_and_update(self, d, depths_b, step_max, data_weight, extra=(), depths_b_scale=1.0):
         """adjoint of pose + projection, rigid energy, (all-reduce of the shared block,) momentum update of every parameter in place"""
         from . import fronthalf
 
         n = d.posed.shape[0]
         fronthalf.fit_pose_project_b(self.vertices, self.transform_quaternion, d.posed, self.camera, d.posed_b, d.grads["ij_b"], depths_b, d.vertices_b,
-                                     d.pose_out, d.scratch)  # fmt: skip
+                                     d.pose_out, d.scratch, depths_b_scale)  # fmt: skip
         self._allreduce_shared(d.shared)
         fronthalf.rigid_energy(self.vertices, self.rigid_energy.vertices_ref, self.mesh.topology, self.cregu, d.g_rigid, d.energy, d.scratch, d.e_data,
                                data_weight)  # fmt: skip
@@ -327,19 +328,17 @@ class MeshDepthFitter(_PoseFitter):
         return diff_image.sum(), e_rigid, g_rigid, depth[:, :, 0], diff_image
 
     def _step_direct(self, d):
-        self._direct_forward(d)
-        torch.mul(d.depths[..., None], self.depthScale, out=d.colors)  # the depth of a vertex is its colour (dr.py:1001-1036)
+        from . import fronthalf
+
+        self._direct_forward(d, d.colors, self.depthScale)  # the scaled depth of a vertex is its colour (dr.py:1001-1036)
         image, _z = d.rasterizer.render(d.ds, self.scene.sigma, out=(d.image, d.z))
-        depth = image.clamp(0, self.max_depth).to(torch.float64)  # [1,H,W,1]
-        residual = depth - self.mesh_image[None, :, :, None]
-        diff_image = (residual * residual)[0, :, :, 0]
-        torch.sum(diff_image, dim=(0, 1), out=d.e_data[0])
-        image_b = (2 * residual * ((image >= 0) & (image <= self.max_depth))).to(image.dtype)  # (clamp passes the gradient on [0, max_depth])
+        if d.depth is None:
+            d.depth, d.diff, d.image_b = torch.empty_like(self.mesh_image), torch.empty_like(self.mesh_image), torch.empty_like(image)
+        fronthalf.depth_residual(image, self.mesh_image, self.max_depth, d.depth, d.diff, d.image_b, d.e_data, d.scratch)  # clamp, residual, loss, adjoint
         d.grads_flat.zero_()
-        d.rasterizer.render_backward(d.ds, image_b=image_b, grads=d.grads)
-        depths_b = d.grads["colors_b"][..., 0] * self.depthScale
-        energy = self._direct_backward_and_update(d, depths_b, (1, 0.1, 0.1), 1.0)
-        return energy, depth[0, :, :, 0], diff_image
+        d.rasterizer.render_backward(d.ds, image_b=d.image_b, grads=d.grads)
+        energy = self._direct_backward_and_update(d, d.grads["colors_b"], (1, 0.1, 0.1), 1.0, depths_b_scale=self.depthScale)
+        return energy, d.depth, d.diff
 
     def step_device(self):
         d = self._direct_iteration(1, False)

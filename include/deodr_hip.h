@@ -156,8 +156,9 @@ int deodr_hip_momentum_update(int n_tensors, double *const *x, double *const *sp
  *
  * deodr_hip_fit_pose_project     vertices [V,3] (centred IN PLACE by vertices_mean [3] when not NULL, mesh_fitter.py:131), raw
  *                                quaternions [n,4] (normalised inside), translations [n,3], cameras as in deodr_hip_project_points
- *                                -> posed [n,V,3], ij [n,V,2], depths [n,V]
- * deodr_hip_fit_pose_project_b   posed_b [n,V,3] (or NULL), ij_b, depths_b (or NULL) -> vertices_b [V,3] summed over the views;
+ *                                -> posed [n,V,3], ij [n,V,2], depths [n,V]; depth_colors [n,V] (or NULL) = depth_scale * depths, the
+ *                                one-channel "colour" a depth image is rendered from (Scene3D.render_depth, dr.py:1001-1036)
+ * deodr_hip_fit_pose_project_b   posed_b [n,V,3] (or NULL), ij_b, depths_b_scale * depths_b (or NULL) -> vertices_b [V,3] summed over the views;
  *                                out [3 + 7 n] = column mean of vertices_b (the data gradient is projected on zero-mean displacements,
  *                                mesh_fitter.py:140, 319), quaternion adjoints [n,4] w.r.t. the RAW quaternions, translation adjoints [n,3]
  * deodr_hip_vertex_shade         posed [n,V,3] -> luminosity [n,V] = max(0, -normal . light) + ambient (dr.py:814-822) with the vertex
@@ -169,16 +170,20 @@ int deodr_hip_momentum_update(int n_tensors, double *const *x, double *const *sp
  *                                (deodr/laplacian_rigid_energy.py:15-41); L^T L as CSR rows m_offsets [V+1], m_cols, m_vals.  With
  *                                data_energy [1] != NULL also energy[1] = data_weight * data_energy[0] + energy[0], the energy a
  *                                fitter's step reports (mesh_fitter.py:147)
+ * deodr_hip_depth_residual       the data term of the depth fitter (mesh_fitter.py:108-123) over `count` pixels of a rendered depth image in
+ *                                the pixel type: depth = clamp(image, 0, max_depth), diff = (depth - obs)^2, loss[0] = sum diff, image_b =
+ *                                2 (depth - obs) where 0 <= image <= max_depth, else 0 (pixel type) -- what deodr_hip_render_scene_b takes
  * deodr_hip_l2_loss              out[0] = sum (image - obs)^2 over `count` values of the pixel type (DEODR_HIP_F32 / _F64), accumulated in
  *                                double: the data energy whose gradient deodr_hip_render_scene_fit back-propagates (mesh_fitter.py:296-318)
  * deodr_hip_momentum_update      (above) grad_scale[k]: weight of grad (not of grad2); grad_mean[k] [3] or NULL: subtracted from every
  *                                row of a [count/3, 3] gradient; mean_out[k] [3] or NULL: column mean of the updated tensor */
 size_t deodr_hip_fit_scratch_bytes(int V, int n);
 int deodr_hip_fit_pose_project(double *vertices, const double *vertices_mean, const double *quaternions, const double *translations, const double *extrinsic,
-							   const double *intrinsic, const double *distortion, double *posed, double *ij, double *depths, int V, int n, void *stream);
+							   const double *intrinsic, const double *distortion, double *posed, double *ij, double *depths, double *depth_colors,
+							   double depth_scale, int V, int n, void *stream);
 int deodr_hip_fit_pose_project_b(const double *vertices, const double *quaternions, const double *posed, const double *extrinsic, const double *intrinsic,
-								 const double *distortion, const double *posed_b, const double *ij_b, const double *depths_b, double *vertices_b, double *out,
-								 void *scratch, size_t scratch_bytes, int V, int n, void *stream);
+								 const double *distortion, const double *posed_b, const double *ij_b, const double *depths_b, double depths_b_scale,
+								 double *vertices_b, double *out, void *scratch, size_t scratch_bytes, int V, int n, void *stream);
 int deodr_hip_vertex_shade(const double *posed, const uint32_t *faces, const uint32_t *vf_offsets, const uint32_t *vf_corners, const double *light,
 						   const double *ambient, const double *color, int C, double *luminosity, double *colors, int V, int n, int clockwise, void *stream);
 int deodr_hip_vertex_shade_b(const double *posed, const uint32_t *faces, const uint32_t *vf_offsets, const uint32_t *vf_corners, const double *light,
@@ -188,6 +193,8 @@ int deodr_hip_rigid_energy(const double *vertices, const double *vertices_ref, c
 						   double cregu, double *gradient, double *energy, const double *data_energy, double data_weight, void *scratch, size_t scratch_bytes,
 						   int V, void *stream);
 int deodr_hip_l2_loss(const void *image, const void *obs, int pixel_dtype, size_t count, double *out, void *scratch, size_t scratch_bytes, void *stream);
+int deodr_hip_depth_residual(const void *image, int pixel_dtype, const double *obs, double max_depth, size_t count, double *depth, double *diff, void *image_b,
+							 double *loss, void *scratch, size_t scratch_bytes, void *stream);
 
 /* Bits of the sticky scene-error word: the index checks of the reference's checkSceneValid
  * (DifferentiableRenderer.h:2700-2712: `faces` entries < nb_vertices, `faces_uv` entries < nb_uv; plus the null-texture

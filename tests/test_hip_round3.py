@@ -457,3 +457,25 @@ def test_l2_loss_kernel():
         fronthalf.l2_loss(a, b, again, scratch)
         ref = float(((a.double() - b.double()) ** 2).sum())
         assert abs(float(out) - ref) <= 1e-12 * ref and float(out) == float(again)
+
+
+def test_depth_residual_kernel():
+    """clamp, residual, loss and its adjoint of the depth fitter's data term in one kernel (deodr/mesh_fitter.py:108-123)"""
+    from deodr_amd import fronthalf
+
+    g = torch.Generator(device="cuda").manual_seed(1)
+    scratch = fronthalf.fit_scratch(100, 1, "cuda")
+    for dtype in (torch.float64, torch.float32):
+        image = (torch.rand((1, 200, 213, 1), dtype=torch.float64, device="cuda", generator=g) * 1.4 - 0.2).to(dtype)  # some below 0, some above 1
+        image[0, 0, 0, 0], image[0, 0, 1, 0] = 0.0, 1.0  # the ends of the clamp pass the gradient
+        obs = torch.rand((200, 213), dtype=torch.float64, device="cuda", generator=g)
+        depth, diff, image_b = torch.empty_like(obs), torch.empty_like(obs), torch.empty_like(image)
+        loss = torch.zeros(1, dtype=torch.float64, device="cuda")
+        fronthalf.depth_residual(image, obs, 1.0, depth, diff, image_b, loss, scratch)
+        x = image.to(torch.float64).requires_grad_(True)
+        d_ref = x.clamp(0, 1.0)[0, :, :, 0]
+        diff_ref = (d_ref - obs) ** 2
+        (g_ref,) = torch.autograd.grad(diff_ref.sum(), [x])
+        assert torch.equal(depth, d_ref.detach()) and rel(diff.cpu(), diff_ref.detach().cpu()) < 1e-15
+        assert abs(float(loss) - float(diff_ref.sum())) <= 1e-12 * float(diff_ref.sum())
+        assert rel(image_b.double().cpu(), g_ref.to(dtype).double().cpu()) < 1e-15 and float((image_b == 0).double().mean()) > 0.1
