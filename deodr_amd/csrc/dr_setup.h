@@ -276,50 +276,68 @@ __global__ __launch_bounds__(PRIM_BLOCK, DR_PRIM_WAVES) void setup_bin_kernel(KP
 			incl += lane >= d ? up : 0;
 		}
 		const int total = __shfl(incl, 63, 64);
-		for (int base = 0; base < total; base += 64)
+		// BIN_ITEMS blocks per lane and round: their slot requests are all in flight before the first answer is used (a round is one
+		// atomic round trip of ~2.5 us whatever the number of requests a lane has pending)
+		constexpr int BIN_ITEMS = 2;
+		uint32_t *cnt = tri_block ? w.tri_cnt : w.edge_cnt;
+		for (int base = 0; base < total; base += 64 * BIN_ITEMS)
 		{
-			const int item = base + lane;
-			int owner = 0; // first lane whose inclusive count exceeds item (lanes past the end: any lane, nothing is written)
+			uint32_t got[BIN_ITEMS][9], use[BIN_ITEMS], prim[BIN_ITEMS];
+			int tile0[BIN_ITEMS];
 #pragma unroll
-			for (int step = 32; step; step >>= 1)
-				owner += __shfl(incl, owner + step - 1, 64) <= item ? step : 0;
-			owner = owner > 63 ? 63 : owner;
-			const int before = __shfl(incl - extra, owner, 64);
-			const bool valid = item < total;
-			double q[12];
-#pragma unroll
-			for (int i = 0; i < 12; i++)
-				q[i] = (tri_block && i >= 9) ? 0.0 : __shfl(hp[i], owner, 64);
-			const int tx0 = __shfl(btx0, owner, 64), ty0 = __shfl(bty0, owner, 64), ntx = __shfl(bntx, owner, 64), nty = __shfl(bnty, owner, 64);
-			const uint32_t prim = (uint32_t)__shfl(bprim, owner, 64);
-			if (!valid)
-				continue;
-			const int nbx = (ntx + 2) / 3, blk = item - before + (first_done ? 1 : 0);
-			const int bx = (blk % nbx) * 3, by = (blk / nbx) * 3;
-			const int keep_dx = (tri_block && !p.strict) ? ntx - 1 : -1; // (non-strict fill rule: see the first block below)
-			const uint32_t outside = tri_block ? tiles3x3_outside_halfplanes<3>(q, tx0 + bx, ty0 + by) : tiles3x3_outside_halfplanes<4>(q, tx0 + bx, ty0 + by);
-			uint32_t *cnt = tri_block ? w.tri_cnt : w.edge_cnt;
-			uint32_t got[9];
-			bool use[9];
-#pragma unroll
-			for (int c = 0; c < 9; c++)
+			for (int u = 0; u < BIN_ITEMS; u++)
 			{
-				const int dx = bx + c % 3, dy = by + c / 3;
-				use[c] = dx < ntx && dy < nty && (!((outside >> c) & 1u) || dx == keep_dx);
-				got[c] = 0;
-				if (use[c])
-					got[c] = atomicAdd(&cnt[(ty0 + dy) * p.L.tiles_x + tx0 + dx], 1u);
+				const int item = base + u * 64 + lane;
+				int owner = 0; // first lane whose inclusive count exceeds item (lanes past the end: any lane, nothing is written)
+#pragma unroll
+				for (int step = 32; step; step >>= 1)
+					owner += __shfl(incl, owner + step - 1, 64) <= item ? step : 0;
+				owner = owner > 63 ? 63 : owner;
+				const int before = __shfl(incl - extra, owner, 64);
+				double q[12];
+#pragma unroll
+				for (int i = 0; i < 12; i++)
+					q[i] = (tri_block && i >= 9) ? 0.0 : __shfl(hp[i], owner, 64);
+				const int tx0 = __shfl(btx0, owner, 64), ty0 = __shfl(bty0, owner, 64), ntx = __shfl(bntx, owner, 64), nty = __shfl(bnty, owner, 64);
+				prim[u] = (uint32_t)__shfl(bprim, owner, 64);
+				use[u] = 0;
+				tile0[u] = 0;
+				if (item < total)
+				{
+					const int nbx = (ntx + 2) / 3, blk = item - before + (first_done ? 1 : 0);
+					const int bx = (blk % nbx) * 3, by = (blk / nbx) * 3;
+					const int keep_dx = (tri_block && !p.strict) ? ntx - 1 : -1; // (non-strict fill rule: see the first block below)
+					const uint32_t outside =
+						tri_block ? tiles3x3_outside_halfplanes<3>(q, tx0 + bx, ty0 + by) : tiles3x3_outside_halfplanes<4>(q, tx0 + bx, ty0 + by);
+					tile0[u] = (ty0 + by) * p.L.tiles_x + tx0 + bx;
+#pragma unroll
+					for (int c = 0; c < 9; c++)
+					{
+						const int dx = bx + c % 3, dy = by + c / 3;
+						if (dx < ntx && dy < nty && (!((outside >> c) & 1u) || dx == keep_dx))
+							use[u] |= 1u << c;
+					}
+				}
+#pragma unroll
+				for (int c = 0; c < 9; c++)
+				{
+					got[u][c] = 0;
+					if ((use[u] >> c) & 1u)
+						got[u][c] = atomicAdd(&cnt[tile0[u] + (c / 3) * p.L.tiles_x + c % 3], 1u);
+				}
 			}
 #pragma unroll
-			for (int c = 0; c < 9; c++)
-				if (use[c])
-				{
-					const int tile = (ty0 + by + c / 3) * p.L.tiles_x + tx0 + bx + c % 3;
-					if (tri_block)
-						place_in_tile(w.tri_list, K_TRI, w.tri_pool, p.L.tri_pool_cap, &w.hdr->tri_spill[cur], tile, prim, got[c]);
-					else
-						place_in_tile(w.edge_list, K_EDGE, w.edge_pool, p.L.edge_pool_cap, &w.hdr->edge_spill[cur], tile, prim, got[c]);
-				}
+			for (int u = 0; u < BIN_ITEMS; u++)
+#pragma unroll
+				for (int c = 0; c < 9; c++)
+					if ((use[u] >> c) & 1u)
+					{
+						const int tile = tile0[u] + (c / 3) * p.L.tiles_x + c % 3;
+						if (tri_block)
+							place_in_tile(w.tri_list, K_TRI, w.tri_pool, p.L.tri_pool_cap, &w.hdr->tri_spill[cur], tile, prim[u], got[u][c]);
+						else
+							place_in_tile(w.edge_list, K_EDGE, w.edge_pool, p.L.edge_pool_cap, &w.hdr->edge_spill[cur], tile, prim[u], got[u][c]);
+					}
 		}
 	};
 	if (tri_block)
