@@ -358,22 +358,26 @@ def main():
     z = torch.empty((B, S, S), dtype=torch.float32, device=dev)
     grads = ds.zero_grads()
     # Multi-GPU: what the ranks share is the mesh -- 3-D vertex positions and vertex colours -- so the all-reduced buffer is
-    # [vertices_b (V x 3), colors_b summed over the views (V x C)].  vertices_b = sum over views of J^T ij_b with J = d ij / d X of
-    # the view's pinhole camera (the adjoint of deodr's Camera.project_points, dr.py:397-438, as one broadcast multiply + one
-    # reduction).  The views of this benchmark do not move, so J is formed once; a fitter recomputes it with the projection.
+    # [vertices_b (V x 3), colors_b summed over the views (V x C)].  vertices_b = sum over the views of the adjoint of the view's
+    # camera projection (deodr's Camera.project_points_backward, dr.py:397-438) applied to ij_b: ONE launch of the library's
+    # pose-and-projection adjoint (deodr_hip_fit_pose_project_b with the identity pose: the kernel the device fitters use), which
+    # also adds the colour gradients up over the views.
     shared = torch.zeros(V * (3 + Cc), dtype=torch.float64, device=dev)  # packed shared-parameter gradient
-    jac = None
+    reduction = None
     if world > 1 or args.force_dist:
+        from deodr_amd import fronthalf
+        from deodr_amd.scene3d import DeviceCamera
+
         verts, _faces = scenes.bumpy_sphere(100, 100)
-        J = np.empty((B, V, 2, 3))
-        for b, a in enumerate(poses):
-            cam = scenes.fit_camera(S, S, 60.0, verts, scenes.rotx(0.37) @ scenes.roty(0.23 + float(a)))
-            R, f = cam.extrinsic[:, :3], cam.intrinsic[0, 0]
-            pc = verts @ R.T + cam.extrinsic[:, 3]
-            for d in range(2):
-                J[b, :, d, :] = f / pc[:, 2:3] * (R[d][None, :] - (pc[:, d] / pc[:, 2])[:, None] * R[2][None, :])
-        assert np.abs(scenes.project(cam, verts)[0] - views[-1].ij).max() < 1e-9  # same cameras as the rendered views
-        jac = torch.as_tensor(J, device=dev)
+        cams = [scenes.fit_camera(S, S, 60.0, verts, scenes.rotx(0.37) @ scenes.roty(0.23 + float(a))) for a in poses]
+        assert np.abs(scenes.project(cams[-1], verts)[0] - views[-1].ij).max() < 1e-9  # same cameras as the rendered views
+        camera = DeviceCamera(np.stack([c.extrinsic for c in cams]), np.stack([c.intrinsic for c in cams]), S, S, None, dev)
+        world_vertices = torch.as_tensor(np.ascontiguousarray(verts, dtype=np.float64), device=dev)
+        reduction = dict(
+            camera=camera, vertices=world_vertices, posed=world_vertices[None].expand(B, -1, -1).contiguous(),
+            identity=torch.tensor([[0.0, 0.0, 0.0, 1.0]] * B, dtype=torch.float64, device=dev),
+            pose_out=torch.zeros(3 + 7 * B, dtype=torch.float64, device=dev), scratch=fronthalf.fit_scratch(V, B, dev), call=fronthalf.fit_pose_project_b,
+        )  # fmt: skip
 
     obs_views = obs.expand(B, S, S, Cc).contiguous()  # one observation per view (here the same synthetic image)
     # The reduction of step k (camera adjoint, packing, RCCL all-reduce) runs on a communication stream while step k + 1 renders:
@@ -409,10 +413,11 @@ def main():
                 comm.wait_event(rendered)
                 if pending[i] is not None:
                     pending[i].wait()  # shared_pp[i] is free again
-                # three kernels: J^T ij_b as a broadcast multiply and a reduction over (views, image axes) written into the
-                # packed buffer, the colour gradients summed over the views next to it
-                torch.sum(g["ij_b"][..., None] * jac, dim=(0, 2), out=shared_pp[i][: 3 * V].view(V, 3))
-                torch.sum(g["colors_b"], dim=0, out=shared_pp[i][3 * V :].view(V, Cc))
+                # one kernel: the projection adjoint of every view applied to ij_b and summed over the views, the colour gradients
+                # summed over the views, both written straight into the packed buffer
+                rd = reduction
+                rd["call"](rd["vertices"], rd["identity"], rd["posed"], rd["camera"], None, g["ij_b"], None, shared_pp[i][: 3 * V].view(V, 3), rd["pose_out"],
+                           rd["scratch"], colors_b=g["colors_b"], colors_sum=shared_pp[i][3 * V :].view(V, Cc))  # fmt: skip
                 reads_done[i] = torch.cuda.Event()
                 reads_done[i].record()
                 pending[i] = dist.all_reduce(shared_pp[i], async_op=True)

@@ -124,7 +124,8 @@ __global__ __launch_bounds__(FH_BLOCK) void fit_pose_project_kernel(double *vert
 __global__ __launch_bounds__(FH_BLOCK) void fit_pose_project_b_kernel(const double *vertices, const double *q, const double *posed, const double *extrinsic,
 																	   const double *intrinsic, const double *distortion, const double *posed_b, const double *ij_b,
 																	   const double *depths_b, double depths_b_scale, double *vertices_b, double *out,
-																	   double *partials, unsigned *counter, int V, int n)
+																	   double *partials, unsigned *counter, int V, int n, const double *colors_b, int C,
+																	   double *colors_sum)
 {
 	__shared__ double s_wave[FH_BLOCK / 64][7 * FIT_MAX_VIEWS + 3];
 	__shared__ double s_quat[FIT_MAX_VIEWS][4];
@@ -135,17 +136,46 @@ __global__ __launch_bounds__(FH_BLOCK) void fit_pose_project_b_kernel(const doub
 	double *mine = partials + (size_t)blockIdx.x * K;
 	const Vec3 c = on ? load3(vertices + 3 * v) : Vec3{0, 0, 0};
 	Vec3 acc = {0, 0, 0};
+	// (the inputs of view b + 1 are requested before view b is worked on: a view is a round trip of ~1.5 us followed by seven
+	// wavefront sums, and the loop is not unrolled by the compiler -- 8 views of a 10 000-vertex mesh took 45 us one after the other)
+	struct ViewIn
+	{
+		Vec3 posed, posed_b;
+		double g0, g1, gd, col[4];
+	};
+	double col_sum[4] = {0, 0, 0, 0};
+	auto load_view = [&](int b) {
+		ViewIn in = {{0, 0, 0}, {0, 0, 0}, 0, 0, 0, {0, 0, 0, 0}};
+		if (on)
+		{
+			if (colors_sum)
+#pragma unroll
+				for (int c = 0; c < 4; c++)
+					if (c < C)
+						in.col[c] = colors_b[((size_t)b * V + v) * C + c];
+			const size_t at = (size_t)b * V + v;
+			in.posed = load3(posed + 3 * at);
+			in.g0 = ij_b[2 * at], in.g1 = ij_b[2 * at + 1];
+			in.gd = depths_b ? depths_b[at] * depths_b_scale : 0.0;
+			if (posed_b)
+				in.posed_b = load3(posed_b + 3 * at);
+		}
+		return in;
+	};
+	ViewIn next = load_view(0);
 	for (int b = 0; b < n; b++)
 	{
+		const ViewIn in = next;
+		next = load_view(b + 1 < n ? b + 1 : b);
+#pragma unroll
+		for (int c = 0; c < 4; c++)
+			col_sum[c] += in.col[c];
 		const UnitQuaternion uq = load_unit_quaternion(q, b);
 		Vec3 g = {0, 0, 0};
 		if (on)
 		{
-			const size_t at = (size_t)b * V + v;
 			const CameraRow cam = load_camera(extrinsic, intrinsic, distortion, b);
-			g = project_point_b(cam, load3(posed + 3 * at), ij_b[2 * at], ij_b[2 * at + 1], depths_b ? depths_b[at] * depths_b_scale : 0.0);
-			if (posed_b)
-				g = add3(g, load3(posed_b + 3 * at));
+			g = add3(project_point_b(cam, in.posed, in.g0, in.g1, in.gd), in.posed_b);
 		}
 		// r = c + 2 w a + 2 bb, a = u x c, bb = u x a   (deodr/tools.py:25-35)
 		const Vec3 &u = uq.u;
@@ -166,6 +196,11 @@ __global__ __launch_bounds__(FH_BLOCK) void fit_pose_project_b_kernel(const doub
 	}
 	if (on)
 		store3(vertices_b + 3 * v, acc);
+	if (on && colors_sum) // per-vertex colours shared by the views (a multi-view fit of a coloured mesh): their adjoints summed over the views
+#pragma unroll
+		for (int c = 0; c < 4; c++)
+			if (c < C)
+				colors_sum[(size_t)v * C + c] = col_sum[c];
 	{
 		const double sums[3] = {acc.x, acc.y, acc.z};
 #pragma unroll
@@ -184,24 +219,38 @@ __global__ __launch_bounds__(FH_BLOCK) void fit_pose_project_b_kernel(const doub
 			s += s_wave[w][k];
 		mine[k] = s;
 	}
-	__threadfence();
 	__syncthreads();
 	if (threadIdx.x == 0)
+	{
+		__threadfence(); // release (one thread, after the barrier: the workgroup's partials are visible to the device before its ticket)
 		s_last = atomicAdd(counter, 1u) == gridDim.x - 1;
+	}
 	__syncthreads();
 	if (!s_last)
 		return;
-	__threadfence();
+	__threadfence(); // acquire
 	double *pose_b = out + 3; // [n,4] then [n,3]
-	// wavefront w adds up the outputs w, w + 4, ...: its lanes share the workgroups' partials (lane l: l, l + 64, ...), then a DPP tree
-	for (int k = wave; k < K; k += FH_BLOCK / 64)
+	// lane k of every wavefront adds up output k (consecutive lanes read consecutive addresses) over the workgroups w, w + 4, ... of its
+	// wavefront w, eight independent partial sums at a time (a lane adding 400 partials one after the other waits 400 times: 142 us for
+	// a 100 000-vertex mesh); the four wavefront sums meet in LDS.  The order depends on the launch geometry only.
+	__syncthreads(); // (s_wave is reused)
+	constexpr int NW = FH_BLOCK / 64;
+	for (int k = lane; k < K; k += 64)
+	{
+		double a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+		for (unsigned blk = wave; blk < gridDim.x; blk += NW * 8)
+#pragma unroll
+			for (int j = 0; j < 8; j++)
+				if (blk + NW * j < gridDim.x)
+					a[j] += partials[(size_t)(blk + NW * j) * K + k];
+		s_wave[wave][k] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+	}
+	__syncthreads();
+	for (int k = threadIdx.x; k < K; k += FH_BLOCK)
 	{
 		double s = 0;
-		for (unsigned blk = lane; blk < gridDim.x; blk += 64)
-			s += partials[(size_t)blk * K + k];
-		s = wave_sum(s);
-		if (lane != 0)
-			continue;
+		for (int w = 0; w < NW; w++)
+			s += s_wave[w][k];
 		if (k >= 7 * n)
 			out[k - 7 * n] = s / V;
 		else if (k % 7 >= 4)

@@ -60,11 +60,13 @@ __device__ __forceinline__ bool grid_sum(const double (&v)[K], double *partials,
 		for (int w = 0; w < FH_BLOCK / 64; w++)
 			s += s_wave[w][threadIdx.x];
 		partials[(size_t)blockIdx.x * K + threadIdx.x] = s;
-		__threadfence(); // release: the partial is visible to the device before this workgroup takes its ticket
 	}
 	__syncthreads();
 	if (threadIdx.x == 0)
+	{
+		__threadfence(); // release (after the barrier: the workgroup's partials are visible to the device before its ticket)
 		s_last = atomicAdd(counter, 1u) == gridDim.x - 1;
+	}
 	__syncthreads();
 	if (!s_last)
 		return false;

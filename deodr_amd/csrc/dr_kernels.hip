@@ -678,16 +678,19 @@ int deodr_hip_fit_pose_project(double *vertices, const double *vertices_mean, co
 
 int deodr_hip_fit_pose_project_b(const double *vertices, const double *quaternions, const double *posed, const double *extrinsic, const double *intrinsic,
 								 const double *distortion, const double *posed_b, const double *ij_b, const double *depths_b, double depths_b_scale,
-								 double *vertices_b, double *out, void *scratch, size_t scratch_bytes, int V, int n, void *stream)
+								 double *vertices_b, double *out, void *scratch, size_t scratch_bytes, int V, int n, const double *colors_b, int nb_colors,
+								 double *colors_sum, void *stream)
 {
 	if (!vertices || !quaternions || !posed || !extrinsic || !intrinsic || !ij_b || !vertices_b || !out || V <= 0 || n <= 0)
 		return fail("fit_pose_project_b: bad arguments");
 	if (n > FIT_MAX_VIEWS)
 		return fail("fit_pose_project_b: at most 64 views per call");
+	if (colors_sum && (!colors_b || nb_colors <= 0 || nb_colors > 4))
+		return fail("fit_pose_project_b: colors_sum needs colors_b with 1 - 4 channels");
 	if (!scratch || scratch_bytes < fit_scratch_need_pose_b(V, n))
 		return fail("fit_pose_project_b: scratch too small (deodr_hip_fit_scratch_bytes)");
 	hipLaunchKernelGGL(fit_pose_project_b_kernel, dim3(fh_blocks(V)), dim3(FH_BLOCK), 0, (hipStream_t)stream, vertices, quaternions, posed, extrinsic, intrinsic,
-					   distortion, posed_b, ij_b, depths_b, depths_b_scale, vertices_b, out, (double *)((char *)scratch + 64), (unsigned *)scratch + FC_POSE_B, V, n);
+					   distortion, posed_b, ij_b, depths_b, depths_b_scale, vertices_b, out, (double *)((char *)scratch + 64), (unsigned *)scratch + FC_POSE_B, V, n, colors_b, nb_colors, colors_sum);
 	return check_hip(hipGetLastError(), "fit_pose_project_b launch");
 }
 

@@ -35,7 +35,7 @@ def _lib():
         L.deodr_hip_momentum_update.argtypes = [i, vp, vp, vp, vp, vp, vp, vp, vp, d, d, vp, vp, vp, vp, C.c_size_t, vp]
         L.deodr_hip_fit_scratch_bytes.argtypes, L.deodr_hip_fit_scratch_bytes.restype = [i, i], C.c_size_t
         L.deodr_hip_fit_pose_project.argtypes = [vp] * 11 + [d, i, i, vp]
-        L.deodr_hip_fit_pose_project_b.argtypes = [vp] * 9 + [d, vp, vp, vp, C.c_size_t, i, i, vp]
+        L.deodr_hip_fit_pose_project_b.argtypes = [vp] * 9 + [d, vp, vp, vp, C.c_size_t, i, i, vp, i, vp, vp]
         L.deodr_hip_vertex_shade.argtypes = [vp] * 7 + [i, vp, vp, i, i, i, vp]
         L.deodr_hip_vertex_shade_b.argtypes = [vp] * 7 + [i, vp, vp, vp, vp, vp, C.c_size_t, i, i, i, vp]
         L.deodr_hip_rigid_energy.argtypes = [vp] * 5 + [d, vp, vp, vp, d, vp, C.c_size_t, i, vp]
@@ -158,14 +158,15 @@ def fit_pose_project(vertices, vertices_mean, quaternions, translations, camera,
                                                  _p(camera.distortion), _p(posed), _p(ij), _p(depths), _p(depth_colors), float(depth_scale), V, n, _stream(posed.device)))  # fmt: skip
 
 
-def fit_pose_project_b(vertices, quaternions, posed, camera, posed_b, ij_b, depths_b, vertices_b, out, scratch, depths_b_scale=1.0):
+def fit_pose_project_b(vertices, quaternions, posed, camera, posed_b, ij_b, depths_b, vertices_b, out, scratch, depths_b_scale=1.0, colors_b=None,
+                       colors_sum=None):
     """adjoint of :func:`fit_pose_project`: -> vertices_b [V,3]; out [3 + 7n] = mean of vertices_b over the vertices, quaternion adjoints
-    [n,4] (raw quaternions), translation adjoints [n,3]"""
+    [n,4] (raw quaternions), translation adjoints [n,3]; colors_sum [V,C] (optional) = colors_b [n,V,C] summed over the views"""
     n, V = posed.shape[0], posed.shape[1]
     with torch.cuda.device(posed.device):
         _check(_lib().deodr_hip_fit_pose_project_b(_p(vertices), _p(quaternions), _p(posed), _p(camera.extrinsic), _p(camera.intrinsic), _p(camera.distortion),
                                                    _p(posed_b), _p(ij_b), _p(depths_b), float(depths_b_scale), _p(vertices_b), _p(out), _p(scratch), scratch.numel(), V, n,
-                                                   _stream(posed.device)))  # fmt: skip
+                                                   _p(colors_b), 0 if colors_b is None else int(colors_b.shape[-1]), _p(colors_sum), _stream(posed.device)))  # fmt: skip
 
 
 def vertex_shade(posed, topology, light, ambient, color=None, luminosity=None, colors=None):

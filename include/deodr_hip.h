@@ -160,7 +160,9 @@ int deodr_hip_momentum_update(int n_tensors, double *const *x, double *const *sp
  *                                one-channel "colour" a depth image is rendered from (Scene3D.render_depth, dr.py:1001-1036)
  * deodr_hip_fit_pose_project_b   posed_b [n,V,3] (or NULL), ij_b, depths_b_scale * depths_b (or NULL) -> vertices_b [V,3] summed over the views;
  *                                out [3 + 7 n] = column mean of vertices_b (the data gradient is projected on zero-mean displacements,
- *                                mesh_fitter.py:140, 319), quaternion adjoints [n,4] w.r.t. the RAW quaternions, translation adjoints [n,3]
+ *                                mesh_fitter.py:140, 319), quaternion adjoints [n,4] w.r.t. the RAW quaternions, translation adjoints [n,3];
+ *                                colors_sum [V,C] (or NULL) = colors_b [n,V,C] summed over the views (per-vertex colours shared by the
+ *                                views: mesh_fitter.py:518-527 adds them up view by view on the host)
  * deodr_hip_vertex_shade         posed [n,V,3] -> luminosity [n,V] = max(0, -normal . light) + ambient (dr.py:814-822) with the vertex
  *                                normals of triangulated_mesh.py:113-151, and/or colors [n,V,C] = color [C] * luminosity (C <= 3).
  *                                vf_offsets [V+1], vf_corners [3T]: for every vertex the slots 3 f + corner it occupies in `faces`
@@ -183,7 +185,8 @@ int deodr_hip_fit_pose_project(double *vertices, const double *vertices_mean, co
 							   double depth_scale, int V, int n, void *stream);
 int deodr_hip_fit_pose_project_b(const double *vertices, const double *quaternions, const double *posed, const double *extrinsic, const double *intrinsic,
 								 const double *distortion, const double *posed_b, const double *ij_b, const double *depths_b, double depths_b_scale,
-								 double *vertices_b, double *out, void *scratch, size_t scratch_bytes, int V, int n, void *stream);
+								 double *vertices_b, double *out, void *scratch, size_t scratch_bytes, int V, int n, const double *colors_b, int nb_colors,
+								 double *colors_sum, void *stream);
 int deodr_hip_vertex_shade(const double *posed, const uint32_t *faces, const uint32_t *vf_offsets, const uint32_t *vf_corners, const double *light,
 						   const double *ambient, const double *color, int C, double *luminosity, double *colors, int V, int n, int clockwise, void *stream);
 int deodr_hip_vertex_shade_b(const double *posed, const uint32_t *faces, const uint32_t *vf_offsets, const uint32_t *vf_corners, const double *light,

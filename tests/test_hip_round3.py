@@ -479,3 +479,50 @@ def test_depth_residual_kernel():
         assert torch.equal(depth, d_ref.detach()) and rel(diff.cpu(), diff_ref.detach().cpu()) < 1e-15
         assert abs(float(loss) - float(diff_ref.sum())) <= 1e-12 * float(diff_ref.sum())
         assert rel(image_b.double().cpu(), g_ref.to(dtype).double().cpu()) < 1e-15 and float((image_b == 0).double().mean()) > 0.1
+
+
+def test_pose_project_adjoint_sums_views_and_colours(monkeypatch):
+    """deodr_hip_fit_pose_project(_b) against autograd through the torch formulas (centring, renormalised quaternions, projection
+    with distortion); the optional sum of per-vertex colour adjoints over the views (bench.py's shared-gradient reduction)"""
+    from deodr_amd import fronthalf
+    from deodr_amd.mesh_fitter import qrot
+    from deodr_amd.scene3d import DeviceCamera
+
+    rs = np.random.RandomState(3)
+    vertices, _faces = hand()
+    n, V, C = 4, len(vertices), 3
+    dev = "cuda"
+    rot = np.array([[1.0, 0, 0], [0, -1, 0], [0, 0, -1]])
+    ext = np.stack([np.column_stack((rot, -rot.T.dot(vertices.mean(axis=0) + np.array([0.3 * i, 0, 8.0 + i]) * np.std(vertices)))) for i in range(n)])
+    K = np.stack([np.array([[250.0 + 10 * i, 0.3, 64], [0, 240.0, 48 + i], [0, 0, 1]]) for i in range(n)])
+    dist = np.stack([np.array([0.1, -0.02, 0.003, -0.004, 0.01]) * (i + 1) for i in range(n)])
+    cam = DeviceCamera(ext, K, 96, 128, dist, dev)
+    v0 = torch.tensor(vertices + 0.01, device=dev)
+    q = torch.tensor(rs.randn(n, 4) * 0.1 + np.array([0, 0, 0, 1.0]), device=dev, requires_grad=True)  # raw: not unit
+    t = torch.tensor(rs.randn(n, 3) * 0.05, device=dev, requires_grad=True)
+    wi, wd, wp = torch.tensor(rs.randn(n, V, 2), device=dev), torch.tensor(rs.randn(n, V), device=dev), torch.tensor(rs.randn(n, V, 3), device=dev)
+    colors_b = torch.tensor(rs.randn(n, V, C), device=dev)
+    # torch formulation
+    x = v0.clone().requires_grad_(True)
+    with monkeypatch.context() as m:
+        m.setattr(fronthalf, "usable", lambda *a: False)
+        centred = x - x.mean(dim=0, keepdim=True)
+        posed_r = qrot(q / q.norm(dim=-1, keepdim=True), centred[None].expand(n, -1, -1)) + t[:, None, :]
+        ij_r, depths_r = cam.project_points(posed_r)
+        g_r = torch.autograd.grad((ij_r * wi).sum() + (depths_r * wd).sum() * 0.7 + (posed_r * wp).sum(), [x, q, t])
+    # kernels
+    xk, mean = v0.clone(), v0.mean(dim=0)
+    posed, ij, depths, dcol = torch.empty((n, V, 3), dtype=torch.float64, device=dev), torch.empty((n, V, 2), dtype=torch.float64, device=dev), torch.empty((n, V), dtype=torch.float64, device=dev), torch.empty((n, V), dtype=torch.float64, device=dev)  # fmt: skip
+    fronthalf.fit_pose_project(xk, mean, q.detach(), t.detach(), cam, posed, ij, depths, depth_colors=dcol, depth_scale=2.5)
+    assert rel(xk.cpu(), (v0 - mean).cpu()) < 1e-15 and rel(posed.cpu(), posed_r.detach().cpu()) < 1e-13
+    assert rel(ij.cpu(), ij_r.detach().cpu()) < 1e-13 and rel(depths.cpu(), depths_r.detach().cpu()) < 1e-14 and rel(dcol.cpu(), 2.5 * depths.cpu()) < 1e-15
+    vertices_b, out = torch.empty((V, 3), dtype=torch.float64, device=dev), torch.empty(3 + 7 * n, dtype=torch.float64, device=dev)
+    colors_sum = torch.empty((V, C), dtype=torch.float64, device=dev)
+    scratch = fronthalf.fit_scratch(V, n, dev)
+    for _ in range(2):  # (twice: the scratch counters must come back to zero)
+        fronthalf.fit_pose_project_b(xk, q.detach(), posed, cam, wp, wi, wd, vertices_b, out, scratch, depths_b_scale=0.7, colors_b=colors_b, colors_sum=colors_sum)
+    # the torch gradient w.r.t. x went through the centring: the projection on zero-mean displacements
+    assert rel((vertices_b - out[:3]).cpu(), g_r[0].cpu()) < 1e-11
+    assert rel(out[3 : 3 + 4 * n].view(n, 4).cpu(), g_r[1].cpu()) < 1e-10 and rel(out[3 + 4 * n :].view(n, 3).cpu(), g_r[2].cpu()) < 1e-11
+    assert rel(colors_sum.cpu(), colors_b.sum(dim=0).cpu()) < 1e-15
+    assert int(scratch[:64].view(torch.int32).abs().sum()) == 0
