@@ -6,25 +6,33 @@
 //   setup_bin_kernel        blocks of 256 threads on a 1-D grid, the edge blocks first: 256 edge slots compacted to the flagged
 //                           ones, or one triangle per thread.  Cull, depth sum, stencil + attribute planes in double and in
 //                           registers (dr_prims.h), edge records (+ the EdgeFin record finalize reads), the index checks of
-//                           checkSceneValid, binning into 8 x 8 tiles (all slot requests of a 3 x 3 block of tiles in flight;
-//                           large boxes by the whole wavefront), optional gradient clearing
+//                           checkSceneValid, binning into 8 x 8 tiles (all slot requests of a 3 x 3 block of tiles in flight; a
+//                           thread bins the first block of its primitive, the other blocks of all primitives of a wavefront
+//                           are dealt out evenly over its lanes), optional gradient clearing
 //   tile_scan_kernel        one thread per tile: counters -> work list of the NON-EMPTY tiles (entries carry the first triangle
 //                           ids; many-primitive tiles first), tile bitmap, three lists of edge tiles by edge count, sweep slots
 //   raster_fwd_fast_kernel  1 wavefront / work-list entry, lane = pixel.  Pass 1 (z-buffered triangles staged 16 at a time
 //                           through LDS, exact scanline spans, winner = min (Z, index)), shading of the winner, pass 2 (ordered
-//                           edge overdraw) fused in registers, ONE write of image / z (/ owner) per pixel.  FUSED: also the
-//                           adjoint of pass 1 for the sum-of-squares residual in tiles without edges (deodr_hip_render_scene_fit)
+//                           edge overdraw) fused in registers, ONE write of image / z (/ owner) per pixel.  FUSED
+//                           (deodr_hip_render_scene_fit): also the adjoint for the sum-of-squares residual -- of every tile of an
+//                           untextured scene (tiles with silhouette edges: reverse sweep + pass 1 by a second instance of the
+//                           walker on the head of the work list; pairs of adjacent edge-free tiles share a wavefront), of the
+//                           edge-free tiles of a textured one
 //   fill_kernel / fill_word background + depth = inf of the empty tiles, runs of tiles written as contiguous 16-byte pieces:
-//                           a kernel on a forked stream (forward-only calls) or extra workgroups of the two kernels below (fit step)
+//                           a kernel on a forked stream (forward-only calls) or extra workgroups of the forward raster and of
+//                           finalize, dealt 2 : 1 (fit step)
 //   raster_bwd_fast_kernel  (two-call path) adjoint of pass 1 in every non-empty tile without edges
-//   raster_bwd_edge_kernel  persistent waves over the listed edge tiles: adjoint of pass 2 (un-blend in reverse order, moments
+//   raster_bwd_edge_kernel  (two-call path, textured fit steps) persistent waves over the listed edge tiles: adjoint of pass 2 (un-blend in reverse order, moments
 //                           by a transposing butterfly, one 15-lane atomic per edge and tile), then of pass 1
 //   finalize_kernel         per primitive: moments -> plane adjoints -> 3x3-inverse adjoint -> vertex gradients
 //   raster_fwd_kernel / raster_bwd_kernel   the same algorithm without LDS staging: nb_colors > 4, antialiase_error
+//   dr_fronthalf.h, dr_fititer.h   the O(V) kernels either side of the rasterizer in a fit iteration (pose + projection, shading,
+//                           silhouette flags, their adjoints, rigid energy, data terms, momentum update): deterministic sums
 //
 // Where: dr_workspace.h (layout, KParams, wave primitives) . dr_setup.h (setup_bin_kernel) . dr_forward.h (tile_scan_kernel, fill,
 // raster_fwd_fast_kernel) . dr_backward.h (raster_bwd_fast_kernel, raster_bwd_edge_kernel) . dr_finalize.h (finalize_kernel) .
-// dr_forward_generic.h / dr_backward_generic.h (the un-staged family, edge ordering) . dr_math.h / dr_prims.h (per-primitive math).
+// dr_forward_generic.h / dr_backward_generic.h (the un-staged family, edge ordering) . dr_math.h / dr_prims.h (per-primitive math) .
+// dr_fronthalf.h / dr_fititer.h (fit iteration).
 //
 // No MFMA anywhere: the path is gather / scatter + streaming writes.  The workspace is self-cleaning (tile counters are
 // zeroed by the scan kernel, spill counters are double-buffered by the parity of the forward count, list counters are zeroed
