@@ -129,7 +129,10 @@ class _DirectIteration:
 
     Layout of ``flat``: [light_b 3 | ambient_b 1 | colour_b C | data energy 1 | vertices_b 3V | mean of vertices_b 3 || quaternion_b 4n |
     translation_b 3n]: everything before the bar is shared by the views and is what ONE all-reduce sums over the ranks of a multi-GPU fit
-    (no packing copies); the pose adjoints after it stay local."""
+    (no packing copies); the pose adjoints after it stay local.
+
+    What ``step_device`` returns on this path (energy, image, ...) are views of these buffers: the next step overwrites them (``step()``
+    converts them to a float and NumPy arrays at once, as the reference's protocol wants)."""
 
     def __init__(self, fitter, nb_colors, shaded):
         from . import fronthalf
@@ -247,7 +250,8 @@ class _PoseFitter:
 
         topo = self.mesh.topology
         params = (self.vertices, self.transform_quaternion, self.transform_translation)
-        if not (self.direct and fronthalf.usable(*params) and all(p.is_contiguous() for p in params) and topo._edge_faces is not None):
+        if not (self.direct and fronthalf.usable(*params) and all(p.is_contiguous() for p in params) and topo._edge_faces is not None
+                and self.camera.n_views <= 64):  # (deodr_hip_fit_pose_project_b: at most 64 views per call)
             return None
         key = (id(self.camera), nb_colors, shaded, self.scene.pixel_dtype, id(self.scene.background_color), id(self.scene.background_image))
         if self._direct_state is None or self._direct_state[0] != key:

@@ -16,7 +16,7 @@ s0 = views[0]
 stack = lambda n: np.stack([np.asarray(getattr(v, n)) for v in views])
 ds = DeviceScene(s0.faces, s0.faces_uv, s0.textured, s0.shaded, s0.uv, stack("ij"), stack("depths"), stack("colors"), stack("shade"),
                  stack("edgeflags"), S, S, texture=None, background_color=s0.background_color, clockwise=s0.clockwise,
-                 vertex_dtype=torch.float64, pixel_dtype=torch.float32, device=dev)
+                 vertex_dtype=torch.float32 if "--vtx32" in sys.argv else torch.float64, pixel_dtype=torch.float32, device=dev)
 r = HipRasterizer.for_scene(ds)
 C = ds.nb_colors
 obs = torch.rand((B, S, S, C), dtype=torch.float32, device=dev)
