@@ -378,6 +378,26 @@ def test_fit_iteration_kernels_equal_the_torch_formulas(monkeypatch):
             assert torch.equal(a, c)  # deterministic
         # a single posed mesh [V,3] goes the same way
         assert rel(scene.vertices_luminosity(posed[0]).detach().cpu(), lum_r[0].detach().cpu()) < 1e-13
+    # ---- a closed mesh whose poles have 30 faces around them (lists longer than the eight lanes that share one), one view
+    sv, sf = scenes.bumpy_sphere(30, 24)
+    sv = np.asarray(sv, dtype=np.float64)
+    mesh = DeviceMesh(sf, sv, colors=np.zeros((len(sv), 3)), device=dev)
+    scene = Scene3DDevice()
+    scene.set_mesh(mesh)
+    scene.light_directional = torch.tensor([0.1, 0.7, -0.4], device=dev, dtype=torch.float64, requires_grad=True)
+    scene.light_ambient = torch.tensor(0.1, device=dev, dtype=torch.float64, requires_grad=True)
+    posed = torch.tensor(sv[None] * (1 + 0.05 * rs.randn(1, len(sv), 1)), device=dev, requires_grad=True)
+    w = torch.tensor(rs.randn(1, len(sv)), device=dev)
+    g = torch.autograd.grad((scene.vertices_luminosity(posed) * w).sum(), [posed, scene.light_directional, scene.light_ambient])
+    sphere_energy = LaplacianRigidEnergyDevice(mesh.topology, sv, 10.0)
+    es, gs = sphere_energy.evaluate(posed[0].detach())
+    with monkeypatch.context() as m:
+        m.setattr(fronthalf, "usable", lambda *a: False)
+        g_r = torch.autograd.grad((scene.vertices_luminosity(posed) * w).sum(), [posed, scene.light_directional, scene.light_ambient])
+        es_r, gs_r = sphere_energy.evaluate(posed[0].detach())
+    for a, b in zip(g, g_r):
+        assert rel(a.cpu(), b.cpu()) < 1e-11
+    assert abs(float(es) - float(es_r)) <= 1e-12 * abs(float(es_r)) and rel(gs.cpu(), gs_r.cpu()) < 1e-12
     # ---- rigid energy
     mesh = DeviceMesh(faces, vertices, device=dev)
     energy = LaplacianRigidEnergyDevice(mesh.topology, vertices, 1000.0)
