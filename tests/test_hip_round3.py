@@ -546,3 +546,24 @@ def test_pose_project_adjoint_sums_views_and_colours(monkeypatch):
     assert rel(out[3 : 3 + 4 * n].view(n, 4).cpu(), g_r[1].cpu()) < 1e-10 and rel(out[3 + 4 * n :].view(n, 3).cpu(), g_r[2].cpu()) < 1e-11
     assert rel(colors_sum.cpu(), colors_b.sum(dim=0).cpu()) < 1e-15
     assert int(scratch[:64].view(torch.int32).abs().sum()) == 0
+
+
+def test_examples_run(capsys):
+    """examples/: the reference's four examples on the device path, a few iterations each; the depth fit lands on the reference's curve"""
+    import importlib
+    import sys as _sys
+
+    ex = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples")
+    _sys.path.insert(0, ex)
+    try:
+        depth = importlib.import_module("depth_image_hand_fitting").main(iterations=10)  # iterations 5 .. 14 (GraphedStep ran 0 .. 4)
+        golden = fixture("depth_hand_fit.npz")["energies"]
+        assert np.abs(depth - golden[5:15]).max() <= 1e-6 * golden.max()
+        rgb = importlib.import_module("rgb_image_hand_fitting").main(iterations=6)
+        assert np.abs(rgb - fixture("rgb_hand_fit.npz")["energies"][5:11]).max() <= 1e-6 * rgb[0]
+        multi = importlib.import_module("rgb_multiview_hand").main(iterations=6, graph=False)
+        assert np.abs(multi - fixture("rgb_multiview_fit.npz")["energies"][:6]).max() <= 1e-6 * multi[0]
+        soup = importlib.import_module("triangle_soup_fitting").main(iterations=8)
+        assert soup[-1] < soup[0]
+    finally:
+        _sys.path.remove(ex)
