@@ -16,8 +16,30 @@ __global__ __launch_bounds__(PRIM_BLOCK, DR_PRIM_WAVES) void finalize_kernel(KPa
   // (Lists of the front-facing triangles / drawn edges compacted by the set-up kernel were tried: a quarter as many wavefronts,
   // all lanes busy -- and 32 -> 41 us: the kernel is a chain of dependent round trips, fewer wavefronts overlap fewer of them.)
 	DR_WAVE_TRACE_SCOPE(1);
+	const int loss_blocks = p.loss_out ? 1 : 0;
+	if (loss_blocks && blockIdx.x == 0)
+	{ // one extra workgroup, the FIRST of the grid (it overlaps the others): loss = background loss of the whole frame + the walkers'
+	  // partials (complete: the forward raster is over; LOSS_SLOTS per view), then lanes (DPP tree) and wavefronts in order.
+		__shared__ double s_loss[PRIM_BLOCK / 64];
+		double s = 0;
+		for (int j = threadIdx.x; j < p.n_views * LOSS_SLOTS; j += PRIM_BLOCK) // (one value per thread and view)
+			s += p.loss_wave[j];
+		s = wave_sum(s);
+		if ((threadIdx.x & 63) == 0)
+			s_loss[threadIdx.x >> 6] = s;
+		__syncthreads();
+		if (threadIdx.x == 0)
+		{
+			double sum = p.loss_tile_bg[0];
+			for (int i = 0; i < PRIM_BLOCK / 64; i++)
+				sum += s_loss[i];
+			p.loss_out[0] = sum;
+		}
+		return;
+	}
 	const int fill_n = fill_share(p.fill_mode, 1, p.L.nwords), fill_blocks = (p.n_views * fill_n + PRIM_BLOCK / 64 - 1) / (PRIM_BLOCK / 64);
-	const int fb = DR_FILL_FIRST ? (int)blockIdx.x : (int)blockIdx.x - p.n_views * prim_blocks(p.T); // index among the fill workgroups
+	const int bx = (int)blockIdx.x - loss_blocks;
+	const int fb = DR_FILL_FIRST ? bx : bx - p.n_views * prim_blocks(p.T); // index among the fill workgroups
 	if (DR_FILL_FIRST ? fb < fill_blocks : fb >= 0)
 	{ // workgroups that stream the background of this kernel's share of the empty tiles (fill_share)
 		const int gw = fb * (PRIM_BLOCK / 64) + (int)(threadIdx.x >> 6);
@@ -28,7 +50,7 @@ __global__ __launch_bounds__(PRIM_BLOCK, DR_PRIM_WAVES) void finalize_kernel(KPa
 #ifndef DR_FIN_EDGE_FIRST
 #define DR_FIN_EDGE_FIRST 1 // (triangle blocks first: finalize 37.5 -> 43.5 us)
 #endif
-	const PrimWork pw = prim_work(p, DR_FIN_EDGE_FIRST, DR_FILL_FIRST ? fill_blocks : 0);
+	const PrimWork pw = prim_work(p, DR_FIN_EDGE_FIRST, (DR_FILL_FIRST ? fill_blocks : 0) + loss_blocks);
 	const int view = pw.view;
 	const bool tri_block = pw.tri;
 	const SceneView s = scene_view(p, view);

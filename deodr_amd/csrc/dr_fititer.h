@@ -505,4 +505,46 @@ __global__ __launch_bounds__(FH_BLOCK) void depth_residual_kernel(const PixT *im
 		loss[0] = total[0];
 }
 
+// ---- the loss of a fit step without a pass over the frame (deodr_hip_render_scene_fit_loss): the caller's table holds, per tile and in
+// total, the loss sum (background - obs)^2 of a frame that is all background -- computed ONCE per observation by the two kernels
+// below --; the forward raster only adds, per non-empty tile, (loss of the tile as rendered - its background loss).
+template <class PixT>
+__global__ __launch_bounds__(64) void background_loss_kernel(KParams p, double *table)
+{ // one wavefront per tile: table[1 + view * ntiles + tile]
+	const int tile = blockIdx.x, view = blockIdx.y, lane = threadIdx.x;
+	const int px = (tile % p.L.tiles_x) * TILE + (lane & 7), py = (tile / p.L.tiles_x) * TILE + (lane >> 3);
+	double r2 = 0;
+	if (px < p.W && py < p.H)
+	{
+		const size_t pix = (size_t)py * p.W + px;
+		const PixT *o = (const PixT *)p.obs + ((size_t)view * p.H * p.W + pix) * p.C;
+		for (int c = 0; c < p.C; c++)
+		{
+			const double d = (double)(PixT)background_channel<PixT>(p, view, pix, c) - (double)o[c]; // (the frame holds the background rounded to PixT)
+			r2 += d * d;
+		}
+	}
+	r2 = wave_sum(r2);
+	if (lane == 0)
+		table[1 + (size_t)view * p.L.ntiles + tile] = r2;
+}
+__global__ __launch_bounds__(FH_BLOCK) void background_loss_total_kernel(double *table, size_t count)
+{ // table[0] = sum of the others, by one workgroup in a fixed order
+	__shared__ double s_wave[FH_BLOCK / 64];
+	double s = 0;
+	for (size_t i = threadIdx.x; i < count; i += FH_BLOCK)
+		s += table[1 + i];
+	s = wave_sum(s);
+	if ((threadIdx.x & 63) == 0)
+		s_wave[threadIdx.x >> 6] = s;
+	__syncthreads();
+	if (threadIdx.x == 0)
+	{
+		double total = 0;
+		for (int w = 0; w < FH_BLOCK / 64; w++)
+			total += s_wave[w];
+		table[0] = total;
+	}
+}
+
 } // namespace

@@ -856,8 +856,9 @@ __host__ __device__ inline int fwd_tile_blocks(int ntiles)
 // triangle listed only in A covers no pixel of B; a triangle listed in both has two slots), so coverage, depth test -- min (Z,
 // index) per pixel -- and therefore every result are those of the two tiles walked one after the other.
 template <class PixT>
-__device__ __forceinline__ void fwd_pair_tiles(const KParams &p, const ViewPtrs &w, WaveLds &S, int view, int lane, int tile, int nA, int nB, uint32_t my_id)
-{
+__device__ __forceinline__ void fwd_pair_tiles(const KParams &p, const ViewPtrs &w, WaveLds &S, int view, int lane, int tile, int nA, int nB, uint32_t my_id,
+											   double *loss_at)
+{ // loss_at (or NULL): this walker's partial of the loss, see tile_loss
 	const int W = p.W, H = p.H, C = p.C, P = p.L.P;
 	const bool strict = p.strict;
 	const int tx = tile % p.L.tiles_x, ty = tile / p.L.tiles_x;
@@ -1008,6 +1009,20 @@ __device__ __forceinline__ void fwd_pair_tiles(const KParams &p, const ViewPtrs 
 	};
 	store_pixel(inbA, pixA, colA, zA);
 	store_pixel(inbB, pixB, colB, zB);
+	if (loss_at)
+	{
+		double r2 = 0;
+#pragma unroll
+		for (int cc = 0; cc < CH; cc++)
+			if (cc < C)
+			{
+				const double dA = inbA ? (double)(PixT)colA[cc] - (double)obA[cc] : 0.0, dB = inbB ? (double)(PixT)colB[cc] - (double)obB[cc] : 0.0;
+				r2 += dA * dA + dB * dB;
+			}
+		r2 = wave_sum(r2);
+		if (lane == 0)
+			atomic_add_f64(loss_at, r2 - (p.loss_tile_bg[1 + (size_t)view * p.L.ntiles + tile] + p.loss_tile_bg[2 + (size_t)view * p.L.ntiles + tile]));
+	}
 	// adjoint of pass 1 for L = sum (image - obs)^2: the colour is rounded to the pixel type first, like the stored frame
 	Tap no_tap;
 	double g[CH];
@@ -1099,7 +1114,8 @@ __device__ __forceinline__ void fwd_tiles(const KParams &p, WaveLds *s_lds, Edge
 		if (FUSED && !TEX && MODE == FWD_NO_EDGES && ((uint32_t)uniform((int)entry.tile) & PAIR_FLAG))
 		{ // two adjacent tiles, two pixels per lane (the scan kernel pairs them up: fwd_pair_tiles)
 			const uint32_t nn = (uint32_t)uniform((int)entry.ntri);
-			fwd_pair_tiles<PixT>(p, w, S, view, lane, (int)((uint32_t)uniform((int)entry.tile) & ~PAIR_FLAG), (int)(nn & 0xffffu), (int)(nn >> 16), ids12);
+			fwd_pair_tiles<PixT>(p, w, S, view, lane, (int)((uint32_t)uniform((int)entry.tile) & ~PAIR_FLAG), (int)(nn & 0xffffu), (int)(nn >> 16), ids12,
+								 p.loss_wave ? p.loss_wave + (size_t)view * LOSS_SLOTS + q % LOSS_SLOTS : nullptr);
 			lds_sync();
 			continue;
 		}
@@ -1118,7 +1134,7 @@ __device__ __forceinline__ void fwd_tiles(const KParams &p, WaveLds *s_lds, Edge
 		{
 		PixT ob[CH] = {0, 0, 0, 0};
 		constexpr bool fuse_edges = MODE == FWD_EDGE_ADJ; // tiles with silhouette edges are back-propagated right here as well
-		if (FUSED && inb && (nedge == 0 ? ntri > 0 : fuse_edges))
+		if (FUSED && inb && ((nedge == 0 ? ntri > 0 : fuse_edges) || p.loss_wave))
 		{ // requested now, used after the last triangle
 			const PixT *o = (const PixT *)p.obs + vpix * C;
 #pragma unroll
@@ -1365,6 +1381,21 @@ __device__ __forceinline__ void fwd_tiles(const KParams &p, WaveLds *s_lds, Edge
 				__builtin_nontemporal_store(pack_owner(st.kbest, st.kind), w.face_id + pix);
 		}
 		DR_FTRACE(5); // frame stores issued
+		if (FUSED && p.loss_wave)
+		{ // this tile's part of the loss sum (image - obs)^2, of the frame as stored (rounded to the pixel type), less what the tile would
+		  // contribute as pure background: the caller's table accounts for every tile as background, empty or not
+			double r2 = 0;
+#pragma unroll
+			for (int cc = 0; cc < CH; cc++)
+				if (cc < C && inb)
+				{
+					const double d = (double)(PixT)col[cc] - (double)ob[cc];
+					r2 += d * d;
+				}
+			r2 = wave_sum(r2);
+			if (lane == 0)
+				atomic_add_f64(p.loss_wave + (size_t)view * LOSS_SLOTS + q % LOSS_SLOTS, r2 - p.loss_tile_bg[1 + (size_t)view * p.L.ntiles + tile]);
+		}
 		if (fuse_edges && nedge > 0)
 		{ // ---- adjoint of a tile with silhouette edges, in the same wavefront: reverse sweep over its edges (near -> far), then pass 1.
 		  // Nothing is saved for a later kernel (no sweep, no snapshots, no owner ids) and the latency of this long dependent chain

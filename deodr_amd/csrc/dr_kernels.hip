@@ -384,7 +384,8 @@ int launch_adjoint(const DeodrHipScene *sc, KParams &p, hipStream_t st, bool own
 	if (p.T > 0)
 	{
 		const int fill_words = fast ? sc->n_views * fill_share(p.fill_mode, 1, p.L.nwords) : 0;
-		dim3 g2((unsigned)prim_blocks(p.T) * (unsigned)sc->n_views + (unsigned)((fill_words + PRIM_BLOCK / 64 - 1) / (PRIM_BLOCK / 64)));
+		dim3 g2((unsigned)prim_blocks(p.T) * (unsigned)sc->n_views + (unsigned)((fill_words + PRIM_BLOCK / 64 - 1) / (PRIM_BLOCK / 64)) +
+				(p.loss_out ? 1u : 0u)); // (+ the workgroup that adds up the loss)
 		ScopedKernelTimer t(KID_FINALIZE, st);
 		hipLaunchKernelGGL(finalize_kernel, g2, dim3(PRIM_BLOCK), 0, st, p);
 	}
@@ -517,8 +518,8 @@ int deodr_hip_render_scene_b(const DeodrHipScene *sc, const void *image, const v
 	return launch_adjoint(sc, p, st, true);
 }
 
-int deodr_hip_render_scene_fit(const DeodrHipScene *sc, void *image, void *z_buffer, double sigma, const void *obs, int clear_gradients,
-							   void *workspace, size_t workspace_bytes, void *stream)
+static int render_scene_fit_impl(const DeodrHipScene *sc, void *image, void *z_buffer, double sigma, const void *obs, int clear_gradients,
+								 const double *tile_loss, double *loss_out, double *loss_scratch, void *workspace, size_t workspace_bytes, void *stream)
 {
 	KParams p;
 	if (fill_params(sc, sigma, workspace, workspace_bytes, p, true))
@@ -538,6 +539,9 @@ int deodr_hip_render_scene_fit(const DeodrHipScene *sc, void *image, void *z_buf
 			return 1;
 	}
 	const bool fused = p.C <= CH && !g_force_generic;
+	const bool loss_in_kernels = loss_out && fused && p.T > 0; // (the tile walkers of the staged forward + finalize's last workgroup)
+	if (loss_in_kernels)
+		p.loss_tile_bg = tile_loss, p.loss_wave = loss_scratch, p.loss_out = loss_out;
 	// the background of the empty tiles rides on the adjoint's kernels (fill_share); without any of them: the side stream
 #ifndef DR_FILL_MASK
 #define DR_FILL_MASK 7 // measurement builds: 0 side stream, 1 edge kernel only, 2 finalize only, 4 forward raster only
@@ -554,7 +558,64 @@ int deodr_hip_render_scene_fit(const DeodrHipScene *sc, void *image, void *z_buf
 		return 1;
 	if (launch_adjoint(sc, p, st, !fused))
 		return 1;
-	return join_side(st, join); // the background fill has been overlapping the adjoint
+	if (join_side(st, join)) // the background fill has been overlapping the adjoint
+		return 1;
+	if (loss_out && !loss_in_kernels)
+	{ // un-staged kernels (more than 4 channels) or a scene without triangles: one pass over the finished frame
+		if (check_hip(hipMemsetAsync(loss_scratch, 0, 64 + 8 * (size_t)L2_BLOCKS, st), "loss scratch"))
+			return 1;
+		return deodr_hip_l2_loss(image, obs, sc->pixel_dtype, (size_t)sc->n_views * sc->height * sc->width * sc->nb_colors, loss_out, loss_scratch,
+								 64 + 8 * (size_t)L2_BLOCKS, stream);
+	}
+	return 0;
+}
+
+int deodr_hip_render_scene_fit(const DeodrHipScene *sc, void *image, void *z_buffer, double sigma, const void *obs, int clear_gradients,
+							   void *workspace, size_t workspace_bytes, void *stream)
+{
+	return render_scene_fit_impl(sc, image, z_buffer, sigma, obs, clear_gradients, nullptr, nullptr, nullptr, workspace, workspace_bytes, stream);
+}
+
+static size_t loss_table_doubles(int height, int width, int n_views)
+{ // [0] the whole frame, then one value per view and tile; never less than the partials of the one-pass fallback
+	const size_t tiles = (size_t)((width + TILE - 1) / TILE) * ((height + TILE - 1) / TILE);
+	size_t n = 1 + (size_t)n_views * tiles;
+	const size_t floors[2] = {(size_t)L2_BLOCKS + 16, (size_t)n_views * LOSS_SLOTS};
+	for (size_t f : floors)
+		n = n > f ? n : f;
+	return n;
+}
+
+size_t deodr_hip_fit_loss_bytes(int height, int width, int n_views)
+{
+	return height > 0 && width > 0 && n_views > 0 ? sizeof(double) * loss_table_doubles(height, width, n_views) : 0;
+}
+
+int deodr_hip_background_loss(const DeodrHipScene *sc, const void *obs, double *tile_loss, void *workspace, size_t workspace_bytes, void *stream)
+{
+	KParams p;
+	if (fill_params(sc, 1.0, workspace, workspace_bytes, p, false))
+		return 1;
+	if (!obs || !tile_loss)
+		return fail("background_loss needs obs and the table");
+	p.obs = obs;
+	p.n_views = sc->n_views;
+	hipStream_t st = (hipStream_t)stream;
+	const dim3 grid((unsigned)p.L.ntiles, (unsigned)sc->n_views);
+	if (sc->pixel_dtype == DEODR_HIP_F64)
+		hipLaunchKernelGGL(background_loss_kernel<double>, grid, dim3(64), 0, st, p, tile_loss);
+	else
+		hipLaunchKernelGGL(background_loss_kernel<float>, grid, dim3(64), 0, st, p, tile_loss);
+	hipLaunchKernelGGL(background_loss_total_kernel, dim3(1), dim3(FH_BLOCK), 0, st, tile_loss, (size_t)sc->n_views * p.L.ntiles);
+	return check_hip(hipGetLastError(), "background_loss launch");
+}
+
+int deodr_hip_render_scene_fit_loss(const DeodrHipScene *sc, void *image, void *z_buffer, double sigma, const void *obs, int clear_gradients,
+									const double *tile_loss, double *loss, void *loss_scratch, void *workspace, size_t workspace_bytes, void *stream)
+{
+	if (!tile_loss || !loss || !loss_scratch)
+		return fail("render_scene_fit_loss needs the background table (deodr_hip_background_loss), the loss and its scratch");
+	return render_scene_fit_impl(sc, image, z_buffer, sigma, obs, clear_gradients, tile_loss, loss, (double *)loss_scratch, workspace, workspace_bytes, stream);
 }
 
 // ---- front half of a fit iteration (dr_fronthalf.h): plain double arrays on the device, asynchronous on `stream`

@@ -223,6 +223,9 @@ __global__ __launch_bounds__(PRIM_BLOCK, DR_PRIM_WAVES) void setup_bin_kernel(KP
 	}
 	if (item <= EDGE_LISTS) // appended to by tile_scan_kernel, the next kernel on the stream
 		w.edge_tile_cnt[item * CNT_STRIDE] = 0;
+	if (p.loss_wave) // (one partial per tile walker of the forward raster, two kernels later)
+		for (int v = item; v < LOSS_SLOTS; v += n_items)
+			p.loss_wave[(size_t)view * LOSS_SLOTS + v] = 0;
 	if (p.clear_grads && view == 0 && p.uv_b)
 		for (int v = item; v < 2 * p.Vuv; v += n_items)
 		{ // shared by the views: zeroed once

@@ -89,6 +89,8 @@ static_assert(offsetof(WsHeader, all_needed_max) == 4 * DEODR_HIP_STATUS_WORD_NE
 				  (int)dr::SCENE_ERR_NO_TEXTURE == DEODR_HIP_ERR_NO_TEXTURE,
 			  "status block layout published in include/deodr_hip.h");
 
+constexpr int LOSS_SLOTS = 256; // partial sums of the loss per view (one per walker was 32 768 values for ONE workgroup to add up: 20 us)
+
 struct Layout
 {
 	size_t hdr, tri_rec, tri_planes, tri_acc, edge_rec, edge_planes, edge_acc, tri_cnt, edge_cnt, edge_saved, tri_list, edge_list, tri_pool,
@@ -180,6 +182,12 @@ struct KParams
 	int fill_mode;
 	int fuse_edges;	 // fit step: the forward raster also runs the adjoint of the tiles that hold silhouette edges (no edge-tile kernel)
 	int clear_grads; // the set-up kernel zeroes the per-view gradient arrays (a fit step that wants fresh gradients: no separate fills)
+	// loss of a fit step, sum (image - obs)^2 (deodr_hip_render_scene_fit_loss): loss_tile_bg[0] = the loss of a frame that is all
+	// background, [1 + view * ntiles + tile] = that of one tile; loss_wave[view * LOSS_SLOTS + q % LOSS_SLOTS]: walker q of the forward
+	// raster adds (loss of a tile - its background loss) for every tile it walks; one workgroup of finalize_kernel writes loss_out[0] =
+	// [0] + sum of those (zeroed by the set-up kernel)
+	const double *loss_tile_bg;
+	double *loss_wave, *loss_out;
 	// workspace
 	char *ws;
 	Layout L;

@@ -20,7 +20,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libdeodr_hip.so")
-ABI_VERSION = 5
+ABI_VERSION = 6
 ERR_FACES, ERR_FACES_UV, ERR_NO_TEXTURE = 1, 2, 4  # include/deodr_hip.h DEODR_HIP_ERR_*
 _STATUS_NEEDED, _STATUS_ERRORS = 11, 12  # words of the 64-byte status block at the start of the workspace
 
@@ -64,6 +64,12 @@ def lib():
         L.deodr_hip_render_scene_fit.restype = C.c_int
         L.deodr_hip_render_scene_fit.argtypes = [C.POINTER(_SceneC), C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, C.c_int, C.c_void_p,
                                                  C.c_size_t, C.c_void_p]  # fmt: skip
+        L.deodr_hip_fit_loss_bytes.restype, L.deodr_hip_fit_loss_bytes.argtypes = C.c_size_t, [C.c_int] * 3
+        L.deodr_hip_background_loss.restype = C.c_int
+        L.deodr_hip_background_loss.argtypes = [C.POINTER(_SceneC), C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+        L.deodr_hip_render_scene_fit_loss.restype = C.c_int
+        L.deodr_hip_render_scene_fit_loss.argtypes = [C.POINTER(_SceneC), C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+                                                      C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]  # fmt: skip
         L.deodr_hip_workspace_status.restype = C.c_int
         L.deodr_hip_workspace_status.argtypes = [C.POINTER(_SceneC), C.c_void_p, C.c_size_t, C.c_void_p, C.POINTER(C.c_int),
                                                  C.POINTER(C.c_ulonglong), C.POINTER(C.c_int)]  # fmt: skip
@@ -403,13 +409,28 @@ class HipRasterizer:
         self._last = (ds, float(sigma), bool(antialiase_error), obs_t, image, err, self.generation, False)
         return (image, z, err) if antialiase_error else (image, z)
 
-    def render_fit(self, ds, obs, sigma=1.0, grads=None, out=None, check_overflow=None, clear_grads=False):
+    def _loss_table(self, ds, sc, obs_t):
+        """the background-loss table of (obs, background) for the loss of a fit step, computed once (deodr_hip_background_loss)"""
+        key = (obs_t.data_ptr(), obs_t._version, tuple(obs_t.shape), None if ds.background_color is None else (ds.background_color.data_ptr(), ds.background_color._version),
+               None if ds.background_image is None else (ds.background_image.data_ptr(), ds.background_image._version))  # fmt: skip
+        cache = getattr(self, "_loss_cache", None)
+        if cache is None or cache[0] != key:
+            L = lib()
+            n = int(L.deodr_hip_fit_loss_bytes(ds.height, ds.width, ds.n_views)) // 8
+            table, scratch = torch.empty(n, dtype=torch.float64, device=self.device), torch.empty(n, dtype=torch.float64, device=self.device)
+            _check(L.deodr_hip_background_loss(C.byref(sc), _ptr(obs_t), _ptr(table), _ptr(self.workspace), self.nbytes, _stream(self.device)))
+            self._loss_cache = cache = (key, table, scratch, obs_t)  # (obs_t kept alive: its address is part of the key)
+        return cache[1], cache[2]
+
+    def render_fit(self, ds, obs, sigma=1.0, grads=None, out=None, check_overflow=None, clear_grads=False, loss_out=None):
         """One fit step in one call: render ``ds`` and back-propagate ``sum((image - obs)**2)``; -> (image, z_buffer, grads).
 
         Same results as :meth:`render` followed by ``render_backward(residual_obs=obs)`` (what the reference's
         ``Scene2D.render_compare_and_backward`` does with ``antialiase_error=False``), but the forward raster already
         back-propagates through every tile without silhouette edges, so the frame is traversed once.  ``clear_grads``: zero
-        ``grads`` first, inside the same kernel launches (otherwise they are accumulated into)."""
+        ``grads`` first, inside the same kernel launches (otherwise they are accumulated into).  ``loss_out``: a float64 device
+        tensor of one element that receives ``sum((image - obs)**2)`` -- from the same launches, without a pass over the frame
+        (``deodr_hip_render_scene_fit_loss``; the table it needs is computed at the first call with this observation)."""
         self._check_scene(ds)
         n, H, W, Cc = ds.n_views, ds.height, ds.width, ds.nb_colors
         pd = ds.pixel_dtype
@@ -425,8 +446,16 @@ class HipRasterizer:
                 grads = ds.zero_grads()
             sc = ds.c_struct(grads)
             self._inspect_poll(sc)
-            _check(lib().deodr_hip_render_scene_fit(C.byref(sc), _ptr(image), _ptr(z), float(sigma), _ptr(obs_t), int(bool(clear_grads)),
-                                                    _ptr(self.workspace), self.nbytes, _stream(self.device)))  # fmt: skip
+            if loss_out is None:
+                _check(lib().deodr_hip_render_scene_fit(C.byref(sc), _ptr(image), _ptr(z), float(sigma), _ptr(obs_t), int(bool(clear_grads)),
+                                                        _ptr(self.workspace), self.nbytes, _stream(self.device)))  # fmt: skip
+            else:
+                if loss_out.dtype != torch.float64 or loss_out.device != ds.device or loss_out.numel() != 1:
+                    raise ValueError("loss_out must be a float64 tensor of one element on the scene's device")
+                table, scratch = self._loss_table(ds, sc, obs_t)
+                _check(lib().deodr_hip_render_scene_fit_loss(C.byref(sc), _ptr(image), _ptr(z), float(sigma), _ptr(obs_t), int(bool(clear_grads)),
+                                                             _ptr(table), _ptr(loss_out), _ptr(scratch), _ptr(self.workspace), self.nbytes,
+                                                             _stream(self.device)))  # fmt: skip
             self._poll()
         self.generation += 1
         self._last = (ds, float(sigma), False, obs_t, image, None, self.generation, True)

@@ -486,8 +486,9 @@ class MeshRGBFitterWithPose(_PoseFitter):
         self._direct_forward(d)
         fronthalf.vertex_shade(d.posed, topo, self.light_directional, self.light_ambient, self.mesh_color, colors=d.colors)
         obs = self._observation()
-        image, _z, _g = d.rasterizer.render_fit(d.ds, obs, self.scene.sigma, grads=d.grads, out=(d.image, d.z), clear_grads=True)
-        fronthalf.l2_loss(image, obs, d.e_data, d.scratch)
+        # image, gradients AND the data energy from the rasterizer's four launches (the residual of every pixel is in the tile walkers'
+        # registers; a separate pass over the 8-view frame was 73 us of a 350 us iteration)
+        image, _z, _g = d.rasterizer.render_fit(d.ds, obs, self.scene.sigma, grads=d.grads, out=(d.image, d.z), clear_grads=True, loss_out=d.e_data)
         fronthalf.vertex_shade_b(d.posed, topo, self.light_directional, self.light_ambient, self.mesh_color, None, d.grads["colors_b"], d.posed_b, d.shade_out,
                                  d.scratch)  # fmt: skip
         extra = []

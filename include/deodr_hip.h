@@ -114,6 +114,20 @@ int deodr_hip_render_scene_b(const DeodrHipScene *scene, const void *image, cons
 int deodr_hip_render_scene_fit(const DeodrHipScene *scene, void *image, void *z_buffer, double sigma, const void *obs,
 							   int clear_gradients, void *workspace, size_t workspace_bytes, void *stream);
 
+/* The same step returning the loss too -- `err` of Scene2D.render_compare_and_backward (dr.py:725-734): loss[0] = sum over views,
+ * pixels and channels of (image - obs)^2, of the frame as stored (rounded to the pixel type) -- without a pass over the frame: the
+ * tile walkers of the forward raster have every residual in registers.  What they cannot see, the background of the tiles that
+ * hold no primitive, is accounted for by a table computed ONCE per (observation, background):
+ *   deodr_hip_background_loss    tile_loss[0] = sum (background - obs)^2 over the whole frame batch, tile_loss[1 + view * ntiles + t]
+ *                                = that of the 8 x 8-pixel tile t of a view (deodr_hip_fit_loss_bytes(H, W, n_views) bytes);
+ *   deodr_hip_render_scene_fit_loss   loss = tile_loss[0] + sum over the non-empty tiles of (loss of the tile - tile_loss[tile]).
+ * loss_scratch: device memory of deodr_hip_fit_loss_bytes bytes (no initialisation needed).  Scenes the staged kernels do not take
+ * (more than 4 channels) or without triangles get the loss from one pass over the finished frame instead. */
+size_t deodr_hip_fit_loss_bytes(int height, int width, int n_views);
+int deodr_hip_background_loss(const DeodrHipScene *scene, const void *obs, double *tile_loss, void *workspace, size_t workspace_bytes, void *stream);
+int deodr_hip_render_scene_fit_loss(const DeodrHipScene *scene, void *image, void *z_buffer, double sigma, const void *obs, int clear_gradients,
+									const double *tile_loss, double *loss, void *loss_scratch, void *workspace, size_t workspace_bytes, void *stream);
+
 /* ---- Front half of a fit iteration: the O(V) algebra between the parameters of a fitter and the 2.5-D
  * scene, and its adjoint, as kernels -- as torch ops one iteration is ~240 launches, most of them this algebra.  Plain double
  * arrays on the device, contiguous, asynchronous on `stream`; n = number of views (poses / cameras), V vertices, T triangles.
@@ -247,7 +261,7 @@ const char *deodr_hip_last_error(void);
 
 /* ABI version of this header; bumped on any incompatible change. */
 int deodr_hip_abi_version(void);
-#define DEODR_HIP_ABI_VERSION 5
+#define DEODR_HIP_ABI_VERSION 6
 
 #ifdef __cplusplus
 }

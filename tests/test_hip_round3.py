@@ -567,3 +567,49 @@ def test_examples_run(capsys):
         assert soup[-1] < soup[0]
     finally:
         _sys.path.remove(ex)
+
+
+def test_fit_step_loss_from_the_rasterizer_kernels():
+    """deodr_hip_render_scene_fit_loss: sum (image - obs)^2 from the tile walkers + the background table, against the sum over the
+    frame the same call stored -- every tile class (pairs, tiles with edges fused or left to the edge kernel, more than 16 edges, tiny
+    frames, frames that are no multiple of the tile), both pixel types, background colour and image, several views, a second step with
+    the same table, and the two fall-backs (more than 4 channels, no triangle at all)"""
+    from hip_util import device_scene
+    from deodr_amd.hip_renderer import HipRasterizer
+
+    g = torch.Generator(device="cuda").manual_seed(5)
+
+    def check(views, dt, sigma=1.0, tol=1e-12):
+        ds = device_scene(views, dt)
+        r = HipRasterizer.for_scene(ds)
+        shape = (ds.n_views, ds.height, ds.width, ds.nb_colors)
+        obs = torch.rand(shape, dtype=dt, device=ds.device, generator=g)
+        loss = torch.zeros(1, dtype=torch.float64, device=ds.device)
+        for step in range(2):
+            image, _z, _grads = r.render_fit(ds, obs, sigma, check_overflow=step == 0, clear_grads=True, loss_out=loss)
+            ref = float(((image.double() - obs.double()) ** 2).sum())
+            assert abs(float(loss) - ref) <= tol * ref, (views[0].height, views[0].width, dt, sigma, step, float(loss), ref)
+        # the gradients are those of the call without the loss
+        g1 = r.render_fit(ds, obs, sigma, clear_grads=True, loss_out=loss)[2]
+        g1 = {k: v.clone() for k, v in g1.items() if v is not None}
+        g0 = r.render_fit(ds, obs, sigma, clear_grads=True)[2]
+        for k, v in g1.items():
+            assert rel(v.cpu(), g0[k].cpu()) < 1e-9, k
+        # another observation: another table
+        obs2 = torch.rand(shape, dtype=dt, device=ds.device, generator=g)
+        image, _z, _grads = r.render_fit(ds, obs2, sigma, clear_grads=True, loss_out=loss)
+        ref = float(((image.double() - obs2.double()) ** 2).sum())
+        assert abs(float(loss) - ref) <= tol * ref
+
+    sphere = lambda **kw: [scenes.sphere_scene(angle=a, **kw) for a in kw.pop("angles", (0.0,))]
+    check([scenes.sphere_scene(size=1024, angle=a) for a in (-0.3, 0.4)], F32, tol=1e-9)  # (float32 frames: the residuals are exact, their sum is double)
+    check([scenes.sphere_scene(size=512, nu=60, n_rings=60, angle=a) for a in (-0.3, 0.0, 0.4)], F64)
+    check([scenes.sphere_scene(size=512, nu=60, n_rings=60)], F64, sigma=2.5)  # more edges per tile
+    check([scenes.sphere_scene(size=520, nu=60, n_rings=60)], F32, tol=1e-9)  # 65 tile columns: no pairs
+    check([scenes.sphere_scene(size=96, nu=20, n_rings=16)], F64)  # tiny frame: one class of walkers
+    check([scenes.sphere_scene(size=512, nu=60, n_rings=60, nb_colors=3, textured=True, texture_size=64, angle=a) for a in (0.0, 0.3)], F64)  # edge tiles NOT fused
+    check([scenes.soup_scene(n_tri=150, width=203, height=117, seed=s, textured_ratio=0.3) for s in (3,)], F64)  # background image, ragged frame, all edges flagged
+    check([scenes.sphere_scene(size=256, nu=40, n_rings=40, nb_colors=6, depth_channel=False)], F64)  # un-staged kernels: one pass over the frame
+    far = scenes.sphere_scene(size=128, nu=20, n_rings=16)
+    far.ij = far.ij + 5000.0  # nothing on the screen
+    check([far], F64)
