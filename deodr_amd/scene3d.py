@@ -236,11 +236,12 @@ class RenderViewsL2Func(torch.autograd.Function):
     @staticmethod
     def forward(ctx, ij, colors, shade, depths, edgeflags, obs, device_scene, rasterizer, sigma):
         device_scene.set_views(ij=ij.detach(), colors=colors.detach(), shade=shade.detach(), depths=depths.detach(), edgeflags=edgeflags)
-        image, z, g = rasterizer.render_fit(device_scene, obs, sigma, clear_grads=False)
+        loss = torch.empty(1, dtype=torch.float64, device=ij.device)  # sum (image - obs)^2, from the same launches (no pass over the frame)
+        image, z, g = rasterizer.render_fit(device_scene, obs, sigma, clear_grads=False, loss_out=loss)
         ctx.save_for_backward(g["ij_b"].to(ij.dtype), g["colors_b"].to(colors.dtype), g["shade_b"].to(shade.dtype))
         ctx.uv_b, ctx.texture_b = g["uv_b"], g["texture_b"]
         ctx.mark_non_differentiable(image)
-        return torch.nn.functional.mse_loss(image.to(torch.float64), obs.to(torch.float64), reduction="sum"), image  # sum (image - obs)^2
+        return loss[0], image
 
     @staticmethod
     def backward(ctx, loss_b, _image_b):

@@ -184,6 +184,49 @@ class FakeLib:
         return 0
 
 
+    # ---- the loss of a fit step: same table semantics as the library (tests/test_hip_round3.py checks the kernels themselves)
+    @staticmethod
+    def _tiles(H, W):
+        return (W + 7) // 8, (H + 7) // 8
+
+    def deodr_hip_fit_loss_bytes(self, H, W, n_views):
+        tx, ty = self._tiles(H, W)
+        return 8 * max(1 + n_views * tx * ty, 256 + 16, n_views * 256)
+
+    @staticmethod
+    def _tile_sums(per_pixel, tx, ty):
+        """[n,H,W] -> [n, ty * tx]: sums over the 8 x 8 tiles (ragged last row / column)"""
+        n, H, W = per_pixel.shape
+        padded = np.zeros((n, ty * 8, tx * 8))
+        padded[:, :H, :W] = per_pixel
+        return padded.reshape(n, ty, 8, tx, 8).sum(axis=(2, 4)).reshape(n, ty * tx)
+
+    def deodr_hip_background_loss(self, sc_ref, obs, table, ws, nbytes, stream):
+        sc, a, pd = self._scene(sc_ref)
+        n, H, W, Cc = sc.n_views, sc.height, sc.width, sc.nb_colors
+        tx, ty = self._tiles(H, W)
+        background = a["background_image"] if a["background_image"] is not None else np.broadcast_to(a["background_color"], (n, H, W, Cc))
+        per_pixel = ((background.astype(np.float64) - _view(obs, (n, H, W, Cc), pd).astype(np.float64)) ** 2).sum(axis=-1)
+        out = _view(table, (1 + n * tx * ty,), np.float64)
+        out[1:] = self._tile_sums(per_pixel, tx, ty).reshape(-1)
+        out[0] = out[1:].sum()
+        return 0
+
+    def deodr_hip_render_scene_fit_loss(self, sc_ref, image, z_buffer, sigma, obs, clear_gradients, tile_loss, loss, loss_scratch, ws, nbytes, stream):
+        rc = self.deodr_hip_render_scene_fit(sc_ref, image, z_buffer, sigma, obs, clear_gradients, ws, nbytes, stream)
+        if rc:
+            return rc
+        sc, _a, pd = self._scene(sc_ref)
+        n, H, W, Cc = sc.n_views, sc.height, sc.width, sc.nb_colors
+        tx, ty = self._tiles(H, W)
+        table = _view(tile_loss, (1 + n * tx * ty,), np.float64)
+        rendered = ((_view(image, (n, H, W, Cc), pd).astype(np.float64) - _view(obs, (n, H, W, Cc), pd).astype(np.float64)) ** 2).sum(axis=-1)
+        tiles = self._tile_sums(rendered, tx, ty).reshape(-1)
+        changed = tiles != table[1:]  # (the library only visits the tiles that hold primitives: the others ARE their background)
+        _view(loss, (1,), np.float64)[0] = table[0] + (tiles[changed] - table[1:][changed]).sum()
+        return 0
+
+
 class _Event:
     def record(self, *a):
         pass

@@ -119,6 +119,31 @@ def test_rasterizer_calls_and_forward_state_stamps(fake, oracle_api):
         HipRasterizer.for_scene(ds).render_backward(ds, residual_obs=obs)
 
 
+def test_fit_step_loss_bookkeeping(fake):
+    """render_fit(loss_out=...): the background table is computed once per (observation, background) and again when either changes --
+    an in-place edit of the observation included --, the loss is that of the stored frame, wrong loss tensors are refused"""
+    from deodr_amd.hip_renderer import HipRasterizer
+    from hip_util import device_scene
+
+    views = [scenes.soup_scene(n_tri=12, width=43, height=29, seed=9 + v, min_area=20.0) for v in range(2)]
+    views[1].textured, views[1].shaded, views[1].uv = views[0].textured, views[0].shaded, views[0].uv
+    ds = device_scene(views, torch.float64)
+    r = HipRasterizer.for_scene(ds)
+    obs = torch.rand(2, 29, 43, 3, dtype=torch.float64)
+    loss = torch.zeros(1, dtype=torch.float64)
+    tables = []
+    for step in range(3):
+        image, _z, _g = r.render_fit(ds, obs, 1.0, clear_grads=True, loss_out=loss)
+        assert abs(float(loss) - float(((image - obs) ** 2).sum())) <= 1e-12 * float(loss)
+        tables.append(r._loss_cache[1])
+    assert tables[0] is tables[1] is tables[2]
+    obs[0, :8, :8] += 0.25  # in place: the version counter of the tensor is part of the key
+    image, _z, _g = r.render_fit(ds, obs, 1.0, clear_grads=True, loss_out=loss)
+    assert r._loss_cache[1] is not tables[0] and abs(float(loss) - float(((image - obs) ** 2).sum())) <= 1e-12 * float(loss)
+    with pytest.raises(ValueError, match="loss_out"):
+        r.render_fit(ds, obs, 1.0, loss_out=torch.zeros(1, dtype=torch.float32))
+
+
 def test_device_scene_validation(fake):
     """checkSceneValid's index checks at construction (H.h:2700-2712), textured triangles without a texture"""
     from hip_util import device_scene
