@@ -485,7 +485,7 @@ __device__ __forceinline__ void bwd_fast_tile(const KParams &p, const ViewPtrs &
 			const PixT *im = (const PixT *)p.image_in + vpix * C, *ob = (const PixT *)p.obs + vpix * C;
 #pragma unroll
 			for (int cc = 0; cc < CH; cc++)
-				g[cc] = (cc < C && inb) ? 2 * ((double)im[cc] - (double)ob[cc]) : 0.0;
+				g[cc] = (cc < C && inb) ? fit_residual<true>(p, (double)im[cc], (double)ob[cc]) : 0.0;
 		}
 	}
 	// what pass 1 left at this pixel

@@ -247,7 +247,7 @@ __device__ __forceinline__ void bwd_tile_generic_impl(const KParams &p, int view
 						g[j] = -2 * ((double)((const PixT *)p.obs)[vpix * C + c0 + j] - base_channel(c0 + j)) * eb;
 					else
 						g[j] = p.image_b ? (double)((const PixT *)p.image_b)[vpix * C + c0 + j]
-										 : 2 * ((double)((const PixT *)p.image_in)[vpix * C + c0 + j] - (double)((const PixT *)p.obs)[vpix * C + c0 + j]);
+										 : fit_residual<true>(p, (double)((const PixT *)p.image_in)[vpix * C + c0 + j], (double)((const PixT *)p.obs)[vpix * C + c0 + j]);
 				}
 			}
 			if (nedge > 0 && !aa_err)

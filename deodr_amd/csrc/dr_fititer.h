@@ -445,8 +445,13 @@ constexpr int L2_BLOCKS = 256; // (every workgroup ends with a ticket on ONE cou
 								// workgroups measured 64 us for a 50 MB frame, 1 024 workgroups 32 us, 512 workgroups 27 us)
 constexpr int L2_ROUND = 4;	   // chunks of 32 bytes per array a thread has in flight
 template <class PixT>
-__global__ __launch_bounds__(FH_BLOCK) void l2_loss_kernel(const PixT *image, const PixT *obs, size_t count, double *out, double *partials, unsigned *counter)
-{
+__global__ __launch_bounds__(FH_BLOCK) void l2_loss_kernel(const PixT *image, const PixT *obs, size_t count, double *out, double *partials, unsigned *counter,
+															int clamp, double clamp_lo, double clamp_hi)
+{ // clamp: sum (clamp(image, clamp_lo, clamp_hi) - obs)^2
+	auto value = [&](PixT v) {
+		const double x = (double)v;
+		return clamp ? (x < clamp_lo ? clamp_lo : (x > clamp_hi ? clamp_hi : x)) : x;
+	};
 	constexpr int W = 32 / sizeof(PixT);
 	struct alignas(32) Chunk
 	{
@@ -469,13 +474,13 @@ __global__ __launch_bounds__(FH_BLOCK) void l2_loss_kernel(const PixT *image, co
 #pragma unroll
 				for (int j = 0; j < W; j++)
 				{
-					const double r = (double)a[u].v[j] - (double)b[u].v[j];
+					const double r = value(a[u].v[j]) - (double)b[u].v[j];
 					s[0] += r * r;
 				}
 	}
 	if (blockIdx.x == 0 && threadIdx.x < count - chunks * W)
 	{
-		const double r = (double)image[chunks * W + threadIdx.x] - (double)obs[chunks * W + threadIdx.x];
+		const double r = value(image[chunks * W + threadIdx.x]) - (double)obs[chunks * W + threadIdx.x];
 		s[0] += r * r;
 	}
 	double total[1];
@@ -520,7 +525,7 @@ __global__ __launch_bounds__(64) void background_loss_kernel(KParams p, double *
 		const PixT *o = (const PixT *)p.obs + ((size_t)view * p.H * p.W + pix) * p.C;
 		for (int c = 0; c < p.C; c++)
 		{
-			const double d = (double)(PixT)background_channel<PixT>(p, view, pix, c) - (double)o[c]; // (the frame holds the background rounded to PixT)
+			const double d = fit_value<true>(p, (double)(PixT)background_channel<PixT>(p, view, pix, c)) - (double)o[c]; // (the frame holds the background rounded to PixT)
 			r2 += d * d;
 		}
 	}

@@ -855,7 +855,7 @@ __host__ __device__ inline int fwd_tile_blocks(int ntiles)
 // benchmark scene pair up.  A slot belongs to ONE of the two tiles (slots 0 .. nA - 1 to A, the others to B: binning is exact, a
 // triangle listed only in A covers no pixel of B; a triangle listed in both has two slots), so coverage, depth test -- min (Z,
 // index) per pixel -- and therefore every result are those of the two tiles walked one after the other.
-template <class PixT>
+template <class PixT, bool CLAMP>
 __device__ __forceinline__ void fwd_pair_tiles(const KParams &p, const ViewPtrs &w, WaveLds &S, int view, int lane, int tile, int nA, int nB, uint32_t my_id,
 											   double *loss_at)
 { // loss_at (or NULL): this walker's partial of the loss, see tile_loss
@@ -1016,7 +1016,8 @@ __device__ __forceinline__ void fwd_pair_tiles(const KParams &p, const ViewPtrs 
 		for (int cc = 0; cc < CH; cc++)
 			if (cc < C)
 			{
-				const double dA = inbA ? (double)(PixT)colA[cc] - (double)obA[cc] : 0.0, dB = inbB ? (double)(PixT)colB[cc] - (double)obB[cc] : 0.0;
+				const double dA = inbA ? fit_value<CLAMP>(p, (double)(PixT)colA[cc]) - (double)obA[cc] : 0.0,
+							 dB = inbB ? fit_value<CLAMP>(p, (double)(PixT)colB[cc]) - (double)obB[cc] : 0.0;
 				r2 += dA * dA + dB * dB;
 			}
 		r2 = wave_sum(r2);
@@ -1030,7 +1031,7 @@ __device__ __forceinline__ void fwd_pair_tiles(const KParams &p, const ViewPtrs 
 	{
 #pragma unroll
 		for (int cc = 0; cc < CH; cc++)
-			g[cc] = (cc < C && inbA) ? 2 * ((double)(PixT)colA[cc] - (double)obA[cc]) : 0.0;
+			g[cc] = (cc < C && inbA) ? fit_residual<CLAMP>(p, (double)(PixT)colA[cc], (double)obA[cc]) : 0.0;
 		lds_sync();
 		owner_adjoint<PixT, false>(p, w, lane, xA, y, kA, kindA, g, no_tap, 0.0, (double *)&S.rec[0], (uint32_t *)&S.cover[0][0]);
 	}
@@ -1038,7 +1039,7 @@ __device__ __forceinline__ void fwd_pair_tiles(const KParams &p, const ViewPtrs 
 	{
 #pragma unroll
 		for (int cc = 0; cc < CH; cc++)
-			g[cc] = (cc < C && inbB) ? 2 * ((double)(PixT)colB[cc] - (double)obB[cc]) : 0.0;
+			g[cc] = (cc < C && inbB) ? fit_residual<CLAMP>(p, (double)(PixT)colB[cc], (double)obB[cc]) : 0.0;
 		lds_sync();
 		owner_adjoint<PixT, false>(p, w, lane, xB, y, kB, kindB, g, no_tap, 0.0, (double *)&S.rec[0], (uint32_t *)&S.cover[0][0]);
 	}
@@ -1057,7 +1058,7 @@ enum FwdMode
 	FWD_EDGE_ADJ = 1, // fit step, head of the list: tiles with edges are back-propagated here as well
 	FWD_NO_EDGES = 2, // fit step, rest of the list: no tile has an edge
 };
-template <class PixT, bool FUSED, bool TEX, int MODE>
+template <class PixT, bool FUSED, bool TEX, int MODE, bool CLAMP>
 __device__ __forceinline__ void fwd_tiles(const KParams &p, WaveLds *s_lds, EdgeSort *s_es)
 {
 	DR_WAVE_TRACE_SCOPE(2);
@@ -1114,7 +1115,7 @@ __device__ __forceinline__ void fwd_tiles(const KParams &p, WaveLds *s_lds, Edge
 		if (FUSED && !TEX && MODE == FWD_NO_EDGES && ((uint32_t)uniform((int)entry.tile) & PAIR_FLAG))
 		{ // two adjacent tiles, two pixels per lane (the scan kernel pairs them up: fwd_pair_tiles)
 			const uint32_t nn = (uint32_t)uniform((int)entry.ntri);
-			fwd_pair_tiles<PixT>(p, w, S, view, lane, (int)((uint32_t)uniform((int)entry.tile) & ~PAIR_FLAG), (int)(nn & 0xffffu), (int)(nn >> 16), ids12,
+			fwd_pair_tiles<PixT, CLAMP>(p, w, S, view, lane, (int)((uint32_t)uniform((int)entry.tile) & ~PAIR_FLAG), (int)(nn & 0xffffu), (int)(nn >> 16), ids12,
 								 p.loss_wave ? p.loss_wave + (size_t)view * LOSS_SLOTS + q % LOSS_SLOTS : nullptr);
 			lds_sync();
 			continue;
@@ -1389,7 +1390,7 @@ __device__ __forceinline__ void fwd_tiles(const KParams &p, WaveLds *s_lds, Edge
 			for (int cc = 0; cc < CH; cc++)
 				if (cc < C && inb)
 				{
-					const double d = (double)(PixT)col[cc] - (double)ob[cc];
+					const double d = fit_value<CLAMP>(p, (double)(PixT)col[cc]) - (double)ob[cc];
 					r2 += d * d;
 				}
 			r2 = wave_sum(r2);
@@ -1403,7 +1404,7 @@ __device__ __forceinline__ void fwd_tiles(const KParams &p, WaveLds *s_lds, Edge
 			double g[CH], base[CH] = {0, 0, 0, 0};
 #pragma unroll
 			for (int cc = 0; cc < CH; cc++)
-				g[cc] = (cc < C && inb) ? 2 * ((double)(PixT)col[cc] - (double)ob[cc]) : 0.0;
+				g[cc] = (cc < C && inb) ? fit_residual<CLAMP>(p, (double)(PixT)col[cc], (double)ob[cc]) : 0.0;
 			if (n_edges > 0)
 			{
 				bool have_base = false;
@@ -1448,7 +1449,7 @@ __device__ __forceinline__ void fwd_tiles(const KParams &p, WaveLds *s_lds, Edge
 												 // after its load, it was spilled (four doubles per lane) through the whole of pass 1
 #pragma unroll
 			for (int cc = 0; cc < CH; cc++)
-				g[cc] = (cc < C && inb) ? 2 * ((double)(PixT)col[cc] - (double)ob[cc]) : 0.0;
+				g[cc] = (cc < C && inb) ? fit_residual<CLAMP>(p, (double)(PixT)col[cc], (double)ob[cc]) : 0.0;
 			lds_sync();
 			if (DR_ABLATE & 256)
 			{
@@ -1480,7 +1481,7 @@ __device__ __forceinline__ void fwd_tiles(const KParams &p, WaveLds *s_lds, Edge
 #ifndef DR_FUSE_EDGES
 #define DR_FUSE_EDGES 1 // (measurement builds: 0 = the tiles with silhouette edges of a fit step wait for raster_bwd_edge_kernel, as in round 2)
 #endif
-template <class PixT, bool FUSED, bool TEX>
+template <class PixT, bool FUSED, bool TEX, bool CLAMP = false> // CLAMP: residual of sum (clamp(image) - obs)^2 (KParams::clamp)
 __global__ __launch_bounds__(64, DR_FWD_WAVES) void raster_fwd_fast_kernel(KParams p)
 {
 	__shared__ WaveLds s_lds[1];
@@ -1498,12 +1499,12 @@ __global__ __launch_bounds__(64, DR_FWD_WAVES) void raster_fwd_fast_kernel(KPara
 		const bool chunked = G % (8 * WORK_CHUNK) == 0;
 		const int q = chunked ? (int)((b >> 3) / p.n_views) * 8 + (int)(b & 7) : 0;
 		if (chunked && q >= G / p.heavy_share)
-			fwd_tiles<PixT, FUSED, TEX, FWD_NO_EDGES>(p, s_lds, s_es); // the rest of the list: no tile with edges
+			fwd_tiles<PixT, FUSED, TEX, FWD_NO_EDGES, CLAMP>(p, s_lds, s_es); // the rest of the list: no tile with edges
 		else
-			fwd_tiles<PixT, FUSED, TEX, FWD_EDGE_ADJ>(p, s_lds, s_es); // the head (tiny frames: the whole list)
+			fwd_tiles<PixT, FUSED, TEX, FWD_EDGE_ADJ, CLAMP>(p, s_lds, s_es); // the head (tiny frames: the whole list)
 	}
 	else
-		fwd_tiles<PixT, FUSED, TEX, FWD_PLAIN>(p, s_lds, s_es);
+		fwd_tiles<PixT, FUSED, TEX, FWD_PLAIN, CLAMP>(p, s_lds, s_es);
 }
 
 } // namespace

@@ -316,7 +316,11 @@ int launch_forward_staged(const KParams &p, bool fused, hipStream_t stream, hipE
 	// (+ the workgroups that stream this kernel's share of the background of the empty tiles, one bitmap word each)
 	const dim3 grid((unsigned)p.n_views * (unsigned)q.tile_blocks + (unsigned)p.n_views * (unsigned)fill_share(p.fill_mode, 2, p.L.nwords));
 	const bool tex = p.texture != nullptr; // (see launch_adjoint_raster)
-	if (fused && tex)
+	if (fused && p.clamp && tex) // (the clamped residual of the depth fitter: its own instances of the fused kernel)
+		hipLaunchKernelGGL((raster_fwd_fast_kernel<PixT, true, true, true>), grid, dim3(64), 0, stream, q);
+	else if (fused && p.clamp)
+		hipLaunchKernelGGL((raster_fwd_fast_kernel<PixT, true, false, true>), grid, dim3(64), 0, stream, q);
+	else if (fused && tex)
 		hipLaunchKernelGGL((raster_fwd_fast_kernel<PixT, true, true>), grid, dim3(64), 0, stream, q);
 	else if (fused)
 		hipLaunchKernelGGL((raster_fwd_fast_kernel<PixT, true, false>), grid, dim3(64), 0, stream, q);
@@ -518,9 +522,18 @@ int deodr_hip_render_scene_b(const DeodrHipScene *sc, const void *image, const v
 	return launch_adjoint(sc, p, st, true);
 }
 
+static int l2_loss_impl(const void *image, const void *obs, int pixel_dtype, size_t count, double *out, void *scratch, size_t scratch_bytes, void *stream,
+					   int clamp, double clamp_lo, double clamp_hi);
+
 static int render_scene_fit_impl(const DeodrHipScene *sc, void *image, void *z_buffer, double sigma, const void *obs, int clear_gradients,
-								 const double *tile_loss, double *loss_out, double *loss_scratch, void *workspace, size_t workspace_bytes, void *stream)
+								 const DeodrHipFitOptions *opt, void *workspace, size_t workspace_bytes, void *stream)
 {
+	const double *tile_loss = opt ? opt->tile_loss : nullptr;
+	double *loss_out = opt ? opt->loss : nullptr, *loss_scratch = opt ? (double *)opt->loss_scratch : nullptr;
+	if (opt && opt->clamp && !(opt->clamp_lo <= opt->clamp_hi))
+		return fail("render_scene_fit: clamp_lo > clamp_hi");
+	if (loss_out && (!tile_loss || !loss_scratch))
+		return fail("render_scene_fit: the loss needs the background table (deodr_hip_background_loss) and its scratch");
 	KParams p;
 	if (fill_params(sc, sigma, workspace, workspace_bytes, p, true))
 		return 1;
@@ -542,6 +555,8 @@ static int render_scene_fit_impl(const DeodrHipScene *sc, void *image, void *z_b
 	const bool loss_in_kernels = loss_out && fused && p.T > 0; // (the tile walkers of the staged forward + finalize's last workgroup)
 	if (loss_in_kernels)
 		p.loss_tile_bg = tile_loss, p.loss_wave = loss_scratch, p.loss_out = loss_out;
+	if (opt && opt->clamp)
+		p.clamp = 1, p.clamp_lo = opt->clamp_lo, p.clamp_hi = opt->clamp_hi;
 	// the background of the empty tiles rides on the adjoint's kernels (fill_share); without any of them: the side stream
 #ifndef DR_FILL_MASK
 #define DR_FILL_MASK 7 // measurement builds: 0 side stream, 1 edge kernel only, 2 finalize only, 4 forward raster only
@@ -564,8 +579,8 @@ static int render_scene_fit_impl(const DeodrHipScene *sc, void *image, void *z_b
 	{ // un-staged kernels (more than 4 channels) or a scene without triangles: one pass over the finished frame
 		if (check_hip(hipMemsetAsync(loss_scratch, 0, 64 + 8 * (size_t)L2_BLOCKS, st), "loss scratch"))
 			return 1;
-		return deodr_hip_l2_loss(image, obs, sc->pixel_dtype, (size_t)sc->n_views * sc->height * sc->width * sc->nb_colors, loss_out, loss_scratch,
-								 64 + 8 * (size_t)L2_BLOCKS, stream);
+		return l2_loss_impl(image, obs, sc->pixel_dtype, (size_t)sc->n_views * sc->height * sc->width * sc->nb_colors, loss_out, loss_scratch,
+							64 + 8 * (size_t)L2_BLOCKS, stream, p.clamp, p.clamp_lo, p.clamp_hi);
 	}
 	return 0;
 }
@@ -573,7 +588,13 @@ static int render_scene_fit_impl(const DeodrHipScene *sc, void *image, void *z_b
 int deodr_hip_render_scene_fit(const DeodrHipScene *sc, void *image, void *z_buffer, double sigma, const void *obs, int clear_gradients,
 							   void *workspace, size_t workspace_bytes, void *stream)
 {
-	return render_scene_fit_impl(sc, image, z_buffer, sigma, obs, clear_gradients, nullptr, nullptr, nullptr, workspace, workspace_bytes, stream);
+	return render_scene_fit_impl(sc, image, z_buffer, sigma, obs, clear_gradients, nullptr, workspace, workspace_bytes, stream);
+}
+
+int deodr_hip_render_scene_fit_ex(const DeodrHipScene *sc, void *image, void *z_buffer, double sigma, const void *obs, int clear_gradients,
+								  const DeodrHipFitOptions *options, void *workspace, size_t workspace_bytes, void *stream)
+{
+	return render_scene_fit_impl(sc, image, z_buffer, sigma, obs, clear_gradients, options, workspace, workspace_bytes, stream);
 }
 
 static size_t loss_table_doubles(int height, int width, int n_views)
@@ -591,13 +612,16 @@ size_t deodr_hip_fit_loss_bytes(int height, int width, int n_views)
 	return height > 0 && width > 0 && n_views > 0 ? sizeof(double) * loss_table_doubles(height, width, n_views) : 0;
 }
 
-int deodr_hip_background_loss(const DeodrHipScene *sc, const void *obs, double *tile_loss, void *workspace, size_t workspace_bytes, void *stream)
+int deodr_hip_background_loss(const DeodrHipScene *sc, const void *obs, const DeodrHipFitOptions *options, double *tile_loss, void *workspace,
+							  size_t workspace_bytes, void *stream)
 {
 	KParams p;
 	if (fill_params(sc, 1.0, workspace, workspace_bytes, p, false))
 		return 1;
 	if (!obs || !tile_loss)
 		return fail("background_loss needs obs and the table");
+	if (options && options->clamp)
+		p.clamp = 1, p.clamp_lo = options->clamp_lo, p.clamp_hi = options->clamp_hi;
 	p.obs = obs;
 	p.n_views = sc->n_views;
 	hipStream_t st = (hipStream_t)stream;
@@ -608,14 +632,6 @@ int deodr_hip_background_loss(const DeodrHipScene *sc, const void *obs, double *
 		hipLaunchKernelGGL(background_loss_kernel<float>, grid, dim3(64), 0, st, p, tile_loss);
 	hipLaunchKernelGGL(background_loss_total_kernel, dim3(1), dim3(FH_BLOCK), 0, st, tile_loss, (size_t)sc->n_views * p.L.ntiles);
 	return check_hip(hipGetLastError(), "background_loss launch");
-}
-
-int deodr_hip_render_scene_fit_loss(const DeodrHipScene *sc, void *image, void *z_buffer, double sigma, const void *obs, int clear_gradients,
-									const double *tile_loss, double *loss, void *loss_scratch, void *workspace, size_t workspace_bytes, void *stream)
-{
-	if (!tile_loss || !loss || !loss_scratch)
-		return fail("render_scene_fit_loss needs the background table (deodr_hip_background_loss), the loss and its scratch");
-	return render_scene_fit_impl(sc, image, z_buffer, sigma, obs, clear_gradients, tile_loss, loss, (double *)loss_scratch, workspace, workspace_bytes, stream);
 }
 
 // ---- front half of a fit iteration (dr_fronthalf.h): plain double arrays on the device, asynchronous on `stream`
@@ -816,7 +832,8 @@ int deodr_hip_rigid_energy(const double *vertices, const double *vertices_ref, c
 	return check_hip(hipGetLastError(), "rigid_energy launch");
 }
 
-int deodr_hip_l2_loss(const void *image, const void *obs, int pixel_dtype, size_t count, double *out, void *scratch, size_t scratch_bytes, void *stream)
+static int l2_loss_impl(const void *image, const void *obs, int pixel_dtype, size_t count, double *out, void *scratch, size_t scratch_bytes, void *stream,
+					   int clamp, double clamp_lo, double clamp_hi)
 {
 	if (!image || !obs || !out || count == 0 || (pixel_dtype != DEODR_HIP_F32 && pixel_dtype != DEODR_HIP_F64))
 		return fail("l2_loss: bad arguments");
@@ -830,11 +847,16 @@ int deodr_hip_l2_loss(const void *image, const void *obs, int pixel_dtype, size_
 	unsigned *counter = (unsigned *)scratch + FC_L2;
 	if (pixel_dtype == DEODR_HIP_F64)
 		hipLaunchKernelGGL(l2_loss_kernel<double>, grid, dim3(FH_BLOCK), 0, (hipStream_t)stream, (const double *)image, (const double *)obs, count, out, partials,
-						   counter);
+						   counter, clamp, clamp_lo, clamp_hi);
 	else
 		hipLaunchKernelGGL(l2_loss_kernel<float>, grid, dim3(FH_BLOCK), 0, (hipStream_t)stream, (const float *)image, (const float *)obs, count, out, partials,
-						   counter);
+						   counter, clamp, clamp_lo, clamp_hi);
 	return check_hip(hipGetLastError(), "l2_loss launch");
+}
+
+int deodr_hip_l2_loss(const void *image, const void *obs, int pixel_dtype, size_t count, double *out, void *scratch, size_t scratch_bytes, void *stream)
+{
+	return l2_loss_impl(image, obs, pixel_dtype, count, out, scratch, scratch_bytes, stream, 0, 0.0, 0.0);
 }
 
 int deodr_hip_depth_residual(const void *image, int pixel_dtype, const double *obs, double max_depth, size_t count, double *depth, double *diff, void *image_b,

@@ -188,6 +188,10 @@ struct KParams
 	// [0] + sum of those (zeroed by the set-up kernel)
 	const double *loss_tile_bg;
 	double *loss_wave, *loss_out;
+	// residual mode with a clamp: L = sum (clamp(image, clamp_lo, clamp_hi) - obs)^2, the data term of the depth fitter
+	// (deodr/mesh_fitter.py:108-123); the gradient passes on the closed interval, as torch.clamp's does
+	int clamp;
+	double clamp_lo, clamp_hi;
 	// workspace
 	char *ws;
 	Layout L;
@@ -211,6 +215,23 @@ struct ViewPtrs
 	uint32_t *edge_tile_cnt, *edge_tiles; // tiles with silhouette edges: EDGE_LISTS (+ 1) counters, EDGE_LISTS lists of ntiles entries
 	EdgeFin *edge_fin;
 };
+
+// value whose squared distance to the observation is the loss, and d loss / d value, of a rendered value v (already rounded to the
+// pixel type) against the observation o
+// CLAMP false: compiled without the clamp (the fused forward raster is at its register limits: the two limits kept in scalar
+// registers cost it 37 more spilled registers and 5 us per 8-view step, so a clamped fit step runs its own instance of that kernel)
+template <bool CLAMP>
+__device__ __forceinline__ double fit_value(const KParams &p, double v)
+{
+	return (CLAMP && p.clamp) ? (v < p.clamp_lo ? p.clamp_lo : (v > p.clamp_hi ? p.clamp_hi : v)) : v;
+}
+template <bool CLAMP>
+__device__ __forceinline__ double fit_residual(const KParams &p, double v, double o)
+{
+	if (CLAMP && p.clamp && (v < p.clamp_lo || v > p.clamp_hi))
+		return 0.0;
+	return 2 * (v - o);
+}
 
 __device__ __forceinline__ ViewPtrs view_ptrs(const KParams &p, int view)
 {

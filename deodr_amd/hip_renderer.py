@@ -39,6 +39,13 @@ class _SceneC(C.Structure):
 _lib = None
 
 
+class _FitOptionsC(C.Structure):
+    """include/deodr_hip.h::DeodrHipFitOptions"""
+
+    _fields_ = [("tile_loss", C.c_void_p), ("loss", C.c_void_p), ("loss_scratch", C.c_void_p), ("clamp", C.c_int), ("clamp_lo", C.c_double),
+                ("clamp_hi", C.c_double)]  # fmt: skip
+
+
 def lib():
     """The HIP library; raises (never falls back) when it has not been built."""
     global _lib
@@ -66,10 +73,10 @@ def lib():
                                                  C.c_size_t, C.c_void_p]  # fmt: skip
         L.deodr_hip_fit_loss_bytes.restype, L.deodr_hip_fit_loss_bytes.argtypes = C.c_size_t, [C.c_int] * 3
         L.deodr_hip_background_loss.restype = C.c_int
-        L.deodr_hip_background_loss.argtypes = [C.POINTER(_SceneC), C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
-        L.deodr_hip_render_scene_fit_loss.restype = C.c_int
-        L.deodr_hip_render_scene_fit_loss.argtypes = [C.POINTER(_SceneC), C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
-                                                      C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]  # fmt: skip
+        L.deodr_hip_background_loss.argtypes = [C.POINTER(_SceneC), C.c_void_p, C.POINTER(_FitOptionsC), C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+        L.deodr_hip_render_scene_fit_ex.restype = C.c_int
+        L.deodr_hip_render_scene_fit_ex.argtypes = [C.POINTER(_SceneC), C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, C.c_int, C.POINTER(_FitOptionsC),
+                                                    C.c_void_p, C.c_size_t, C.c_void_p]  # fmt: skip
         L.deodr_hip_workspace_status.restype = C.c_int
         L.deodr_hip_workspace_status.argtypes = [C.POINTER(_SceneC), C.c_void_p, C.c_size_t, C.c_void_p, C.POINTER(C.c_int),
                                                  C.POINTER(C.c_ulonglong), C.POINTER(C.c_int)]  # fmt: skip
@@ -409,20 +416,22 @@ class HipRasterizer:
         self._last = (ds, float(sigma), bool(antialiase_error), obs_t, image, err, self.generation, False)
         return (image, z, err) if antialiase_error else (image, z)
 
-    def _loss_table(self, ds, sc, obs_t):
-        """the background-loss table of (obs, background) for the loss of a fit step, computed once (deodr_hip_background_loss)"""
+    def _loss_table(self, ds, sc, obs_t, options):
+        """the background-loss table of (obs, background, clamp) for the loss of a fit step, computed once (deodr_hip_background_loss)"""
         key = (obs_t.data_ptr(), obs_t._version, tuple(obs_t.shape), None if ds.background_color is None else (ds.background_color.data_ptr(), ds.background_color._version),
-               None if ds.background_image is None else (ds.background_image.data_ptr(), ds.background_image._version))  # fmt: skip
+               None if ds.background_image is None else (ds.background_image.data_ptr(), ds.background_image._version),
+               (options.clamp, options.clamp_lo, options.clamp_hi))  # fmt: skip
         cache = getattr(self, "_loss_cache", None)
         if cache is None or cache[0] != key:
             L = lib()
             n = int(L.deodr_hip_fit_loss_bytes(ds.height, ds.width, ds.n_views)) // 8
             table, scratch = torch.empty(n, dtype=torch.float64, device=self.device), torch.empty(n, dtype=torch.float64, device=self.device)
-            _check(L.deodr_hip_background_loss(C.byref(sc), _ptr(obs_t), _ptr(table), _ptr(self.workspace), self.nbytes, _stream(self.device)))
+            _check(L.deodr_hip_background_loss(C.byref(sc), _ptr(obs_t), C.byref(options), _ptr(table), _ptr(self.workspace), self.nbytes,
+                                               _stream(self.device)))  # fmt: skip
             self._loss_cache = cache = (key, table, scratch, obs_t)  # (obs_t kept alive: its address is part of the key)
         return cache[1], cache[2]
 
-    def render_fit(self, ds, obs, sigma=1.0, grads=None, out=None, check_overflow=None, clear_grads=False, loss_out=None):
+    def render_fit(self, ds, obs, sigma=1.0, grads=None, out=None, check_overflow=None, clear_grads=False, loss_out=None, clamp=None):
         """One fit step in one call: render ``ds`` and back-propagate ``sum((image - obs)**2)``; -> (image, z_buffer, grads).
 
         Same results as :meth:`render` followed by ``render_backward(residual_obs=obs)`` (what the reference's
@@ -430,7 +439,9 @@ class HipRasterizer:
         back-propagates through every tile without silhouette edges, so the frame is traversed once.  ``clear_grads``: zero
         ``grads`` first, inside the same kernel launches (otherwise they are accumulated into).  ``loss_out``: a float64 device
         tensor of one element that receives ``sum((image - obs)**2)`` -- from the same launches, without a pass over the frame
-        (``deodr_hip_render_scene_fit_loss``; the table it needs is computed at the first call with this observation)."""
+        (``deodr_hip_render_scene_fit_ex``; the table it needs is computed at the first call with this observation).  ``clamp`` =
+        (lo, hi): the loss is ``sum((image.clamp(lo, hi) - obs)**2)``, the depth fitter's data term (deodr/mesh_fitter.py:108-123);
+        the returned image is the un-clamped rendering."""
         self._check_scene(ds)
         n, H, W, Cc = ds.n_views, ds.height, ds.width, ds.nb_colors
         pd = ds.pixel_dtype
@@ -446,16 +457,20 @@ class HipRasterizer:
                 grads = ds.zero_grads()
             sc = ds.c_struct(grads)
             self._inspect_poll(sc)
-            if loss_out is None:
+            if loss_out is None and clamp is None:
                 _check(lib().deodr_hip_render_scene_fit(C.byref(sc), _ptr(image), _ptr(z), float(sigma), _ptr(obs_t), int(bool(clear_grads)),
                                                         _ptr(self.workspace), self.nbytes, _stream(self.device)))  # fmt: skip
             else:
-                if loss_out.dtype != torch.float64 or loss_out.device != ds.device or loss_out.numel() != 1:
-                    raise ValueError("loss_out must be a float64 tensor of one element on the scene's device")
-                table, scratch = self._loss_table(ds, sc, obs_t)
-                _check(lib().deodr_hip_render_scene_fit_loss(C.byref(sc), _ptr(image), _ptr(z), float(sigma), _ptr(obs_t), int(bool(clear_grads)),
-                                                             _ptr(table), _ptr(loss_out), _ptr(scratch), _ptr(self.workspace), self.nbytes,
-                                                             _stream(self.device)))  # fmt: skip
+                options = _FitOptionsC()
+                if clamp is not None:
+                    options.clamp, options.clamp_lo, options.clamp_hi = 1, float(clamp[0]), float(clamp[1])
+                if loss_out is not None:
+                    if loss_out.dtype != torch.float64 or loss_out.device != ds.device or loss_out.numel() != 1:
+                        raise ValueError("loss_out must be a float64 tensor of one element on the scene's device")
+                    table, scratch = self._loss_table(ds, sc, obs_t, options)
+                    options.tile_loss, options.loss, options.loss_scratch = table.data_ptr(), loss_out.data_ptr(), scratch.data_ptr()
+                _check(lib().deodr_hip_render_scene_fit_ex(C.byref(sc), _ptr(image), _ptr(z), float(sigma), _ptr(obs_t), int(bool(clear_grads)),
+                                                           C.byref(options), _ptr(self.workspace), self.nbytes, _stream(self.device)))  # fmt: skip
             self._poll()
         self.generation += 1
         self._last = (ds, float(sigma), False, obs_t, image, None, self.generation, True)

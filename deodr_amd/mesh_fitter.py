@@ -331,16 +331,25 @@ class MeshDepthFitter(_PoseFitter):
         e_rigid, g_rigid = self.rigid_energy.evaluate(self.vertices_leaf.detach())
         return diff_image.sum(), e_rigid, g_rigid, depth[:, :, 0], diff_image
 
+    def _observation(self):
+        """the target depth image as the rasterizer's fit step takes it: [1,H,W,1] in its pixel dtype, converted once"""
+        if getattr(self, "_obs_key", None) is not self.mesh_image:
+            self._obs_key, self._obs = self.mesh_image, self.mesh_image[None, :, :, None].to(self.scene.pixel_dtype).contiguous()
+        return self._obs
+
     def _step_direct(self, d):
         from . import fronthalf
 
         self._direct_forward(d, d.colors, self.depthScale)  # the scaled depth of a vertex is its colour (dr.py:1001-1036)
-        image, _z = d.rasterizer.render(d.ds, self.scene.sigma, out=(d.image, d.z))
+        # the data term sum (clip(depth image, 0, max_depth) - target)^2, its gradients and its value from the rasterizer's one-call fit
+        # step (four launches; render + residual + render_backward were nine)
+        image, _z, _g = d.rasterizer.render_fit(d.ds, self._observation(), self.scene.sigma, grads=d.grads, out=(d.image, d.z), clear_grads=True,
+                                                loss_out=d.e_data, clamp=(0.0, self.max_depth))  # fmt: skip
         if d.depth is None:
             d.depth, d.diff, d.image_b = torch.empty_like(self.mesh_image), torch.empty_like(self.mesh_image), torch.empty_like(image)
-        fronthalf.depth_residual(image, self.mesh_image, self.max_depth, d.depth, d.diff, d.image_b, d.e_data, d.scratch)  # clamp, residual, loss, adjoint
-        d.grads_flat.zero_()
-        d.rasterizer.render_backward(d.ds, image_b=d.image_b, grads=d.grads)
+            d.display_loss = torch.zeros(1, dtype=torch.float64, device=self.device)
+        # (what a step returns for display: the clipped depth image and the squared difference per pixel)
+        fronthalf.depth_residual(image, self.mesh_image, self.max_depth, d.depth, d.diff, d.image_b, d.display_loss, d.scratch)
         energy = self._direct_backward_and_update(d, d.grads["colors_b"], (1, 0.1, 0.1), 1.0, depths_b_scale=self.depthScale)
         return energy, d.depth, d.diff
 

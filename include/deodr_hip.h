@@ -114,19 +114,33 @@ int deodr_hip_render_scene_b(const DeodrHipScene *scene, const void *image, cons
 int deodr_hip_render_scene_fit(const DeodrHipScene *scene, void *image, void *z_buffer, double sigma, const void *obs,
 							   int clear_gradients, void *workspace, size_t workspace_bytes, void *stream);
 
-/* The same step returning the loss too -- `err` of Scene2D.render_compare_and_backward (dr.py:725-734): loss[0] = sum over views,
- * pixels and channels of (image - obs)^2, of the frame as stored (rounded to the pixel type) -- without a pass over the frame: the
- * tile walkers of the forward raster have every residual in registers.  What they cannot see, the background of the tiles that
- * hold no primitive, is accounted for by a table computed ONCE per (observation, background):
- *   deodr_hip_background_loss    tile_loss[0] = sum (background - obs)^2 over the whole frame batch, tile_loss[1 + view * ntiles + t]
- *                                = that of the 8 x 8-pixel tile t of a view (deodr_hip_fit_loss_bytes(H, W, n_views) bytes);
- *   deodr_hip_render_scene_fit_loss   loss = tile_loss[0] + sum over the non-empty tiles of (loss of the tile - tile_loss[tile]).
- * loss_scratch: device memory of deodr_hip_fit_loss_bytes bytes (no initialisation needed).  Scenes the staged kernels do not take
- * (more than 4 channels) or without triangles get the loss from one pass over the finished frame instead. */
+/* The same step with options (NULL: none).
+ *
+ * The loss -- `err` of Scene2D.render_compare_and_backward (dr.py:725-734): loss[0] = sum over views, pixels and channels of
+ * (image - obs)^2, of the frame as stored (rounded to the pixel type) -- WITHOUT a pass over the frame: the tile walkers of the
+ * forward raster have every residual in registers.  What they cannot see, the background of the tiles that hold no primitive, is
+ * accounted for by a table computed ONCE per (observation, background, clamp) by deodr_hip_background_loss: tile_loss[0] = the loss
+ * of a frame batch that is all background, tile_loss[1 + view * ntiles + t] = that of the 8 x 8-pixel tile t of a view
+ * (deodr_hip_fit_loss_bytes(H, W, n_views) bytes); the step returns tile_loss[0] + sum over the non-empty tiles of (loss of the tile
+ * - tile_loss[tile]).  loss_scratch: device memory of deodr_hip_fit_loss_bytes bytes (no initialisation needed).  Scenes the staged
+ * kernels do not take (more than 4 channels) or without triangles get the loss from one pass over the finished frame instead.
+ *
+ * clamp: the residual is that of L = sum (clamp(image, clamp_lo, clamp_hi) - obs)^2 -- the data term of the reference's depth fitter
+ * (deodr/mesh_fitter.py:108-123: the rendered depth image is clipped to [0, max_depth] before it is compared) --, its gradient
+ * passing on the closed interval as NumPy's / torch's clip does.  The stored image is the un-clamped rendering. */
+typedef struct DeodrHipFitOptions
+{
+	const double *tile_loss; /* table of deodr_hip_background_loss (made with the same clamp), or NULL: no loss wanted */
+	double *loss;			 /* [1], device */
+	void *loss_scratch;		 /* deodr_hip_fit_loss_bytes bytes, device */
+	int clamp;
+	double clamp_lo, clamp_hi;
+} DeodrHipFitOptions;
 size_t deodr_hip_fit_loss_bytes(int height, int width, int n_views);
-int deodr_hip_background_loss(const DeodrHipScene *scene, const void *obs, double *tile_loss, void *workspace, size_t workspace_bytes, void *stream);
-int deodr_hip_render_scene_fit_loss(const DeodrHipScene *scene, void *image, void *z_buffer, double sigma, const void *obs, int clear_gradients,
-									const double *tile_loss, double *loss, void *loss_scratch, void *workspace, size_t workspace_bytes, void *stream);
+int deodr_hip_background_loss(const DeodrHipScene *scene, const void *obs, const DeodrHipFitOptions *options, double *tile_loss, void *workspace,
+							  size_t workspace_bytes, void *stream);
+int deodr_hip_render_scene_fit_ex(const DeodrHipScene *scene, void *image, void *z_buffer, double sigma, const void *obs, int clear_gradients,
+								  const DeodrHipFitOptions *options, void *workspace, size_t workspace_bytes, void *stream);
 
 /* ---- Front half of a fit iteration: the O(V) algebra between the parameters of a fitter and the 2.5-D
  * scene, and its adjoint, as kernels -- as torch ops one iteration is ~240 launches, most of them this algebra.  Plain double

@@ -201,29 +201,50 @@ class FakeLib:
         padded[:, :H, :W] = per_pixel
         return padded.reshape(n, ty, 8, tx, 8).sum(axis=(2, 4)).reshape(n, ty * tx)
 
-    def deodr_hip_background_loss(self, sc_ref, obs, table, ws, nbytes, stream):
+    @staticmethod
+    def _clamped(values, options):
+        o = None if options is None else options._obj
+        return np.clip(values, o.clamp_lo, o.clamp_hi) if o is not None and o.clamp else values
+
+    def deodr_hip_background_loss(self, sc_ref, obs, options, table, ws, nbytes, stream):
         sc, a, pd = self._scene(sc_ref)
         n, H, W, Cc = sc.n_views, sc.height, sc.width, sc.nb_colors
         tx, ty = self._tiles(H, W)
         background = a["background_image"] if a["background_image"] is not None else np.broadcast_to(a["background_color"], (n, H, W, Cc))
-        per_pixel = ((background.astype(np.float64) - _view(obs, (n, H, W, Cc), pd).astype(np.float64)) ** 2).sum(axis=-1)
+        per_pixel = ((self._clamped(background.astype(np.float64), options) - _view(obs, (n, H, W, Cc), pd).astype(np.float64)) ** 2).sum(axis=-1)
         out = _view(table, (1 + n * tx * ty,), np.float64)
         out[1:] = self._tile_sums(per_pixel, tx, ty).reshape(-1)
         out[0] = out[1:].sum()
         return 0
 
-    def deodr_hip_render_scene_fit_loss(self, sc_ref, image, z_buffer, sigma, obs, clear_gradients, tile_loss, loss, loss_scratch, ws, nbytes, stream):
-        rc = self.deodr_hip_render_scene_fit(sc_ref, image, z_buffer, sigma, obs, clear_gradients, ws, nbytes, stream)
-        if rc:
-            return rc
-        sc, _a, pd = self._scene(sc_ref)
+    def deodr_hip_render_scene_fit_ex(self, sc_ref, image, z_buffer, sigma, obs, clear_gradients, options, ws, nbytes, stream):
+        o = options._obj
+        sc, a, pd = self._scene(sc_ref)
         n, H, W, Cc = sc.n_views, sc.height, sc.width, sc.nb_colors
+        if not o.clamp:
+            rc = self.deodr_hip_render_scene_fit(sc_ref, image, z_buffer, sigma, obs, clear_gradients, ws, nbytes, stream)
+        else:  # the adjoint of sum (clamp(image) - obs)^2: image_b = 2 (clamp(image) - obs) where the clamp passes
+            if self._check(sc, a, True):
+                return 1
+            if clear_gradients:
+                for k in ("uv_b", "ij_b", "shade_b", "colors_b", "texture_b"):
+                    if a[k] is not None:
+                        a[k][...] = 0
+            rc = self.deodr_hip_render_scene(sc_ref, image, z_buffer, sigma, 0, None, None, ws, nbytes, stream)
+            self.calls["render_scene"] -= 1
+            self.calls["render_scene_fit"] += 1
+            if not rc:
+                img, ob = _view(image, (n, H, W, Cc), pd).astype(np.float64), _view(obs, (n, H, W, Cc), pd).astype(np.float64)
+                image_b = np.where((img >= o.clamp_lo) & (img <= o.clamp_hi), 2 * (img - ob), 0.0).astype(pd)
+                self._adjoint(sc, a, pd, sigma, 0, image_b, None, None)
+        if rc or not o.loss:
+            return rc
         tx, ty = self._tiles(H, W)
-        table = _view(tile_loss, (1 + n * tx * ty,), np.float64)
-        rendered = ((_view(image, (n, H, W, Cc), pd).astype(np.float64) - _view(obs, (n, H, W, Cc), pd).astype(np.float64)) ** 2).sum(axis=-1)
+        table = _view(o.tile_loss, (1 + n * tx * ty,), np.float64)
+        rendered = ((self._clamped(_view(image, (n, H, W, Cc), pd).astype(np.float64), options) - _view(obs, (n, H, W, Cc), pd).astype(np.float64)) ** 2).sum(axis=-1)
         tiles = self._tile_sums(rendered, tx, ty).reshape(-1)
         changed = tiles != table[1:]  # (the library only visits the tiles that hold primitives: the others ARE their background)
-        _view(loss, (1,), np.float64)[0] = table[0] + (tiles[changed] - table[1:][changed]).sum()
+        _view(o.loss, (1,), np.float64)[0] = table[0] + (tiles[changed] - table[1:][changed]).sum()
         return 0
 
 

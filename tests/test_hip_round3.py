@@ -613,3 +613,29 @@ def test_fit_step_loss_from_the_rasterizer_kernels():
     far = scenes.sphere_scene(size=128, nu=20, n_rings=16)
     far.ij = far.ij + 5000.0  # nothing on the screen
     check([far], F64)
+
+    # ---- with a clamp: L = sum (clamp(image, lo, hi) - obs)^2 (the depth fitter's data term): loss and gradients against the two-call
+    # path fed with the residual formed in torch, for the staged kernels (pairs, fused edge tiles, a textured scene) and the un-staged ones
+    def check_clamped(views, dt, lo, hi):
+        ds = device_scene(views, dt)
+        r = HipRasterizer.for_scene(ds)
+        obs = torch.rand((ds.n_views, ds.height, ds.width, ds.nb_colors), dtype=dt, device=ds.device, generator=g)
+        loss = torch.zeros(1, dtype=torch.float64, device=ds.device)
+        image, _z, grads = r.render_fit(ds, obs, 1.0, check_overflow=True, clear_grads=True, loss_out=loss, clamp=(lo, hi))
+        grads = {k: v.clone() for k, v in grads.items() if v is not None}
+        clamped = image.double().clamp(lo, hi)
+        ref = float(((clamped - obs.double()) ** 2).sum())
+        inside = float(((image >= lo) & (image <= hi)).double().mean())
+        assert 0.02 < inside < 0.98, inside  # (the clamp is active somewhere and passes somewhere)
+        assert abs(float(loss) - ref) <= 1e-9 * ref
+        image2, _z2 = r.render(ds, 1.0)
+        assert torch.equal(image2, image)
+        image_b = (2 * (clamped - obs.double()) * ((image >= lo) & (image <= hi))).to(dt)
+        g_ref = r.render_backward(ds, image_b=image_b)
+        for k, v in grads.items():
+            assert rel(v.cpu(), g_ref[k].cpu()) < (1e-9 if dt == F64 else 1e-5), k
+
+    check_clamped([scenes.sphere_scene(size=512, nu=60, n_rings=60, angle=a) for a in (-0.3, 0.4)], F64, 0.35, 0.8)
+    check_clamped([scenes.sphere_scene(size=1024)], F32, 0.35, 0.8)
+    check_clamped([scenes.sphere_scene(size=256, nu=40, n_rings=40, nb_colors=3, textured=True, texture_size=64)], F64, 0.3, 0.7)
+    check_clamped([scenes.sphere_scene(size=256, nu=40, n_rings=40, nb_colors=6, depth_channel=False)], F64, 0.3, 0.7)

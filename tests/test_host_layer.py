@@ -142,6 +142,17 @@ def test_fit_step_loss_bookkeeping(fake):
     assert r._loss_cache[1] is not tables[0] and abs(float(loss) - float(((image - obs) ** 2).sum())) <= 1e-12 * float(loss)
     with pytest.raises(ValueError, match="loss_out"):
         r.render_fit(ds, obs, 1.0, loss_out=torch.zeros(1, dtype=torch.float32))
+    # with a clamp: another table; loss and gradients are those of sum (clamp(image) - obs)^2
+    before = r._loss_cache[1]
+    image, _z, g = r.render_fit(ds, obs, 1.0, clear_grads=True, loss_out=loss, clamp=(0.3, 0.7))
+    assert r._loss_cache[1] is not before
+    clamped = image.clamp(0.3, 0.7)
+    assert abs(float(loss) - float(((clamped - obs) ** 2).sum())) <= 1e-12 * float(loss)
+    g = {k: v.clone() for k, v in g.items() if v is not None}
+    r.render(ds, 1.0)
+    g_ref = r.render_backward(ds, image_b=2 * (clamped - obs) * ((image >= 0.3) & (image <= 0.7)))
+    for k, v in g.items():
+        assert rel(v, g_ref[k]) < 1e-12, k
 
 
 def test_device_scene_validation(fake):
