@@ -438,8 +438,9 @@ __global__ __launch_bounds__(SCAN_BLOCK) void tile_scan_kernel(KParams p)
 		static_assert(ENTRY_IDS == 12 && K_TRI >= ENTRY_IDS, "three 16-byte pieces of the tile's inline list");
 		const uint4 *ids = (const uint4 *)(w.tri_list + (size_t)tile * K_TRI);
 		ida = ids[0];
-		idb = ntri > 4 ? ids[1] : ida;
-		idc = ntri > 8 ? ids[2] : ida;
+		// (`ntri > 4 ? ids[1] : ida` became a select between two ADDRESSES, which put ida into scratch memory for every thread)
+		idb = ids[ntri > 4 ? 1 : 0];
+		idc = ids[ntri > 8 ? 2 : 0];
 	}
 	if (work)
 	{ // self-cleaning counters
@@ -523,21 +524,34 @@ __global__ __launch_bounds__(SCAN_BLOCK) void tile_scan_kernel(KParams p)
 	if (pair_right)
 	{ // this tile's ids behind the left tile's, in the left tile's entry
 		uint32_t *ids = w.work_list[left_pos].ids + left_ntri;
-		const uint32_t mine[8] = {ida.x, ida.y, ida.z, ida.w, idb.x, idb.y, idb.z, idb.w};
-#pragma unroll
-		for (int j = 0; j < 8; j++) // (a paired tile is not in the head: at most FIRST_PRIMS = 8 triangles)
-			if ((uint32_t)j < ntri)
-				ids[j] = mine[j];
+		// (a paired tile is not in the head: at most FIRST_PRIMS = 8 triangles.  Component by component, no array: an array of the
+		// eight ids sent `ida` through scratch memory, store + reload, in every thread of the kernel)
+#define DR_PUT_ID(j, v)      \
+	if ((uint32_t)(j) < ntri) \
+	ids[j] = (v)
+		DR_PUT_ID(0, ida.x);
+		DR_PUT_ID(1, ida.y);
+		DR_PUT_ID(2, ida.z);
+		DR_PUT_ID(3, ida.w);
+		DR_PUT_ID(4, idb.x);
+		DR_PUT_ID(5, idb.y);
+		DR_PUT_ID(6, idb.z);
+		DR_PUT_ID(7, idb.w);
 	}
 	else if (pair_left)
 	{
 		WorkEntry &e = w.work_list[my_pos];
 		((uint4 *)&e)[0] = make_uint4((uint32_t)tile | PAIR_FLAG, ntri | (ntri_right << 16), 0u, 0u);
-		const uint32_t mine[8] = {ida.x, ida.y, ida.z, ida.w, idb.x, idb.y, idb.z, idb.w};
-#pragma unroll
-		for (int j = 0; j < 8; j++)
-			if ((uint32_t)j < ntri)
-				e.ids[j] = mine[j];
+		uint32_t *ids = e.ids; // (only its own ids: the right tile's thread writes behind them)
+		DR_PUT_ID(0, ida.x);
+		DR_PUT_ID(1, ida.y);
+		DR_PUT_ID(2, ida.z);
+		DR_PUT_ID(3, ida.w);
+		DR_PUT_ID(4, idb.x);
+		DR_PUT_ID(5, idb.y);
+		DR_PUT_ID(6, idb.z);
+		DR_PUT_ID(7, idb.w);
+#undef DR_PUT_ID
 	}
 	else if (work)
 	{
