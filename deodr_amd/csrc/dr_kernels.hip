@@ -347,7 +347,10 @@ int launch_forward(const DeodrHipScene *sc, KParams &p, hipStream_t stream, hipE
 	{
 		dim3 grid((unsigned)prim_blocks(p.T) * (unsigned)n_views);
 		ScopedKernelTimer t(KID_SETUP, stream);
-		hipLaunchKernelGGL(setup_bin_kernel, grid, dim3(PRIM_BLOCK), 0, stream, p);
+		if (p.vtx_f64)
+			hipLaunchKernelGGL(setup_bin_kernel<true>, grid, dim3(PRIM_BLOCK), 0, stream, p);
+		else
+			hipLaunchKernelGGL(setup_bin_kernel<false>, grid, dim3(PRIM_BLOCK), 0, stream, p);
 	}
 	{
 		ScopedKernelTimer t(KID_RASTER_FWD, stream);
@@ -391,7 +394,10 @@ int launch_adjoint(const DeodrHipScene *sc, KParams &p, hipStream_t st, bool own
 		dim3 g2((unsigned)prim_blocks(p.T) * (unsigned)sc->n_views + (unsigned)((fill_words + PRIM_BLOCK / 64 - 1) / (PRIM_BLOCK / 64)) +
 				(p.loss_out ? 1u : 0u)); // (+ the workgroup that adds up the loss)
 		ScopedKernelTimer t(KID_FINALIZE, st);
-		hipLaunchKernelGGL(finalize_kernel, g2, dim3(PRIM_BLOCK), 0, st, p);
+		if (p.vtx_f64)
+			hipLaunchKernelGGL(finalize_kernel<true>, g2, dim3(PRIM_BLOCK), 0, st, p);
+		else
+			hipLaunchKernelGGL(finalize_kernel<false>, g2, dim3(PRIM_BLOCK), 0, st, p);
 	}
 	return check_hip(hipGetLastError(), "backward launch");
 }

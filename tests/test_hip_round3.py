@@ -639,3 +639,41 @@ def test_fit_step_loss_from_the_rasterizer_kernels():
     check_clamped([scenes.sphere_scene(size=1024)], F32, 0.35, 0.8)
     check_clamped([scenes.sphere_scene(size=256, nu=40, n_rings=40, nb_colors=3, textured=True, texture_size=64)], F64, 0.3, 0.7)
     check_clamped([scenes.sphere_scene(size=256, nu=40, n_rings=40, nb_colors=6, depth_channel=False)], F64, 0.3, 0.7)
+
+
+def test_float32_vertex_arrays_equal_float64_vertex_arrays_of_the_same_values():
+    """vertex_dtype float32 (ij, depths, colours, shade, uv and their adjoints stored in float32: SURVEY 8d's "fp32 device buffers"):
+    on inputs that are exactly representable in float32 the frames are those of the float64 arrays bit for bit (all arithmetic is double
+    either way), the gradients agree to float32 accumulation; untextured (fused fit step) and textured (five-launch fit step), two-call path"""
+    import copy
+
+    from hip_util import device_scene
+    from deodr_amd.hip_renderer import HipRasterizer
+
+    def rounded(view):
+        v = copy.deepcopy(view)
+        for name in ("ij", "depths", "colors", "shade", "uv"):
+            setattr(v, name, np.asarray(getattr(v, name), dtype=np.float64).astype(np.float32).astype(np.float64))
+        return v
+
+    g = torch.Generator(device="cuda").manual_seed(7)
+    for views in ([scenes.sphere_scene(size=512, nu=60, n_rings=60, angle=a) for a in (-0.3, 0.4)],
+                  [scenes.sphere_scene(size=256, nu=40, n_rings=40, nb_colors=3, textured=True, texture_size=64)]):  # fmt: skip
+        views = [rounded(v) for v in views]
+        results = {}
+        for vd in (torch.float64, torch.float32):
+            ds = device_scene(views, torch.float64, vertex_dtype=vd)
+            assert ds.ij.dtype == vd and ds.colors.dtype == vd
+            r = HipRasterizer.for_scene(ds)
+            obs = torch.rand((ds.n_views, ds.height, ds.width, ds.nb_colors), dtype=torch.float64, device=ds.device, generator=torch.Generator(device="cuda").manual_seed(11))
+            image, z, grads = r.render_fit(ds, obs, 1.0, check_overflow=True, clear_grads=True)
+            fit = {k: v.double().clone() for k, v in grads.items() if v is not None}
+            image2, _z2 = r.render(ds, 1.0)
+            two = {k: v.double() for k, v in r.render_backward(ds, residual_obs=obs).items() if v is not None}
+            assert all(v.dtype == vd for k, v in grads.items() if v is not None and k != "texture_b")
+            results[vd] = (image.clone(), z.clone(), image2, fit, two)
+        a, b = results[torch.float64], results[torch.float32]
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
+        for which in (3, 4):
+            for k in a[which]:
+                assert rel(b[which][k].cpu(), a[which][k].cpu()) < 2e-6, (which, k)
