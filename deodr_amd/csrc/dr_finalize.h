@@ -11,13 +11,15 @@ namespace
 
 // ------------------------------------------------------------------------------------------------------- finalize
 
-template <bool VTX64> // (the dtype of the vertex arrays at compile time: see setup_bin_kernel)
+template <bool VTX64, int NC> // (the dtype of the vertex arrays and the channel count at compile time: see setup_bin_kernel)
 __global__ __launch_bounds__(PRIM_BLOCK, DR_PRIM_WAVES) void finalize_kernel(KParams p)
 { // same split as setup_bin_kernel: triangle blocks, then edge-slot blocks compacted to the flagged slots.
   // (Lists of the front-facing triangles / drawn edges compacted by the set-up kernel were tried: a quarter as many wavefronts,
   // all lanes busy -- and 32 -> 41 us: the kernel is a chain of dependent round trips, fewer wavefronts overlap fewer of them.)
 	DR_WAVE_TRACE_SCOPE(1);
 	p.vtx_f64 = VTX64 ? 1 : 0;
+	if (NC)
+		p.C = NC, p.L.P = NC < 3 ? 3 : NC;
 	const int loss_blocks = p.loss_out ? 1 : 0;
 	if (loss_blocks && blockIdx.x == 0)
 	{ // one extra workgroup, the FIRST of the grid (it overlaps the others): loss = background loss of the whole frame + the walkers'

@@ -1495,9 +1495,19 @@ __device__ __forceinline__ void fwd_tiles(const KParams &p, WaveLds *s_lds, Edge
 #ifndef DR_FUSE_EDGES
 #define DR_FUSE_EDGES 1 // (measurement builds: 0 = the tiles with silhouette edges of a fit step wait for raster_bwd_edge_kernel, as in round 2)
 #endif
-template <class PixT, bool FUSED, bool TEX, bool CLAMP = false> // CLAMP: residual of sum (clamp(image) - obs)^2 (KParams::clamp)
+// CLAMP: residual of sum (clamp(image) - obs)^2 (KParams::clamp).  NC: the channel count at compile time (0: whatever the scene says).
+// Every per-channel statement of the walkers is guarded by `cc < C`; with C known the guards and the code behind the false ones go:
+// the 8-view benchmark step (C = 4) 0.160 -> 0.150 ms.  The host picks the instance (3 and 4 channels, the fit step's kernels).
+template <class PixT, bool FUSED, bool TEX, bool CLAMP = false, int NC = 0>
 __global__ __launch_bounds__(64, DR_FWD_WAVES) void raster_fwd_fast_kernel(KParams p)
 {
+	if (NC)
+	{ // (what the host passed, now known to the compiler: the walkers read p.C and p.L.P)
+		p.C = NC;
+		p.L.P = NC < 3 ? 3 : NC;
+	}
+	if (FUSED)
+		p.persp = 0; // (a fit step: fill_params refuses perspective_correct for anything with an adjoint, as the reference does, H.h:810)
 	__shared__ WaveLds s_lds[1];
 	__shared__ EdgeSort s_es[1];
 	if ((long long)blockIdx.x >= (long long)p.n_views * p.tile_blocks)

@@ -320,8 +320,14 @@ int launch_forward_staged(const KParams &p, bool fused, hipStream_t stream, hipE
 		hipLaunchKernelGGL((raster_fwd_fast_kernel<PixT, true, true, true>), grid, dim3(64), 0, stream, q);
 	else if (fused && p.clamp)
 		hipLaunchKernelGGL((raster_fwd_fast_kernel<PixT, true, false, true>), grid, dim3(64), 0, stream, q);
+	else if (fused && tex && p.C == 3) // (the channel counts that occur: RGB, RGB + depth; others take the run-time instance)
+		hipLaunchKernelGGL((raster_fwd_fast_kernel<PixT, true, true, false, 3>), grid, dim3(64), 0, stream, q);
 	else if (fused && tex)
 		hipLaunchKernelGGL((raster_fwd_fast_kernel<PixT, true, true>), grid, dim3(64), 0, stream, q);
+	else if (fused && p.C == 4)
+		hipLaunchKernelGGL((raster_fwd_fast_kernel<PixT, true, false, false, 4>), grid, dim3(64), 0, stream, q);
+	else if (fused && p.C == 3)
+		hipLaunchKernelGGL((raster_fwd_fast_kernel<PixT, true, false, false, 3>), grid, dim3(64), 0, stream, q);
 	else if (fused)
 		hipLaunchKernelGGL((raster_fwd_fast_kernel<PixT, true, false>), grid, dim3(64), 0, stream, q);
 	else if (tex)
@@ -347,10 +353,24 @@ int launch_forward(const DeodrHipScene *sc, KParams &p, hipStream_t stream, hipE
 	{
 		dim3 grid((unsigned)prim_blocks(p.T) * (unsigned)n_views);
 		ScopedKernelTimer t(KID_SETUP, stream);
-		if (p.vtx_f64)
-			hipLaunchKernelGGL(setup_bin_kernel<true>, grid, dim3(PRIM_BLOCK), 0, stream, p);
-		else
-			hipLaunchKernelGGL(setup_bin_kernel<false>, grid, dim3(PRIM_BLOCK), 0, stream, p);
+		// (instances for the vertex dtype and for the channel counts that occur -- RGB, RGB + depth --; other counts: the run-time one)
+#define DR_LAUNCH_PRIM(kernel, grid_, stream_)                                                                              \
+	do                                                                                                                      \
+	{                                                                                                                       \
+		if (p.vtx_f64 && p.C == 4)                                                                                          \
+			hipLaunchKernelGGL((kernel<true, 4>), grid_, dim3(PRIM_BLOCK), 0, stream_, p);                                  \
+		else if (p.vtx_f64 && p.C == 3)                                                                                     \
+			hipLaunchKernelGGL((kernel<true, 3>), grid_, dim3(PRIM_BLOCK), 0, stream_, p);                                  \
+		else if (p.vtx_f64)                                                                                                 \
+			hipLaunchKernelGGL((kernel<true, 0>), grid_, dim3(PRIM_BLOCK), 0, stream_, p);                                  \
+		else if (p.C == 4)                                                                                                  \
+			hipLaunchKernelGGL((kernel<false, 4>), grid_, dim3(PRIM_BLOCK), 0, stream_, p);                                 \
+		else if (p.C == 3)                                                                                                  \
+			hipLaunchKernelGGL((kernel<false, 3>), grid_, dim3(PRIM_BLOCK), 0, stream_, p);                                 \
+		else                                                                                                                \
+			hipLaunchKernelGGL((kernel<false, 0>), grid_, dim3(PRIM_BLOCK), 0, stream_, p);                                 \
+	} while (0)
+		DR_LAUNCH_PRIM(setup_bin_kernel, grid, stream);
 	}
 	{
 		ScopedKernelTimer t(KID_RASTER_FWD, stream);
@@ -394,10 +414,7 @@ int launch_adjoint(const DeodrHipScene *sc, KParams &p, hipStream_t st, bool own
 		dim3 g2((unsigned)prim_blocks(p.T) * (unsigned)sc->n_views + (unsigned)((fill_words + PRIM_BLOCK / 64 - 1) / (PRIM_BLOCK / 64)) +
 				(p.loss_out ? 1u : 0u)); // (+ the workgroup that adds up the loss)
 		ScopedKernelTimer t(KID_FINALIZE, st);
-		if (p.vtx_f64)
-			hipLaunchKernelGGL(finalize_kernel<true>, g2, dim3(PRIM_BLOCK), 0, st, p);
-		else
-			hipLaunchKernelGGL(finalize_kernel<false>, g2, dim3(PRIM_BLOCK), 0, st, p);
+		DR_LAUNCH_PRIM(finalize_kernel, g2, st);
 	}
 	return check_hip(hipGetLastError(), "backward launch");
 }

@@ -205,10 +205,13 @@ struct WaveTrace
 // VTX64: the dtype of the vertex arrays as a compile-time constant.  As a run-time flag every vertex value was loaded behind its own
 // branch, and a float32 value converted -- i.e. waited for -- right behind its load: 21 memory round trips one after the other for
 // the inputs of one triangle.
-template <bool VTX64>
+// NC: the channel count at compile time (0: whatever the scene says), as for raster_fwd_fast_kernel.
+template <bool VTX64, int NC>
 __global__ __launch_bounds__(PRIM_BLOCK, DR_PRIM_WAVES) void setup_bin_kernel(KParams p)
 {
 	p.vtx_f64 = VTX64 ? 1 : 0; // (what the host passed: now known to the compiler; scene_view() copies it)
+	if (NC)
+		p.C = NC, p.L.P = NC < 3 ? 3 : NC;
 	DR_WAVE_TRACE_SCOPE(0);
 	const PrimWork pw = prim_work(p);
 	const int view = pw.view;
