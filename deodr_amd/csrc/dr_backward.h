@@ -638,13 +638,15 @@ __device__ __forceinline__ void bwd_fast_tile(const KParams &p, const ViewPtrs &
 #undef DR_TRACE
 }
 
-template <class PixT, bool TEX>
+template <class PixT, bool TEX, int NC = 0> // NC: the channel count at compile time (0: the scene's), as for raster_fwd_fast_kernel
 __global__ __launch_bounds__(64, 6) void raster_bwd_fast_kernel(KParams p)
 { // (two-call path) the forward's work list of the non-empty tiles, walked exactly as raster_fwd_fast_kernel walks it (same grid,
   // same entry of the list for the same workgroup); the tiles with silhouette edges are left to raster_bwd_edge_kernel.  One
   // wavefront per tile OF THE FRAME, which found out from the tile bitmap that two out of three had nothing to do, took ~51 us
   // per 8-view launch; this one ~43 (two-call step 0.254 -> 0.246 ms).
 	__shared__ BwdLds s_lds;
+	if (NC)
+		p.C = NC, p.L.P = NC < 3 ? 3 : NC;
 	const int lane = threadIdx.x & 63;
 	const int G = p.tile_blocks;
 	const long long b = blockIdx.x;
@@ -674,9 +676,11 @@ __global__ __launch_bounds__(64, 6) void raster_bwd_fast_kernel(KParams p)
 #ifndef DR_EDGE_OCC
 #define DR_EDGE_OCC 4 // waves per SIMD of the untextured edge kernel (3: no spills, 5: more) -- swept, 4 stays
 #endif
-template <class PixT, bool TEX>
+template <class PixT, bool TEX, int NC = 0>
 __global__ __launch_bounds__(64, TEX ? 2 : DR_EDGE_OCC) void raster_bwd_edge_kernel(KParams p)
-{ // persistent waves over the lists of tiles that hold silhouette edges (built by tile_scan_kernel).  Grid (views, waves):
+{
+	if (NC)
+		p.C = NC, p.L.P = NC < 3 ? 3 : NC; // persistent waves over the lists of tiles that hold silhouette edges (built by tile_scan_kernel).  Grid (views, waves):
   // the first waves dispatched are wave 0 of every view, and every wave starts with the many-edged tiles -- the kernel
   // lasts as long as its slowest tile, so those must not start late.  Wave g takes the work items g, g + gridDim.y, ...
 	__shared__ BwdLds s_lds;

@@ -210,18 +210,27 @@ void launch_adjoint_raster(const KParams &p, bool fast, bool owner_tiles, dim3 g
 		q.tile_blocks = fwd_tile_blocks(p.L.ntiles); // the grid of the forward that built the work list
 		q.heavy_share = heavy_share_for(p.n_views, q.tile_blocks, false);
 		const dim3 grid((unsigned)p.n_views * (unsigned)q.tile_blocks);
-		if (tex)
-			hipLaunchKernelGGL((raster_bwd_fast_kernel<PixT, true>), grid, dim3(64), 0, st, q);
-		else
-			hipLaunchKernelGGL((raster_bwd_fast_kernel<PixT, false>), grid, dim3(64), 0, st, q);
+		// (instances for the channel counts that occur: RGB, RGB + depth -- see raster_fwd_fast_kernel)
+#define DR_LAUNCH_NC(kernel, tex_, grid_, q_)                                                        \
+	do                                                                                               \
+	{                                                                                                \
+		if (tex_ && (q_).C == 3)                                                                     \
+			hipLaunchKernelGGL((kernel<PixT, true, 3>), grid_, dim3(64), 0, st, q_);                 \
+		else if (tex_)                                                                               \
+			hipLaunchKernelGGL((kernel<PixT, true, 0>), grid_, dim3(64), 0, st, q_);                 \
+		else if ((q_).C == 4)                                                                        \
+			hipLaunchKernelGGL((kernel<PixT, false, 4>), grid_, dim3(64), 0, st, q_);                \
+		else if ((q_).C == 3)                                                                        \
+			hipLaunchKernelGGL((kernel<PixT, false, 3>), grid_, dim3(64), 0, st, q_);                \
+		else                                                                                         \
+			hipLaunchKernelGGL((kernel<PixT, false, 0>), grid_, dim3(64), 0, st, q_);                \
+	} while (0)
+		DR_LAUNCH_NC(raster_bwd_fast_kernel, tex, grid, q);
 	}
 	// (running the two kernels side by side on a forked stream was measured: no gain, the edge kernel just stretches)
 	if (p.sigma > 0 && !p.fuse_edges) // (a fit step back-propagates the tiles with edges inside its forward raster)
 	{
-		if (tex)
-			hipLaunchKernelGGL((raster_bwd_edge_kernel<PixT, true>), edge_grid, dim3(64), 0, st, p);
-		else
-			hipLaunchKernelGGL((raster_bwd_edge_kernel<PixT, false>), edge_grid, dim3(64), 0, st, p);
+		DR_LAUNCH_NC(raster_bwd_edge_kernel, tex, edge_grid, p);
 	}
 }
 
@@ -318,6 +327,8 @@ int launch_forward_staged(const KParams &p, bool fused, hipStream_t stream, hipE
 	const bool tex = p.texture != nullptr; // (see launch_adjoint_raster)
 	if (fused && p.clamp && tex) // (the clamped residual of the depth fitter: its own instances of the fused kernel)
 		hipLaunchKernelGGL((raster_fwd_fast_kernel<PixT, true, true, true>), grid, dim3(64), 0, stream, q);
+	else if (fused && p.clamp && p.C == 1) // (a depth image)
+		hipLaunchKernelGGL((raster_fwd_fast_kernel<PixT, true, false, true, 1>), grid, dim3(64), 0, stream, q);
 	else if (fused && p.clamp)
 		hipLaunchKernelGGL((raster_fwd_fast_kernel<PixT, true, false, true>), grid, dim3(64), 0, stream, q);
 	else if (fused && tex && p.C == 3) // (the channel counts that occur: RGB, RGB + depth; others take the run-time instance)
@@ -330,8 +341,14 @@ int launch_forward_staged(const KParams &p, bool fused, hipStream_t stream, hipE
 		hipLaunchKernelGGL((raster_fwd_fast_kernel<PixT, true, false, false, 3>), grid, dim3(64), 0, stream, q);
 	else if (fused)
 		hipLaunchKernelGGL((raster_fwd_fast_kernel<PixT, true, false>), grid, dim3(64), 0, stream, q);
+	else if (tex && p.C == 3)
+		hipLaunchKernelGGL((raster_fwd_fast_kernel<PixT, false, true, false, 3>), grid, dim3(64), 0, stream, q);
 	else if (tex)
 		hipLaunchKernelGGL((raster_fwd_fast_kernel<PixT, false, true>), grid, dim3(64), 0, stream, q);
+	else if (p.C == 4)
+		hipLaunchKernelGGL((raster_fwd_fast_kernel<PixT, false, false, false, 4>), grid, dim3(64), 0, stream, q);
+	else if (p.C == 3)
+		hipLaunchKernelGGL((raster_fwd_fast_kernel<PixT, false, false, false, 3>), grid, dim3(64), 0, stream, q);
 	else
 		hipLaunchKernelGGL((raster_fwd_fast_kernel<PixT, false, false>), grid, dim3(64), 0, stream, q);
 	return 0;
