@@ -325,6 +325,7 @@ int launch_forward_staged(const KParams &p, bool fused, hipStream_t stream, hipE
 	// (+ the workgroups that stream this kernel's share of the background of the empty tiles, one bitmap word each)
 	const dim3 grid((unsigned)p.n_views * (unsigned)q.tile_blocks + (unsigned)p.n_views * (unsigned)fill_share(p.fill_mode, 2, p.L.nwords));
 	const bool tex = p.texture != nullptr; // (see launch_adjoint_raster)
+	const bool common = p.strict && p.W % TILE == 0 && p.H % TILE == 0;
 	if (fused && p.clamp && tex) // (the clamped residual of the depth fitter: its own instances of the fused kernel)
 		hipLaunchKernelGGL((raster_fwd_fast_kernel<PixT, true, true, true>), grid, dim3(64), 0, stream, q);
 	else if (fused && p.clamp && p.C == 1) // (a depth image)
@@ -335,6 +336,10 @@ int launch_forward_staged(const KParams &p, bool fused, hipStream_t stream, hipE
 		hipLaunchKernelGGL((raster_fwd_fast_kernel<PixT, true, true, false, 3>), grid, dim3(64), 0, stream, q);
 	else if (fused && tex)
 		hipLaunchKernelGGL((raster_fwd_fast_kernel<PixT, true, true>), grid, dim3(64), 0, stream, q);
+	else if (fused && p.C == 4 && common)
+		hipLaunchKernelGGL((raster_fwd_fast_kernel<PixT, true, false, false, 4, true>), grid, dim3(64), 0, stream, q);
+	else if (fused && p.C == 3 && common)
+		hipLaunchKernelGGL((raster_fwd_fast_kernel<PixT, true, false, false, 3, true>), grid, dim3(64), 0, stream, q);
 	else if (fused && p.C == 4)
 		hipLaunchKernelGGL((raster_fwd_fast_kernel<PixT, true, false, false, 4>), grid, dim3(64), 0, stream, q);
 	else if (fused && p.C == 3)

@@ -192,6 +192,7 @@ struct KParams
 	// (deodr/mesh_fitter.py:108-123); the gradient passes on the closed interval, as torch.clamp's does
 	int clamp;
 	double clamp_lo, clamp_hi;
+	int aligned; // set INSIDE raster_fwd_fast_kernel from a template argument: width and height are multiples of the tile (no pixel of a tile is outside)
 	// workspace
 	char *ws;
 	Layout L;
