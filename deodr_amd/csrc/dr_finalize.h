@@ -99,10 +99,13 @@ __global__ __launch_bounds__(PRIM_BLOCK, DR_PRIM_WAVES) void finalize_kernel(KPa
 		DR_WAVE_PHASE_T(3);
 		return;
 	}
-	const int slot = compact_flagged_slots(p, s.edgeflags, pw.index);
+	const uint32_t n_flagged = compact_flagged_slots(p, s.edgeflags, pw.index);
 	DR_WAVE_PHASE(1); // flags compacted
-	if (slot >= 0)
-	{
+	for (int round = 0; round * PRIM_BLOCK < (int)n_flagged; round++)
+	{ // (a round per PRIM_BLOCK flagged slots: see setup_bin_kernel)
+		const int slot = edge_round_slot(n_flagged, round);
+		if (slot < 0)
+			continue;
 		// Record, finalize inputs and accumulators of the slot are all requested at once: ONE memory round trip before the
 		// arithmetic.  The set-up kernel of this forward wrote the record's kind for EVERY flagged slot (KIND_NONE for an edge of
 		// a back-facing triangle), so nothing read here is stale.
@@ -127,7 +130,7 @@ __global__ __launch_bounds__(PRIM_BLOCK, DR_PRIM_WAVES) void finalize_kernel(KPa
 			asm volatile("" : "+v"(x2b[0]), "+v"(la[0]), "+v"(lt[0]), "+v"(fin.V[0][0]));
 			DR_WAVE_PHASE(2); // inputs arrived
 			if (kind == KIND_NONE)
-				return;
+				continue;
 			if (fin.has_att)
 				finalize_edge_fin(s, g, kind, x2b, fin, la, lt, DeviceAdd());
 			else
@@ -136,7 +139,7 @@ __global__ __launch_bounds__(PRIM_BLOCK, DR_PRIM_WAVES) void finalize_kernel(KPa
 		else
 		{
 			if (kind == KIND_NONE)
-				return;
+				continue;
 			finalize_edge(s, g, slot / 3, slot % 3, er, acc, DeviceAdd());
 		}
 		DR_WAVE_PHASE(3); // arithmetic done, atomics issued

@@ -97,7 +97,13 @@ constexpr int PRIM_BLOCK = DR_PRIM_BLOCK;
 #endif
 
 __host__ __device__ inline int prim_tri_blocks(int T) { return (T + PRIM_BLOCK - 1) / PRIM_BLOCK; }
-__host__ __device__ inline int prim_blocks(int T) { return prim_tri_blocks(T) + (3 * T + PRIM_BLOCK - 1) / PRIM_BLOCK; }
+// An edge-slot block looks at EDGE_SLOTS consecutive slots per thread (a few per cent of the slots are flagged as silhouette edges:
+// with one slot per thread three quarters of both kernels' wavefronts did nothing but look at 64 flags)
+#ifndef DR_EDGE_SLOTS
+#define DR_EDGE_SLOTS 4
+#endif
+constexpr int EDGE_SLOTS = DR_EDGE_SLOTS, EDGE_BLOCK_SLOTS = PRIM_BLOCK * EDGE_SLOTS;
+__host__ __device__ inline int prim_blocks(int T) { return prim_tri_blocks(T) + (3 * T + EDGE_BLOCK_SLOTS - 1) / EDGE_BLOCK_SLOTS; }
 
 // Grid of the per-primitive kernels: 1-D, n_views * prim_blocks(T) workgroups.  The edge-slot blocks of every view come first,
 // then the triangle blocks (views fastest inside each class): the wavefront that works on flagged edges is the longest
@@ -132,17 +138,31 @@ __device__ __forceinline__ PrimWork prim_work(const KParams &p, bool edge_first 
 	return w;
 }
 
-// -> the slot this thread works on, or -1.  Called by every thread of an edge block.
-__device__ __forceinline__ int compact_flagged_slots(const KParams &p, const uint8_t *edgeflags, int edge_block)
+// Compacts the flagged slots of an edge block into s_slots (LDS) and returns how many there are; the threads of the block then take
+// them PRIM_BLOCK at a time: round r, thread t -> edge_round_slot(total, r) (or -1).  Called by every thread of an edge block.
+__shared__ uint32_t s_edge_slots[EDGE_BLOCK_SLOTS];
+__device__ __forceinline__ uint32_t compact_flagged_slots(const KParams &p, const uint8_t *edgeflags, int edge_block)
 {
-	__shared__ uint32_t s_slots[PRIM_BLOCK];
 	__shared__ uint32_t s_count[PRIM_BLOCK / 64];
 	const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-	const int slot = edge_block * PRIM_BLOCK + tid;
-	const bool flagged = p.sigma > 0 && slot < 3 * p.T && edgeflags[slot] != 0;
-	const unsigned long long m = __ballot(flagged);
-	if (lane == 0)
-		s_count[wave] = (uint32_t)__popcll(m);
+	const int slot0 = (edge_block * PRIM_BLOCK + tid) * EDGE_SLOTS;
+	uint32_t flags = 0; // bit i: slot0 + i is flagged
+	if (p.sigma > 0)
+#pragma unroll
+		for (int i = 0; i < EDGE_SLOTS; i++)
+			if (slot0 + i < 3 * p.T && edgeflags[slot0 + i] != 0)
+				flags |= 1u << i;
+	const uint32_t mine = (uint32_t)__popc(flags);
+	// exclusive prefix of `mine` over the lanes of the wavefront, then over the wavefronts
+	uint32_t incl = mine;
+#pragma unroll
+	for (int d = 1; d < 64; d <<= 1)
+	{
+		const uint32_t up = (uint32_t)__shfl_up((int)incl, d, 64);
+		incl += lane >= d ? up : 0u;
+	}
+	if (lane == 63)
+		s_count[wave] = incl;
 	__syncthreads();
 	uint32_t before = 0, total = 0;
 #pragma unroll
@@ -152,10 +172,18 @@ __device__ __forceinline__ int compact_flagged_slots(const KParams &p, const uin
 		before += i < wave ? c : 0u;
 		total += c;
 	}
-	if (flagged)
-		s_slots[before + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)slot;
+	uint32_t at = before + incl - mine;
+#pragma unroll
+	for (int i = 0; i < EDGE_SLOTS; i++)
+		if ((flags >> i) & 1u)
+			s_edge_slots[at++] = (uint32_t)(slot0 + i);
 	__syncthreads();
-	return (uint32_t)tid < total ? (int)s_slots[tid] : -1;
+	return total;
+}
+__device__ __forceinline__ int edge_round_slot(uint32_t total, int round)
+{
+	const uint32_t i = (uint32_t)round * PRIM_BLOCK + threadIdx.x;
+	return i < total ? (int)s_edge_slots[i] : -1;
 }
 
 #ifdef DR_WAVE_TRACE
@@ -435,9 +463,15 @@ __global__ __launch_bounds__(PRIM_BLOCK, DR_PRIM_WAVES) void setup_bin_kernel(KP
 	}
 	// nothing is written for the ~97 % of slots that are not silhouette edges: records are only reached through the
 	// tile lists, and finalize_kernel works from the same flags
-	const int slot = compact_flagged_slots(p, s.edgeflags, pw.index);
+	const uint32_t n_flagged = compact_flagged_slots(p, s.edgeflags, pw.index);
 	DR_WAVE_PHASE(1); // flags compacted
-	{
+	// A round per PRIM_BLOCK flagged slots: one, unless most edges of the block are flagged (a triangle soup).  The first round is
+	// written out and the others loop over a second copy of the same code: as ONE loop the body kept its loop-invariant values in
+	// registers across a loop that runs once (93 spilled registers, on the path of every edge block).
+	auto edge_round = [&](int round) {
+		if ((threadIdx.x >> 6) * 64 + round * PRIM_BLOCK >= (int)n_flagged)
+			return; // (a wavefront without a slot in this round)
+		const int slot = edge_round_slot(n_flagged, round);
 		int extra = 0;
 		double hp[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 		int btx0 = 0, bty0 = 0, bntx = 0, bnty = 0, bprim = 0;
@@ -481,7 +515,12 @@ __global__ __launch_bounds__(PRIM_BLOCK, DR_PRIM_WAVES) void setup_bin_kernel(KP
 		} while (false);
 		DR_WAVE_PHASE(5); // record done
 		bin_rest(extra, false, hp, btx0, bty0, bntx, bnty, bprim);
-	}
+	};
+	if (n_flagged > 0)
+		edge_round(0);
+	if (n_flagged > (uint32_t)PRIM_BLOCK)
+		for (int round = 1; round * PRIM_BLOCK < (int)n_flagged; round++)
+			edge_round(round);
 }
 
 } // namespace
