@@ -329,9 +329,9 @@ __device__ __forceinline__ Vec3 accumulated_normal(const ShadeArgs &a, const dou
 }
 
 // grid: (V GATHER_LANES / FH_BLOCK, n)
-__global__ __launch_bounds__(FH_BLOCK) void vertex_shade_kernel(ShadeArgs a, double *lum_out, double *colors_out)
+__device__ __forceinline__ void vertex_shade_block(const ShadeArgs &a, double *lum_out, double *colors_out, int bx, int b)
 {
-	const int t = blockIdx.x * FH_BLOCK + threadIdx.x, v = t / GATHER_LANES, sub = t % GATHER_LANES, b = blockIdx.y;
+	const int t = bx * FH_BLOCK + threadIdx.x, v = t / GATHER_LANES, sub = t % GATHER_LANES;
 	const bool on = v < a.V;
 	const Vec3 acc = accumulated_normal(a, a.posed + (size_t)b * a.V * 3, v, sub, on);
 	if (!on || sub != 0)
@@ -346,6 +346,10 @@ __global__ __launch_bounds__(FH_BLOCK) void vertex_shade_kernel(ShadeArgs a, dou
 	if (colors_out)
 		for (int c = 0; c < a.C; c++)
 			colors_out[at * a.C + c] = a.color[c] * lum;
+}
+__global__ __launch_bounds__(FH_BLOCK) void vertex_shade_kernel(ShadeArgs a, double *lum_out, double *colors_out)
+{
+	vertex_shade_block(a, lum_out, colors_out, blockIdx.x, blockIdx.y);
 }
 
 // b1: per (view, vertex), a 1-D grid over n V GATHER_LANES threads.  -> acc_b [n,V,3] (adjoint of the accumulated, not yet normalised,
@@ -410,33 +414,78 @@ __global__ __launch_bounds__(FH_BLOCK) void vertex_shade_b2_kernel(ShadeArgs a, 
 
 // ---- rigid energy over a CSR of M = L^T L: grad = c M (x - ref), energy[0] = 0.5 (x - ref) . grad; with a data term at hand,
 // energy[1] = data_weight * data_energy[0] + energy[0] (what a fitter's step reports, mesh_fitter.py:147).  grid: V GATHER_LANES / FH_BLOCK
-__global__ __launch_bounds__(FH_BLOCK) void rigid_energy_kernel(const double *x, const double *ref, const uint32_t *offsets, const uint32_t *cols,
-																 const double *vals, double cregu, double *grad, double *energy, const double *data_energy,
-																 double data_weight, double *partials, unsigned *counter, int V)
+struct RigidArgs
 {
-	const int t = blockIdx.x * FH_BLOCK + threadIdx.x, v = t / GATHER_LANES, sub = t % GATHER_LANES;
-	const bool on = v < V;
+	const double *x, *ref;
+	const uint32_t *offsets, *cols;
+	const double *vals;
+	double cregu;
+	double *grad, *energy;
+	const double *data_energy;
+	double data_weight;
+	double *partials;
+	unsigned *counter;
+	int V;
+};
+__device__ __forceinline__ void rigid_energy_block(const RigidArgs &a, unsigned bx, unsigned nblocks)
+{
+	const int t = bx * FH_BLOCK + threadIdx.x, v = t / GATHER_LANES, sub = t % GATHER_LANES;
+	const bool on = v < a.V;
 	Vec3 g = {0, 0, 0};
-	const uint32_t begin = on ? offsets[v] : 0, end = on ? offsets[v + 1] : 0;
+	const uint32_t begin = on ? a.offsets[v] : 0, end = on ? a.offsets[v + 1] : 0;
 	for (uint32_t k = begin + sub; k < end; k += GATHER_LANES)
 	{
-		const size_t j = cols[k];
-		g = add3(g, scale3(vals[k], sub3(load3(x + 3 * j), load3(ref + 3 * j))));
+		const size_t j = a.cols[k];
+		g = add3(g, scale3(a.vals[k], sub3(load3(a.x + 3 * j), load3(a.ref + 3 * j))));
 	}
-	g = scale3(cregu, lanes_sum3(g));
+	g = scale3(a.cregu, lanes_sum3(g));
 	double e[1] = {0};
 	if (on && sub == 0)
 	{
-		store3(grad + 3 * (size_t)v, g);
-		e[0] = 0.5 * dot3(sub3(load3(x + 3 * (size_t)v), load3(ref + 3 * (size_t)v)), g);
+		store3(a.grad + 3 * (size_t)v, g);
+		e[0] = 0.5 * dot3(sub3(load3(a.x + 3 * (size_t)v), load3(a.ref + 3 * (size_t)v)), g);
 	}
 	double total[1];
-	if (grid_sum<1>(e, partials, counter, total) && threadIdx.x == 0)
+	if (grid_sum<1>(e, a.partials, a.counter, total, bx, nblocks) && threadIdx.x == 0)
 	{
-		energy[0] = total[0];
-		if (data_energy)
-			energy[1] = data_weight * data_energy[0] + total[0];
+		a.energy[0] = total[0];
+		if (a.data_energy)
+			a.energy[1] = a.data_weight * a.data_energy[0] + total[0];
 	}
+}
+__global__ __launch_bounds__(FH_BLOCK) void rigid_energy_kernel(RigidArgs a) { rigid_energy_block(a, blockIdx.x, gridDim.x); }
+
+// ---- what lies between pose + projection and the rasterizer in a fit iteration -- silhouette flags (from ij), vertex colours (from the
+// posed vertices) and the rigid energy with its gradient (from the vertices) -- does not depend on one another: ONE launch, the
+// workgroups of the three kernels side by side (each kernel of a replayed iteration costs 3 - 5 us whatever it does).
+// grid: rigid_blocks + shade_x n + sil_x n workgroups (a part with no workgroups is not wanted)
+struct FrontArgs
+{
+	RigidArgs rigid;
+	ShadeArgs shade;
+	double *lum_out, *colors_out;
+	const double *ij;
+	const uint32_t *faces, *edge_faces;
+	uint8_t *flags;
+	int T, V, clockwise;
+	unsigned rigid_blocks, shade_x, sil_x;
+};
+__global__ __launch_bounds__(FH_BLOCK) void fit_front_kernel(FrontArgs a)
+{
+	unsigned bx = blockIdx.x;
+	if (bx < a.rigid_blocks)
+	{ // (first: its last workgroup adds the partial energies up)
+		rigid_energy_block(a.rigid, bx, a.rigid_blocks);
+		return;
+	}
+	bx -= a.rigid_blocks;
+	if (bx < a.shade_x * (unsigned)a.shade.n)
+	{
+		vertex_shade_block(a.shade, a.lum_out, a.colors_out, (int)(bx % a.shade_x), (int)(bx / a.shade_x));
+		return;
+	}
+	bx -= a.shade_x * (unsigned)a.shade.n;
+	silhouette_flags_block(a.ij, a.faces, a.edge_faces, a.flags, a.T, a.V, a.clockwise, (int)(bx % a.sil_x), (int)(bx / a.sil_x));
 }
 
 // ---- sum (image - obs)^2 over a frame batch in the pixel type PixT, accumulated in double: the data energy of the colour fitters

@@ -41,8 +41,9 @@ constexpr int FH_BLOCK = 256;
 // workgroup i is added by thread i mod FH_BLOCK in the order i, i + FH_BLOCK, ...; then the lanes of a wavefront (DPP tree), then
 // the wavefronts in order -- fixed by the launch geometry alone.
 template <int K>
-__device__ __forceinline__ bool grid_sum(const double (&v)[K], double *partials, unsigned *counter, double (&total)[K])
-{
+__device__ __forceinline__ bool grid_sum(const double (&v)[K], double *partials, unsigned *counter, double (&total)[K], unsigned block = blockIdx.x,
+										 unsigned nblocks = gridDim.x)
+{ // (block / nblocks: the position of this workgroup among the ones that take part, for kernels that are a part of a launch)
 	__shared__ double s_wave[FH_BLOCK / 64][K];
 	__shared__ int s_last;
 	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -59,13 +60,13 @@ __device__ __forceinline__ bool grid_sum(const double (&v)[K], double *partials,
 		double s = 0;
 		for (int w = 0; w < FH_BLOCK / 64; w++)
 			s += s_wave[w][threadIdx.x];
-		partials[(size_t)blockIdx.x * K + threadIdx.x] = s;
+		partials[(size_t)block * K + threadIdx.x] = s;
 	}
 	__syncthreads();
 	if (threadIdx.x == 0)
 	{
 		__threadfence(); // release (after the barrier: the workgroup's partials are visible to the device before its ticket)
-		s_last = atomicAdd(counter, 1u) == gridDim.x - 1;
+		s_last = atomicAdd(counter, 1u) == nblocks - 1;
 	}
 	__syncthreads();
 	if (!s_last)
@@ -75,7 +76,7 @@ __device__ __forceinline__ bool grid_sum(const double (&v)[K], double *partials,
 #pragma unroll
 	for (int k = 0; k < K; k++)
 		mine[k] = 0;
-	for (unsigned i = threadIdx.x; i < gridDim.x; i += FH_BLOCK)
+	for (unsigned i = threadIdx.x; i < nblocks; i += FH_BLOCK)
 #pragma unroll
 		for (int k = 0; k < K; k++)
 			mine[k] += partials[(size_t)i * K + k];
@@ -245,10 +246,10 @@ __global__ __launch_bounds__(FH_BLOCK) void project_points_b_kernel(const double
 
 // ---- silhouette flags: flag[b][f][e] = 1 when exactly one face on edge e of face f is front-facing in view b.
 // edge_faces [T,3]: the face on the other side of edge (v_e, v_{e+1}) of face f, or 0xffffffff on a boundary (static per mesh).
-__global__ __launch_bounds__(FH_BLOCK) void silhouette_flags_kernel(const double *ij, const uint32_t *faces, const uint32_t *edge_faces, uint8_t *flags, int T,
-																	 int V, int clockwise)
+__device__ __forceinline__ void silhouette_flags_block(const double *ij, const uint32_t *faces, const uint32_t *edge_faces, uint8_t *flags, int T, int V,
+													   int clockwise, int bx, int b)
 {
-	const int f = blockIdx.x * FH_BLOCK + threadIdx.x, b = blockIdx.y;
+	const int f = bx * FH_BLOCK + threadIdx.x;
 	if (f >= T)
 		return;
 	const double *p = ij + (size_t)b * V * 2;
@@ -267,6 +268,11 @@ __global__ __launch_bounds__(FH_BLOCK) void silhouette_flags_kernel(const double
 		flags[((size_t)b * T + f) * 3 + e] = count == 1 ? 1 : 0;
 	}
 }
+__global__ __launch_bounds__(FH_BLOCK) void silhouette_flags_kernel(const double *ij, const uint32_t *faces, const uint32_t *edge_faces, uint8_t *flags, int T,
+																	 int V, int clockwise)
+{
+	silhouette_flags_block(ij, faces, edge_faces, flags, T, V, clockwise, blockIdx.x, blockIdx.y);
+}
 
 // ---- momentum update of up to MOMENTUM_MAX parameter tensors in one launch, IN PLACE
 constexpr int MOMENTUM_MAX = 8;
@@ -281,6 +287,9 @@ struct MomentumArgs
 	int n;
 	double inertia, damping;
 	double *partials; // 3 doubles per workgroup and tensor (mean_out)
+	double *energy;	  // optional [2]: energy[1] = data_weight * data_energy[0] + energy[0], what a fitter's step reports (mesh_fitter.py:147)
+	const double *data_energy;
+	double data_weight;
 	unsigned *counters; // one word per tensor
 };
 __device__ __forceinline__ double momentum_step(const MomentumArgs &a, int k, int at, int column)
@@ -301,6 +310,8 @@ __global__ __launch_bounds__(FH_BLOCK) void momentum_update_kernel(MomentumArgs 
 	const int k = blockIdx.y;
 	const int i = blockIdx.x * FH_BLOCK + threadIdx.x;
 	const int rows = a.normalize_rows[k];
+	if (a.energy && k == 0 && i == 0)
+		a.energy[1] = a.data_weight * a.data_energy[0] + a.energy[0];
 	if (rows > 0)
 	{ // one thread per row (a handful of quaternions)
 		const int nrow = a.count[k] / rows;

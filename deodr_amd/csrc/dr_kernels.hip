@@ -763,9 +763,11 @@ size_t deodr_hip_fit_scratch_bytes(int V, int n)
 
 int deodr_hip_momentum_update(int n_tensors, double *const *x, double *const *speed, const double *const *grad, const double *const *grad2,
 							  const double *factor, const double *step_max, const int *count, const int *normalize_rows, double inertia, double damping,
-							  const double *grad_scale, const double *const *grad_mean, double *const *mean_out, void *scratch, size_t scratch_bytes,
-							  void *stream)
+							  const double *grad_scale, const double *const *grad_mean, double *const *mean_out, double *energy, const double *data_energy,
+							  double data_weight, void *scratch, size_t scratch_bytes, void *stream)
 {
+	if (energy && !data_energy)
+		return fail("momentum_update: energy[1] = data_weight * data_energy[0] + energy[0] needs data_energy");
 	if (n_tensors <= 0 || n_tensors > MOMENTUM_MAX || !x || !speed || !grad || !factor || !step_max || !count)
 		return fail("momentum_update: bad arguments (at most 8 tensors per call)");
 	MomentumArgs a;
@@ -789,6 +791,7 @@ int deodr_hip_momentum_update(int n_tensors, double *const *x, double *const *sp
 	if (means && (!scratch || scratch_bytes < fit_scratch_need_momentum(most)))
 		return fail("momentum_update: mean_out needs the fit scratch (deodr_hip_fit_scratch_bytes)");
 	a.n = n_tensors, a.inertia = inertia, a.damping = damping;
+	a.energy = energy, a.data_energy = data_energy, a.data_weight = data_weight;
 	a.counters = scratch ? (unsigned *)scratch + FC_MOMENTUM : nullptr;
 	a.partials = scratch ? (double *)((char *)scratch + 64) : nullptr;
 	hipLaunchKernelGGL(momentum_update_kernel, dim3((most + FH_BLOCK - 1) / FH_BLOCK, n_tensors), dim3(FH_BLOCK), 0, (hipStream_t)stream, a);
@@ -872,9 +875,53 @@ int deodr_hip_rigid_energy(const double *vertices, const double *vertices_ref, c
 		return fail("rigid_energy: bad arguments");
 	if (!scratch || scratch_bytes < fit_scratch_need_rigid(V))
 		return fail("rigid_energy: scratch too small (deodr_hip_fit_scratch_bytes)");
-	hipLaunchKernelGGL(rigid_energy_kernel, dim3(fh_blocks((long long)V * GATHER_LANES)), dim3(FH_BLOCK), 0, (hipStream_t)stream, vertices, vertices_ref, m_offsets, m_cols, m_vals, cregu,
-					   gradient, energy, data_energy, data_weight, (double *)((char *)scratch + 64), (unsigned *)scratch + FC_RIGID, V);
+	const RigidArgs a = {vertices, vertices_ref, m_offsets, m_cols, m_vals, cregu, gradient, energy, data_energy, data_weight, (double *)((char *)scratch + 64),
+						 (unsigned *)scratch + FC_RIGID, V};
+	hipLaunchKernelGGL(rigid_energy_kernel, dim3(fh_blocks((long long)V * GATHER_LANES)), dim3(FH_BLOCK), 0, (hipStream_t)stream, a);
 	return check_hip(hipGetLastError(), "rigid_energy launch");
+}
+
+int deodr_hip_fit_front(const double *ij, const uint32_t *faces, const uint32_t *edge_faces, uint8_t *flags, int T, const double *posed,
+						const uint32_t *vf_offsets, const uint32_t *vf_corners, const double *light, const double *ambient, const double *color, int C,
+						double *luminosity, double *colors, const double *vertices, const double *vertices_ref, const uint32_t *m_offsets, const uint32_t *m_cols,
+						const double *m_vals, double cregu, double *gradient, double *energy, void *scratch, size_t scratch_bytes, int V, int n, int clockwise,
+						void *stream)
+{
+	if (!faces || V <= 0 || n <= 0)
+		return fail("fit_front: bad arguments");
+	FrontArgs a;
+	memset(&a, 0, sizeof a);
+	a.V = V, a.clockwise = clockwise, a.faces = faces;
+	if (flags)
+	{
+		if (!ij || !edge_faces || T <= 0)
+			return fail("fit_front: silhouette flags need ij, edge_faces and the number of faces");
+		a.ij = ij, a.edge_faces = edge_faces, a.flags = flags, a.T = T, a.sil_x = (unsigned)fh_blocks(T);
+	}
+	a.shade.n = n;
+	if (luminosity || colors)
+	{
+		if (shade_args(a.shade, posed, faces, vf_offsets, vf_corners, light, ambient, color, C, V, n, clockwise))
+			return 1;
+		if (colors && !color)
+			return fail("fit_front: colours asked for without a colour");
+		a.lum_out = luminosity, a.colors_out = colors, a.shade_x = (unsigned)fh_blocks((long long)V * GATHER_LANES);
+	}
+	if (gradient)
+	{
+		if (!vertices || !vertices_ref || !m_offsets || !m_cols || !m_vals || !energy)
+			return fail("fit_front: the rigid energy needs vertices, reference, the CSR of L^T L and energy[2]");
+		if (!scratch || scratch_bytes < fit_scratch_need_rigid(V))
+			return fail("fit_front: scratch too small (deodr_hip_fit_scratch_bytes)");
+		a.rigid = RigidArgs{vertices, vertices_ref, m_offsets, m_cols, m_vals, cregu, gradient, energy, nullptr, 0.0, (double *)((char *)scratch + 64),
+							(unsigned *)scratch + FC_RIGID, V};
+		a.rigid_blocks = (unsigned)fh_blocks((long long)V * GATHER_LANES);
+	}
+	const unsigned blocks = a.rigid_blocks + (a.shade_x + a.sil_x) * (unsigned)n;
+	if (!blocks)
+		return fail("fit_front: nothing to do");
+	hipLaunchKernelGGL(fit_front_kernel, dim3(blocks), dim3(FH_BLOCK), 0, (hipStream_t)stream, a);
+	return check_hip(hipGetLastError(), "fit_front launch");
 }
 
 static int l2_loss_impl(const void *image, const void *obs, int pixel_dtype, size_t count, double *out, void *scratch, size_t scratch_bytes, void *stream,

@@ -32,7 +32,8 @@ def _lib():
         L.deodr_hip_project_points.argtypes = [vp] * 6 + [i, i, vp]
         L.deodr_hip_project_points_b.argtypes = [vp] * 7 + [i, i, vp]
         L.deodr_hip_silhouette_flags.argtypes = [vp, vp, vp, vp, i, i, i, i, vp]
-        L.deodr_hip_momentum_update.argtypes = [i, vp, vp, vp, vp, vp, vp, vp, vp, d, d, vp, vp, vp, vp, C.c_size_t, vp]
+        L.deodr_hip_momentum_update.argtypes = [i, vp, vp, vp, vp, vp, vp, vp, vp, d, d, vp, vp, vp, vp, vp, d, vp, C.c_size_t, vp]
+        L.deodr_hip_fit_front.argtypes = [vp] * 4 + [i] + [vp] * 6 + [i] + [vp] * 7 + [d, vp, vp, vp, C.c_size_t, i, i, i, vp]
         L.deodr_hip_fit_scratch_bytes.argtypes, L.deodr_hip_fit_scratch_bytes.restype = [i, i], C.c_size_t
         L.deodr_hip_fit_pose_project.argtypes = [vp] * 11 + [d, i, i, vp]
         L.deodr_hip_fit_pose_project_b.argtypes = [vp] * 9 + [d, vp, vp, vp, C.c_size_t, i, i, vp, i, vp, vp]
@@ -42,7 +43,7 @@ def _lib():
         L.deodr_hip_l2_loss.argtypes = [vp, vp, i, C.c_size_t, vp, vp, C.c_size_t, vp]
         L.deodr_hip_depth_residual.argtypes = [vp, i, vp, d, C.c_size_t, vp, vp, vp, vp, vp, C.c_size_t, vp]
         for f in ("rigid_transform", "rigid_transform_b", "project_points", "project_points_b", "silhouette_flags", "momentum_update", "fit_pose_project",
-                  "fit_pose_project_b", "vertex_shade", "vertex_shade_b", "rigid_energy", "l2_loss", "depth_residual"):  # fmt: skip
+                  "fit_pose_project_b", "vertex_shade", "vertex_shade_b", "rigid_energy", "l2_loss", "depth_residual", "fit_front"):  # fmt: skip
             getattr(L, "deodr_hip_" + f).restype = i
         _bound = True
     return L
@@ -112,10 +113,11 @@ def silhouette_flags(ij, faces_u32, edge_faces_u32, clockwise, out=None):
     return flags
 
 
-def momentum_update(entries, inertia, damping, scratch=None):
+def momentum_update(entries, inertia, damping, scratch=None, energy=None, data_energy=None, data_weight=1.0):
     """entries: [(x, speed, grad, grad2 | None, factor, step_max | None, normalize_rows[, grad_scale, grad_mean | None, mean_out | None])];
     x and speed are updated IN PLACE: s = (1 - damping)(inertia s + (1 - inertia) clamp(-factor (grad_scale (grad - grad_mean) + grad2))),
-    x += s (deodr/mesh_fitter.py:153-190); mean_out [3] receives the column mean of the updated [.,3] tensor (needs ``scratch``)"""
+    x += s (deodr/mesh_fitter.py:153-190); mean_out [3] receives the column mean of the updated [.,3] tensor (needs ``scratch``);
+    with ``energy`` [2] and ``data_energy`` [1]: energy[1] = data_weight * data_energy[0] + energy[0] on the way"""
     k = len(entries)
     assert 0 < k <= 8
     entries = [tuple(e) + (1.0, None, None)[len(e) - 7 :] for e in entries]
@@ -130,7 +132,8 @@ def momentum_update(entries, inertia, damping, scratch=None):
         assert e[0].is_contiguous() and e[1].is_contiguous() and e[2].is_contiguous() and (e[3] is None or e[3].is_contiguous())
     with torch.cuda.device(dev):
         _check(_lib().deodr_hip_momentum_update(k, ptrs(0), ptrs(1), ptrs(2), ptrs(3), factor, step_max, count, rows, float(inertia), float(damping), scale,
-                                                ptrs(8), ptrs(9), _p(scratch), 0 if scratch is None else scratch.numel(), _stream(dev)))  # fmt: skip
+                                                ptrs(8), ptrs(9), _p(energy), _p(data_energy), float(data_weight), _p(scratch),
+                                                0 if scratch is None else scratch.numel(), _stream(dev)))  # fmt: skip
 
 
 # ---- one fit iteration without an autograd graph (deodr_amd/csrc/dr_fititer.h) ----------------------------------------------------
@@ -176,6 +179,19 @@ def vertex_shade(posed, topology, light, ambient, color=None, luminosity=None, c
         _check(_lib().deodr_hip_vertex_shade(_p(posed), _p(topology._faces_u32), _p(topology._vf_offsets), _p(topology._vf_corners), _p(light), _p(ambient),
                                              _p(color), 0 if color is None else color.numel(), _p(luminosity), _p(colors), V, n, int(topology.clockwise),
                                              _stream(posed.device)))  # fmt: skip
+
+
+def fit_front(topology, n, scratch, ij=None, flags=None, posed=None, light=None, ambient=None, color=None, luminosity=None, colors=None, vertices=None,
+              vertices_ref=None, cregu=0.0, gradient=None, energy=None):
+    """:func:`silhouette_flags` (``flags`` given), :func:`vertex_shade` (``luminosity`` or ``colors`` given) and :func:`rigid_energy`
+    (``gradient`` given; energy[0] only) in ONE launch -- the three do not depend on one another.  Same results bit for bit."""
+    off, cols, vals = topology._m_csr if gradient is not None else (None, None, None)
+    dev = scratch.device
+    with torch.cuda.device(dev):
+        _check(_lib().deodr_hip_fit_front(_p(ij), _p(topology._faces_u32), _p(topology._edge_faces), _p(flags), topology.nb_faces, _p(posed), _p(topology._vf_offsets),
+                                          _p(topology._vf_corners), _p(light), _p(ambient), _p(color), 0 if color is None else color.numel(), _p(luminosity), _p(colors),
+                                          _p(vertices), _p(vertices_ref), _p(off), _p(cols), _p(vals), float(cregu), _p(gradient), _p(energy), _p(scratch),
+                                          scratch.numel(), topology.nb_vertices, int(n), int(topology.clockwise), _stream(dev)))  # fmt: skip
 
 
 def vertex_shade_b(posed, topology, light, ambient, color, luminosity_b, colors_b, posed_b, out, scratch):

@@ -260,27 +260,29 @@ class _PoseFitter:
         d.sync(self)
         return d
 
-    def _direct_forward(self, d, depth_colors=None, depth_scale=1.0):
-        """parameters -> posed vertices, image coordinates, depths, silhouette flags (in the rasterizer's own arrays)"""
+    def _direct_forward(self, d, depth_colors=None, depth_scale=1.0, shade=None):
+        """parameters -> posed vertices, image coordinates, depths (in the rasterizer's own arrays); then, in ONE launch, what depends on
+        them but not on one another: silhouette flags, vertex colours (``shade`` = (light, ambient, colour)), rigid energy + gradient"""
         from . import fronthalf
 
         topo = self.mesh.topology
         d.ds.set_views(ij=d.ij, depths=d.depths, colors=d.colors, shade=d.shade, edgeflags=d.flags)  # (no copies; another render may have rebound them)
         fronthalf.fit_pose_project(self.vertices, d.vmean, self.transform_quaternion, self.transform_translation, self.camera, d.posed, d.ij, d.depths,
                                    depth_colors, depth_scale)  # fmt: skip
-        if self.scene.sigma > 0:
-            fronthalf.silhouette_flags(d.ij, topo._faces_u32, topo._edge_faces, topo.clockwise, out=d.flags)
+        light, ambient, color = shade if shade is not None else (None, None, None)
+        fronthalf.fit_front(topo, d.posed.shape[0], d.scratch, ij=d.ij, flags=d.flags if self.scene.sigma > 0 else None, posed=d.posed, light=light,
+                            ambient=ambient, color=color, colors=d.colors if shade is not None else None, vertices=self.vertices,
+                            vertices_ref=self.rigid_energy.vertices_ref, cregu=self.cregu, gradient=d.g_rigid, energy=d.energy)  # fmt: skip
 
     def _direct_backward_and_update(self, d, depths_b, step_max, data_weight, extra=(), depths_b_scale=1.0):
-        """adjoint of pose + projection, rigid energy, (all-reduce of the shared block,) momentum update of every parameter in place"""
+        """adjoint of pose + projection, (all-reduce of the shared block,) momentum update of every parameter in place (which also adds the
+        data energy to the rigid energy of :meth:`_direct_forward`)"""
         from . import fronthalf
 
         n = d.posed.shape[0]
         fronthalf.fit_pose_project_b(self.vertices, self.transform_quaternion, d.posed, self.camera, d.posed_b, d.grads["ij_b"], depths_b, d.vertices_b,
                                      d.pose_out, d.scratch, depths_b_scale)  # fmt: skip
         self._allreduce_shared(d.shared)
-        fronthalf.rigid_energy(self.vertices, self.rigid_energy.vertices_ref, self.mesh.topology, self.cregu, d.g_rigid, d.energy, d.scratch, d.e_data,
-                               data_weight)  # fmt: skip
         def speed(name, x):
             if name not in self.momentum.speed:
                 self.momentum.speed[name] = torch.zeros_like(x)
@@ -293,7 +295,7 @@ class _PoseFitter:
             (self.transform_translation, speed("translation", self.transform_translation), d.pose_out[3 + 4 * n :], None, self.step_factor_translation,
              step_max[2], 0, data_weight, None, None),
         ] + [(x, speed(name, x), g, None, factor, None, 0, data_weight, None, None) for name, x, g, factor in extra]  # fmt: skip
-        fronthalf.momentum_update(entries, self.inertia, self.damping, scratch=d.scratch)
+        fronthalf.momentum_update(entries, self.inertia, self.damping, scratch=d.scratch, energy=d.energy, data_energy=d.e_data, data_weight=data_weight)
         self.iter += 1
         return d.energy[1]
 
@@ -492,8 +494,7 @@ class MeshRGBFitterWithPose(_PoseFitter):
         from . import fronthalf
 
         topo = self.mesh.topology
-        self._direct_forward(d)
-        fronthalf.vertex_shade(d.posed, topo, self.light_directional, self.light_ambient, self.mesh_color, colors=d.colors)
+        self._direct_forward(d, shade=(self.light_directional, self.light_ambient, self.mesh_color))
         obs = self._observation()
         # image, gradients AND the data energy from the rasterizer's four launches (the residual of every pixel is in the tile walkers'
         # registers; a separate pass over the 8-view frame was 73 us of a 350 us iteration)

@@ -172,8 +172,8 @@ int deodr_hip_silhouette_flags(const double *ij, const uint32_t *faces, const ui
 							   void *stream);
 int deodr_hip_momentum_update(int n_tensors, double *const *x, double *const *speed, const double *const *grad, const double *const *grad2,
 							  const double *factor, const double *step_max, const int *count, const int *normalize_rows, double inertia, double damping,
-							  const double *grad_scale, const double *const *grad_mean, double *const *mean_out, void *scratch, size_t scratch_bytes,
-							  void *stream);
+							  const double *grad_scale, const double *const *grad_mean, double *const *mean_out, double *energy, const double *data_energy,
+							  double data_weight, void *scratch, size_t scratch_bytes, void *stream);
 
 /* ---- One fit iteration without an autograd graph (deodr/mesh_fitter.py:108-190, 287-376, 529-632): the chain parameters -> posed and
  * projected vertices -> shading -> [silhouette flags, deodr_hip_render_scene_fit] -> adjoints -> rigid energy -> momentum update, about
@@ -206,8 +206,18 @@ int deodr_hip_momentum_update(int n_tensors, double *const *x, double *const *sp
  * deodr_hip_l2_loss              out[0] = sum (image - obs)^2 over `count` values of the pixel type (DEODR_HIP_F32 / _F64), accumulated in
  *                                double: the data energy whose gradient deodr_hip_render_scene_fit back-propagates (mesh_fitter.py:296-318)
  * deodr_hip_momentum_update      (above) grad_scale[k]: weight of grad (not of grad2); grad_mean[k] [3] or NULL: subtracted from every
- *                                row of a [count/3, 3] gradient; mean_out[k] [3] or NULL: column mean of the updated tensor */
+ *                                row of a [count/3, 3] gradient; mean_out[k] [3] or NULL: column mean of the updated tensor; energy [2] or NULL:
+ *                                energy[1] = data_weight * data_energy[0] + energy[0] (mesh_fitter.py:147; energy[0] from deodr_hip_fit_front)
+ * deodr_hip_fit_front            what lies between deodr_hip_fit_pose_project and the rasterizer, in ONE launch (none of the three depends on
+ *                                another): deodr_hip_silhouette_flags (flags != NULL), deodr_hip_vertex_shade (luminosity or colors != NULL) and
+ *                                the rigid energy with its gradient (gradient != NULL; energy[0] written, energy[1] left to
+ *                                deodr_hip_momentum_update: the data energy is not known yet).  Same results, bit for bit, as the three calls */
 size_t deodr_hip_fit_scratch_bytes(int V, int n);
+int deodr_hip_fit_front(const double *ij, const uint32_t *faces, const uint32_t *edge_faces, uint8_t *flags, int T, const double *posed,
+						const uint32_t *vf_offsets, const uint32_t *vf_corners, const double *light, const double *ambient, const double *color, int C,
+						double *luminosity, double *colors, const double *vertices, const double *vertices_ref, const uint32_t *m_offsets, const uint32_t *m_cols,
+						const double *m_vals, double cregu, double *gradient, double *energy, void *scratch, size_t scratch_bytes, int V, int n, int clockwise,
+						void *stream);
 int deodr_hip_fit_pose_project(double *vertices, const double *vertices_mean, const double *quaternions, const double *translations, const double *extrinsic,
 							   const double *intrinsic, const double *distortion, double *posed, double *ij, double *depths, double *depth_colors,
 							   double depth_scale, int V, int n, void *stream);
@@ -275,7 +285,7 @@ const char *deodr_hip_last_error(void);
 
 /* ABI version of this header; bumped on any incompatible change. */
 int deodr_hip_abi_version(void);
-#define DEODR_HIP_ABI_VERSION 6
+#define DEODR_HIP_ABI_VERSION 7
 
 #ifdef __cplusplus
 }

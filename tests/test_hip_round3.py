@@ -412,6 +412,49 @@ def test_fit_iteration_kernels_equal_the_torch_formulas(monkeypatch):
     assert torch.equal(energy.evaluate(x)[0], e.detach()) or float(energy.evaluate(x)[0]) == float(e)
 
 
+def test_fit_front_equals_its_three_kernels():
+    """deodr_hip_fit_front -- silhouette flags, vertex colours and the rigid energy of a fit iteration in ONE launch -- against the three
+    separate launches, bit for bit, with every subset of the parts; the total energy the momentum update adds up on the way"""
+    from deodr_amd import fronthalf
+    from deodr_amd.scene3d import DeviceMesh
+
+    rs = np.random.RandomState(5)
+    vertices, faces = hand()
+    n, V, dev = 3, len(vertices), "cuda"
+    t = lambda a: torch.tensor(np.asarray(a, dtype=np.float64), device=dev)
+    for clockwise in (False, True):
+        topo = DeviceMesh(faces, vertices, clockwise=clockwise, device=dev).topology
+        T = topo.nb_faces
+        posed, ij = t(vertices[None] + 0.02 * rs.randn(n, V, 3)), t(100 * rs.rand(n, V, 2))
+        x, ref = t(vertices + 0.01 * rs.randn(V, 3)), t(vertices)
+        light, amb, color = t([0.3, -0.5, 0.6]), t(0.25), t([0.7, 0.5, 0.4])
+        scratch = fronthalf.fit_scratch(V, n, dev)
+        flags_r = fronthalf.silhouette_flags(ij, topo._faces_u32, topo._edge_faces, clockwise)
+        colors_r, lum_r = torch.zeros((n, V, 3), dtype=torch.float64, device=dev), torch.zeros((n, V), dtype=torch.float64, device=dev)
+        fronthalf.vertex_shade(posed, topo, light, amb, color, luminosity=lum_r, colors=colors_r)
+        grad_r, energy_r = torch.zeros((V, 3), dtype=torch.float64, device=dev), torch.zeros(2, dtype=torch.float64, device=dev)
+        fronthalf.rigid_energy(x, ref, topo, 500.0, grad_r, energy_r, scratch)
+        assert 0 < int(flags_r.sum()) < flags_r.numel() and float(energy_r[0]) > 0
+        for want_flags, want_shade, want_rigid in [(1, 1, 1), (1, 0, 1), (0, 1, 1), (1, 1, 0), (0, 0, 1), (1, 0, 0), (0, 1, 0)]:
+            flags = torch.full((n, T, 3), 7, dtype=torch.uint8, device=dev)
+            colors, lum = torch.full_like(colors_r, -1), torch.full_like(lum_r, -1)
+            grad, energy = torch.full_like(grad_r, -1), torch.full_like(energy_r, -1)
+            fronthalf.fit_front(topo, n, scratch, ij=ij, flags=flags if want_flags else None, posed=posed, light=light, ambient=amb, color=color,
+                                luminosity=lum if want_shade else None, colors=colors if want_shade else None, vertices=x, vertices_ref=ref, cregu=500.0,
+                                gradient=grad if want_rigid else None, energy=energy)  # fmt: skip
+            assert torch.equal(flags, flags_r) if want_flags else bool((flags == 7).all())
+            assert (torch.equal(colors, colors_r) and torch.equal(lum, lum_r)) if want_shade else bool((colors == -1).all())
+            if want_rigid:
+                assert torch.equal(grad, grad_r) and float(energy[0]) == float(energy_r[0]) and float(energy[1]) == -1
+            else:
+                assert bool((grad == -1).all()) and bool((energy == -1).all())
+        # energy[1] = data_weight * data energy + energy[0], by the momentum update
+        data = t([3.25])
+        xs, speed, g = t(rs.randn(5, 3)), t(np.zeros((5, 3))), t(rs.randn(5, 3))
+        fronthalf.momentum_update([(xs, speed, g, None, 0.1, None, 0)], 0.9, 0.05, energy=energy_r, data_energy=data, data_weight=0.5)
+        assert float(energy_r[1]) == 0.5 * 3.25 + float(energy_r[0])
+
+
 def test_direct_fit_iteration_equals_the_autograd_iteration():
     """The fitters' iteration as a fixed kernel sequence (_DirectIteration, the default on float64 ROCm tensors) against the same
     iteration through autograd (``direct = False``): energies and every parameter, step by step, for the three fitters (the multi-frame
