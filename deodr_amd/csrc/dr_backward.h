@@ -13,9 +13,9 @@ namespace
 //
 // nb_colors <= 4, no antialiase_error, at most K_EDGE edges in the tile (other tiles call bwd_tile_generic).
 // Differences from the generic tile: edges are staged / ranked / span-tested exactly as in raster_fwd_fast_kernel, and the
-// segmented reductions "sum over the pixels of a primitive" are done with LDS atomics (ds_add_f64, one slot per distinct
-// primitive of the tile) followed by ONE global atomic per (primitive, moment), issued by 64 lanes in parallel -- instead
-// of a 64-lane butterfly per moment and primitive.
+// segmented reductions "sum over the pixels of a primitive" are a head-flag scan over the 8 lanes of every pixel row (DPP, no LDS),
+// a table of run totals in LDS, and ONE global atomic per (primitive, moment) issued by 64 lanes in parallel -- instead of a
+// 64-lane butterfly per moment and primitive (owner_adjoint).  The texture gradient alone goes through LDS atomics (ds_add_f64).
 
 constexpr int NMOM = 12; // moments per owner slot: 3 per channel (or 9 for a textured owner)
 
