@@ -21,7 +21,7 @@ constexpr int NMOM = 12; // moments per owner slot: 3 per channel (or 9 for a te
 
 struct alignas(16) BwdLds
 {
-	EdgeRec rec[TB];
+	RecSlot rec[TB]; // (the layout of WaveLds: edge_reverse_sweep and stage_edge_batch take either)
 	double planes[TB * 12];
 	uint32_t ids[TB];
 	uint8_t cover[TILE][TB];
@@ -249,7 +249,7 @@ __device__ __forceinline__ void edge_reverse_sweep(const KParams &p, const ViewP
 	const int C = p.C, P = p.L.P;
 	const PixT *texture = (const PixT *)p.texture;
 	PixT *texture_b = (PixT *)p.texture_b;
-	const EdgeRec *erec = (const EdgeRec *)&S.rec[0]; // (the staging area holds EdgeRec and TriRec alike: same size)
+	const RecSlot *erec = &S.rec[0]; // (the staging area holds EdgeRec and TriRec alike)
 	// pass B, near -> far (H.h:2961-3052)
 	for (int b = b_hi; b >= b_lo; b--)
 	{
@@ -272,7 +272,7 @@ __device__ __forceinline__ void edge_reverse_sweep(const KParams &p, const ViewP
 			const bool hit = (tmb >> r) & 1u;
 			if (__ballot(hit) == 0)
 				continue;
-			const EdgeRec &e = erec[r];
+			const EdgeRec &e = erec[r].edge();
 			const double *ep = &S.planes[r * 12];
 			// colour before this edge: un-blend like the reference (H.h:1738) when T is safely away from 0, otherwise
 			// replay every earlier edge from the un-antialiased colour (the reference yields inf / NaN there)
@@ -560,7 +560,7 @@ __device__ __forceinline__ void bwd_fast_tile(const KParams &p, const ViewPtrs &
 				const bool c = (ecov >> j) & 1u;
 				if (__ballot(c) == 0)
 					continue;
-				const EdgeRec &eq = S.rec[j];
+				const EdgeRec &eq = S.rec[j].edge();
 				if (c && plane_at(eq.xZ, x, y) < zown)
 				{
 					tmb |= 1u << j;

@@ -20,9 +20,21 @@ namespace
 
 constexpr int TB = 16; // triangles (or edges) staged per batch: small, so that LDS never limits the number of resident waves
 
+// A staged record: 128 bytes of TriRec or EdgeRec (same size) in a slot of 144 -- with a stride of 128 bytes (32 banks of 4 bytes) the
+// same field of every record lies in the same bank, and the span lanes (eight triangles per pass) or the pixel lanes of a depth test
+// (a few candidates per wavefront) were served one record after the other; 36 banks apart, eight records do not meet.
+struct alignas(16) RecSlot
+{
+	uint4 bytes[8];
+	uint4 pad;
+	__device__ __forceinline__ const TriRec &tri() const { return *(const TriRec *)this; }
+	__device__ __forceinline__ const EdgeRec &edge() const { return *(const EdgeRec *)this; }
+};
+static_assert(sizeof(TriRec) == 128 && sizeof(EdgeRec) == 128 && sizeof(RecSlot) == 144, "staged records");
+
 struct alignas(16) WaveLds
 {
-	TriRec rec[TB];			   // EdgeRec has the same size and is staged in the same place
+	RecSlot rec[TB];		   // TriRec or EdgeRec
 	double planes[TB * 12];	   // 3 * P doubles per primitive, P <= 4
 	uint32_t ids[TB];
 	uint8_t cover[TILE][TB];   // [row][primitive] -> bit x set when the primitive covers column x of the row
@@ -136,7 +148,7 @@ __device__ __forceinline__ void tri_batch(const KParams &p, WaveLds &S, int nb, 
 		uint32_t m = 0;
 		if (j < nb)
 		{
-			const TriRec &rec = S.rec[j];
+			const TriRec &rec = S.rec[j].tri();
 			if (DR_ABLATE & 512)
 				m = 0xffu;
 			else if (rec.kind != KIND_NONE)
@@ -187,7 +199,7 @@ __device__ __forceinline__ void tri_batch(const KParams &p, WaveLds &S, int nb, 
 		const bool act = todo != 0;
 		const int j = act ? __ffs((int)todo) - 1 : 0;
 		todo &= todo - 1;
-		double Z = plane_at(S.rec[j].xZ, x, y);
+		double Z = plane_at(S.rec[j].tri().xZ, x, y);
 		if (persp)
 			Z = 1 / Z;
 		const int k = (int)S.ids[j];
@@ -202,7 +214,7 @@ __device__ __forceinline__ void tri_batch(const KParams &p, WaveLds &S, int nb, 
 	if (jbest >= 0)
 	{ // per-lane reads of the winner's record and planes (LDS, a few distinct slots per tile)
 		st.slot = jbest;
-		const int kind = S.rec[jbest].kind;
+		const int kind = S.rec[jbest].tri().kind;
 		const double *pl = &S.planes[jbest * 12];
 		const double Z = st.zbest;
 		st.kind = kind;
@@ -296,7 +308,7 @@ __device__ __forceinline__ uint32_t stage_edge_batch(WaveLds &S, const EdgeSort 
 	lds_sync();
 	stage_batch(S, w.edge_rec, w.edge_planes, P, nb, lane);
 	lds_sync();
-	const EdgeRec *erec = (const EdgeRec *)S.rec;
+	const RecSlot *erec = S.rec;
 #pragma unroll
 	for (int q = 0; q < TB / 8; q++)
 	{
@@ -304,7 +316,7 @@ __device__ __forceinline__ uint32_t stage_edge_batch(WaveLds &S, const EdgeSort 
 		uint32_t m = 0;
 		if (j < nb)
 		{
-			const EdgeRec &e = erec[j];
+			const EdgeRec &e = erec[j].edge();
 			const int yy = y0 + r;
 			if (yy >= e.y_begin && yy <= e.y_end)
 			{
@@ -915,7 +927,7 @@ __device__ __forceinline__ void fwd_pair_tiles(const KParams &p, const ViewPtrs 
 		uint32_t m = 0;
 		if (j < nb)
 		{
-			const TriRec &rec = S.rec[j];
+			const TriRec &rec = S.rec[j].tri();
 			if (rec.kind != KIND_NONE)
 			{
 				const int yy = y0 + r, xs = j < nA ? x0 : x0 + TILE;
@@ -947,7 +959,7 @@ __device__ __forceinline__ void fwd_pair_tiles(const KParams &p, const ViewPtrs 
 			const bool act = todoA != 0;
 			const int j = act ? __ffs((int)todoA) - 1 : 0;
 			todoA &= todoA - 1;
-			const double Z = plane_at(S.rec[j].xZ, xA, y);
+			const double Z = plane_at(S.rec[j].tri().xZ, xA, y);
 			const int k = (int)S.ids[j];
 			if (act && (Z < zA || (Z == zA && k < kA)))
 				zA = Z, kA = k, jA = j;
@@ -956,7 +968,7 @@ __device__ __forceinline__ void fwd_pair_tiles(const KParams &p, const ViewPtrs 
 			const bool act = todoB != 0;
 			const int j = act ? __ffs((int)todoB) - 1 : nA;
 			todoB &= todoB - 1;
-			const double Z = plane_at(S.rec[j].xZ, xB, y);
+			const double Z = plane_at(S.rec[j].tri().xZ, xB, y);
 			const int k = (int)S.ids[j];
 			if (act && (Z < zB || (Z == zB && k < kB)))
 				zB = Z, kB = k, jB = j;
@@ -967,7 +979,7 @@ __device__ __forceinline__ void fwd_pair_tiles(const KParams &p, const ViewPtrs 
 	int kindA = KIND_NONE, kindB = KIND_NONE;
 	if (jA >= 0)
 	{
-		kindA = S.rec[jA].kind;
+		kindA = S.rec[jA].tri().kind;
 		const double *pl = &S.planes[jA * 12];
 #pragma unroll
 		for (int cc = 0; cc < CH; cc++)
@@ -983,7 +995,7 @@ __device__ __forceinline__ void fwd_pair_tiles(const KParams &p, const ViewPtrs 
 	}
 	if (jB >= 0)
 	{
-		kindB = S.rec[jB].kind;
+		kindB = S.rec[jB].tri().kind;
 		const double *pl = &S.planes[jB * 12];
 #pragma unroll
 		for (int cc = 0; cc < CH; cc++)
@@ -1270,7 +1282,7 @@ __device__ __forceinline__ void fwd_tiles(const KParams &p, WaveLds *s_lds, Edge
 				if (lane == 0)
 					*(uint32_t *)(w.edge_sweep + (size_t)(sweep_slot - 1) * SWEEP_BYTES + SWEEP_SNAP) = snap;
 			}
-			const EdgeRec *erec = (const EdgeRec *)S.rec;
+			const RecSlot *erec = S.rec;
 			for (int first = 0; first < n_edges; first += TB)
 			{
 				const int nb = n_edges - first < TB ? n_edges - first : TB;
@@ -1281,7 +1293,7 @@ __device__ __forceinline__ void fwd_tiles(const KParams &p, WaveLds *s_lds, Edge
 					const bool c = (ecov >> j) & 1u;
 					if (__ballot(c) == 0)
 						continue;
-					const EdgeRec &e = erec[j];
+					const EdgeRec &e = erec[j].edge();
 					double Ze = plane_at(e.xZ, x, y);
 					if (persp)
 						Ze = 1 / Ze;
