@@ -21,6 +21,8 @@ The JSON line carries, besides the driver's contract:
                 bytes somebody actually moves
   parity        views 0 and last of the TIMED launch compared with oracle/_ref after the timed region (image 1e-5, gradients
                 1e-4 of the largest reference entry): the number belongs to a correct result
+  reduction_check  (N > 1 or --force-dist) the all-reduced shared gradient of the LAST timed step against the same reduction done
+                again synchronously from that step's gradient arrays (relative error, asserted < 1e-12)
   hbm_probe     device-to-device copy / write-only / read-only bandwidth of this box (1 GiB buffers)
   single_view   the same fit step for ONE view (latency case): eager and replayed from a captured HIP graph
   other_configs fit-step time of BASELINE configs[1], [3], [4] (outside the timed headline; skipped with --no-other-configs)
@@ -293,6 +295,9 @@ def main():
     ap.add_argument("--time-every", type=int, default=20, help="steps between two steps whose kernels are timed with hipEvents (0: never)")
     ap.add_argument("--two-pass", action="store_true", help="render and render_backward as two calls (default: the fused fit step, same outputs)")
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed even for one rank (exercises the RCCL path)")
+    ap.add_argument("--test-backend", choices=["nccl", "gloo"], default="nccl",
+                    help="gloo: for the regression test of the multi-rank path on a ONE-GPU box (tests/test_hip_round3.py): the ranks share "
+                         "the visible GPUs and all-reduce over gloo.  Never a measurement: the line says so in config.env_overrides")
     args = ap.parse_args()
 
     # Nothing outside the command line may change what is timed: the library reads no environment variable, and a variable
@@ -304,6 +309,9 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)"
+    if args.test_backend == "gloo":
+        overrides = overrides + ["--test-backend gloo: ranks share the GPUs of the box, NOT a measurement"]
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
@@ -320,7 +328,10 @@ def main():
         saved_fd = os.dup(1)
         os.dup2(2, 1)
         try:
-            dist.init_process_group(backend="nccl", device_id=dev)  # RCCL over xGMI
+            if args.test_backend == "gloo":
+                dist.init_process_group(backend="gloo")
+            else:
+                dist.init_process_group(backend="nccl", device_id=dev)  # RCCL over xGMI
             warm = torch.zeros(1, device=dev)
             dist.all_reduce(warm)  # creates the communicator now
             torch.cuda.synchronize()
@@ -457,6 +468,21 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
+    # the shared gradient the pipeline all-reduced in the last timed step against the same reduction done again, step by step and
+    # synchronously, from that step's gradient arrays (every rank takes part: it is a collective)
+    reduction_check = None
+    if dist is not None:
+        last_i = (it[0] - 1) % len(grads_pp)
+        g, rd, again = grads_pp[last_i], reduction, torch.zeros_like(shared)
+        rd["call"](rd["vertices"], rd["identity"], rd["posed"], rd["camera"], None, g["ij_b"], None, again[: 3 * V].view(V, 3), rd["pose_out"], rd["scratch"],
+                   colors_b=g["colors_b"], colors_sum=again[3 * V :].view(V, Cc))  # fmt: skip
+        local_max = float(again.abs().max())
+        dist.all_reduce(again)
+        torch.cuda.synchronize()
+        err = float((shared_pp[last_i] - again).abs().max() / again.abs().max())
+        reduction_check = {"ranks": world, "rel_err": err, "ok": bool(err < 1e-12 and local_max > 0), "values": int(again.numel())}
+        assert reduction_check["ok"], f"bench: the all-reduced shared gradient of the timed loop differs from a synchronous reduction: {reduction_check}"
+
     # spill pool never overflowed and the scene was valid during the run (deferred check, outside the timed region)
     over, need, errs = r.status(ds)
     assert not over and not errs, "spill pool overflowed (or invalid scene) during the benchmark"
@@ -514,6 +540,8 @@ def main():
                          "kernel_time_fraction_of_step": kernel_ms / (step_s * 1e3), "per_kernel": per_kernel},
             "hbm_probe": probe,
         }  # fmt: skip
+        if reduction_check is not None:
+            out["reduction_check"] = reduction_check
         if not args.no_parity_check:
             # the launch that was timed (its last step's outputs are still in image / z / the gradient set it wrote), views 0 and last
             last = grads_pp[(it[0] - 1) % len(grads_pp)]

@@ -720,3 +720,29 @@ def test_float32_vertex_arrays_equal_float64_vertex_arrays_of_the_same_values():
         for which in (3, 4):
             for k in a[which]:
                 assert rel(b[which][k].cpu(), a[which][k].cpu()) < 2e-6, (which, k)
+
+
+def test_bench_two_ranks_on_one_gpu():
+    """bench.py as the driver launches it for N > 1 (torch.distributed.run, one process per rank, views sharded, overlapped reduction of
+    the shared gradient, MAX over the ranks' times, ONE JSON line from rank 0) -- with two ranks that share this box's GPU and all-reduce
+    over gloo (`--test-backend gloo`: RCCL refuses two ranks on one device).  The line's own checks must hold: the timed launch against
+    the unmodified reference, the all-reduced gradient against a synchronous reduction."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29547",
+           os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2", "--size", "256", "--views", "2", "--test-backend", "gloo"]  # fmt: skip
+    run = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert run.returncode == 0, run.stderr[-3000:]
+    lines = [ln for ln in run.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, run.stdout[-2000:]  # rank 0 alone prints
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 6 and out["scaling"] == "weak" and out["value"] > 0
+    assert out["config"]["global_views"] == 4 and out["config"]["views_per_gpu"] == 2
+    assert any("NOT a measurement" in o for o in out["config"]["env_overrides"])
+    assert out["parity_checked"] is True
+    assert out["reduction_check"]["ok"] and out["reduction_check"]["ranks"] == 2
+    assert "cpu_baseline" not in out  # rank 0 at N = 1 only
