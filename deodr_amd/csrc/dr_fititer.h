@@ -89,22 +89,42 @@ __device__ __forceinline__ UnitQuaternion load_unit_quaternion(const double *q, 
 	return {{x / norm, y / norm, z / norm}, w / norm, norm};
 }
 
-// ---- forward: one thread per vertex walks the views.  vertices [V,3] are centred IN PLACE when `mean` is given (the reference
-// re-centres its vertices at the start of every step, mesh_fitter.py:131); quaternions are the raw parameters (normalised here)
+// The gathers of the shading and rigid-energy kernels give every list (the faces around a vertex, a row of L^T L) to GATHER_LANES adjacent lanes: one list entry is a
+// chain of dependent loads (slot -> vertex ids -> positions, ~1 us each on an idle chip), and a list of 6 - 20 entries walked by one
+// lane IS the kernel's duration (measured: 15 - 20 us per kernel, one lane per list).  Lane s takes the entries s, s + GATHER_LANES, ...
+// in order; the lanes' sums meet in a butterfly -- an order fixed by the list alone.
+constexpr int GATHER_LANES = 8;
+__device__ __forceinline__ double lanes_sum(double v)
+{ // all lanes of the wavefront call it; -> the sum over each group of GATHER_LANES adjacent lanes, in every lane of the group
+	v += __shfl_xor(v, 1);
+	v += __shfl_xor(v, 2);
+	v += __shfl_xor(v, 4);
+	return v;
+}
+__device__ __forceinline__ Vec3 lanes_sum3(const Vec3 &a) { return {lanes_sum(a.x), lanes_sum(a.y), lanes_sum(a.z)}; }
+
+constexpr int VIEW_LANES = GATHER_LANES; // lanes of a vertex in the pose kernels: one view each
+
+// ---- forward.  The GATHER_LANES (8) adjacent lanes of a vertex take the views b = sub, sub + 8, ... (one thread per vertex walking
+// the views one after the other made 8 views cost 8.4 us against 4.7 for one).  vertices [V,3] are centred IN PLACE when `mean` is
+// given (the reference re-centres its vertices at the start of every step, mesh_fitter.py:131): the eight lanes of a vertex read it
+// in ONE load instruction, lane 0 of them stores the centred value afterwards.  Quaternions are the raw parameters (normalised here).
+// grid: V GATHER_LANES / FH_BLOCK
 __global__ __launch_bounds__(FH_BLOCK) void fit_pose_project_kernel(double *vertices, const double *mean, const double *q, const double *t,
 																	 const double *extrinsic, const double *intrinsic, const double *distortion, double *posed,
 																	 double *ij, double *depths, double *depth_colors, double depth_scale, int V, int n)
 {
-	const int v = blockIdx.x * FH_BLOCK + threadIdx.x;
+	const int th = blockIdx.x * FH_BLOCK + threadIdx.x, v = th / VIEW_LANES, sub = th % VIEW_LANES;
 	if (v >= V)
 		return;
 	Vec3 c = load3(vertices + 3 * v);
 	if (mean)
 	{
 		c = sub3(c, load3(mean));
-		store3(vertices + 3 * v, c);
+		if (sub == 0)
+			store3(vertices + 3 * v, c);
 	}
-	for (int b = 0; b < n; b++)
+	for (int b = sub; b < n; b += VIEW_LANES)
 	{
 		const UnitQuaternion uq = load_unit_quaternion(q, b);
 		const Vec3 p = add3(qrot_point(uq.u, uq.w, c), load3(t + 3 * b));
@@ -130,53 +150,43 @@ __global__ __launch_bounds__(FH_BLOCK) void fit_pose_project_b_kernel(const doub
 	__shared__ double s_wave[FH_BLOCK / 64][7 * FIT_MAX_VIEWS + 3];
 	__shared__ double s_quat[FIT_MAX_VIEWS][4];
 	__shared__ int s_last;
-	const int v = blockIdx.x * FH_BLOCK + threadIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	// The VIEW_LANES (8) adjacent lanes of a vertex take the views b = sub, sub + 8, ...: one round trip for eight views (one thread per
+	// vertex walking the views: 19 us for the 8 views of the hand, 25 - 35 us for those of a 10 000-vertex mesh).  Sums over the views
+	// of a vertex: a butterfly over lane bits 0-2; sums over the vertices of a view: a butterfly over lane bits 3-5 (the eight vertices of
+	// the wavefront), then the wavefronts through LDS, the workgroups through `partials` -- orders fixed by the launch geometry alone.
+	const int th = blockIdx.x * FH_BLOCK + threadIdx.x, v = th / VIEW_LANES, sub = th % VIEW_LANES, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 	const bool on = v < V;
 	const int K = 7 * n + 3;
 	double *mine = partials + (size_t)blockIdx.x * K;
 	const Vec3 c = on ? load3(vertices + 3 * v) : Vec3{0, 0, 0};
 	Vec3 acc = {0, 0, 0};
-	// (the inputs of view b + 1 are requested before view b is worked on: a view is a round trip of ~1.5 us followed by seven
-	// wavefront sums, and the loop is not unrolled by the compiler -- 8 views of a 10 000-vertex mesh took 45 us one after the other)
-	struct ViewIn
-	{
-		Vec3 posed, posed_b;
-		double g0, g1, gd, col[4];
+	auto vertices_sum = [](double x) { // over the eight vertices of the wavefront, for this lane's view; in every lane
+		x += __shfl_xor(x, 8);
+		x += __shfl_xor(x, 16);
+		x += __shfl_xor(x, 32);
+		return x;
 	};
 	double col_sum[4] = {0, 0, 0, 0};
-	auto load_view = [&](int b) {
-		ViewIn in = {{0, 0, 0}, {0, 0, 0}, 0, 0, 0, {0, 0, 0, 0}};
-		if (on)
+	for (int b0 = 0; b0 < n; b0 += VIEW_LANES)
+	{
+		const int b = b0 + sub;
+		const bool act = on && b < n;
+		const int bq = b < n ? b : 0;
+		Vec3 g = {0, 0, 0};
+		if (act)
 		{
+			const size_t at = (size_t)b * V + v;
 			if (colors_sum)
 #pragma unroll
-				for (int c = 0; c < 4; c++)
-					if (c < C)
-						in.col[c] = colors_b[((size_t)b * V + v) * C + c];
-			const size_t at = (size_t)b * V + v;
-			in.posed = load3(posed + 3 * at);
-			in.g0 = ij_b[2 * at], in.g1 = ij_b[2 * at + 1];
-			in.gd = depths_b ? depths_b[at] * depths_b_scale : 0.0;
-			if (posed_b)
-				in.posed_b = load3(posed_b + 3 * at);
-		}
-		return in;
-	};
-	ViewIn next = load_view(0);
-	for (int b = 0; b < n; b++)
-	{
-		const ViewIn in = next;
-		next = load_view(b + 1 < n ? b + 1 : b);
-#pragma unroll
-		for (int c = 0; c < 4; c++)
-			col_sum[c] += in.col[c];
-		const UnitQuaternion uq = load_unit_quaternion(q, b);
-		Vec3 g = {0, 0, 0};
-		if (on)
-		{
+				for (int cc = 0; cc < 4; cc++)
+					if (cc < C)
+						col_sum[cc] += colors_b[at * C + cc];
 			const CameraRow cam = load_camera(extrinsic, intrinsic, distortion, b);
-			g = add3(project_point_b(cam, in.posed, in.g0, in.g1, in.gd), in.posed_b);
+			g = project_point_b(cam, load3(posed + 3 * at), ij_b[2 * at], ij_b[2 * at + 1], depths_b ? depths_b[at] * depths_b_scale : 0.0);
+			if (posed_b)
+				g = add3(g, load3(posed_b + 3 * at));
 		}
+		const UnitQuaternion uq = load_unit_quaternion(q, bq);
 		// r = c + 2 w a + 2 bb, a = u x c, bb = u x a   (deodr/tools.py:25-35)
 		const Vec3 &u = uq.u;
 		const Vec3 a = cross3(u, c);
@@ -184,29 +194,34 @@ __global__ __launch_bounds__(FH_BLOCK) void fit_pose_project_b_kernel(const doub
 		const Vec3 bb_b = scale3(2, g);
 		const Vec3 a_b = add3(scale3(2 * uq.w, g), cross3(bb_b, u));
 		const Vec3 u_b = add3(cross3(a, bb_b), cross3(c, a_b));
-		acc = add3(acc, add3(g, cross3(a_b, u)));
+		acc = add3(acc, add3(g, cross3(a_b, u))); // (g = 0 for a lane without a view: nothing added)
 		const double sums[7] = {u_b.x, u_b.y, u_b.z, w_b, g.x, g.y, g.z};
 #pragma unroll
 		for (int i = 0; i < 7; i++)
 		{
-			const double s = wave_sum(sums[i]); // (every lane takes part: lanes beyond V hold zeros)
-			if (lane == 0)
+			const double s = vertices_sum(sums[i]); // (every lane takes part: lanes beyond V or n hold zeros)
+			if (lane < VIEW_LANES && b < n)
 				s_wave[wave][7 * b + i] = s;
 		}
 	}
-	if (on)
+	acc = lanes_sum3(acc); // over the views of the vertex
+	if (on && sub == 0)
 		store3(vertices_b + 3 * v, acc);
-	if (on && colors_sum) // per-vertex colours shared by the views (a multi-view fit of a coloured mesh): their adjoints summed over the views
+	if (colors_sum) // per-vertex colours shared by the views (a multi-view fit of a coloured mesh): their adjoints summed over the views
 #pragma unroll
-		for (int c = 0; c < 4; c++)
-			if (c < C)
-				colors_sum[(size_t)v * C + c] = col_sum[c];
+		for (int cc = 0; cc < 4; cc++)
+			if (cc < C)
+			{
+				const double t = lanes_sum(col_sum[cc]);
+				if (on && sub == 0)
+					colors_sum[(size_t)v * C + cc] = t;
+			}
 	{
 		const double sums[3] = {acc.x, acc.y, acc.z};
 #pragma unroll
 		for (int i = 0; i < 3; i++)
 		{
-			const double s = wave_sum(sums[i]);
+			const double s = vertices_sum(sums[i]); // (the eight lanes of a vertex hold the same sum: lane 0 = the wavefront's eight vertices)
 			if (lane == 0)
 				s_wave[wave][7 * n + i] = s;
 		}
@@ -303,20 +318,6 @@ struct ShadeArgs
 	int C, V, n;
 	double sign; // -1: clockwise faces
 };
-
-// The gathers below give every list (the faces around a vertex, a row of L^T L) to GATHER_LANES adjacent lanes: one list entry is a
-// chain of dependent loads (slot -> vertex ids -> positions, ~1 us each on an idle chip), and a list of 6 - 20 entries walked by one
-// lane IS the kernel's duration (measured: 15 - 20 us per kernel, one lane per list).  Lane s takes the entries s, s + GATHER_LANES, ...
-// in order; the lanes' sums meet in a butterfly -- an order fixed by the list alone.
-constexpr int GATHER_LANES = 8;
-__device__ __forceinline__ double lanes_sum(double v)
-{ // all lanes of the wavefront call it; -> the sum over each group of GATHER_LANES adjacent lanes, in every lane of the group
-	v += __shfl_xor(v, 1);
-	v += __shfl_xor(v, 2);
-	v += __shfl_xor(v, 4);
-	return v;
-}
-__device__ __forceinline__ Vec3 lanes_sum3(const Vec3 &a) { return {lanes_sum(a.x), lanes_sum(a.y), lanes_sum(a.z)}; }
 
 // sign * sum of the unit normals of the faces around vertex v (`on` false: an empty list); in every lane of the group
 __device__ __forceinline__ Vec3 accumulated_normal(const ShadeArgs &a, const double *P, int v, int sub, bool on)
