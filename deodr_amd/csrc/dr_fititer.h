@@ -104,6 +104,7 @@ __device__ __forceinline__ double lanes_sum(double v)
 __device__ __forceinline__ Vec3 lanes_sum3(const Vec3 &a) { return {lanes_sum(a.x), lanes_sum(a.y), lanes_sum(a.z)}; }
 
 constexpr int VIEW_LANES = GATHER_LANES; // lanes of a vertex in the pose kernels: one view each
+constexpr int POSE_B_BLOCKS = 64;		 // workgroups of fit_pose_project_b_kernel at most
 
 // ---- forward.  The GATHER_LANES (8) adjacent lanes of a vertex take the views b = sub, sub + 8, ... (one thread per vertex walking
 // the views one after the other made 8 views cost 8.4 us against 4.7 for one).  vertices [V,3] are centred IN PLACE when `mean` is
@@ -154,76 +155,85 @@ __global__ __launch_bounds__(FH_BLOCK) void fit_pose_project_b_kernel(const doub
 	// vertex walking the views: 19 us for the 8 views of the hand, 25 - 35 us for those of a 10 000-vertex mesh).  Sums over the views
 	// of a vertex: a butterfly over lane bits 0-2; sums over the vertices of a view: a butterfly over lane bits 3-5 (the eight vertices of
 	// the wavefront), then the wavefronts through LDS, the workgroups through `partials` -- orders fixed by the launch geometry alone.
-	const int th = blockIdx.x * FH_BLOCK + threadIdx.x, v = th / VIEW_LANES, sub = th % VIEW_LANES, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-	const bool on = v < V;
+	// At most POSE_B_BLOCKS workgroups, each walking the vertices in strides: with one workgroup per 32 vertices the 313 of a
+	// 10 000-vertex mesh cost a render loop that overlaps this kernel on a second stream 26 us per step instead of 15 (bench.py's
+	// shared-gradient reduction), and the last workgroup's sum over the workgroups grows with their number.
+	const int sub = threadIdx.x % VIEW_LANES, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 	const int K = 7 * n + 3;
 	double *mine = partials + (size_t)blockIdx.x * K;
-	const Vec3 c = on ? load3(vertices + 3 * v) : Vec3{0, 0, 0};
-	Vec3 acc = {0, 0, 0};
+	for (int k = lane; k < K; k += 64)
+		s_wave[wave][k] = 0; // (a wavefront's own line: written and read by its lanes only until the sums below are gathered)
+	__syncthreads();
 	auto vertices_sum = [](double x) { // over the eight vertices of the wavefront, for this lane's view; in every lane
 		x += __shfl_xor(x, 8);
 		x += __shfl_xor(x, 16);
 		x += __shfl_xor(x, 32);
 		return x;
 	};
-	double col_sum[4] = {0, 0, 0, 0};
-	for (int b0 = 0; b0 < n; b0 += VIEW_LANES)
+	constexpr int PER_BLOCK = FH_BLOCK / VIEW_LANES;
+	for (int base = blockIdx.x * PER_BLOCK; base < V; base += gridDim.x * PER_BLOCK) // (the same trips for every thread of the workgroup)
 	{
-		const int b = b0 + sub;
-		const bool act = on && b < n;
-		const int bq = b < n ? b : 0;
-		Vec3 g = {0, 0, 0};
-		if (act)
+		const int v = base + threadIdx.x / VIEW_LANES;
+		const bool on = v < V;
+		const Vec3 c = on ? load3(vertices + 3 * v) : Vec3{0, 0, 0};
+		Vec3 acc = {0, 0, 0};
+		double col_sum[4] = {0, 0, 0, 0};
+		for (int b0 = 0; b0 < n; b0 += VIEW_LANES)
 		{
-			const size_t at = (size_t)b * V + v;
-			if (colors_sum)
-#pragma unroll
-				for (int cc = 0; cc < 4; cc++)
-					if (cc < C)
-						col_sum[cc] += colors_b[at * C + cc];
-			const CameraRow cam = load_camera(extrinsic, intrinsic, distortion, b);
-			g = project_point_b(cam, load3(posed + 3 * at), ij_b[2 * at], ij_b[2 * at + 1], depths_b ? depths_b[at] * depths_b_scale : 0.0);
-			if (posed_b)
-				g = add3(g, load3(posed_b + 3 * at));
-		}
-		const UnitQuaternion uq = load_unit_quaternion(q, bq);
-		// r = c + 2 w a + 2 bb, a = u x c, bb = u x a   (deodr/tools.py:25-35)
-		const Vec3 &u = uq.u;
-		const Vec3 a = cross3(u, c);
-		const double w_b = 2 * dot3(g, a);
-		const Vec3 bb_b = scale3(2, g);
-		const Vec3 a_b = add3(scale3(2 * uq.w, g), cross3(bb_b, u));
-		const Vec3 u_b = add3(cross3(a, bb_b), cross3(c, a_b));
-		acc = add3(acc, add3(g, cross3(a_b, u))); // (g = 0 for a lane without a view: nothing added)
-		const double sums[7] = {u_b.x, u_b.y, u_b.z, w_b, g.x, g.y, g.z};
-#pragma unroll
-		for (int i = 0; i < 7; i++)
-		{
-			const double s = vertices_sum(sums[i]); // (every lane takes part: lanes beyond V or n hold zeros)
-			if (lane < VIEW_LANES && b < n)
-				s_wave[wave][7 * b + i] = s;
-		}
-	}
-	acc = lanes_sum3(acc); // over the views of the vertex
-	if (on && sub == 0)
-		store3(vertices_b + 3 * v, acc);
-	if (colors_sum) // per-vertex colours shared by the views (a multi-view fit of a coloured mesh): their adjoints summed over the views
-#pragma unroll
-		for (int cc = 0; cc < 4; cc++)
-			if (cc < C)
+			const int b = b0 + sub;
+			const bool act = on && b < n;
+			const int bq = b < n ? b : 0;
+			Vec3 g = {0, 0, 0};
+			if (act)
 			{
-				const double t = lanes_sum(col_sum[cc]);
-				if (on && sub == 0)
-					colors_sum[(size_t)v * C + cc] = t;
+				const size_t at = (size_t)b * V + v;
+				if (colors_sum)
+#pragma unroll
+					for (int cc = 0; cc < 4; cc++)
+						if (cc < C)
+							col_sum[cc] += colors_b[at * C + cc];
+				const CameraRow cam = load_camera(extrinsic, intrinsic, distortion, b);
+				g = project_point_b(cam, load3(posed + 3 * at), ij_b[2 * at], ij_b[2 * at + 1], depths_b ? depths_b[at] * depths_b_scale : 0.0);
+				if (posed_b)
+					g = add3(g, load3(posed_b + 3 * at));
 			}
-	{
+			const UnitQuaternion uq = load_unit_quaternion(q, bq);
+			// r = c + 2 w a + 2 bb, a = u x c, bb = u x a   (deodr/tools.py:25-35)
+			const Vec3 &u = uq.u;
+			const Vec3 a = cross3(u, c);
+			const double w_b = 2 * dot3(g, a);
+			const Vec3 bb_b = scale3(2, g);
+			const Vec3 a_b = add3(scale3(2 * uq.w, g), cross3(bb_b, u));
+			const Vec3 u_b = add3(cross3(a, bb_b), cross3(c, a_b));
+			acc = add3(acc, add3(g, cross3(a_b, u))); // (g = 0 for a lane without a view: nothing added)
+			const double sums[7] = {u_b.x, u_b.y, u_b.z, w_b, g.x, g.y, g.z};
+#pragma unroll
+			for (int i = 0; i < 7; i++)
+			{
+				const double t = vertices_sum(sums[i]); // (every lane takes part: lanes beyond V or n hold zeros)
+				if (lane < VIEW_LANES && b < n)
+					s_wave[wave][7 * b + i] += t;
+			}
+		}
+		acc = lanes_sum3(acc); // over the views of the vertex
+		if (on && sub == 0)
+			store3(vertices_b + 3 * v, acc);
+		if (colors_sum) // per-vertex colours shared by the views (a multi-view fit of a coloured mesh): their adjoints summed over the views
+#pragma unroll
+			for (int cc = 0; cc < 4; cc++)
+				if (cc < C)
+				{
+					const double t = lanes_sum(col_sum[cc]);
+					if (on && sub == 0)
+						colors_sum[(size_t)v * C + cc] = t;
+				}
 		const double sums[3] = {acc.x, acc.y, acc.z};
 #pragma unroll
 		for (int i = 0; i < 3; i++)
 		{
-			const double s = vertices_sum(sums[i]); // (the eight lanes of a vertex hold the same sum: lane 0 = the wavefront's eight vertices)
+			const double t = vertices_sum(sums[i]); // (the eight lanes of a vertex hold the same sum: lane 0 = the wavefront's eight vertices)
 			if (lane == 0)
-				s_wave[wave][7 * n + i] = s;
+				s_wave[wave][7 * n + i] += t;
 		}
 	}
 	__syncthreads();

@@ -735,7 +735,7 @@ int deodr_hip_silhouette_flags(const double *ij, const uint32_t *faces, const ui
 
 // scratch of the fit-iteration kernels: 16 counter words (zero between launches: allocate zero-filled once), then doubles
 static size_t fh_blocks(long long count) { return (size_t)((count + FH_BLOCK - 1) / FH_BLOCK); }
-static size_t fit_scratch_need_pose_b(int V, int n) { return 64 + 8 * fh_blocks((long long)V * GATHER_LANES) * (size_t)(7 * n + 3); }
+static size_t fit_scratch_need_pose_b(int, int n) { return 64 + 8 * (size_t)POSE_B_BLOCKS * (size_t)(7 * n + 3); }
 static size_t fit_scratch_need_shade_b(int V, int n) { return 64 + 8 * (3 * (size_t)n * V + 7 * fh_blocks((long long)n * V * GATHER_LANES)); }
 static size_t fit_scratch_need_rigid(int V) { return 64 + 8 * fh_blocks((long long)V * GATHER_LANES); }
 static size_t fit_scratch_need_l2(void) { return 64 + 8 * (size_t)L2_BLOCKS; }
@@ -822,7 +822,8 @@ int deodr_hip_fit_pose_project_b(const double *vertices, const double *quaternio
 		return fail("fit_pose_project_b: colors_sum needs colors_b with 1 - 4 channels");
 	if (!scratch || scratch_bytes < fit_scratch_need_pose_b(V, n))
 		return fail("fit_pose_project_b: scratch too small (deodr_hip_fit_scratch_bytes)");
-	hipLaunchKernelGGL(fit_pose_project_b_kernel, dim3(fh_blocks((long long)V * GATHER_LANES)), dim3(FH_BLOCK), 0, (hipStream_t)stream, vertices, quaternions, posed, extrinsic, intrinsic,
+	const size_t pose_blocks = fh_blocks((long long)V * GATHER_LANES);
+	hipLaunchKernelGGL(fit_pose_project_b_kernel, dim3((unsigned)(pose_blocks < (size_t)POSE_B_BLOCKS ? pose_blocks : (size_t)POSE_B_BLOCKS)), dim3(FH_BLOCK), 0, (hipStream_t)stream, vertices, quaternions, posed, extrinsic, intrinsic,
 					   distortion, posed_b, ij_b, depths_b, depths_b_scale, vertices_b, out, (double *)((char *)scratch + 64), (unsigned *)scratch + FC_POSE_B, V, n, colors_b, nb_colors, colors_sum);
 	return check_hip(hipGetLastError(), "fit_pose_project_b launch");
 }
