@@ -103,19 +103,19 @@ __device__ __forceinline__ double lanes_sum(double v)
 }
 __device__ __forceinline__ Vec3 lanes_sum3(const Vec3 &a) { return {lanes_sum(a.x), lanes_sum(a.y), lanes_sum(a.z)}; }
 
-constexpr int VIEW_LANES = GATHER_LANES; // lanes of a vertex in the pose kernels: one view each
 constexpr int POSE_B_BLOCKS = 64;		 // workgroups of fit_pose_project_b_kernel at most
 
-// ---- forward.  The GATHER_LANES (8) adjacent lanes of a vertex take the views b = sub, sub + 8, ... (one thread per vertex walking
+// ---- forward.  The L (8; 1 for a single view) adjacent lanes of a vertex take the views b = sub, sub + L, ... (one thread per vertex walking
 // the views one after the other made 8 views cost 8.4 us against 4.7 for one).  vertices [V,3] are centred IN PLACE when `mean` is
 // given (the reference re-centres its vertices at the start of every step, mesh_fitter.py:131): the eight lanes of a vertex read it
 // in ONE load instruction, lane 0 of them stores the centred value afterwards.  Quaternions are the raw parameters (normalised here).
 // grid: V GATHER_LANES / FH_BLOCK
+template <int L>
 __global__ __launch_bounds__(FH_BLOCK) void fit_pose_project_kernel(double *vertices, const double *mean, const double *q, const double *t,
 																	 const double *extrinsic, const double *intrinsic, const double *distortion, double *posed,
 																	 double *ij, double *depths, double *depth_colors, double depth_scale, int V, int n)
 {
-	const int th = blockIdx.x * FH_BLOCK + threadIdx.x, v = th / VIEW_LANES, sub = th % VIEW_LANES;
+	const int th = blockIdx.x * FH_BLOCK + threadIdx.x, v = th / L, sub = th % L;
 	if (v >= V)
 		return;
 	Vec3 c = load3(vertices + 3 * v);
@@ -125,7 +125,7 @@ __global__ __launch_bounds__(FH_BLOCK) void fit_pose_project_kernel(double *vert
 		if (sub == 0)
 			store3(vertices + 3 * v, c);
 	}
-	for (int b = sub; b < n; b += VIEW_LANES)
+	for (int b = sub; b < n; b += L)
 	{
 		const UnitQuaternion uq = load_unit_quaternion(q, b);
 		const Vec3 p = add3(qrot_point(uq.u, uq.w, c), load3(t + 3 * b));
@@ -142,6 +142,7 @@ __global__ __launch_bounds__(FH_BLOCK) void fit_pose_project_kernel(double *vert
 // rasterizer's.  -> vertices_b [V,3] (sum over the views), out[0..3) = column mean of vertices_b, then pose_b: quaternion adjoints
 // [n,4] (w.r.t. the RAW quaternions: through the normalisation) and translation adjoints [n,3].  partials: (7 n + 3) doubles per
 // workgroup.
+template <int L> // lanes per vertex: 8, or 1 for a single view
 __global__ __launch_bounds__(FH_BLOCK) void fit_pose_project_b_kernel(const double *vertices, const double *q, const double *posed, const double *extrinsic,
 																	   const double *intrinsic, const double *distortion, const double *posed_b, const double *ij_b,
 																	   const double *depths_b, double depths_b_scale, double *vertices_b, double *out,
@@ -151,34 +152,41 @@ __global__ __launch_bounds__(FH_BLOCK) void fit_pose_project_b_kernel(const doub
 	__shared__ double s_wave[FH_BLOCK / 64][7 * FIT_MAX_VIEWS + 3];
 	__shared__ double s_quat[FIT_MAX_VIEWS][4];
 	__shared__ int s_last;
-	// The VIEW_LANES (8) adjacent lanes of a vertex take the views b = sub, sub + 8, ...: one round trip for eight views (one thread per
+	// The L (8; 1 for a single view: seven idle lanes per vertex cost the one-view fitters 2 us) adjacent lanes of a vertex take the views
+	// b = sub, sub + L, ...: one round trip for eight views (one thread per
 	// vertex walking the views: 19 us for the 8 views of the hand, 25 - 35 us for those of a 10 000-vertex mesh).  Sums over the views
 	// of a vertex: a butterfly over lane bits 0-2; sums over the vertices of a view: a butterfly over lane bits 3-5 (the eight vertices of
 	// the wavefront), then the wavefronts through LDS, the workgroups through `partials` -- orders fixed by the launch geometry alone.
 	// At most POSE_B_BLOCKS workgroups, each walking the vertices in strides: with one workgroup per 32 vertices the 313 of a
 	// 10 000-vertex mesh cost a render loop that overlaps this kernel on a second stream 26 us per step instead of 15 (bench.py's
 	// shared-gradient reduction), and the last workgroup's sum over the workgroups grows with their number.
-	const int sub = threadIdx.x % VIEW_LANES, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	const int sub = threadIdx.x % L, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 	const int K = 7 * n + 3;
 	double *mine = partials + (size_t)blockIdx.x * K;
 	for (int k = lane; k < K; k += 64)
 		s_wave[wave][k] = 0; // (a wavefront's own line: written and read by its lanes only until the sums below are gathered)
 	__syncthreads();
-	auto vertices_sum = [](double x) { // over the eight vertices of the wavefront, for this lane's view; in every lane
-		x += __shfl_xor(x, 8);
-		x += __shfl_xor(x, 16);
-		x += __shfl_xor(x, 32);
+	auto vertices_sum = [](double x) { // over the 64 / L vertices of the wavefront, for this lane's view; in every lane
+#pragma unroll
+		for (int d = L; d < 64; d <<= 1)
+			x += __shfl_xor(x, d);
 		return x;
 	};
-	constexpr int PER_BLOCK = FH_BLOCK / VIEW_LANES;
+	auto views_sum = [](double x) { // over the L lanes (views) of a vertex; in every lane of the vertex
+#pragma unroll
+		for (int d = 1; d < L; d <<= 1)
+			x += __shfl_xor(x, d);
+		return x;
+	};
+	constexpr int PER_BLOCK = FH_BLOCK / L;
 	for (int base = blockIdx.x * PER_BLOCK; base < V; base += gridDim.x * PER_BLOCK) // (the same trips for every thread of the workgroup)
 	{
-		const int v = base + threadIdx.x / VIEW_LANES;
+		const int v = base + threadIdx.x / L;
 		const bool on = v < V;
 		const Vec3 c = on ? load3(vertices + 3 * v) : Vec3{0, 0, 0};
 		Vec3 acc = {0, 0, 0};
 		double col_sum[4] = {0, 0, 0, 0};
-		for (int b0 = 0; b0 < n; b0 += VIEW_LANES)
+		for (int b0 = 0; b0 < n; b0 += L)
 		{
 			const int b = b0 + sub;
 			const bool act = on && b < n;
@@ -211,11 +219,11 @@ __global__ __launch_bounds__(FH_BLOCK) void fit_pose_project_b_kernel(const doub
 			for (int i = 0; i < 7; i++)
 			{
 				const double t = vertices_sum(sums[i]); // (every lane takes part: lanes beyond V or n hold zeros)
-				if (lane < VIEW_LANES && b < n)
+				if (lane < L && b < n)
 					s_wave[wave][7 * b + i] += t;
 			}
 		}
-		acc = lanes_sum3(acc); // over the views of the vertex
+		acc = {views_sum(acc.x), views_sum(acc.y), views_sum(acc.z)};
 		if (on && sub == 0)
 			store3(vertices_b + 3 * v, acc);
 		if (colors_sum) // per-vertex colours shared by the views (a multi-view fit of a coloured mesh): their adjoints summed over the views
@@ -223,7 +231,7 @@ __global__ __launch_bounds__(FH_BLOCK) void fit_pose_project_b_kernel(const doub
 			for (int cc = 0; cc < 4; cc++)
 				if (cc < C)
 				{
-					const double t = lanes_sum(col_sum[cc]);
+					const double t = views_sum(col_sum[cc]);
 					if (on && sub == 0)
 						colors_sum[(size_t)v * C + cc] = t;
 				}
@@ -231,7 +239,7 @@ __global__ __launch_bounds__(FH_BLOCK) void fit_pose_project_b_kernel(const doub
 #pragma unroll
 		for (int i = 0; i < 3; i++)
 		{
-			const double t = vertices_sum(sums[i]); // (the eight lanes of a vertex hold the same sum: lane 0 = the wavefront's eight vertices)
+			const double t = vertices_sum(sums[i]); // (the L lanes of a vertex hold the same sum: lane 0 = the wavefront's vertices)
 			if (lane == 0)
 				s_wave[wave][7 * n + i] += t;
 		}

@@ -804,7 +804,11 @@ int deodr_hip_fit_pose_project(double *vertices, const double *vertices_mean, co
 {
 	if (!vertices || !quaternions || !translations || !extrinsic || !intrinsic || !posed || !ij || !depths || V <= 0 || n <= 0)
 		return fail("fit_pose_project: bad arguments");
-	hipLaunchKernelGGL(fit_pose_project_kernel, dim3(fh_blocks((long long)V * GATHER_LANES)), dim3(FH_BLOCK), 0, (hipStream_t)stream, vertices, vertices_mean, quaternions, translations,
+	if (n == 1)
+		hipLaunchKernelGGL(fit_pose_project_kernel<1>, dim3(fh_blocks(V)), dim3(FH_BLOCK), 0, (hipStream_t)stream, vertices, vertices_mean, quaternions, translations,
+					   extrinsic, intrinsic, distortion, posed, ij, depths, depth_colors, depth_scale, V, n);
+	else
+		hipLaunchKernelGGL(fit_pose_project_kernel<GATHER_LANES>, dim3(fh_blocks((long long)V * GATHER_LANES)), dim3(FH_BLOCK), 0, (hipStream_t)stream, vertices, vertices_mean, quaternions, translations,
 					   extrinsic, intrinsic, distortion, posed, ij, depths, depth_colors, depth_scale, V, n);
 	return check_hip(hipGetLastError(), "fit_pose_project launch");
 }
@@ -822,8 +826,13 @@ int deodr_hip_fit_pose_project_b(const double *vertices, const double *quaternio
 		return fail("fit_pose_project_b: colors_sum needs colors_b with 1 - 4 channels");
 	if (!scratch || scratch_bytes < fit_scratch_need_pose_b(V, n))
 		return fail("fit_pose_project_b: scratch too small (deodr_hip_fit_scratch_bytes)");
-	const size_t pose_blocks = fh_blocks((long long)V * GATHER_LANES);
-	hipLaunchKernelGGL(fit_pose_project_b_kernel, dim3((unsigned)(pose_blocks < (size_t)POSE_B_BLOCKS ? pose_blocks : (size_t)POSE_B_BLOCKS)), dim3(FH_BLOCK), 0, (hipStream_t)stream, vertices, quaternions, posed, extrinsic, intrinsic,
+	const size_t pose_blocks = fh_blocks(n == 1 ? (long long)V : (long long)V * GATHER_LANES);
+	const dim3 pose_grid((unsigned)(pose_blocks < (size_t)POSE_B_BLOCKS ? pose_blocks : (size_t)POSE_B_BLOCKS));
+	if (n == 1)
+		hipLaunchKernelGGL(fit_pose_project_b_kernel<1>, pose_grid, dim3(FH_BLOCK), 0, (hipStream_t)stream, vertices, quaternions, posed, extrinsic, intrinsic,
+					   distortion, posed_b, ij_b, depths_b, depths_b_scale, vertices_b, out, (double *)((char *)scratch + 64), (unsigned *)scratch + FC_POSE_B, V, n, colors_b, nb_colors, colors_sum);
+	else
+		hipLaunchKernelGGL(fit_pose_project_b_kernel<GATHER_LANES>, pose_grid, dim3(FH_BLOCK), 0, (hipStream_t)stream, vertices, quaternions, posed, extrinsic, intrinsic,
 					   distortion, posed_b, ij_b, depths_b, depths_b_scale, vertices_b, out, (double *)((char *)scratch + 64), (unsigned *)scratch + FC_POSE_B, V, n, colors_b, nb_colors, colors_sum);
 	return check_hip(hipGetLastError(), "fit_pose_project_b launch");
 }
