@@ -419,6 +419,10 @@ __host__ inline int heavy_share_for(int n_views, int tile_blocks, bool fuse_edge
 	// when the head also holds every tile with silhouette edges and runs their adjoint (a fit step: ~1 000 head entries per view of
 	// the benchmark scene, 20 - 60 us each -- with 256 walkers per view the forward ended 14 us after its last short tile)
 	const long long want = ((long long)n_views * tile_blocks + (fuse_edges ? 4095 : 2047)) / (fuse_edges ? 4096 : 2048);
+	// (the final code of round 3, fit step of the benchmark scene, same-box A/B: 8 views 1/2 0.1316, 1/4 0.1305, 1/8 0.1328, 1/16 0.148 ms;
+	// 16 views 1/4 0.2538, 1/16 0.2483; 32 views 1/4 0.515, 1/16 0.500: about one head entry per head walker up to 8 views of 1024^2)
+	if (fuse_edges && want <= 8)
+		return 4;
 	int share = 4;
 	while (share < 16 && share < want)
 		share *= 2;
