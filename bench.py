@@ -73,13 +73,42 @@ def algorithmic_bytes(H, W, C, T, V, n_views, fused, nonempty_frac=None):
     return {k: v * n_views for k, v in per_view.items()}
 
 
+GUIDE_COPY_GBS = 6290.0  # float4 copy measured on MI355X in MI355X_MICROARCH.md: the practical ceiling of a read + write stream
+
+
+def survey_8d_bytes(H, W, C, T, V, n_views, Vuv=0, tex_hw=None, bg_image=False):
+    """SURVEY.md section 8d, algorithmic bytes of forward + adjoint of n_views views (float32 buffers), textured terms included:
+    B_fwd = 4 [H W (C+1) + (bg image: H W C) + V (3+C) + 3T (+ 3T + 2 Vuv + V + Ht Wt C)]
+    B_bwd = 4 [H W C + H W + V (3+C) + 3T + V (2+C) (+ 3T + 2 Vuv + V + Ht Wt C read + 2 Vuv + V + Ht Wt C gradient write)]"""
+    px = H * W
+    fwd = px * (C + 1) + (px * C if bg_image else 0) + V * (3 + C) + 3 * T
+    bwd = px * C + px + V * (3 + C) + 3 * T + V * (2 + C)
+    if tex_hw is not None:
+        tex = tex_hw[0] * tex_hw[1] * C
+        fwd += 3 * T + 2 * Vuv + V + tex
+        bwd += 3 * T + 2 * Vuv + V + tex + 2 * Vuv + V + tex
+    return 4 * (fwd + bwd) * n_views
+
+
 def hbm_probe(dev, nbytes=1 << 30, reps=10):
     """Copy / write-only / read-only bandwidth of this box (GB/s): the ceilings SURVEY.md section 8d asks to report next to the
-    8 TB/s of the data sheet.  torch device kernels on 1 GiB buffers, hipEvent timing, best of `reps`."""
+    8 TB/s of the data sheet.  `lib_*`: the library's own 16-byte non-temporal streaming kernel (deodr_hip_copy_probe: the access
+    pattern of its frame stores and background fill); `copy / write / read`: torch device kernels.  1 GiB buffers, hipEvent
+    timing, best of `reps`.  `best_copy_GBps` (the larger of the two copies) is what `frac_of_measured` is quoted against."""
+    import deodr_amd.hip_renderer as hr
+
     a = torch.empty(nbytes // 4, dtype=torch.float32, device=dev).normal_()
     b = torch.empty_like(a)
+    st = torch.cuda.current_stream(dev).cuda_stream
+
+    def lib_call(mode):
+        rc = hr.lib().deodr_hip_copy_probe(b.data_ptr(), a.data_ptr(), nbytes, mode, 1, st)
+        assert rc == 0, hr.lib().deodr_hip_last_error()
+
     out = {}
-    for name, fn, moved in (("copy", lambda: b.copy_(a), 2 * nbytes), ("write", lambda: b.fill_(1.0), nbytes), ("read", lambda: a.sum(), nbytes)):
+    cases = (("copy", lambda: b.copy_(a), 2 * nbytes), ("write", lambda: b.fill_(1.0), nbytes), ("read", lambda: a.sum(), nbytes),
+             ("lib_copy", lambda: lib_call(0), 2 * nbytes), ("lib_write", lambda: lib_call(1), nbytes), ("lib_read", lambda: lib_call(2), nbytes))  # fmt: skip
+    for name, fn, moved in cases:
         fn()
         best = 1e9
         for _ in range(reps):
@@ -90,6 +119,8 @@ def hbm_probe(dev, nbytes=1 << 30, reps=10):
             e1.synchronize()
             best = min(best, e0.elapsed_time(e1) * 1e-3)
         out[name + "_GBps"] = moved / best / 1e9
+    out["best_copy_GBps"] = max(out["copy_GBps"], out["lib_copy_GBps"])
+    out["guide_copy_GBps"] = GUIDE_COPY_GBS
     del a, b
     return out
 
@@ -154,7 +185,12 @@ def other_configs(dev):
         for _ in range(5):
             fit()
         dt = timed_steps(fit, steps)
-        out.append({"config": name, "views": n, "ms_per_step": dt * 1e3, "Mpixels_s": n * H * W / dt / 1e6})
+        tex_hw = (ds.texture.shape[0], ds.texture.shape[1]) if ds.texture is not None else None
+        alg = survey_8d_bytes(H, W, Cc, ds.nb_triangles, int(ds.depths.shape[1]), n, Vuv=int(ds.uv.shape[0]), tex_hw=tex_hw,
+                              bg_image=ds.background_image is not None)  # fmt: skip
+        out.append({"config": name, "views": n, "ms_per_step": dt * 1e3, "Mpixels_s": n * H * W / dt / 1e6,
+                    "roofline": {"alg_bytes": alg, "GBps": alg / dt / 1e9, "frac": alg / dt / 1e9 / HBM_PEAK_GBS, "peak": HBM_PEAK_GBS,
+                                 "note": "SURVEY 8d bytes of the whole step / step time (whole-step fraction, as roofline.whole_step)"}})  # fmt: skip
         del ds, r, obs, image, z, grads
     return out
 
@@ -437,7 +473,8 @@ def main():
     r.render(ds, args.sigma, out=(image, z), check_overflow=True)
     # the step time settles after a few dozen steps (clocks, caches, allocator): initialisation brings the untimed steps to at
     # least 50 whatever --warmup says, so that a short timed region measures the steady state
-    for _ in range(max(args.warmup, 50)):
+    warmup_run = max(args.warmup, 50)
+    for _ in range(warmup_run):
         step()
 
     def barrier():
@@ -452,7 +489,9 @@ def main():
 
     # per-kernel hipEvents on every 4th step of the timed region (an event pair takes ~3 us of stream time: timing all
     # launches of every step would add ~10 % to the step being measured)
-    hr.lib().deodr_hip_profile_enable(args.time_every)
+    # (at least five timed steps whatever --steps is: the driver's --steps 20 used to leave ONE sample per kernel)
+    time_every = min(args.time_every, max(1, args.steps // 5)) if args.time_every > 0 else 0
+    hr.lib().deodr_hip_profile_enable(time_every)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -515,10 +554,10 @@ def main():
         whole = sum(v for k, v in alg_8d.items() if k != "not_moved")
         moved = sum(v for k, v in alg.items() if k != "not_moved")
         probe = hbm_probe(dev)
-        peak_meas = probe["copy_GBps"]
+        peak_meas = probe["best_copy_GBps"]
         out = {
             "metric": "Mpixels/s forward+backward, 1024^2 20k-tri scene", "value": px / dt / 1e6, "unit": "Mpixels/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": step_s * 1e3,
+            "n_gpus": world, "steps": args.steps, "warmup": warmup_run, "warmup_requested": args.warmup, "ms_per_step": step_s * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"BASELINE configs[2]: {S}x{S}, {T}-triangle bumpy sphere, C={Cc} (RGB+depth), sigma=1, "
                                    f"{B} views per GPU per step, float32 pixel buffers / float64 vertex arrays, all-double arithmetic",
@@ -533,8 +572,10 @@ def main():
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": per_kernel[dom]["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": (per_kernel[dom]["GBps"] or 0) / HBM_PEAK_GBS, "traffic": traffic,
                          "peak_measured": peak_meas, "frac_of_measured": (per_kernel[dom]["GBps"] or 0) / peak_meas,
+                         "timed_every": time_every,
                          "whole_step": {"alg_bytes": whole, "GBps": whole / step_s / 1e9, "frac": whole / step_s / 1e9 / HBM_PEAK_GBS,
-                                        "frac_of_measured": whole / step_s / 1e9 / peak_meas, "moved_bytes": moved,
+                                        "frac_of_measured": whole / step_s / 1e9 / peak_meas,
+                                        "frac_of_guide_copy": whole / step_s / 1e9 / GUIDE_COPY_GBS, "moved_bytes": moved,
                                         "frac_moved_bytes": moved / step_s / 1e9 / HBM_PEAK_GBS},
                          "not_moved_bytes": alg.get("not_moved"),
                          "kernel_time_fraction_of_step": kernel_ms / (step_s * 1e3), "per_kernel": per_kernel},

@@ -459,6 +459,37 @@ bool last_forward_was_fused(const void *workspace)
 	return g_fused_ws.count(workspace) != 0;
 }
 
+// Streaming copy / fill / read with 16-byte non-temporal accesses, the access pattern of the rasterizer's own frame stores and
+// background fill (deodr_hip_copy_probe: the copy ceiling of the box a roofline fraction may also be quoted against).
+typedef uint32_t probe_u4 __attribute__((ext_vector_type(4)));
+template <int MODE>
+__global__ __launch_bounds__(256) void copy_probe_kernel(probe_u4 *dst, const probe_u4 *src, size_t n16)
+{
+	const size_t stride = (size_t)gridDim.x * 256 * 4;
+	probe_u4 acc = {0, 0, 0, 0};
+	for (size_t i = (size_t)blockIdx.x * 256 * 4 + threadIdx.x; i < n16; i += stride)
+	{ // four independent 16-byte pieces per thread and round, consecutive lanes on consecutive pieces
+		probe_u4 v[4];
+#pragma unroll
+		for (int u = 0; u < 4; u++)
+			if (MODE != 1 && i + u * 256 < n16)
+				v[u] = __builtin_nontemporal_load(src + i + u * 256);
+			else
+				v[u] = probe_u4{1, 2, 3, 4};
+#pragma unroll
+		for (int u = 0; u < 4; u++)
+			if (i + u * 256 < n16)
+			{
+				if (MODE == 2)
+					acc ^= v[u];
+				else
+					__builtin_nontemporal_store(v[u], dst + i + u * 256);
+			}
+	}
+	if (MODE == 2 && (acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x9e3779b9u)
+		((uint32_t *)dst)[0] = acc.x; // (never true for real data: keeps the loads alive)
+}
+
 } // namespace
 
 extern "C" {
@@ -499,6 +530,26 @@ int deodr_hip_profile_read(double ms_sum[4], unsigned long long launches[4])
 	}
 	g_prof_events.clear();
 	return 0;
+}
+
+int deodr_hip_copy_probe(void *dst, const void *src, size_t bytes, int mode, int reps, void *stream)
+{
+	if (!dst || (mode != 1 && !src) || bytes < 16 || (bytes & 15) || ((uintptr_t)dst & 15) || ((uintptr_t)src & 15) || mode < 0 || mode > 2 || reps <= 0)
+		return fail("copy_probe: bad arguments");
+	const size_t n16 = bytes / 16;
+	size_t blocks = (n16 + 1023) / 1024;
+	if (blocks > 256 * 32)
+		blocks = 256 * 32; // 32 workgroups per CU, grid-stride beyond
+	for (int r = 0; r < reps; r++)
+	{
+		if (mode == 0)
+			hipLaunchKernelGGL(copy_probe_kernel<0>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (probe_u4 *)dst, (const probe_u4 *)src, n16);
+		else if (mode == 1)
+			hipLaunchKernelGGL(copy_probe_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (probe_u4 *)dst, (const probe_u4 *)src, n16);
+		else
+			hipLaunchKernelGGL(copy_probe_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (probe_u4 *)dst, (const probe_u4 *)src, n16);
+	}
+	return check_hip(hipGetLastError(), "copy_probe launch");
 }
 
 const char *deodr_hip_last_error(void) { return g_error; }

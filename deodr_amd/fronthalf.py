@@ -74,6 +74,16 @@ class RigidTransformFunc(torch.autograd.Function):
         return v_b, pose_b[: 4 * n].view(n, 4), pose_b[4 * n :].view(n, 3)
 
 
+def _check_cameras(n, extrinsic, intrinsic, distortion):
+    """The kernels read `extrinsic[12 b + i]`, `intrinsic[9 b + i]`, `distortion[5 b + i]` of view b < n: one contiguous matrix PER VIEW
+    (a camera shared by the views must have been expanded, as DeviceCamera does) -- anything else would be read out of bounds."""
+    for name, a, shape in (("extrinsic", extrinsic, (3, 4)), ("intrinsic", intrinsic, (3, 3)), ("distortion", distortion, (5,))):
+        if a is None:
+            continue
+        if tuple(a.shape) != (n,) + shape or not a.is_contiguous():
+            raise ValueError(f"{name}: expected a contiguous [{n}, {', '.join(map(str, shape))}] tensor (one per view), got {tuple(a.shape)}")
+
+
 class ProjectPointsFunc(torch.autograd.Function):
     """(points [n,V,3]; extrinsic [n,3,4], intrinsic [n,3,3], distortion [n,5] | None: constants) -> (ij [n,V,2], depths [n,V]);
     Camera.project_points / project_points_backward (deodr/differentiable_renderer.py:341-438)"""
@@ -82,6 +92,7 @@ class ProjectPointsFunc(torch.autograd.Function):
     def forward(ctx, points, extrinsic, intrinsic, distortion):
         pts = points.contiguous()
         n, V = pts.shape[0], pts.shape[1]
+        _check_cameras(n, extrinsic, intrinsic, distortion)
         ij = torch.empty((n, V, 2), dtype=torch.float64, device=pts.device)
         depths = torch.empty((n, V), dtype=torch.float64, device=pts.device)
         with torch.cuda.device(pts.device):
@@ -156,6 +167,7 @@ def fit_pose_project(vertices, vertices_mean, quaternions, translations, camera,
     """centre ``vertices`` [V,3] in place (when a mean [3] is given), pose them with every view's quaternion (normalised inside) and
     translation, project them with every view's camera -> posed [n,V,3], ij [n,V,2], depths [n,V] (all written)"""
     n, V = posed.shape[0], posed.shape[1]
+    _check_cameras(n, camera.extrinsic, camera.intrinsic, camera.distortion)
     with torch.cuda.device(posed.device):
         _check(_lib().deodr_hip_fit_pose_project(_p(vertices), _p(vertices_mean), _p(quaternions), _p(translations), _p(camera.extrinsic), _p(camera.intrinsic),
                                                  _p(camera.distortion), _p(posed), _p(ij), _p(depths), _p(depth_colors), float(depth_scale), V, n, _stream(posed.device)))  # fmt: skip
@@ -166,6 +178,7 @@ def fit_pose_project_b(vertices, quaternions, posed, camera, posed_b, ij_b, dept
     """adjoint of :func:`fit_pose_project`: -> vertices_b [V,3]; out [3 + 7n] = mean of vertices_b over the vertices, quaternion adjoints
     [n,4] (raw quaternions), translation adjoints [n,3]; colors_sum [V,C] (optional) = colors_b [n,V,C] summed over the views"""
     n, V = posed.shape[0], posed.shape[1]
+    _check_cameras(n, camera.extrinsic, camera.intrinsic, camera.distortion)
     with torch.cuda.device(posed.device):
         _check(_lib().deodr_hip_fit_pose_project_b(_p(vertices), _p(quaternions), _p(posed), _p(camera.extrinsic), _p(camera.intrinsic), _p(camera.distortion),
                                                    _p(posed_b), _p(ij_b), _p(depths_b), float(depths_b_scale), _p(vertices_b), _p(out), _p(scratch), scratch.numel(), V, n,

@@ -20,7 +20,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libdeodr_hip.so")
-ABI_VERSION = 7
+ABI_VERSION = 8
 ERR_FACES, ERR_FACES_UV, ERR_NO_TEXTURE = 1, 2, 4  # include/deodr_hip.h DEODR_HIP_ERR_*
 _STATUS_NEEDED, _STATUS_ERRORS = 11, 12  # words of the 64-byte status block at the start of the workspace
 
@@ -85,6 +85,8 @@ def lib():
                                                  C.POINTER(C.c_ulonglong)]  # fmt: skip
         L.deodr_hip_workspace_pool_pairs.restype = C.c_int
         L.deodr_hip_workspace_pool_pairs.argtypes = [C.POINTER(_SceneC), C.c_size_t, C.POINTER(C.c_ulonglong)]
+        L.deodr_hip_copy_probe.restype = C.c_int
+        L.deodr_hip_copy_probe.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p]
         _lib = L
     return _lib
 
@@ -287,6 +289,8 @@ class HipRasterizer:
         self._checked = False
         self._pool_cap = None
         self._last = None
+        self._loss_cache = None  # (the background-loss table belongs to one (observation, background, clamp) of one workspace)
+        self.alloc_count = getattr(self, "alloc_count", 0) + 1  # a captured HIP graph holds the OLD workspace address: see GraphedStep
 
     @classmethod
     def for_scene(cls, ds, pool_pairs=0):
@@ -335,7 +339,7 @@ class HipRasterizer:
             return
         self._inspect_poll(self._last[0].c_struct())
         self._polls = getattr(self, "_polls", 0) + 1
-        if self._status_event is None and self._polls % self.poll_every == 1:  # (a copy + event per replay is ~13 us of a ~200 us iteration)
+        if self._status_event is None and (self._polls - 1) % max(self.poll_every, 1) == 0:  # (a copy + event per replay is ~13 us of a ~200 us iteration)
             self._forwards = max(self._forwards, 2)
             self._status_host.copy_(self._status_words, non_blocking=True)
             self._status_event = torch.cuda.Event()
@@ -428,7 +432,8 @@ class HipRasterizer:
             table, scratch = torch.empty(n, dtype=torch.float64, device=self.device), torch.empty(n, dtype=torch.float64, device=self.device)
             _check(L.deodr_hip_background_loss(C.byref(sc), _ptr(obs_t), C.byref(options), _ptr(table), _ptr(self.workspace), self.nbytes,
                                                _stream(self.device)))  # fmt: skip
-            self._loss_cache = cache = (key, table, scratch, obs_t)  # (obs_t kept alive: its address is part of the key)
+            # (every tensor whose address is part of the key is kept alive by the cache: a new tensor cannot land on a keyed address)
+            self._loss_cache = cache = (key, table, scratch, (obs_t, ds.background_color, ds.background_image))
         return cache[1], cache[2]
 
     def render_fit(self, ds, obs, sigma=1.0, grads=None, out=None, check_overflow=None, clear_grads=False, loss_out=None, clamp=None):

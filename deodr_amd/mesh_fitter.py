@@ -112,12 +112,24 @@ class GraphedStep:
         return tuple(o.detach() if torch.is_tensor(o) else o for o in out)
 
     def step_device(self):
-        """one iteration = one graph launch; -> the (static) output tensors of ``fitter.step_device``"""
+        """one iteration = one graph launch; -> the (static) output tensors of ``fitter.step_device``.
+
+        A spill-pool overflow (or invalid indices) inside a replay surfaces at a LATER call as an exception of ``poll_status``; by
+        then the rasterizer has regrown -- i.e. freed -- the workspace whose address the graph holds, and the replays since the
+        last poll (up to ``poll_every``) applied momentum updates computed from incomplete frames.  The graph is therefore
+        dropped: every further call raises until the caller restores the fitter's state from its own checkpoint and builds a
+        new ``GraphedStep`` (size the pool with headroom at capture time: ``HipRasterizer(pool_pairs=...)``)."""
+        if self.graph is None:
+            raise RuntimeError("GraphedStep: the captured graph was invalidated by a workspace overflow; restore the fitter's state and capture again")
         self.graph.replay()
         self.fitter.iter += 1
         r = self.fitter.scene._state[2] if self.fitter.scene._state is not None else None
         if r is not None:
-            r.poll_status()  # (asynchronous: a spill-pool overflow inside a replay surfaces at a later call)
+            try:
+                r.poll_status()  # (asynchronous: a spill-pool overflow inside a replay surfaces at a later call)
+            except Exception:
+                self.graph = None  # the workspace the graph writes to is gone: never replay it again
+                raise
         return self.outputs
 
 
@@ -356,6 +368,13 @@ class MeshDepthFitter(_PoseFitter):
         return energy, d.depth, d.diff
 
     def step_device(self):
+        """One iteration on the device -> (energy, image, difference image) as device tensors.
+
+        OUTPUT LIFETIME: on the direct path (float64 ROCm tensors, manifold mesh: a fixed kernel sequence over persistent buffers,
+        `_DirectIteration`) the returned tensors -- and ``self.vertices``, the pose, light and colour parameters -- are the SAME
+        storage every step: they are updated in place, so a value kept across iterations (a trajectory, an energy history) must be
+        ``.clone()``d by the caller.  The autograd path (CPU tensors, float32, non-manifold meshes) rebinds fresh tensors each step,
+        as the reference does.  ``step()`` is safe either way: it converts to a float and NumPy arrays at once."""
         d = self._direct_iteration(1, False)
         if d is not None:
             return self._step_direct(d)
@@ -510,6 +529,13 @@ class MeshRGBFitterWithPose(_PoseFitter):
         return energy, image
 
     def step_device(self):
+        """One iteration on the device -> (energy, image, difference image) as device tensors.
+
+        OUTPUT LIFETIME: on the direct path (float64 ROCm tensors, manifold mesh: a fixed kernel sequence over persistent buffers,
+        `_DirectIteration`) the returned tensors -- and ``self.vertices``, the pose, light and colour parameters -- are the SAME
+        storage every step: they are updated in place, so a value kept across iterations (a trajectory, an energy history) must be
+        ``.clone()``d by the caller.  The autograd path (CPU tensors, float32, non-manifold meshes) rebinds fresh tensors each step,
+        as the reference does.  ``step()`` is safe either way: it converts to a float and NumPy arrays at once."""
         d = None if self.light_directional is None else self._direct_iteration(int(self.mesh_color.numel()), True)
         if d is not None and fronthalf_usable(self.mesh_color, self.light_directional, self.light_ambient):
             return self._step_direct(d)

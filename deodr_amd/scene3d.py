@@ -33,7 +33,14 @@ class DeviceCamera:
         e, k = _t(extrinsic, self.device, dtype), _t(intrinsic, self.device, dtype)
         self.extrinsic = e[None] if e.dim() == 2 else e
         self.intrinsic = k[None] if k.dim() == 2 else k
-        self.n_views = int(self.extrinsic.shape[0])
+        # one camera matrix shared by n views (extrinsic [n,3,4] with one intrinsic [3,3], or the other way round): every array is
+        # expanded to n views HERE -- the fused kernels index all three per view (`intrinsic[9 b + i]`, `extrinsic[12 b + i]`)
+        self.n_views = max(int(self.extrinsic.shape[0]), int(self.intrinsic.shape[0]))
+        for name in ("extrinsic", "intrinsic"):
+            a = getattr(self, name)
+            if a.shape[0] not in (1, self.n_views):
+                raise ValueError(f"DeviceCamera: {name} has {a.shape[0]} views, expected 1 or {self.n_views}")
+            setattr(self, name, a.expand(self.n_views, *a.shape[1:]))
         self.height, self.width = int(height), int(width)
         self.distortion = None
         if distortion is not None:
@@ -61,7 +68,8 @@ class DeviceCamera:
         """-> (image coordinates [n,V,2] with x = column first, depths [n,V]); differentiable (dr.py:341-395)."""
         from . import fronthalf
 
-        if fronthalf.usable(points_3d, self.extrinsic, self.intrinsic) and (self.distortion is None or fronthalf.usable(self.distortion)):
+        batch_ok = points_3d.dim() == 2 or int(points_3d.shape[0]) == self.n_views  # (else: the torch path below broadcasts, or raises)
+        if batch_ok and fronthalf.usable(points_3d, self.extrinsic, self.intrinsic) and (self.distortion is None or fronthalf.usable(self.distortion)):
             # one kernel (two with its adjoint) instead of ~15 + ~25 torch kernels
             p = points_3d if points_3d.dim() == 3 else points_3d[None].expand(self.n_views, -1, -1)
             return fronthalf.ProjectPointsFunc.apply(p, self.extrinsic, self.intrinsic, self.distortion)

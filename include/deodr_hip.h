@@ -275,6 +275,12 @@ int deodr_hip_profile_read(double ms_sum[4], unsigned long long launches[4]);
 int deodr_hip_workspace_census(const DeodrHipScene *scene, void *workspace, size_t workspace_bytes, void *stream,
 							   unsigned long long *nonempty_tiles, unsigned long long *edge_tiles);
 
+/* Measurement hook (bench.py's hbm_probe): `reps` back-to-back device-to-device copies of `bytes` bytes (a multiple of 16, both
+ * pointers 16-byte aligned) with the library's own streaming 16-byte non-temporal loads and stores -- the ceiling the fill and frame
+ * stores of the rasterizer live under on THIS box, next to the 8 TB/s of the data sheet.  mode 0: copy, 1: write only (src unused),
+ * 2: read only (dst: 8 bytes receiving a checksum so that the loads are not removed).  Asynchronous on `stream`. */
+int deodr_hip_copy_probe(void *dst, const void *src, size_t bytes, int mode, int reps, void *stream);
+
 /* Test hook: non-zero makes every call use the generic (un-staged) kernels that otherwise only serve nb_colors > 4 and
  * antialiase_error, so that the parity suite can exercise both code paths on the same scenes.  This (and the profiling
  * hook above) is the only process-wide state; the library reads NO environment variable. */
@@ -285,7 +291,7 @@ const char *deodr_hip_last_error(void);
 
 /* ABI version of this header; bumped on any incompatible change. */
 int deodr_hip_abi_version(void);
-#define DEODR_HIP_ABI_VERSION 7
+#define DEODR_HIP_ABI_VERSION 8
 
 #ifdef __cplusplus
 }
