@@ -11,6 +11,57 @@ namespace
 
 // ------------------------------------------------------------------------------------------------------- finalize
 
+// Vertex adjoints of the triangles of one workgroup, merged in LDS before they leave (round 4).  A vertex receives contributions
+// from the ~6 triangles around it, and neighbouring triangles usually sit in the same workgroup; written straight to the gradient
+// arrays, every contribution is one memory-side atomic, and an atomic INSTRUCTION whose 64 lanes name 64 different vertices touches
+// 64 cache lines (tools/probes/order_atomic_probe.hip: 160 000 triangles x 18 adds take 117 us that way, 14 us through a table like
+// this one -- 38 us even when no two triangles share a vertex, because the table is flushed vertex-major: the lanes of one
+// instruction add to consecutive addresses).  Open addressing on the vertex index; a corner that finds no slot after VT_PROBES
+// steps falls back to the direct atomics.  Only KIND_INTERP triangles with nb_colors <= 4 (row: ij 2 + colours 4).
+#ifndef DR_FIN_MERGE
+#define DR_FIN_MERGE 1 // (measurement builds: 0 = every contribution straight to the gradient arrays, as in round 3)
+#endif
+constexpr int VT_SLOTS = 512, VT_ROW = 6, VT_PROBES = 8;
+struct VertexTable
+{
+	uint32_t key[VT_SLOTS];
+	double val[VT_SLOTS][VT_ROW];
+};
+__device__ __forceinline__ int vertex_slot(VertexTable &t, uint32_t v)
+{
+	uint32_t h = (v * 2654435761u) >> (32 - 9);
+	static_assert(VT_SLOTS == 512, "hash width");
+#pragma unroll 1
+	for (int i = 0; i < VT_PROBES; i++, h = (h + 1) & (VT_SLOTS - 1))
+	{
+		const uint32_t old = atomicCAS(&t.key[h], 0xffffffffu, v);
+		if (old == 0xffffffffu || old == v)
+			return (int)h;
+	}
+	return -1;
+}
+struct MergeSink // finalize_triangle's sink: corner i of the triangle adds into row slot[i] of the table (or, without a slot, to memory)
+{
+	const SceneView &s;
+	const GradView &g;
+	VertexTable &t;
+	uint32_t f[3];
+	int slot[3];
+	__device__ __forceinline__ void put(int i, int col, void *arr, size_t at, double v)
+	{
+		if (v == 0)
+			return;
+		if (slot[i] >= 0)
+			unsafeAtomicAdd(&t.val[slot[i]][col], v);
+		else
+			DeviceAdd()(arr, at, s.vtx_f64, v);
+	}
+	__device__ __forceinline__ void color(int i, int c, double v) { put(i, 2 + c, g.colors_b, (size_t)f[i] * s.C + c, v); }
+	__device__ __forceinline__ void ij(int i, int d, double v) { put(i, d, g.ij_b, 2 * (size_t)f[i] + d, v); }
+	__device__ __forceinline__ void shade(int, double) {}	  // (KIND_INTERP triangles only)
+	__device__ __forceinline__ void uv(int, int, double) {} // (KIND_INTERP triangles only)
+};
+
 template <bool VTX64, int NC> // (the dtype of the vertex arrays and the channel count at compile time: see setup_bin_kernel)
 __global__ __launch_bounds__(PRIM_BLOCK, DR_PRIM_WAVES) void finalize_kernel(KParams p)
 { // same split as setup_bin_kernel: triangle blocks, then edge-slot blocks compacted to the flagged slots.
@@ -69,34 +120,76 @@ __global__ __launch_bounds__(PRIM_BLOCK, DR_PRIM_WAVES) void finalize_kernel(KPa
 	if (tri_block)
 	{
 		const int k = pw.index * PRIM_BLOCK + threadIdx.x;
-		if (k >= p.T)
-			return;
 		// the vertex indices are requested together with the flag (one memory round trip, not two): using them in the branch
 		// condition keeps the compiler from sinking the loads below it (an index never has its top bit set: V < 2^31)
-		const uint32_t flag = w.tri_flag[k];
-		const uint32_t f0 = p.faces[3 * (size_t)k], f1 = p.faces[3 * (size_t)k + 1], f2 = p.faces[3 * (size_t)k + 2];
-		double *acc = w.tri_acc + (size_t)k * 3 * P;
-		if (!(flag & 4u) || (flag & 3u) == KIND_NONE || (int32_t)(f0 | f1 | f2) < 0)
-			return; // culled triangles own no accumulators
-		DR_WAVE_PHASE_T(1); // flags + indices arrived
-		AtomicSink sink = {s, g, {f0, f1, f2}, {p.faces_uv[3 * (size_t)k], p.faces_uv[3 * (size_t)k + 1], p.faces_uv[3 * (size_t)k + 2]}};
-		if (P <= 4)
-		{ // a register copy of the accumulators: all twelve loads in flight together (read through the pointer, each plane's
-		  // loads would wait behind the atomics of the plane before: they might alias)
-			double la[12];
-#pragma unroll
-			for (int i = 0; i < 12; i++)
-				la[i] = i < 3 * P ? acc[i] : 0.0;
-			finalize_triangle<true>(s, k, (int)(flag & 3u), la, sink);
+		uint32_t flag = 0, f0 = 0, f1 = 0, f2 = 0;
+		if (k < p.T)
+		{
+			flag = w.tri_flag[k];
+			f0 = p.faces[3 * (size_t)k], f1 = p.faces[3 * (size_t)k + 1], f2 = p.faces[3 * (size_t)k + 2];
 		}
-		else
-			finalize_triangle<false>(s, k, (int)(flag & 3u), acc, sink);
-		// (merging the adjoints of the triangles of a wavefront that share a vertex in an LDS table before they leave -- a third
-		// fewer atomic requests at the memory side -- was measured: 34 -> 35 us)
-		DR_WAVE_PHASE_T(2); // arithmetic done, atomics issued
-		for (int i = 0; i < 3 * P; i++)
-			acc[i] = 0; // self-cleaning accumulators
-		DR_WAVE_PHASE_T(3);
+		// culled triangles own no accumulators
+		const bool live = k < p.T && (flag & 4u) && (flag & 3u) != KIND_NONE && (int32_t)(f0 | f1 | f2) >= 0;
+		// (the table's 26 KB are only touched by a block that has a triangle for it: half the blocks of a closed mesh are all back-facing)
+		__shared__ VertexTable s_vt;
+		const bool merge = DR_FIN_MERGE && P <= 4 && __syncthreads_or(live && (flag & 3u) == KIND_INTERP);
+		if (merge)
+		{
+			for (int i = threadIdx.x; i < VT_SLOTS; i += PRIM_BLOCK)
+				s_vt.key[i] = 0xffffffffu;
+			for (int i = threadIdx.x; i < VT_SLOTS * VT_ROW; i += PRIM_BLOCK)
+				(&s_vt.val[0][0])[i] = 0;
+			__syncthreads();
+		}
+		if (live)
+		{
+			double *acc = w.tri_acc + (size_t)k * 3 * P;
+			DR_WAVE_PHASE_T(1); // flags + indices arrived
+			if (P <= 4)
+			{ // a register copy of the accumulators: all twelve loads in flight together (read through the pointer, each plane's
+			  // loads would wait behind the atomics of the plane before: they might alias)
+				double la[12];
+#pragma unroll
+				for (int i = 0; i < 12; i++)
+					la[i] = i < 3 * P ? acc[i] : 0.0;
+				if (merge && (flag & 3u) == KIND_INTERP)
+				{
+					MergeSink sink = {s, g, s_vt, {f0, f1, f2}, {vertex_slot(s_vt, f0), vertex_slot(s_vt, f1), vertex_slot(s_vt, f2)}};
+					finalize_triangle<true>(s, k, KIND_INTERP, la, sink);
+				}
+				else
+				{
+					AtomicSink sink = {s, g, {f0, f1, f2}, {p.faces_uv[3 * (size_t)k], p.faces_uv[3 * (size_t)k + 1], p.faces_uv[3 * (size_t)k + 2]}};
+					finalize_triangle<true>(s, k, (int)(flag & 3u), la, sink);
+				}
+			}
+			else
+			{
+				AtomicSink sink = {s, g, {f0, f1, f2}, {p.faces_uv[3 * (size_t)k], p.faces_uv[3 * (size_t)k + 1], p.faces_uv[3 * (size_t)k + 2]}};
+				finalize_triangle<false>(s, k, (int)(flag & 3u), acc, sink);
+			}
+			DR_WAVE_PHASE_T(2); // arithmetic done, contributions issued
+			for (int i = 0; i < 3 * P; i++)
+				acc[i] = 0; // self-cleaning accumulators
+			DR_WAVE_PHASE_T(3);
+		}
+		if (merge)
+		{ // flush, vertex-major: eight lanes per row (six used), i.e. one instruction adds to the 16 + 32 contiguous bytes of eight vertices
+			__syncthreads();
+			for (int i = threadIdx.x; i < VT_SLOTS * 8; i += PRIM_BLOCK)
+			{
+				const int row = i >> 3, col = i & 7;
+				const uint32_t v = s_vt.key[row];
+				if (col < 2 + p.C && v != 0xffffffffu)
+				{
+					const double x = s_vt.val[row][col];
+					if (col < 2)
+						DeviceAdd()(g.ij_b, 2 * (size_t)v + col, p.vtx_f64, x);
+					else
+						DeviceAdd()(g.colors_b, (size_t)v * p.C + (col - 2), p.vtx_f64, x);
+				}
+			}
+		}
 		return;
 	}
 	const uint32_t n_flagged = compact_flagged_slots(p, s.edgeflags, pw.index);

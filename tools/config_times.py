@@ -49,9 +49,16 @@ def run(name, views, steps=20):
           f"   [set-up {per[0]:.3f}, forward {per[1]:.3f}, edge tiles {per[2]:.3f}, finalize {per[3]:.3f} ms]")
 
 
-run("configs[1] hand, textured", [scenes.hand_scene(GOLD, size=1024, angle=0.2, textured=True)])
-run("configs[3] hand, 8 views", [scenes.hand_scene(GOLD, size=1024, angle=float(a), textured=False) for a in np.linspace(-0.5, 0.5, 8)])
-run("configs[2] sphere 20k", [scenes.sphere_scene(size=1024, angle=float(a)) for a in np.linspace(-0.5, 0.5, 8)])
+ONLY = sys.argv[sys.argv.index("--only") + 1] if "--only" in sys.argv else ""  # e.g. --only "configs[4] shape, 8" (profiling one configuration)
+_run = run
+def run(name, views, steps=20):
+    if ONLY in name:
+        _run(name, views() if callable(views) else views, steps)
+
+
+run("configs[1] hand, textured", lambda: [scenes.hand_scene(GOLD, size=1024, angle=0.2, textured=True)])
+run("configs[3] hand, 8 views", lambda: [scenes.hand_scene(GOLD, size=1024, angle=float(a), textured=False) for a in np.linspace(-0.5, 0.5, 8)])
+run("configs[2] sphere 20k", lambda: [scenes.sphere_scene(size=1024, angle=float(a)) for a in np.linspace(-0.5, 0.5, 8)])
 big = dict(size=2048, nu=224, n_rings=224, nb_colors=3, textured=True, texture_size=1024)
-run("configs[4] shape, 1 view", [scenes.sphere_scene(**big)])
-run("configs[4] shape, 8 views", [scenes.sphere_scene(angle=float(a), **big) for a in np.linspace(-0.5, 0.5, 8)], steps=10)
+run("configs[4] shape, 1 view", lambda: [scenes.sphere_scene(**big)])
+run("configs[4] shape, 8 views", lambda: [scenes.sphere_scene(angle=float(a), **big) for a in np.linspace(-0.5, 0.5, 8)], steps=10)
