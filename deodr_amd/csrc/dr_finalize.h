@@ -63,7 +63,10 @@ struct MergeSink // finalize_triangle's sink: corner i of the triangle adds into
 };
 
 template <bool VTX64, int NC> // (the dtype of the vertex arrays and the channel count at compile time: see setup_bin_kernel)
-__global__ __launch_bounds__(PRIM_BLOCK, DR_PRIM_WAVES) void finalize_kernel(KParams p)
+#ifndef DR_FIN_WAVES
+#define DR_FIN_WAVES 4 // waves per SIMD finalize_kernel is compiled for (3: 144 registers with the vertex table, 21.4 -> 22.4 us)
+#endif
+__global__ __launch_bounds__(PRIM_BLOCK, DR_FIN_WAVES) void finalize_kernel(KParams p)
 { // same split as setup_bin_kernel: triangle blocks, then edge-slot blocks compacted to the flagged slots.
   // (Lists of the front-facing triangles / drawn edges compacted by the set-up kernel were tried: a quarter as many wavefronts,
   // all lanes busy -- and 32 -> 41 us: the kernel is a chain of dependent round trips, fewer wavefronts overlap fewer of them.)
@@ -132,7 +135,7 @@ __global__ __launch_bounds__(PRIM_BLOCK, DR_PRIM_WAVES) void finalize_kernel(KPa
 		const bool live = k < p.T && (flag & 4u) && (flag & 3u) != KIND_NONE && (int32_t)(f0 | f1 | f2) >= 0;
 		// (the table's 26 KB are only touched by a block that has a triangle for it: half the blocks of a closed mesh are all back-facing)
 		__shared__ VertexTable s_vt;
-		const bool merge = DR_FIN_MERGE && P <= 4 && __syncthreads_or(live && (flag & 3u) == KIND_INTERP);
+		const bool merge = DR_FIN_MERGE && p.prim_tables && P <= 4 && __syncthreads_or(live && (flag & 3u) == KIND_INTERP);
 		if (merge)
 		{
 			for (int i = threadIdx.x; i < VT_SLOTS; i += PRIM_BLOCK)

@@ -182,6 +182,10 @@ struct KParams
 	int fill_mode;
 	int fuse_edges;	 // fit step: the forward raster also runs the adjoint of the tiles that hold silhouette edges (no edge-tile kernel)
 	int clear_grads; // the set-up kernel zeroes the per-view gradient arrays (a fit step that wants fresh gradients: no separate fills)
+	// set by the host per launch: the per-primitive kernels go through their per-workgroup LDS tables (finalize: vertex adjoints merged
+	// before they leave; set-up: one slot request per tile and workgroup) -- worth it when the launch is large enough to be bound by the
+	// rate of memory-side atomics rather than by the latency of one wavefront's chain (a single 20 k-triangle view is not: + 1.7 us)
+	int prim_tables;
 	// loss of a fit step, sum (image - obs)^2 (deodr_hip_render_scene_fit_loss): loss_tile_bg[0] = the loss of a frame that is all
 	// background, [1 + view * ntiles + tile] = that of one tile; loss_wave[view * LOSS_SLOTS + q % LOSS_SLOTS]: walker q of the forward
 	// raster adds (loss of a tile - its background loss) for every tile it walks; one workgroup of finalize_kernel writes loss_out[0] =
