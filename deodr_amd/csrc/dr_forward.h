@@ -464,6 +464,20 @@ __global__ __launch_bounds__(SCAN_BLOCK) void tile_scan_kernel(KParams p)
 		w.edge_cnt[tile] = 0;
 	}
 	const unsigned long long wm = __ballot(work);
+	if (p.fin_in_fwd)
+	{ // how many walkers the finalize workgroups of the forward raster have to wait for, per block of BLK x BLK tiles
+		const int ty = tile / p.L.tiles_x, tx = tile - ty * p.L.tiles_x;
+		uint32_t *expected = w.blk_sync + (ty / BLK) * p.L.blk_x + tx / BLK;
+		static_assert(BLK == 8, "eight consecutive lanes = the eight tiles of one block row");
+		if ((p.L.tiles_x & 7) == 0)
+		{
+			const uint32_t cnt = (uint32_t)__popcll((wm >> (lane & ~7)) & 0xffull);
+			if ((lane & 7) == 0 && cnt)
+				atomicAdd(expected, cnt);
+		}
+		else if (work)
+			atomicAdd(expected, 1u);
+	}
 	if (lane == 0 && valid)
 		w.tile_bits[tile >> 5] = (uint32_t)wm;
 	if (lane == 32 && valid)
@@ -852,6 +866,33 @@ __device__ __forceinline__ void owner_adjoint_mfma(const KParams &p, const ViewP
 	}
 }
 
+// (dr_finalize.h) the per-primitive adjoint algebra as workgroups of the forward raster: see raster_fwd_fast_kernel
+template <bool VTX64>
+__device__ __forceinline__ void fin_in_fwd_role(const KParams &p, char *lds, long long fi);
+constexpr int FIN_EDGE_WGS = 32;	   // workgroups per view that walk the list of drawn edges (persistent: the list's length is only known on the device)
+constexpr size_t FIN_LDS_BYTES = 128 * (4 + 6 * 8); // their vertex table (dr_finalize.h: FinTable), carved out of the walkers' staging area
+
+// A walker has finished `n` tiles of the block that holds `tile`: its accumulator atomics have been performed (vmcnt(0): returnless
+// atomics are counted like stores; they are executed at the memory side, where the finalize workgroup's loads will find them), then
+// the block's counter goes up.  No cache write-back: nothing else the walker wrote is read before the kernel ends.
+__device__ __forceinline__ void signal_tiles_done(const KParams &p, const ViewPtrs &w, int tile, uint32_t n, int lane)
+{
+	if (!p.fin_in_fwd)
+		return;
+#ifndef DR_FIN_PROBE
+#define DR_FIN_PROBE 0 // measurement builds (WRONG gradients): 1 = the finalize workgroups return at once, 2 = the walkers do not wait for their atomics
+#endif
+	__atomic_signal_fence(__ATOMIC_SEQ_CST);
+	if (DR_FIN_PROBE != 2)
+		__builtin_amdgcn_s_waitcnt(0);
+	__atomic_signal_fence(__ATOMIC_SEQ_CST);
+	if (lane == 0)
+	{
+		const int ty = tile / p.L.tiles_x, tx = tile - ty * p.L.tiles_x;
+		__hip_atomic_fetch_add(w.blk_sync + p.L.nblk + (ty / BLK) * p.L.blk_x + tx / BLK, n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	}
+}
+
 // Grid of the staged forward (1-D, one wavefront per workgroup).  Workgroup b: view (b / 8) % n_views,
 // q = (b / 8 / n_views) * 8 + b % 8 in [0, p.tile_blocks); it walks the entries rank(q), rank(q) + tile_blocks, ... of the
 // view's work list (usually one or two).  rank() deals the list to the XCDs in chunks of 64 consecutive entries (workgroup b
@@ -1089,8 +1130,8 @@ enum FwdMode
 	FWD_NO_EDGES = 2, // fit step, rest of the list: no tile has an edge
 };
 template <class PixT, bool FUSED, bool TEX, int MODE, bool CLAMP>
-__device__ __forceinline__ void fwd_tiles(const KParams &p, WaveLds *s_lds, EdgeSort *s_es)
-{
+__device__ __forceinline__ void fwd_tiles(const KParams &p, WaveLds *s_lds, EdgeSort *s_es, const long long b)
+{ // b: index of this walker among the walkers of the grid (the workgroup index, unless fill workgroups are dealt among them)
 	DR_WAVE_TRACE_SCOPE(2);
 #ifdef DR_FWD_TRACE
 	// per-tile phase timing (tools/fwd_trace.py): eight counters over the first row of the tile in the z buffer
@@ -1102,7 +1143,6 @@ __device__ __forceinline__ void fwd_tiles(const KParams &p, WaveLds *s_lds, Edge
 	constexpr int wave = 0;
 	const int lane0 = threadIdx.x & 63;
 	const int G = p.tile_blocks;
-	const long long b = blockIdx.x;
 	int view, q;
 	const bool chunked = G % (8 * WORK_CHUNK) == 0;
 	if (chunked)
@@ -1147,6 +1187,7 @@ __device__ __forceinline__ void fwd_tiles(const KParams &p, WaveLds *s_lds, Edge
 			const uint32_t nn = (uint32_t)uniform((int)entry.ntri);
 			fwd_pair_tiles<PixT, CLAMP>(p, w, S, view, lane, (int)((uint32_t)uniform((int)entry.tile) & ~PAIR_FLAG), (int)(nn & 0xffffu), (int)(nn >> 16), ids12,
 								 p.loss_wave ? p.loss_wave + (size_t)view * LOSS_SLOTS + q % LOSS_SLOTS : nullptr);
+			signal_tiles_done(p, w, (int)((uint32_t)uniform((int)entry.tile) & ~PAIR_FLAG), 2u, lane);
 			lds_sync();
 			continue;
 		}
@@ -1502,7 +1543,17 @@ __device__ __forceinline__ void fwd_tiles(const KParams &p, WaveLds *s_lds, Edge
 #endif
 		}
 		}
+		if (FUSED)
+			signal_tiles_done(p, w, tile, 1u, lane);
 		lds_sync(); // the next tile of this wavefront reuses the staging area
+	}
+	if (FUSED && p.fin_in_fwd && p.loss_out)
+	{ // (the workgroup that adds up the loss waits for every walker of every view: their partial sums are complete)
+		__atomic_signal_fence(__ATOMIC_SEQ_CST);
+		__builtin_amdgcn_s_waitcnt(0);
+		__atomic_signal_fence(__ATOMIC_SEQ_CST);
+		if (lane0 == 0)
+			__hip_atomic_fetch_add(w.blk_sync + 2 * p.L.nblk + SYNC_WALKERS, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 	}
 	if (q == 0 && threadIdx.x == 0)
 		close_epoch(p, w, FUSED);
@@ -1529,27 +1580,61 @@ __global__ __launch_bounds__(64, DR_FWD_WAVES) void raster_fwd_fast_kernel(KPara
 	}
 	if (FUSED)
 		p.persp = 0; // (a fit step: fill_params refuses perspective_correct for anything with an adjoint, as the reference does, H.h:810)
-	__shared__ WaveLds s_lds[1];
-	__shared__ EdgeSort s_es[1];
-	if ((long long)blockIdx.x >= (long long)p.n_views * p.tile_blocks)
-	{ // the last workgroups of the grid stream the background of this kernel's share of the empty tiles (fill_share)
-		const int fi = (int)((long long)blockIdx.x - (long long)p.n_views * p.tile_blocks);
-		fill_share_word(p, 2, fi % p.n_views, fi / p.n_views, threadIdx.x & 63);
+	// (one raw buffer: the finalize workgroups of a fit step reuse the walkers' staging area for their vertex table)
+	constexpr size_t LDS_BYTES = sizeof(WaveLds) + sizeof(EdgeSort) > FIN_LDS_BYTES ? sizeof(WaveLds) + sizeof(EdgeSort) : FIN_LDS_BYTES;
+	__shared__ __attribute__((aligned(16))) char s_mem[LDS_BYTES];
+	WaveLds *const s_lds = (WaveLds *)s_mem;
+	EdgeSort *const s_es = (EdgeSort *)(s_mem + sizeof(WaveLds));
+	// Roles of the grid: the tile walkers, the workgroups that stream the background of this kernel's share of the empty tiles
+	// (fill_share), and -- fit step that finalizes here -- the per-primitive adjoint algebra (finalize_kernel's work) at the very end.
+	// Without finalize workgroups the fill workgroups follow the walkers.  With them they are dealt among the walkers, eight (one per
+	// XCD) behind every 64: dispatched last they START when the last walker has a slot, and the kernel then ends a fill later (all of
+	// the fill, 110 MB per 8-view step, is this kernel's now); the finalize workgroups need that tail for themselves.
+	const long long n_walk = (long long)p.n_views * p.tile_blocks, n_fill = (long long)p.n_views * fill_share(p.fill_mode, 2, p.L.nwords);
+#ifndef DR_FILL_DEAL
+#define DR_FILL_DEAL 1
+#endif
+	const long long dealt = (DR_FILL_DEAL && FUSED && !TEX && p.fin_in_fwd && n_walk >= 8 * n_fill) ? n_fill / 8 : 0; // groups of 64 walkers + 8 fill workgroups
+	long long b = blockIdx.x, fi = -1;
+	if (b < dealt * 72)
+	{
+		const long long grp = b / 72, r = b - grp * 72;
+		if (r < 64)
+			b = grp * 64 + r;
+		else
+			fi = grp * 8 + (r - 64);
+	}
+	else
+	{
+		b -= dealt * 8;
+		if (b >= n_walk)
+			fi = dealt * 8 + (b - n_walk);
+	}
+	if (fi >= 0)
+	{
+		if (fi < n_fill)
+			fill_share_word(p, 2, (int)(fi % p.n_views), (int)(fi / p.n_views), threadIdx.x & 63);
+		else if (FUSED && !TEX && DR_FIN_PROBE != 1)
+		{
+			if (p.vtx_f64)
+				fin_in_fwd_role<true>(p, s_mem, fi - n_fill);
+			else
+				fin_in_fwd_role<false>(p, s_mem, fi - n_fill);
+		}
 		return;
 	}
 	if (FUSED && DR_FUSE_EDGES && !TEX)
 	{ // (p.fuse_edges is set: the host and the scan kernel follow the same rule -- fit step of an untextured scene)
 		const int G = p.tile_blocks;
-		const long long b = blockIdx.x;
 		const bool chunked = G % (8 * WORK_CHUNK) == 0;
 		const int q = chunked ? (int)((b >> 3) / p.n_views) * 8 + (int)(b & 7) : 0;
 		if (chunked && q >= G / p.heavy_share)
-			fwd_tiles<PixT, FUSED, TEX, FWD_NO_EDGES, CLAMP>(p, s_lds, s_es); // the rest of the list: no tile with edges
+			fwd_tiles<PixT, FUSED, TEX, FWD_NO_EDGES, CLAMP>(p, s_lds, s_es, b); // the rest of the list: no tile with edges
 		else
-			fwd_tiles<PixT, FUSED, TEX, FWD_EDGE_ADJ, CLAMP>(p, s_lds, s_es); // the head (tiny frames: the whole list)
+			fwd_tiles<PixT, FUSED, TEX, FWD_EDGE_ADJ, CLAMP>(p, s_lds, s_es, b); // the head (tiny frames: the whole list)
 	}
 	else
-		fwd_tiles<PixT, FUSED, TEX, FWD_PLAIN, CLAMP>(p, s_lds, s_es);
+		fwd_tiles<PixT, FUSED, TEX, FWD_PLAIN, CLAMP>(p, s_lds, s_es, b);
 }
 
 } // namespace

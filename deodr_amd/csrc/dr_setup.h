@@ -259,6 +259,11 @@ __global__ __launch_bounds__(PRIM_BLOCK, DR_PRIM_WAVES) void setup_bin_kernel(KP
 	}
 	if (item <= EDGE_LISTS) // appended to by tile_scan_kernel, the next kernel on the stream
 		w.edge_tile_cnt[item * CNT_STRIDE] = 0;
+	// (block counters of a forward that also finalizes: written by the scan kernel and the forward raster, both later on the stream)
+	for (int v = item; v < 2 * p.L.nblk + 1; v += n_items)
+		w.blk_sync[v] = 0;
+	if (item == 0)
+		w.blk_sync[2 * p.L.nblk + SYNC_DRAWN + (1 - cur)] = 0;
 	if (p.loss_wave) // (one partial per tile walker of the forward raster, two kernels later)
 		for (int v = item; v < LOSS_SLOTS; v += n_items)
 			p.loss_wave[(size_t)view * LOSS_SLOTS + v] = 0;
@@ -501,6 +506,8 @@ __global__ __launch_bounds__(PRIM_BLOCK, DR_PRIM_WAVES) void setup_bin_kernel(KP
 			for (int i = 0; i < 7; i++)
 				e.pad0[i] = 0;
 			eout = e;
+			if (p.fin_in_fwd) // the list the finalize workgroups of the forward raster walk (a few hundred edges per view)
+				w.drawn_edges[atomicAdd(&w.blk_sync[2 * p.L.nblk + SYNC_DRAWN + cur], 1u)] = (uint32_t)slot;
 			DR_WAVE_PHASE(4); // record stored
 			if (e.x_begin > e.x_end || e.y_begin > e.y_end)
 				break;

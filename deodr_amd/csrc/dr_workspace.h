@@ -57,6 +57,8 @@ constexpr size_t SNAP_BYTES = (CHUNKS - 1) * CH * 64 * sizeof(double);
 // Entry of the staged forward's work list (one per non-empty tile, written by tile_scan_kernel): everything a wavefront needs to
 // start on the tile comes with ONE memory round trip -- the header with a scalar load, the first triangle ids with a vector
 // load issued at the same time (a tile with more triangles reads its inline list / the spill pool as well).
+constexpr int BLK = 8; // tiles per side of a synchronisation block (64 x 64 pixels)
+constexpr int SYNC_WALKERS = 0, SYNC_DRAWN = 1; // words behind the two per-block arrays of ViewPtrs::blk_sync
 constexpr int ENTRY_IDS = 12;
 struct alignas(64) WorkEntry
 {
@@ -97,7 +99,9 @@ struct Layout
 		edge_pool, face_id, tile_bits, tri_flag, work_list, edge_tile_cnt, edge_tiles, edge_slot, edge_sweep, edge_snap, view_bytes;
 	uint32_t tri_pool_cap, edge_pool_cap;
 	size_t edge_fin;
+	size_t blk_sync, drawn_edges;
 	int tiles_x, tiles_y, ntiles, nwords, P, sweep_cap;
+	int blk_x, blk_y, nblk; // blocks of BLK x BLK tiles: the grain at which the finalize workgroups of a fused forward wait for the tile walkers
 };
 
 size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -153,6 +157,15 @@ Layout make_layout(int T, int H, int W, int C, size_t pool_pairs)
 	// instead of three -- indices, vertices, record)
 	L.edge_fin = take(sizeof(EdgeFin) * 3 * (size_t)T);
 	L.edge_snap = take(SNAP_BYTES * SNAP_CAP);
+	// Finalize inside the forward raster (fit step of an untextured scene, round 4): [0, nblk) non-empty tiles per block of BLK x BLK tiles
+	// (tile_scan_kernel), [nblk, 2 nblk) tiles of the block whose walker has finished (raster_fwd_fast_kernel), [2 nblk] walkers that
+	// have left the kernel; all zeroed by the set-up kernel.  drawn_edges: the slots of the silhouette edges set-up has drawn, their number
+	// in words [2 nblk + 1 + parity of the forward] (double-buffered like the spill counters: set-up counts into one, clears the other).
+	L.blk_x = (L.tiles_x + BLK - 1) / BLK;
+	L.blk_y = (L.tiles_y + BLK - 1) / BLK;
+	L.nblk = L.blk_x * L.blk_y;
+	L.blk_sync = take(sizeof(uint32_t) * (2 * (size_t)L.nblk + 16));
+	L.drawn_edges = take(sizeof(uint32_t) * 3 * (size_t)T);
 	L.view_bytes = o;
 	return L;
 }
@@ -186,6 +199,10 @@ struct KParams
 	// before they leave; set-up: one slot request per tile and workgroup) -- worth it when the launch is large enough to be bound by the
 	// rate of memory-side atomics rather than by the latency of one wavefront's chain (a single 20 k-triangle view is not: + 1.7 us)
 	int prim_tables;
+	// fit step of an untextured scene (round 4): the per-primitive adjoint algebra of finalize_kernel runs INSIDE the forward raster, by
+	// extra workgroups at the end of its grid that wait, block of tiles by block of tiles, for the walkers (set by the host; the
+	// set-up kernel then lists the edges it draws, the scan kernel counts the non-empty tiles of every block)
+	int fin_in_fwd;
 	// loss of a fit step, sum (image - obs)^2 (deodr_hip_render_scene_fit_loss): loss_tile_bg[0] = the loss of a frame that is all
 	// background, [1 + view * ntiles + tile] = that of one tile; loss_wave[view * LOSS_SLOTS + q % LOSS_SLOTS]: walker q of the forward
 	// raster adds (loss of a tile - its background loss) for every tile it walks; one workgroup of finalize_kernel writes loss_out[0] =
@@ -219,6 +236,7 @@ struct ViewPtrs
 	WorkEntry *work_list;
 	uint32_t *edge_tile_cnt, *edge_tiles; // tiles with silhouette edges: EDGE_LISTS (+ 1) counters, EDGE_LISTS lists of ntiles entries
 	EdgeFin *edge_fin;
+	uint32_t *blk_sync, *drawn_edges;
 };
 
 // value whose squared distance to the observation is the loss, and d loss / d value, of a rendered value v (already rounded to the
@@ -266,6 +284,8 @@ __device__ __forceinline__ ViewPtrs view_ptrs(const KParams &p, int view)
 	v.edge_fin = (EdgeFin *)(b + p.L.edge_fin);
 	v.edge_sweep = b + p.L.edge_sweep;
 	v.edge_snap = b + p.L.edge_snap;
+	v.blk_sync = (uint32_t *)(b + p.L.blk_sync);
+	v.drawn_edges = (uint32_t *)(b + p.L.drawn_edges);
 	return v;
 }
 

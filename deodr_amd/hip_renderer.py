@@ -21,7 +21,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libdeodr_hip.so")
 ABI_VERSION = 8
-ERR_FACES, ERR_FACES_UV, ERR_NO_TEXTURE = 1, 2, 4  # include/deodr_hip.h DEODR_HIP_ERR_*
+ERR_FACES, ERR_FACES_UV, ERR_NO_TEXTURE, ERR_INTERNAL = 1, 2, 4, 8  # include/deodr_hip.h DEODR_HIP_ERR_*
 _STATUS_NEEDED, _STATUS_ERRORS = 11, 12  # words of the 64-byte status block at the start of the workspace
 
 
@@ -114,6 +114,8 @@ def scene_error_message(bits):
         what.append("an entry of scene.faces_uv is >= the number of uv vertices")
     if bits & ERR_NO_TEXTURE:
         what.append("a triangle is textured and shaded but the scene has no texture")
+    if bits & ERR_INTERNAL:
+        what.append("internal: a finalize workgroup of a fit step gave up waiting for the tile walkers (gradients incomplete)")
     return "invalid scene (checkSceneValid): " + "; ".join(what)
 
 

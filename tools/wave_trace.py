@@ -10,7 +10,7 @@ from deodr_amd import scenes, hip_renderer as hr
 from deodr_amd.hip_renderer import DeviceScene, HipRasterizer
 
 dev = torch.device("cuda:0")
-S, B = 1024, 8
+S, B = 1024, (int(sys.argv[sys.argv.index('--views') + 1]) if '--views' in sys.argv else 8)
 views = [scenes.sphere_scene(size=S, angle=float(a)) for a in np.linspace(-0.5, 0.5, B)]
 s0 = views[0]
 stack = lambda name: np.stack([np.asarray(getattr(v, name)) for v in views])
@@ -28,10 +28,15 @@ L = hr.lib()
 L.deodr_hip_debug_wave_trace.argtypes = [C.c_void_p, C.c_size_t]
 assert L.deodr_hip_debug_wave_trace(buf.ctypes.data, buf.nbytes) == 0
 T = ds.nb_triangles
-for which, name in enumerate(("setup_bin_kernel", "finalize_kernel", "raster_fwd_fast_kernel")):
+for which, name in enumerate(("setup_bin_kernel", "finalize_kernel (or the finalize workgroups of the forward raster)", "raster_fwd_fast_kernel (walkers)")):
     t = buf[which].astype(np.int64)
     ok = t[:, 1] > 0
     t = t[ok]
+    if len(t) == 0:
+        continue
+    if which == 1 and (buf[2][:, 1] > 0).any():  # same clock: finalize workgroups inside the forward raster are shown on the walkers' time axis
+        t0_fwd = buf[2].astype(np.int64)[buf[2][:, 1] > 0][:, 0].min()
+        print(f"   (first of these wavefronts starts {(t[:, 0].min() - t0_fwd) * 0.01:.1f} us after the first walker, the last one ends {(t[:, 1].max() - t0_fwd) * 0.01:.1f} us after it)")
     t0 = t[:, 0].min()
     start, end = (t[:, 0] - t0) * 0.01, (t[:, 1] - t0) * 0.01  # microseconds
     dur = end - start
