@@ -464,7 +464,7 @@ __global__ __launch_bounds__(SCAN_BLOCK) void tile_scan_kernel(KParams p)
 		w.edge_cnt[tile] = 0;
 	}
 	const unsigned long long wm = __ballot(work);
-	if (p.fin_in_fwd)
+	if (DR_FIN_IN_FWD && p.fin_in_fwd)
 	{ // how many walkers the finalize workgroups of the forward raster have to wait for, per block of BLK x BLK tiles
 		const int ty = tile / p.L.tiles_x, tx = tile - ty * p.L.tiles_x;
 		uint32_t *expected = w.blk_sync + (ty / BLK) * p.L.blk_x + tx / BLK;
@@ -877,7 +877,7 @@ constexpr size_t FIN_LDS_BYTES = 128 * (4 + 6 * 8); // their vertex table (dr_fi
 // the block's counter goes up.  No cache write-back: nothing else the walker wrote is read before the kernel ends.
 __device__ __forceinline__ void signal_tiles_done(const KParams &p, const ViewPtrs &w, int tile, uint32_t n, int lane)
 {
-	if (!p.fin_in_fwd)
+	if (!DR_FIN_IN_FWD || !p.fin_in_fwd)
 		return;
 #ifndef DR_FIN_PROBE
 #define DR_FIN_PROBE 0 // measurement builds (WRONG gradients): 1 = the finalize workgroups return at once, 2 = the walkers do not wait for their atomics
@@ -1547,7 +1547,7 @@ __device__ __forceinline__ void fwd_tiles(const KParams &p, WaveLds *s_lds, Edge
 			signal_tiles_done(p, w, tile, 1u, lane);
 		lds_sync(); // the next tile of this wavefront reuses the staging area
 	}
-	if (FUSED && p.fin_in_fwd && p.loss_out)
+	if (DR_FIN_IN_FWD && FUSED && p.fin_in_fwd && p.loss_out)
 	{ // (the workgroup that adds up the loss waits for every walker of every view: their partial sums are complete)
 		__atomic_signal_fence(__ATOMIC_SEQ_CST);
 		__builtin_amdgcn_s_waitcnt(0);
@@ -1594,7 +1594,7 @@ __global__ __launch_bounds__(64, DR_FWD_WAVES) void raster_fwd_fast_kernel(KPara
 #ifndef DR_FILL_DEAL
 #define DR_FILL_DEAL 1
 #endif
-	const long long dealt = (DR_FILL_DEAL && FUSED && !TEX && p.fin_in_fwd && n_walk >= 8 * n_fill) ? n_fill / 8 : 0; // groups of 64 walkers + 8 fill workgroups
+	const long long dealt = (DR_FIN_IN_FWD && DR_FILL_DEAL && FUSED && !TEX && p.fin_in_fwd && n_walk >= 8 * n_fill) ? n_fill / 8 : 0; // groups of 64 walkers + 8 fill workgroups
 	long long b = blockIdx.x, fi = -1;
 	if (b < dealt * 72)
 	{
@@ -1614,7 +1614,7 @@ __global__ __launch_bounds__(64, DR_FWD_WAVES) void raster_fwd_fast_kernel(KPara
 	{
 		if (fi < n_fill)
 			fill_share_word(p, 2, (int)(fi % p.n_views), (int)(fi / p.n_views), threadIdx.x & 63);
-		else if (FUSED && !TEX && DR_FIN_PROBE != 1)
+		else if (DR_FIN_IN_FWD && FUSED && !TEX && DR_FIN_PROBE != 1)
 		{
 			if (p.vtx_f64)
 				fin_in_fwd_role<true>(p, s_mem, fi - n_fill);

@@ -669,9 +669,6 @@ static int render_scene_fit_impl(const DeodrHipScene *sc, void *image, void *z_b
 	// the reverse sweep (128 registers at four waves per SIMD, 400 spilled on the edge path; 2048^2 / 100 k triangles / 1 view:
 	// 0.264 -> 0.407 ms with fused edges), its tiles with edges wait for raster_bwd_edge_kernel.
 	p.fuse_edges = DR_FUSE_EDGES && fused && !p.texture;
-#ifndef DR_FIN_IN_FWD
-#define DR_FIN_IN_FWD 0 // 1 = finalize under the forward raster (dr_finalize.h: parity-green, 244 GPU tests; NOT faster -- profiles/README.md, r04j)
-#endif
 	// ... and then also runs the per-primitive adjoint algebra (extra workgroups that wait for the walkers block by block: dr_finalize.h)
 	p.fin_in_fwd = DR_FIN_IN_FWD && p.fuse_edges && p.T > 0;
 	p.fill_mode = fused ? ((((sigma > 0 && !p.fuse_edges) ? 1 : 0) | ((p.T > 0 && !p.fin_in_fwd) ? 2 : 0) | ((p.T > 0 && p.fuse_edges) ? 4 : 0)) & DR_FILL_MASK) : 0;

@@ -506,7 +506,7 @@ __global__ __launch_bounds__(PRIM_BLOCK, DR_PRIM_WAVES) void setup_bin_kernel(KP
 			for (int i = 0; i < 7; i++)
 				e.pad0[i] = 0;
 			eout = e;
-			if (p.fin_in_fwd) // the list the finalize workgroups of the forward raster walk (a few hundred edges per view)
+			if (DR_FIN_IN_FWD && p.fin_in_fwd) // the list the finalize workgroups of the forward raster walk (a few hundred edges per view)
 				w.drawn_edges[atomicAdd(&w.blk_sync[2 * p.L.nblk + SYNC_DRAWN + cur], 1u)] = (uint32_t)slot;
 			DR_WAVE_PHASE(4); // record stored
 			if (e.x_begin > e.x_end || e.y_begin > e.y_end)

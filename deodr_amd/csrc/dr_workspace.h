@@ -57,6 +57,10 @@ constexpr size_t SNAP_BYTES = (CHUNKS - 1) * CH * 64 * sizeof(double);
 // Entry of the staged forward's work list (one per non-empty tile, written by tile_scan_kernel): everything a wavefront needs to
 // start on the tile comes with ONE memory round trip -- the header with a scalar load, the first triangle ids with a vector
 // load issued at the same time (a tile with more triangles reads its inline list / the spill pool as well).
+#ifndef DR_FIN_IN_FWD
+#define DR_FIN_IN_FWD 0 // 1 = finalize under the forward raster (dr_finalize.h: parity-green, 244 GPU tests; NOT faster -- profiles/README.md, r04j).
+						// With 0 nothing of it is compiled into the kernels (KParams::fin_in_fwd is never set).
+#endif
 constexpr int BLK = 8; // tiles per side of a synchronisation block (64 x 64 pixels)
 constexpr int SYNC_WALKERS = 0, SYNC_DRAWN = 1; // words behind the two per-block arrays of ViewPtrs::blk_sync
 constexpr int ENTRY_IDS = 12;
