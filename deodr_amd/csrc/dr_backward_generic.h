@@ -12,27 +12,33 @@ namespace
 // ------------------------------------------------------------------------------------------------ backward raster
 
 // adds  sum over the wave of  v * [x, y, 1]  to acc[0..2]
-__device__ __forceinline__ void add_moments(double *acc, double v, double x, double y, int lane)
+// (det: KParams::det, the deterministic mode of the un-staged kernels -- a compile-time false wherever this is inlined into a staged kernel)
+__device__ __forceinline__ void add_moments(double *acc, double v, double x, double y, int lane, bool det = false)
 {
 	double mx = wave_sum(v * x), my = wave_sum(v * y), m1 = wave_sum(v);
 	if (lane == 0)
 	{
 		if (mx != 0)
-			atomic_add_f64(acc + 0, mx);
+			acc_add(acc + 0, mx, det);
 		if (my != 0)
-			atomic_add_f64(acc + 1, my);
+			acc_add(acc + 1, my, det);
 		if (m1 != 0)
-			atomic_add_f64(acc + 2, m1);
+			acc_add(acc + 2, m1, det);
 	}
 }
 
 template <class PixT>
-__device__ __forceinline__ void texture_scatter(PixT *texture_b, const Tap &tap, int c, const double wgt[4])
+__device__ __forceinline__ void texture_scatter(PixT *texture_b, const Tap &tap, int c, const double wgt[4], long long *det_texture = nullptr)
 {
 #pragma unroll
 	for (int q = 0; q < 4; q++)
 		if (wgt[q] != 0)
-			unsafeAtomicAdd(texture_b + tap.idx[q] + c, (PixT)wgt[q]);
+		{
+			if (det_texture)
+				det_add(det_texture + tap.idx[q] + c, wgt[q]);
+			else
+				unsafeAtomicAdd(texture_b + tap.idx[q] + c, (PixT)wgt[q]);
+		}
 }
 
 // adjoint of one tile, any channel count / edge count / mode; `order` is a per-wave LDS array of MAX_SORTED entries.
@@ -44,6 +50,8 @@ __device__ __forceinline__ void bwd_tile_generic_impl(const KParams &p, int view
 	const ViewPtrs w = view_ptrs(p, view);
 	const int W = p.W, H = p.H, C = p.C, P = p.L.P;
 	const bool aa_err = !LEAN && p.aa_err;
+	const bool det = !LEAN && p.det; // (the deterministic mode runs on raster_bwd_kernel only)
+	long long *const det_tex = det ? p.det_texture : nullptr;
 	const PixT *texture = (const PixT *)p.texture;
 	PixT *texture_b = (PixT *)p.texture_b;
 	const int tile = ty * p.L.tiles_x + tx;
@@ -214,21 +222,21 @@ __device__ __forceinline__ void bwd_tile_generic_impl(const KParams &p, int view
 							double wgt[4];
 							bilinear_mix_adjoint(etap, diff_B * eL, i00, i10, i01, i11, wgt, e_B);
 							if (texture_b)
-								texture_scatter(texture_b, etap, c, wgt);
+								texture_scatter(texture_b, etap, c, wgt, det_tex);
 						}
 						else // H.h:2579-2588, with the row fold the reference forgot (defect D2) restored
 							A_B = 2 * (interp_channel(ep, c, x, y, false, 0.0) - (double)obs[c]) * Err_B;
 					}
 					if (e.kind != KIND_TEXTURED || !TEX)
-						add_moments(eacc + 3 * c, A_B, x, y, lane);
+						add_moments(eacc + 3 * c, A_B, x, y, lane, det);
 				}
 				if (e.kind == KIND_TEXTURED && TEX)
 				{
-					add_moments(eacc + 0, (hit && !etap.out[0]) ? e_B[0] : 0.0, x, y, lane);
-					add_moments(eacc + 3, (hit && !etap.out[1]) ? e_B[1] : 0.0, x, y, lane);
-					add_moments(eacc + 6, L_B, x, y, lane);
+					add_moments(eacc + 0, (hit && !etap.out[0]) ? e_B[0] : 0.0, x, y, lane, det);
+					add_moments(eacc + 3, (hit && !etap.out[1]) ? e_B[1] : 0.0, x, y, lane, det);
+					add_moments(eacc + 6, L_B, x, y, lane, det);
 				}
-				add_moments(eacc + 3 * P, T_B, x, y, lane);
+				add_moments(eacc + 3 * P, T_B, x, y, lane, det);
 			}
 		}
 	}
@@ -368,7 +376,7 @@ __device__ __forceinline__ void bwd_tile_generic_impl(const KParams &p, int view
 								double wgt[4];
 								bilinear_mix_adjoint(etap, a_b, i00, i10, i01, i11, wgt, e_B);
 								if (texture_b)
-									texture_scatter(texture_b, etap, c, wgt);
+									texture_scatter(texture_b, etap, c, wgt, det_tex);
 							}
 							else
 							{ // H.h:1726-1746
@@ -379,15 +387,15 @@ __device__ __forceinline__ void bwd_tile_generic_impl(const KParams &p, int view
 							g[j] *= Tr;
 						}
 						if (e.kind != KIND_TEXTURED || !TEX)
-							add_moments(eacc + 3 * c, A_B, x, y, lane);
+							add_moments(eacc + 3 * c, A_B, x, y, lane, det);
 					}
 					if (e.kind == KIND_TEXTURED && TEX)
 					{
-						add_moments(eacc + 0, (hit && !etap.out[0]) ? e_B[0] : 0.0, x, y, lane);
-						add_moments(eacc + 3, (hit && !etap.out[1]) ? e_B[1] : 0.0, x, y, lane);
-						add_moments(eacc + 6, L_B, x, y, lane);
+						add_moments(eacc + 0, (hit && !etap.out[0]) ? e_B[0] : 0.0, x, y, lane, det);
+						add_moments(eacc + 3, (hit && !etap.out[1]) ? e_B[1] : 0.0, x, y, lane, det);
+						add_moments(eacc + 6, L_B, x, y, lane, det);
 					}
-					add_moments(eacc + 3 * P, T_B, x, y, lane);
+					add_moments(eacc + 3 * P, T_B, x, y, lane, det);
 				}
 			}
 			// adjoint of pass 1: what is left of g belongs to the triangle that owns the pixel (H.h:1024-1037, 1320-1353)
@@ -406,7 +414,7 @@ __device__ __forceinline__ void bwd_tile_generic_impl(const KParams &p, int view
 					double wgt[4];
 					bilinear_mix_adjoint(tap, g[j] * L, i00, i10, i01, i11, wgt, own_e_B);
 					if (texture_b)
-						texture_scatter(texture_b, tap, c, wgt);
+						texture_scatter(texture_b, tap, c, wgt, det_tex);
 				}
 			}
 			// segmented wave reduction over the distinct interpolated owners of the tile
@@ -421,7 +429,7 @@ __device__ __forceinline__ void bwd_tile_generic_impl(const KParams &p, int view
 #pragma unroll
 				for (int j = 0; j < CH; j++)
 					if (c0 + j < C)
-						add_moments(acc + 3 * (c0 + j), mine ? g[j] : 0.0, x, y, lane);
+						add_moments(acc + 3 * (c0 + j), mine ? g[j] : 0.0, x, y, lane, det);
 			}
 		}
 	}
@@ -434,9 +442,9 @@ __device__ __forceinline__ void bwd_tile_generic_impl(const KParams &p, int view
 		const bool mine = owner == cur && kind == KIND_TEXTURED && TEX;
 		rem &= ~__ballot(owner == cur);
 		double *acc = w.tri_acc + (size_t)cur * 3 * P;
-		add_moments(acc + 0, (mine && !tap.out[0]) ? own_e_B[0] : 0.0, x, y, lane);
-		add_moments(acc + 3, (mine && !tap.out[1]) ? own_e_B[1] : 0.0, x, y, lane);
-		add_moments(acc + 6, mine ? own_L_B : 0.0, x, y, lane);
+		add_moments(acc + 0, (mine && !tap.out[0]) ? own_e_B[0] : 0.0, x, y, lane, det);
+		add_moments(acc + 3, (mine && !tap.out[1]) ? own_e_B[1] : 0.0, x, y, lane, det);
+		add_moments(acc + 6, mine ? own_L_B : 0.0, x, y, lane, det);
 	}
 }
 

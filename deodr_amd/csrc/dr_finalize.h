@@ -62,7 +62,9 @@ struct MergeSink // finalize_triangle's sink: corner i of the triangle adds into
 	__device__ __forceinline__ void uv(int, int, double) {} // (KIND_INTERP triangles only)
 };
 
-template <bool VTX64, int NC> // (the dtype of the vertex arrays and the channel count at compile time: see setup_bin_kernel)
+// DET: the deterministic mode (KParams::det): accumulators are read as int64 fixed point, contributions go to the int64 shadow arrays,
+// no vertex table (its LDS atomics are shared by four wavefronts: their order is not reproducible).
+template <bool VTX64, int NC, bool DET = false> // (the dtype of the vertex arrays and the channel count at compile time: see setup_bin_kernel)
 #ifndef DR_FIN_WAVES
 #define DR_FIN_WAVES 4 // waves per SIMD finalize_kernel is compiled for (3: 144 registers with the vertex table, 21.4 -> 22.4 us)
 #endif
@@ -120,6 +122,47 @@ __global__ __launch_bounds__(PRIM_BLOCK, DR_FIN_WAVES) void finalize_kernel(KPar
 	g.shade_b = (char *)p.shade_b + (size_t)view * p.V * es;
 	g.uv_b = p.uv_b;
 	const int P = s.P;
+	if constexpr (DET)
+	{ // the deterministic mode: plain and slow (one round trip after the other) -- it exists for tests, not for speed
+		const DetAdd dadd = {g.ij_b, g.colors_b, g.shade_b, p.det_ij + (size_t)view * p.V * 2, p.det_colors + (size_t)view * p.V * p.C,
+							 p.det_shade + (size_t)view * p.V, p.det_uv};
+		double la[3 * DEODR_HIP_MAX_COLORS + 3];
+		if (tri_block)
+		{
+			const int k = pw.index * PRIM_BLOCK + threadIdx.x;
+			if (k >= p.T)
+				return;
+			const uint32_t flag = w.tri_flag[k];
+			const uint32_t f0 = p.faces[3 * (size_t)k], f1 = p.faces[3 * (size_t)k + 1], f2 = p.faces[3 * (size_t)k + 2];
+			if (!(flag & 4u) || (flag & 3u) == KIND_NONE || (int32_t)(f0 | f1 | f2) < 0)
+				return;
+			double *acc = w.tri_acc + (size_t)k * 3 * P;
+			for (int i = 0; i < 3 * P; i++)
+				la[i] = det_value(acc + i);
+			AtomicSinkT<DetAdd> sink = {s, g, {f0, f1, f2}, {p.faces_uv[3 * (size_t)k], p.faces_uv[3 * (size_t)k + 1], p.faces_uv[3 * (size_t)k + 2]}, dadd};
+			finalize_triangle<false>(s, k, (int)(flag & 3u), la, sink);
+			for (int i = 0; i < 3 * P; i++)
+				acc[i] = 0;
+			return;
+		}
+		const uint32_t n_flagged = compact_flagged_slots(p, s.edgeflags, pw.index);
+		for (int round = 0; round * PRIM_BLOCK < (int)n_flagged; round++)
+		{
+			const int slot = edge_round_slot(n_flagged, round);
+			if (slot < 0)
+				continue;
+			const EdgeRec &er = w.edge_rec[slot];
+			if (er.kind == KIND_NONE)
+				continue;
+			double *acc = w.edge_acc + (size_t)slot * (3 * P + 3);
+			for (int i = 0; i < 3 * P + 3; i++)
+				la[i] = det_value(acc + i);
+			finalize_edge(s, g, slot / 3, slot % 3, er, la, dadd);
+			for (int i = 0; i < 3 * P + 3; i++)
+				acc[i] = 0;
+		}
+		return;
+	}
 	if (tri_block)
 	{
 		const int k = pw.index * PRIM_BLOCK + threadIdx.x;
@@ -245,6 +288,23 @@ __global__ __launch_bounds__(PRIM_BLOCK, DR_FIN_WAVES) void finalize_kernel(KPar
 	}
 }
 
+
+// Deterministic mode, last step: every element of a gradient array receives the integer sum of its shadow (one thread per element: a
+// fixed order of two operands) and the shadow is cleared for the next call.
+__global__ __launch_bounds__(256) void det_convert_kernel(long long *shadow, void *out, size_t n, int f64)
+{
+	const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+	if (i >= n)
+		return;
+	const long long v = shadow[i];
+	if (v == 0)
+		return;
+	shadow[i] = 0;
+	if (f64)
+		((double *)out)[i] += (double)v * DET_INV_SCALE;
+	else
+		((float *)out)[i] += (float)((double)v * DET_INV_SCALE);
+}
 
 // ------------------------------------------------------------------------ finalize under the forward raster (round 4)
 //

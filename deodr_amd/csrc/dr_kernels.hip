@@ -191,6 +191,65 @@ bool g_profile = false;	  // the launches of the current call are bracketed by e
 int g_profile_every = 0;	  // deodr_hip_profile_enable(n): 0 off, n > 0: every n-th forward (and the adjoint that follows it)
 unsigned g_profile_calls = 0; // forwards seen since profiling was enabled
 bool g_force_generic = false; // deodr_hip_force_generic(1): run the un-staged kernels (the parity suite covers both families)
+bool g_det = false;			  // deodr_hip_set_deterministic(1): un-staged kernels + integer accumulation (KParams::det)
+
+// int64 shadows of the gradient arrays in the deterministic mode: ONE library-owned buffer per device, grown on demand (the only
+// allocation the library ever makes, and only in this mode: a test mode), zero between calls (det_convert_kernel clears what it reads)
+struct DetScratch
+{
+	long long *ptr = nullptr;
+	size_t words = 0;
+};
+std::mutex g_det_mutex;
+std::vector<DetScratch> g_det_scratch;
+int det_shadows(KParams &p, int n_views, hipStream_t st)
+{
+	const size_t n_ij = (size_t)n_views * p.V * 2, n_col = (size_t)n_views * p.V * p.C, n_sh = (size_t)n_views * p.V, n_uv = (size_t)p.Vuv * 2,
+				 n_tex = p.texture_b ? (size_t)p.tex_h * p.tex_w * p.C : 0, need = n_ij + n_col + n_sh + n_uv + n_tex;
+	int dev = 0;
+	if (check_hip(hipGetDevice(&dev), "hipGetDevice"))
+		return 1;
+	std::lock_guard<std::mutex> lock(g_det_mutex);
+	if ((size_t)dev >= g_det_scratch.size())
+		g_det_scratch.resize(dev + 1);
+	DetScratch &sc = g_det_scratch[dev];
+	if (sc.words < need)
+	{
+		hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+		(void)hipStreamIsCapturing(st, &cap);
+		if (cap != hipStreamCaptureStatusNone)
+			return fail("deterministic mode: the shadow buffer has to grow, which cannot happen under stream capture (run the step once before capturing)");
+		if (check_hip(hipDeviceSynchronize(), "deterministic mode: synchronise"))
+			return 1;
+		if (sc.ptr)
+			(void)hipFree(sc.ptr);
+		sc.ptr = nullptr, sc.words = 0;
+		if (check_hip(hipMalloc((void **)&sc.ptr, 8 * need), "deterministic mode: shadow buffer") || check_hip(hipMemset(sc.ptr, 0, 8 * need), "deterministic mode: clear"))
+			return 1;
+		sc.words = need;
+	}
+	p.det = 1;
+	p.det_ij = sc.ptr;
+	p.det_colors = p.det_ij + n_ij;
+	p.det_shade = p.det_colors + n_col;
+	p.det_uv = p.det_shade + n_sh;
+	p.det_texture = n_tex ? p.det_uv + n_uv : nullptr;
+	return 0;
+}
+void det_convert(const KParams &p, int n_views, hipStream_t st)
+{
+	const size_t n_ij = (size_t)n_views * p.V * 2, n_col = (size_t)n_views * p.V * p.C, n_sh = (size_t)n_views * p.V, n_uv = (size_t)p.Vuv * 2,
+				 n_tex = p.det_texture ? (size_t)p.tex_h * p.tex_w * p.C : 0;
+	auto run = [&](long long *shadow, void *out, size_t n, int f64) {
+		if (n && out)
+			hipLaunchKernelGGL(det_convert_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, shadow, out, n, f64);
+	};
+	run(p.det_ij, p.ij_b, n_ij, p.vtx_f64);
+	run(p.det_colors, p.colors_b, n_col, p.vtx_f64);
+	run(p.det_shade, p.shade_b, n_sh, p.vtx_f64);
+	run(p.det_uv, p.uv_b, n_uv, p.vtx_f64);
+	run(p.det_texture, p.texture_b, n_tex, p.pix_f64);
+}
 // Tuning constants (measured in round 1, profiles/README.md); deliberately NOT read from the environment: nothing outside the
 // arguments of a call may change what the call launches.
 #ifndef DR_EDGE_WAVES
@@ -377,7 +436,7 @@ int launch_forward(const DeodrHipScene *sc, KParams &p, hipStream_t stream, hipE
 	*join = nullptr;
 	g_profile = g_profile_every > 0 && (g_profile_calls++ % (unsigned)g_profile_every) == 0;
 	p.n_views = n_views;
-	const bool fast = !p.aa_err && p.C <= CH && !g_force_generic;
+	const bool fast = !p.aa_err && p.C <= CH && !g_force_generic && !g_det;
 	if (p.T > 0)
 	{
 		dim3 grid((unsigned)prim_blocks(p.T) * (unsigned)n_views);
@@ -423,8 +482,10 @@ int join_side(hipStream_t stream, hipEvent_t join) { return join ? check_hip(hip
 // adjoint raster and the per-primitive finalize; owner_tiles = false after a fused forward
 int launch_adjoint(const DeodrHipScene *sc, KParams &p, hipStream_t st, bool owner_tiles)
 {
-	const bool fast = !p.aa_err && p.C <= CH && !g_force_generic;
+	const bool fast = !p.aa_err && p.C <= CH && !g_force_generic && !g_det;
 	p.n_views = sc->n_views;
+	if (g_det && det_shadows(p, sc->n_views, st))
+		return 1;
 	// persistent waves of the edge kernel: enough to cover a silhouette-heavy single view, few enough that with many views
 	// the waves that find their sub-list exhausted cost nothing
 	const int edge_waves = p.L.ntiles < EDGE_WAVES ? p.L.ntiles : EDGE_WAVES;
@@ -443,8 +504,15 @@ int launch_adjoint(const DeodrHipScene *sc, KParams &p, hipStream_t st, bool own
 		dim3 g2((unsigned)prim_blocks(p.T) * (unsigned)sc->n_views + (unsigned)((fill_words + PRIM_BLOCK / 64 - 1) / (PRIM_BLOCK / 64)) +
 				(p.loss_out ? 1u : 0u)); // (+ the workgroup that adds up the loss)
 		ScopedKernelTimer t(KID_FINALIZE, st);
-		DR_LAUNCH_PRIM(finalize_kernel, g2, st);
+		if (p.det && p.vtx_f64)
+			hipLaunchKernelGGL((finalize_kernel<true, 0, true>), g2, dim3(PRIM_BLOCK), 0, st, p);
+		else if (p.det)
+			hipLaunchKernelGGL((finalize_kernel<false, 0, true>), g2, dim3(PRIM_BLOCK), 0, st, p);
+		else
+			DR_LAUNCH_PRIM(finalize_kernel, g2, st);
 	}
+	if (p.det)
+		det_convert(p, sc->n_views, st);
 	return check_hip(hipGetLastError(), "backward launch");
 }
 
@@ -506,6 +574,12 @@ int deodr_hip_abi_version(void) { return DEODR_HIP_ABI_VERSION; }
 int deodr_hip_force_generic(int on)
 {
 	g_force_generic = on != 0;
+	return 0;
+}
+
+int deodr_hip_set_deterministic(int on)
+{
+	g_det = on != 0;
 	return 0;
 }
 
@@ -654,7 +728,7 @@ static int render_scene_fit_impl(const DeodrHipScene *sc, void *image, void *z_b
 		if (p.texture_b && check_hip(hipMemsetAsync(p.texture_b, 0, (size_t)p.tex_h * p.tex_w * p.C * ps, st), "clear texture_b"))
 			return 1;
 	}
-	const bool fused = p.C <= CH && !g_force_generic;
+	const bool fused = p.C <= CH && !g_force_generic && !g_det;
 	const bool loss_in_kernels = loss_out && fused && p.T > 0; // (the tile walkers of the staged forward + finalize's last workgroup)
 	if (loss_in_kernels)
 		p.loss_tile_bg = tile_loss, p.loss_wave = loss_scratch, p.loss_out = loss_out;

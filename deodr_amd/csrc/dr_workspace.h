@@ -207,6 +207,13 @@ struct KParams
 	// extra workgroups at the end of its grid that wait, block of tiles by block of tiles, for the walkers (set by the host; the
 	// set-up kernel then lists the edges it draws, the scan kernel counts the non-empty tiles of every block)
 	int fin_in_fwd;
+	// Deterministic accumulation (deodr_hip_set_deterministic; the un-staged kernels only): every gradient sum is an INTEGER sum of
+	// contributions rounded to multiples of 2^-32 -- integer addition is associative, so the order in which the memory system executes
+	// the atomics no longer shows in the result (the reference is bit-reproducible by construction: one thread, H.h:1029-1037).  The
+	// moment accumulators of the workspace hold int64 then (zero is zero in both readings); the vertex / texture gradients are summed
+	// in int64 shadow arrays (det_*: library-owned scratch) and added to the caller's arrays by one thread per element afterwards.
+	int det;
+	long long *det_ij, *det_colors, *det_shade, *det_uv, *det_texture;
 	// loss of a fit step, sum (image - obs)^2 (deodr_hip_render_scene_fit_loss): loss_tile_bg[0] = the loss of a frame that is all
 	// background, [1 + view * ntiles + tile] = that of one tile; loss_wave[view * LOSS_SLOTS + q % LOSS_SLOTS]: walker q of the forward
 	// raster adds (loss of a tile - its background loss) for every tile it walks; one workgroup of finalize_kernel writes loss_out[0] =
@@ -345,6 +352,22 @@ __device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirs
 
 __device__ __forceinline__ void atomic_add_f64(double *p, double v) { unsafeAtomicAdd(p, v); }
 
+// fixed point of the deterministic mode: |sum| < 2^31, resolution 2^-32
+constexpr double DET_SCALE = 4294967296.0, DET_INV_SCALE = 1.0 / 4294967296.0;
+__device__ __forceinline__ void det_add(void *slot, double v)
+{
+	atomicAdd((unsigned long long *)slot, (unsigned long long)__double2ll_rn(v * DET_SCALE));
+}
+__device__ __forceinline__ double det_value(const double *slot) { return (double)*(const long long *)slot * DET_INV_SCALE; }
+// accumulate into a moment accumulator of the workspace
+__device__ __forceinline__ void acc_add(double *slot, double v, bool det)
+{
+	if (det)
+		det_add(slot, v);
+	else
+		unsafeAtomicAdd(slot, v);
+}
+
 // Cross-lane moves on the VALU (DPP), no LDS round trip.  CTRL: 0x110 + n = row_shr:n (lane i <- lane i - n inside its
 // 16-lane row), 0x100 + n = row_shl:n (lane i <- lane i + n); lanes without a source read 0.
 template <int CTRL>
@@ -410,6 +433,18 @@ __device__ __forceinline__ double wave_sum16(double *v, int lane)
 	return r;
 }
 
+struct DetAdd // deterministic mode: the same contribution into the int64 shadow of the array (KParams::det_*, this view's part)
+{
+	const void *ij_b, *colors_b, *shade_b; // the view's arrays as the caller of the functor names them
+	long long *ij, *colors, *shade, *uv;
+	__device__ __forceinline__ void operator()(void *arr, size_t i, bool, double v) const
+	{
+		if (v == 0)
+			return;
+		det_add((arr == ij_b ? ij : (arr == colors_b ? colors : (arr == shade_b ? shade : uv))) + i, v);
+	}
+};
+
 struct DeviceAdd // accumulate a vertex gradient (the reference's `+=` into scene.*_b)
 {
 	__device__ __forceinline__ void operator()(void *arr, size_t i, bool f64, double v) const
@@ -423,22 +458,21 @@ struct DeviceAdd // accumulate a vertex gradient (the reference's `+=` into scen
 	}
 };
 
-// finalize_triangle's sinks (dr_prims.h).  AtomicSink: every contribution goes straight to the gradient arrays.
-struct AtomicSink
+// finalize_triangle's sinks (dr_prims.h).  AtomicSink: every contribution goes straight to the gradient arrays (Add = DeviceAdd), or to
+// their int64 shadows (DetAdd).
+template <class Add = DeviceAdd>
+struct AtomicSinkT
 {
 	const SceneView &s;
 	const GradView &g;
 	uint32_t f[3], fuv[3];
-	__device__ __forceinline__ void color(int i, int c, double v)
-	{
-		if ((DR_ABLATE & 131072) && c >= 2) // (measurement build: a third fewer atomic instructions per triangle)
-			return;
-		DeviceAdd()(g.colors_b, (size_t)f[i] * s.C + c, s.vtx_f64, v);
-	}
-	__device__ __forceinline__ void shade(int i, double v) { DeviceAdd()(g.shade_b, f[i], s.vtx_f64, v); }
-	__device__ __forceinline__ void uv(int i, int c, double v) { DeviceAdd()(g.uv_b, 2 * (size_t)fuv[i] + c, s.vtx_f64, v); }
-	__device__ __forceinline__ void ij(int i, int d, double v) { DeviceAdd()(g.ij_b, 2 * (size_t)f[i] + d, s.vtx_f64, v); }
+	Add add;
+	__device__ __forceinline__ void color(int i, int c, double v) { add(g.colors_b, (size_t)f[i] * s.C + c, s.vtx_f64, v); }
+	__device__ __forceinline__ void shade(int i, double v) { add(g.shade_b, f[i], s.vtx_f64, v); }
+	__device__ __forceinline__ void uv(int i, int c, double v) { add(g.uv_b, 2 * (size_t)fuv[i] + c, s.vtx_f64, v); }
+	__device__ __forceinline__ void ij(int i, int d, double v) { add(g.ij_b, 2 * (size_t)f[i] + d, s.vtx_f64, v); }
 };
+typedef AtomicSinkT<DeviceAdd> AtomicSink;
 // XCD-aware block order: the dispatcher sends block b to XCD b % 8; give every XCD one contiguous band of the
 // screen so that neighbouring tiles (which share triangle records) share an L2.  Bijective for any block count.
 __device__ __forceinline__ int xcd_band(int b, int n)

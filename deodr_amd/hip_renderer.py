@@ -20,7 +20,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libdeodr_hip.so")
-ABI_VERSION = 8
+ABI_VERSION = 9
 ERR_FACES, ERR_FACES_UV, ERR_NO_TEXTURE, ERR_INTERNAL = 1, 2, 4, 8  # include/deodr_hip.h DEODR_HIP_ERR_*
 _STATUS_NEEDED, _STATUS_ERRORS = 11, 12  # words of the 64-byte status block at the start of the workspace
 
@@ -89,6 +89,12 @@ def lib():
         L.deodr_hip_copy_probe.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p]
         _lib = L
     return _lib
+
+
+def set_deterministic(on):
+    """``deodr_hip_set_deterministic``: integer accumulation on the un-staged kernels -- gradients bit-identical from run to run (slow;
+    for tests and for debugging an optimiser).  Process-wide."""
+    lib().deodr_hip_set_deterministic(int(bool(on)))
 
 
 def force_generic(on):

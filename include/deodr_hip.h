@@ -287,12 +287,22 @@ int deodr_hip_copy_probe(void *dst, const void *src, size_t bytes, int mode, int
  * hook above) is the only process-wide state; the library reads NO environment variable. */
 int deodr_hip_force_generic(int on);
 
+/* Deterministic accumulation (the reference is bit-reproducible by construction -- one thread,
+ * DifferentiableRenderer.h:1029-1037).  Non-zero: every later call runs the un-staged kernels with INTEGER accumulation -- each
+ * contribution to a moment accumulator, a vertex gradient or the texture gradient is rounded to a multiple of 2^-32 and added as a
+ * 64-bit integer, so the order in which the memory system executes the atomics no longer shows: gradients (and, in a fit step, the
+ * loss) are bit-identical from run to run.  Limits: |any gradient sum| < 2^31, resolution 2^-32 (~2.3e-10) per contribution;
+ * several times slower than the default path (it is a mode for tests and for debugging an optimiser, default off); the library
+ * allocates an int64 shadow of the gradient arrays the first time (hipMalloc: not under stream capture).  Process-wide, like
+ * deodr_hip_force_generic. */
+int deodr_hip_set_deterministic(int on);
+
 /* Message of the last error returned on this host thread. */
 const char *deodr_hip_last_error(void);
 
 /* ABI version of this header; bumped on any incompatible change. */
 int deodr_hip_abi_version(void);
-#define DEODR_HIP_ABI_VERSION 8
+#define DEODR_HIP_ABI_VERSION 9
 
 #ifdef __cplusplus
 }

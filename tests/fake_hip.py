@@ -60,6 +60,9 @@ class FakeLib:
         a._obj.value, b._obj.value = 0, 0
         return 0
 
+    def deodr_hip_set_deterministic(self, on):
+        return 0  # (the checker is single-threaded: always deterministic)
+
     def deodr_hip_force_generic(self, on):
         self.generic = int(on)
 

@@ -1,0 +1,173 @@
+"""GPU tests added in round 4 (through the C ABI, like the others):
+
+* the deterministic mode (deodr_hip_set_deterministic, SURVEY.md section 7 "provide a deterministic two-stage mode for tests"): every
+  gradient -- texture gradient and loss included -- BIT-IDENTICAL from run to run, within the usual tolerance of the checker, on a
+  textured soup, an 8-view mesh batch, the antialiase_error variant; a 30-iteration fit run twice, bit for bit;
+* finalize_kernel with and without its per-workgroup vertex table (launches on either side of the size threshold) against the checker;
+* a camera shared by several views (`DeviceCamera` expands every array per view);
+* the library's streaming-copy probe moves the bytes it says.
+"""
+
+import numpy as np
+import pytest
+import torch
+
+from deodr_amd import scenes
+from test_oracle import random_scene
+
+pytestmark = pytest.mark.gpu
+
+F32, F64 = torch.float32, torch.float64
+
+
+def checker(api, fixed=False):
+    return api.ref(fixed=fixed) or api.port(fixed=fixed)
+
+
+@pytest.fixture
+def deterministic():
+    from deodr_amd import hip_renderer as hr
+
+    hr.set_deterministic(True)
+    yield
+    hr.set_deterministic(False)
+
+
+def _clone(g):
+    return {k: v.clone() for k, v in g.items() if v is not None}
+
+
+def _all_equal(a, b):
+    return all(torch.equal(a[k], b[k]) for k in a)
+
+
+@pytest.mark.parametrize("dt", [F32, F64])
+def test_deterministic_mode_textured_soup_bit_identical_and_right(oracle_api, deterministic, dt):
+    """two-call path (render + render_backward) and the fit step, mixed textured / untextured soup with silhouette edges everywhere"""
+    from hip_util import device_scene, rel_err
+    from deodr_amd.hip_renderer import HipRasterizer
+
+    s = random_scene(4100)  # 24 slanted triangles, half of them textured, every edge flagged
+    s.backface_culling = True
+    ds = device_scene(s, dt)
+    r = HipRasterizer.for_scene(ds)
+    rng = np.random.RandomState(3)
+    image_b = torch.as_tensor(rng.randn(1, s.height, s.width, s.nb_colors), device=ds.device).to(dt)
+    obs = torch.as_tensor(rng.rand(1, s.height, s.width, s.nb_colors), device=ds.device).to(dt)
+    runs, fits = [], []
+    for _ in range(3):
+        image, z = r.render(ds, 1.0, check_overflow=True)
+        runs.append(_clone(r.render_backward(ds, image_b=image_b)))
+        image_f, z_f, g = r.render_fit(ds, obs, 1.0, check_overflow=True, clear_grads=True)
+        fits.append(_clone(g))
+        torch.cuda.synchronize()
+    assert all(_all_equal(runs[0], x) for x in runs[1:]), "two-call gradients differ from run to run in the deterministic mode"
+    assert all(_all_equal(fits[0], x) for x in fits[1:]), "fit-step gradients differ from run to run in the deterministic mode"
+    ref = checker(oracle_api, fixed=True)
+    img_ref, z_ref = ref.render(s, 1.0)
+    g_ref = ref.grads(s, 1.0, img_ref, z_ref, image_b[0].cpu().numpy().astype(np.float64))
+    tol = 1e-4 if dt == F32 else 1e-6  # (contributions are rounded to 2^-32: not the 1e-8 of the floating-point path)
+    for k in ("ij_b", "colors_b", "uv_b", "shade_b", "texture_b"):
+        got = runs[0][k].cpu().numpy()
+        got = got[0] if k in ("ij_b", "colors_b", "shade_b") else got
+        assert rel_err(got, g_ref[k]) < tol, k
+
+
+def test_deterministic_mode_eight_views_and_error_buffer(oracle_api, deterministic):
+    from hip_util import device_scene
+    from deodr_amd.hip_renderer import HipRasterizer
+
+    views = [scenes.sphere_scene(size=256, nu=40, n_rings=40, angle=float(a), textured=True, texture_size=64, nb_colors=3) for a in np.linspace(-0.4, 0.4, 8)]
+    ds = device_scene(views, F32)
+    r = HipRasterizer.for_scene(ds)
+    obs = torch.as_tensor(np.random.RandomState(5).rand(8, 256, 256, 3).astype(np.float32), device=ds.device)
+    fits = []
+    for _ in range(3):
+        _, _, g = r.render_fit(ds, obs, 1.0, check_overflow=True, clear_grads=True)
+        fits.append(_clone(g))
+    assert all(_all_equal(fits[0], x) for x in fits[1:])
+    assert float(fits[0]["texture_b"].abs().max()) > 0 and float(fits[0]["uv_b"].abs().max()) > 0
+    # antialiase_error: forward err buffer, adjoint from err_buffer_b
+    errs = []
+    for _ in range(2):
+        image, z, err = r.render(ds, 1.0, True, obs, check_overflow=True)
+        errs.append(_clone(r.render_backward(ds, err_buffer_b=torch.ones_like(err))))
+    assert _all_equal(errs[0], errs[1])
+
+
+def test_deterministic_mode_fit_twice_bit_for_bit(oracle_api, deterministic):
+    """a 30-iteration soup fit through Scene2D.render_compare_and_backward (the loop of deodr/examples/triangle_soup_fitting.py:100-184):
+    losses and final vertices identical, bit for bit, in two runs -- as the single-threaded reference is"""
+    from conftest import golden_soup
+
+    def run():
+        gt, _ = golden_soup(0, "gt_")
+        target = checker(oracle_api).render(gt, 1)[0]
+        scene, _ = golden_soup(0, "init_")
+        speed = np.zeros_like(scene.ij)
+        losses = []
+        for _ in range(30):
+            scene.clear_gradients()
+            _, _, _, loss = scene.render_compare_and_backward(obs=target, sigma=1, antialiase_error=False)
+            losses.append(loss)
+            speed = 0.80 * speed - scene.ij_b * 0.01
+            scene.ij = scene.ij + speed
+        return np.array(losses), np.array(scene.ij)
+
+    l1, ij1 = run()
+    l2, ij2 = run()
+    assert np.array_equal(l1, l2) and np.array_equal(ij1, ij2)
+    assert l1[-1] < 0.6 * l1[0]  # (and it does fit: 4186 -> 2116 in 30 iterations)
+
+
+@pytest.mark.parametrize("n_views", [1, 3])
+def test_finalize_with_and_without_vertex_table(oracle_api, n_views):
+    """20 000 triangles: one view stays below the size at which finalize_kernel merges vertex adjoints in its LDS table, three views
+    are above it -- same gradients (to rounding) as the checker's, view by view"""
+    from hip_util import device_scene, rel_err
+    from deodr_amd.hip_renderer import HipRasterizer
+
+    views = [scenes.sphere_scene(size=256, angle=float(a)) for a in np.linspace(-0.3, 0.3, n_views)]
+    ds = device_scene(views, F64)
+    r = HipRasterizer.for_scene(ds)
+    obs = torch.as_tensor(np.random.RandomState(6).rand(n_views, 256, 256, 4), device=ds.device)
+    image, z, g = r.render_fit(ds, obs, 1.0, check_overflow=True, clear_grads=True)
+    torch.cuda.synchronize()
+    ref = checker(oracle_api)
+    for i, s in enumerate(views):
+        img_ref, z_ref = ref.render(s, 1.0)
+        g_ref = ref.grads(s, 1.0, img_ref, z_ref, 2 * (img_ref - obs[i].cpu().numpy()))
+        for k in ("ij_b", "colors_b"):
+            assert rel_err(g[k][i].cpu().numpy(), g_ref[k]) < 1e-8, (k, i)
+
+
+def test_camera_shared_by_the_views_is_expanded():
+    """extrinsic [n,3,4] with ONE intrinsic [3,3] (and the other way round): the fused projection indexes every array per view"""
+    from deodr_amd.scene3d import DeviceCamera
+
+    rng = np.random.RandomState(0)
+    pts = torch.as_tensor(rng.rand(50, 3) + np.array([0, 0, 4.0]), device="cuda")
+    K = np.array([[300.0, 0, 64], [0, 300.0, 48], [0, 0, 1]])
+    E = np.stack([np.column_stack((np.eye(3), np.array([0.1 * i, 0, 0]))) for i in range(4)])
+    shared = DeviceCamera(E, K, 96, 128)  # one intrinsic for four views
+    full = DeviceCamera(E, np.stack([K] * 4), 96, 128)
+    ij_a, d_a = shared.project_points(pts)
+    ij_b, d_b = full.project_points(pts)
+    assert ij_a.shape == (4, 50, 2) and torch.equal(ij_a, ij_b) and torch.equal(d_a, d_b)
+    one_e = DeviceCamera(E[0], np.stack([K, 2 * K]), 96, 128)  # one extrinsic for two intrinsics
+    ij_c, _ = one_e.project_points(pts)
+    assert ij_c.shape == (2, 50, 2) and torch.allclose(ij_c[0], ij_a[0])
+    with pytest.raises(ValueError):
+        DeviceCamera(E, np.stack([K] * 3), 96, 128)
+
+
+def test_copy_probe_copies():
+    from deodr_amd import hip_renderer as hr
+
+    a = torch.arange(1 << 20, dtype=torch.int32, device="cuda")
+    b = torch.zeros_like(a)
+    st = torch.cuda.current_stream().cuda_stream
+    assert hr.lib().deodr_hip_copy_probe(b.data_ptr(), a.data_ptr(), a.numel() * 4, 0, 1, st) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(a, b)
+    assert hr.lib().deodr_hip_copy_probe(b.data_ptr(), a.data_ptr(), 24, 0, 1, st) != 0  # not a multiple of 16
