@@ -12,7 +12,7 @@ multi-view fitter does on the host at deodr/mesh_fitter.py:518-527).  Views shar
 collective, per-GPU work is fixed as N grows ("weak").
 
 The JSON line carries, besides the driver's contract:
-  roofline      dominant kernel group (largest summed hipEvent time; "raster_fwd_kernel" = tile scan + forward raster -- which in a
+  roofline      dominant kernel group (largest average duration, from device time stamps of EVERY step of the timed region; "raster_fwd_kernel" = tile scan + forward raster -- which in a
                 fit step also back-propagates every tile and streams two thirds of the background fill --, "finalize_kernel" =
                 finalize + the last third of the fill): achieved = SURVEY.md 8d bytes that group moves (float32 buffers) / its
                 average duration, measured with hipEvents on the launch stream inside the timed region; `peak` = 8 TB/s (spec),
@@ -328,7 +328,7 @@ def main():
     ap.add_argument("--no-single-view", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true")
     ap.add_argument("--no-parity-check", action="store_true")
-    ap.add_argument("--time-every", type=int, default=20, help="steps between two steps whose kernels are timed with hipEvents (0: never)")
+    ap.add_argument("--time-every", type=int, default=20, help="0: no per-kernel timing (otherwise: device time stamps on every step, hipEvents on 6 steps after the timed region)")
     ap.add_argument("--two-pass", action="store_true", help="render and render_backward as two calls (default: the fused fit step, same outputs)")
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed even for one rank (exercises the RCCL path)")
     ap.add_argument("--test-backend", choices=["nccl", "gloo"], default="nccl",
@@ -487,31 +487,45 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # per-kernel hipEvents on every 4th step of the timed region (an event pair takes ~3 us of stream time: timing all
-    # launches of every step would add ~10 % to the step being measured)
-    # (at least five timed steps whatever --steps is: the driver's --steps 20 used to leave ONE sample per kernel)
-    time_every = min(args.time_every, max(1, args.steps // 5)) if args.time_every > 0 else 0
-    if time_every:
-        # the hipEvents of the timed steps come from the library's pool: fill it now (a hipEventCreate inside the timed region costs
-        # more than the kernel it brackets: 20 steps with 5 timed ones read 0.1376 ms per step against 0.1277 for the same code)
-        n_timed = -(-args.steps // time_every)
-        hr.lib().deodr_hip_profile_enable(1)
-        for _ in range(n_timed + 1):
-            step()
-        torch.cuda.synchronize()
-        hr.lib().deodr_hip_profile_read((C.c_double * 4)(), (C.c_ulonglong * 4)())
-        warmup_run += n_timed + 1
-    hr.lib().deodr_hip_profile_enable(time_every)
+    # Per-kernel durations of the timed region: device time stamps (deodr_hip_profile_stamps: the first thread of set-up / tile scan /
+    # finalize writes the 100 MHz realtime counter; kernels of one stream run back to back, so consecutive stamps bracket the kernels
+    # between them).  EVERY step of the timed region is sampled and nothing is inserted between the launches -- a hipEvent pair per
+    # kernel costs the step it brackets ~ 36 us: with 5 of 20 steps bracketed the same code read 0.1368 ms per step instead of 0.1277.
+    # hipEvents are still used, AFTER the timed region, as a cross-check of the stamps (`avg_ms_events`).
+    stamps = torch.zeros((args.steps + 1, 4), dtype=torch.int64, device=dev) if args.time_every > 0 else None
     barrier()
+    if stamps is not None:
+        hr.lib().deodr_hip_profile_stamps(stamps.data_ptr(), args.steps + 1)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     barrier()
     dt = time.perf_counter() - t0
-    hr.lib().deodr_hip_profile_enable(0)
     ms_sum = (C.c_double * 4)()
     launches = (C.c_ulonglong * 4)()
-    hr.lib().deodr_hip_profile_read(ms_sum, launches)
+    stamp_ms = None
+    if stamps is not None:
+        step()  # (one more, untimed: its set-up stamp is the end of the last timed finalize)
+        barrier()
+        hr.lib().deodr_hip_profile_stamps(None, 0)
+        st = stamps.cpu().numpy().astype(np.int64)
+        K = args.steps
+        nxt = st[1 : K + 1, 0]
+        ok = (st[:K, 0] > 0) & (st[:K, 1] > 0) & (st[:K, 2] > 0) & (nxt > 0)
+        if args.two_pass or not ok.any():
+            stamp_ms = None  # (the two-call step runs set-up twice per step: the rows do not line up with steps; hipEvents below)
+        else:
+            tick = 1e-5  # ms per tick of the 100 MHz counter
+            stamp_ms = {"setup_bin_kernel": float(((st[:K, 1] - st[:K, 0])[ok]).mean() * tick), "raster_fwd_kernel": float(((st[:K, 2] - st[:K, 1])[ok]).mean() * tick),
+                        "raster_bwd_kernel": 0.0, "finalize_kernel": float(((nxt - st[:K, 2])[ok]).mean() * tick), "samples": int(ok.sum()),
+                        "step_ms_by_stamps": float(((nxt - st[:K, 0])[ok]).mean() * tick)}  # fmt: skip
+        # cross-check with hipEvents on a few more steps (outside the timed region: they perturb what they measure)
+        hr.lib().deodr_hip_profile_enable(1)
+        for _ in range(6):
+            step()
+        barrier()
+        hr.lib().deodr_hip_profile_enable(0)
+        hr.lib().deodr_hip_profile_read(ms_sum, launches)
     if dist is not None:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -551,9 +565,10 @@ def main():
         per_kernel = {}
         for i, k in enumerate(KERNELS):
             n = max(int(launches[i]), 1)
-            avg_ms = ms_sum[i] / n
-            per_kernel[k] = {"avg_ms": avg_ms, "launches": int(launches[i]), "alg_bytes": alg[k],
-                             "GBps": alg[k] / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 and alg[k] else None}  # fmt: skip
+            ev_ms = ms_sum[i] / n
+            avg_ms, samples = (stamp_ms[k], stamp_ms["samples"]) if stamp_ms is not None else (ev_ms, int(launches[i]))
+            per_kernel[k] = {"avg_ms": avg_ms, "launches": samples, "alg_bytes": alg[k], "GBps": alg[k] / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 and alg[k] else None,
+                             "avg_ms_events": ev_ms, "event_launches": int(launches[i])}  # fmt: skip
         dom = max(KERNELS, key=lambda k: per_kernel[k]["avg_ms"])
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
@@ -582,7 +597,9 @@ def main():
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": per_kernel[dom]["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": (per_kernel[dom]["GBps"] or 0) / HBM_PEAK_GBS, "traffic": traffic,
                          "peak_measured": peak_meas, "frac_of_measured": (per_kernel[dom]["GBps"] or 0) / peak_meas,
-                         "timed_every": time_every,
+                         "timing": ("device time stamps of every step of the timed region (deodr_hip_profile_stamps); avg_ms_events = hipEvents on 6 steps after it"
+                                    if stamp_ms is not None else "hipEvents on steps after the timed region"),
+                         "step_ms_by_stamps": None if stamp_ms is None else stamp_ms["step_ms_by_stamps"],
                          "whole_step": {"alg_bytes": whole, "GBps": whole / step_s / 1e9, "frac": whole / step_s / 1e9 / HBM_PEAK_GBS,
                                         "frac_of_measured": whole / step_s / 1e9 / peak_meas,
                                         "frac_of_guide_copy": whole / step_s / 1e9 / GUIDE_COPY_GBS, "moved_bytes": moved,

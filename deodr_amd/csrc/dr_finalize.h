@@ -76,6 +76,7 @@ __global__ __launch_bounds__(PRIM_BLOCK, DR_FIN_WAVES) void finalize_kernel(KPar
 	p.vtx_f64 = VTX64 ? 1 : 0;
 	if (NC)
 		p.C = NC, p.L.P = NC < 3 ? 3 : NC;
+	kernel_stamp(p, 2);
 	const int loss_blocks = p.loss_out ? 1 : 0;
 	if (loss_blocks && blockIdx.x == 0)
 	{ // one extra workgroup, the FIRST of the grid (it overlaps the others): loss = background loss of the whole frame + the walkers'

@@ -436,6 +436,7 @@ __global__ __launch_bounds__(SCAN_BLOCK) void tile_scan_kernel(KParams p)
 	constexpr int NCLS = 3 + EDGE_LISTS;
 	__shared__ uint32_t s_cnt[NCLS][SCAN_BLOCK / 64];
 	__shared__ uint32_t s_base[NCLS];
+	kernel_stamp(p, 1);
 	const int view = blockIdx.y;
 	const ViewPtrs w = view_ptrs(p, view);
 	const int tile = blockIdx.x * SCAN_BLOCK + threadIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -898,13 +899,18 @@ __device__ __forceinline__ void signal_tiles_done(const KParams &p, const ViewPt
 // view's work list (usually one or two).  rank() deals the list to the XCDs in chunks of 64 consecutive entries (workgroup b
 // runs on XCD b % 8; consecutive entries are neighbouring tiles, which share triangle records and should share an L2).
 
-__host__ __device__ inline int fwd_tile_blocks(int ntiles)
-{ // workgroups per view that walk the work list: a quarter of the tiles (about a third of a frame's tiles hold primitives)
+__host__ __device__ inline int fwd_tile_blocks(int ntiles, int n_views, bool dealt_fill)
+{ // workgroups per view that walk the work list: a quarter of the tiles (about a third of a frame's tiles hold primitives, and most
+  // of those pair up: about one entry per walker) -- a sixth from 8 views up in a fit step of an untextured scene (dealt_fill): with the
+  // fill workgroups dealt among the walkers, fewer
+  // and longer walkers win there (same-box A/B, 8 views of the benchmark scene: /4 0.1242 - 0.1252, /5 0.1208 - 0.1214, /6 0.1211 - 0.1213,
+  // /8 0.1271 - 0.1280 ms; 8 views of the hand 0.103 -> 0.096; 1 / 2 / 4 views lose 1 - 3 % at /6, 16 views are level: profiles/r04n)
 	const int unit = 8 * WORK_CHUNK;
 #ifndef DR_TILE_DIV
-#define DR_TILE_DIV 4
+#define DR_TILE_DIV 0 // (measurement builds: a fixed divisor)
 #endif
-	const int g = ((ntiles / DR_TILE_DIV + unit - 1) / unit) * unit;
+	const int div = DR_TILE_DIV ? DR_TILE_DIV : ((dealt_fill && n_views >= 8) ? 6 : 4);
+	const int g = ((ntiles / div + unit - 1) / unit) * unit;
 	return g > 0 && g <= ntiles ? g : ntiles; // tiny frames: one workgroup per tile, plain order
 }
 
@@ -1586,15 +1592,16 @@ __global__ __launch_bounds__(64, DR_FWD_WAVES) void raster_fwd_fast_kernel(KPara
 	WaveLds *const s_lds = (WaveLds *)s_mem;
 	EdgeSort *const s_es = (EdgeSort *)(s_mem + sizeof(WaveLds));
 	// Roles of the grid: the tile walkers, the workgroups that stream the background of this kernel's share of the empty tiles
-	// (fill_share), and -- fit step that finalizes here -- the per-primitive adjoint algebra (finalize_kernel's work) at the very end.
-	// Without finalize workgroups the fill workgroups follow the walkers.  With them they are dealt among the walkers, eight (one per
-	// XCD) behind every 64: dispatched last they START when the last walker has a slot, and the kernel then ends a fill later (all of
-	// the fill, 110 MB per 8-view step, is this kernel's now); the finalize workgroups need that tail for themselves.
+	// (fill_share), and -- DR_FIN_IN_FWD builds -- the per-primitive adjoint algebra (finalize_kernel's work) at the very end.
+	// In a fit step of an untextured scene the fill workgroups are DEALT among the walkers, eight (one per XCD) behind every 64:
+	// dispatched behind the last walker they START when the last walker has a slot, and the kernel then ends a fill later (73 MB of
+	// stores per 8-view step: same-box A/B 0.1279 / 0.1274 -> 0.1238 / 0.1232 ms, profiles/r04l).  (Round 3 measured "spread evenly:
+	// nothing" -- with the heavy tiles still deciding when the kernel ends.)
 	const long long n_walk = (long long)p.n_views * p.tile_blocks, n_fill = (long long)p.n_views * fill_share(p.fill_mode, 2, p.L.nwords);
 #ifndef DR_FILL_DEAL
-#define DR_FILL_DEAL 1
+#define DR_FILL_DEAL 1 // (measurement builds: 0 = the fill workgroups behind the walkers, as in round 3)
 #endif
-	const long long dealt = (DR_FIN_IN_FWD && DR_FILL_DEAL && FUSED && !TEX && p.fin_in_fwd && n_walk >= 8 * n_fill) ? n_fill / 8 : 0; // groups of 64 walkers + 8 fill workgroups
+	const long long dealt = (DR_FILL_DEAL && FUSED && !TEX && p.fuse_edges && n_walk >= 8 * n_fill) ? n_fill / 8 : 0; // groups of 64 walkers + 8 fill workgroups
 	long long b = blockIdx.x, fi = -1;
 	if (b < dealt * 72)
 	{

@@ -190,6 +190,9 @@ struct ProfEvent
 bool g_profile = false;	  // the launches of the current call are bracketed by events
 int g_profile_every = 0;	  // deodr_hip_profile_enable(n): 0 off, n > 0: every n-th forward (and the adjoint that follows it)
 unsigned g_profile_calls = 0; // forwards seen since profiling was enabled
+unsigned long long *g_stamps = nullptr; // deodr_hip_profile_stamps: device buffer of g_stamp_rows x 4 words, one row per forward
+int g_stamp_rows = 0;
+unsigned g_stamp_calls = 0;
 bool g_force_generic = false; // deodr_hip_force_generic(1): run the un-staged kernels (the parity suite covers both families)
 bool g_det = false;			  // deodr_hip_set_deterministic(1): un-staged kernels + integer accumulation (KParams::det)
 
@@ -271,7 +274,7 @@ void launch_adjoint_raster(const KParams &p, bool fast, bool owner_tiles, dim3 g
 	if (owner_tiles) // (after a fused forward the tiles without edges have already been back-propagated)
 	{
 		KParams q = p;
-		q.tile_blocks = fwd_tile_blocks(p.L.ntiles); // the grid of the forward that built the work list
+		q.tile_blocks = fwd_tile_blocks(p.L.ntiles, p.n_views, false); // the grid of the forward that built the work list (never a fused one)
 		q.heavy_share = heavy_share_for(p.n_views, q.tile_blocks, false);
 		const dim3 grid((unsigned)p.n_views * (unsigned)q.tile_blocks);
 		// (instances for the channel counts that occur: RGB, RGB + depth -- see raster_fwd_fast_kernel)
@@ -371,7 +374,7 @@ template <class PixT>
 int launch_forward_staged(const KParams &p, bool fused, hipStream_t stream, hipEvent_t *join)
 {
 	KParams q = p;
-	q.tile_blocks = fwd_tile_blocks(p.L.ntiles);
+	q.tile_blocks = fwd_tile_blocks(p.L.ntiles, p.n_views, fused && p.fuse_edges);
 	q.heavy_share = heavy_share_for(p.n_views, q.tile_blocks, fused && p.fuse_edges);
 	hipLaunchKernelGGL(tile_scan_kernel, dim3((p.L.ntiles + SCAN_BLOCK - 1) / SCAN_BLOCK, p.n_views), dim3(SCAN_BLOCK), 0, stream, q);
 	if (p.fill_mode == 0)
@@ -435,6 +438,7 @@ int launch_forward(const DeodrHipScene *sc, KParams &p, hipStream_t stream, hipE
 	const int n_views = sc->n_views;
 	*join = nullptr;
 	g_profile = g_profile_every > 0 && (g_profile_calls++ % (unsigned)g_profile_every) == 0;
+	p.stamp = (g_stamps && g_stamp_calls < (unsigned)g_stamp_rows) ? g_stamps + 4 * (size_t)g_stamp_calls++ : nullptr;
 	p.n_views = n_views;
 	const bool fast = !p.aa_err && p.C <= CH && !g_force_generic && !g_det;
 	if (p.T > 0)
@@ -588,6 +592,14 @@ int deodr_hip_profile_enable(int every)
 	g_profile_every = every > 0 ? every : 0;
 	g_profile_calls = 0;
 	g_profile = false;
+	return 0;
+}
+
+int deodr_hip_profile_stamps(void *device_buffer, int rows)
+{
+	g_stamps = (unsigned long long *)device_buffer;
+	g_stamp_rows = device_buffer && rows > 0 ? rows : 0;
+	g_stamp_calls = 0;
 	return 0;
 }
 

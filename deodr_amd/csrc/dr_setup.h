@@ -240,6 +240,7 @@ __global__ __launch_bounds__(PRIM_BLOCK, DR_PRIM_WAVES) void setup_bin_kernel(KP
 	p.vtx_f64 = VTX64 ? 1 : 0; // (what the host passed: now known to the compiler; scene_view() copies it)
 	if (NC)
 		p.C = NC, p.L.P = NC < 3 ? 3 : NC;
+	kernel_stamp(p, 0);
 	DR_WAVE_TRACE_SCOPE(0);
 	const PrimWork pw = prim_work(p);
 	const int view = pw.view;

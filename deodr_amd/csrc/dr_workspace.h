@@ -214,6 +214,10 @@ struct KParams
 	// in int64 shadow arrays (det_*: library-owned scratch) and added to the caller's arrays by one thread per element afterwards.
 	int det;
 	long long *det_ij, *det_colors, *det_shade, *det_uv, *det_texture;
+	// Measurement (deodr_hip_profile_stamps): the first thread of set-up / tile scan / finalize writes the 100 MHz realtime counter into
+	// stamp[0 / 1 / 2] -- kernels of one stream run back to back, so the difference of two consecutive stamps IS the duration of the kernel(s)
+	// between them, with no event packet between the launches (a hipEvent pair per kernel costs the step it measures ~ 36 us)
+	unsigned long long *stamp;
 	// loss of a fit step, sum (image - obs)^2 (deodr_hip_render_scene_fit_loss): loss_tile_bg[0] = the loss of a frame that is all
 	// background, [1 + view * ntiles + tile] = that of one tile; loss_wave[view * LOSS_SLOTS + q % LOSS_SLOTS]: walker q of the forward
 	// raster adds (loss of a tile - its background loss) for every tile it walks; one workgroup of finalize_kernel writes loss_out[0] =
@@ -344,6 +348,12 @@ __device__ __forceinline__ void unpack_owner(int32_t raw, int &owner, int &kind)
 	owner = kind == 3 ? -1 : (int)(u & 0x3fffffffu);
 	if (kind == 3)
 		kind = KIND_NONE;
+}
+
+__device__ __forceinline__ void kernel_stamp(const KParams &p, int id)
+{
+	if (p.stamp && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0)
+		p.stamp[id] = __builtin_amdgcn_s_memrealtime();
 }
 
 // ------------------------------------------------------------------------------------------------ wave primitives

@@ -20,7 +20,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libdeodr_hip.so")
-ABI_VERSION = 9
+ABI_VERSION = 10
 ERR_FACES, ERR_FACES_UV, ERR_NO_TEXTURE, ERR_INTERNAL = 1, 2, 4, 8  # include/deodr_hip.h DEODR_HIP_ERR_*
 _STATUS_NEEDED, _STATUS_ERRORS = 11, 12  # words of the 64-byte status block at the start of the workspace
 
@@ -85,6 +85,7 @@ def lib():
                                                  C.POINTER(C.c_ulonglong)]  # fmt: skip
         L.deodr_hip_workspace_pool_pairs.restype = C.c_int
         L.deodr_hip_workspace_pool_pairs.argtypes = [C.POINTER(_SceneC), C.c_size_t, C.POINTER(C.c_ulonglong)]
+        L.deodr_hip_profile_stamps.restype, L.deodr_hip_profile_stamps.argtypes = C.c_int, [C.c_void_p, C.c_int]
         L.deodr_hip_copy_probe.restype = C.c_int
         L.deodr_hip_copy_probe.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p]
         _lib = L

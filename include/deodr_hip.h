@@ -270,6 +270,13 @@ int deodr_hip_workspace_pool_pairs(const DeodrHipScene *scene, size_t workspace_
  * the summed elapsed milliseconds and the number of timed launches since the previous read.  Not thread-safe. */
 int deodr_hip_profile_enable(int every);
 int deodr_hip_profile_read(double ms_sum[4], unsigned long long launches[4]);
+/* The same measurement without event packets between the launches (a hipEvent pair per kernel costs the step it measures ~ 36 us: with the
+ * launches of every 4th step bracketed, a 20-step run reads 7 % slow).  device_buffer: rows x 4 uint64 on the device, zero-filled by the
+ * caller; forward number r (counted from this call) writes row r: [0] the 100 MHz realtime counter (10 ns ticks) when the first thread of
+ * setup_bin_kernel starts, [1] tile_scan_kernel, [2] finalize_kernel (0 where a kernel did not run).  Kernels of one stream run back to
+ * back, so set-up lasts [1] - [0], tile scan + forward raster (+ the adjoint raster kernels of a two-call step) [2] - [1], finalize until
+ * the [0] of the next step.  Rows beyond `rows` are not written; NULL / 0 switches it off.  Not thread-safe. */
+int deodr_hip_profile_stamps(void *device_buffer, int rows);
 
 /* Measurement hook (bench.py's "necessary bytes"): synchronises `stream` and counts, over all views of the last forward, the
  * 8 x 8-pixel tiles that received at least one primitive and those that hold silhouette edges. */
@@ -302,7 +309,7 @@ const char *deodr_hip_last_error(void);
 
 /* ABI version of this header; bumped on any incompatible change. */
 int deodr_hip_abi_version(void);
-#define DEODR_HIP_ABI_VERSION 9
+#define DEODR_HIP_ABI_VERSION 10
 
 #ifdef __cplusplus
 }
