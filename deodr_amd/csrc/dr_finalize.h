@@ -423,189 +423,112 @@ __device__ __forceinline__ void run_when_ready(const KParams &p, const ViewPtrs 
 	}
 }
 
-template <bool VTX64>
-__device__ __forceinline__ void fin_in_fwd_role(const KParams &p0, char *lds, long long fi)
+// One triangle per lane (k < 0: none): vertex colours interpolated linearly (the only kind a scene without texture draws; the set-up kernel
+// drops the others with DEODR_HIP_ERR_NO_TEXTURE), at most four channels, written for FEW REGISTERS: this code shares the register budget of
+// the tile walkers (96), where finalize_triangle -- every input in flight at once, the reference's cofactor sweep for the adjoint of the
+// 3 x 3 inverse -- spilled 280.  Same algebra (H.h:841-858) with the channels streamed two at a time and  S_B = -T^T T_B T^T  for the
+// inverse's adjoint (T = S^-1; agrees with the sweep to rounding).  All 64 lanes call it; contributions go to the wavefront's table.
+__device__ __forceinline__ void fin_role_triangles(const KParams &p, const SceneView &s, const ViewPtrs &w, const GradView &g, FinTable &vt, int k)
 {
-	KParams p = p0;
-	p.vtx_f64 = VTX64 ? 1 : 0;
-	DR_WAVE_TRACE_SCOPE(1); // (tools/wave_trace.py: these wavefronts take finalize_kernel's place in the trace)
-	DR_WAVE_PHASE(1);
-	const int lane = threadIdx.x & 63;
-	const int tri_wgs = (p.T + 63) / 64, per_view = tri_wgs + FIN_EDGE_WGS;
-	if (fi >= (long long)p.n_views * per_view)
-	{ // the one workgroup behind them all: the loss, once every walker of every view has added its partial sums
-		if (!p.loss_out || fi > (long long)p.n_views * per_view)
-			return;
-		uint32_t polls = 0;
-		while (true)
-		{
-			bool ready = true;
-			if (lane < p.n_views)
-				ready = sync_load(view_ptrs(p, lane).blk_sync + 2 * p.L.nblk + SYNC_WALKERS) >= (uint32_t)p.tile_blocks;
-			for (int v = 64 + lane; v < p.n_views; v += 64)
-				ready = ready && sync_load(view_ptrs(p, v).blk_sync + 2 * p.L.nblk + SYNC_WALKERS) >= (uint32_t)p.tile_blocks;
-			if (__ballot(!ready) == 0)
-				break;
-			__builtin_amdgcn_s_sleep(32);
-			if (++polls > (1u << 22))
-			{
-				atomicOr(&view_ptrs(p, 0).hdr->scene_errors, (uint32_t)DEODR_HIP_ERR_INTERNAL);
-				break;
-			}
-		}
-		__atomic_signal_fence(__ATOMIC_SEQ_CST);
-		double sum = 0;
-		for (int j = lane; j < p.n_views * LOSS_SLOTS; j += 64)
-			sum += sync_load(p.loss_wave + j);
-		sum = wave_sum(sum);
-		if (lane == 0)
-			p.loss_out[0] = p.loss_tile_bg[0] + sum;
-		return;
-	}
-	// tri workgroups first (views fastest, triangles in index order: for a mesh in strip order, roughly the order in which the
-	// walkers finish the frame), then the edge workgroups (their tiles are the long ones)
-	const long long n_tri = (long long)p.n_views * tri_wgs;
-	const bool tri_role = fi < n_tri;
-	const int view = (int)((tri_role ? fi : fi - n_tri) % p.n_views), index = (int)((tri_role ? fi : fi - n_tri) / p.n_views);
-	const SceneView s = scene_view(p, view);
-	const ViewPtrs w = view_ptrs(p, view);
-	const size_t es = p.vtx_f64 ? 8 : 4;
-	GradView g;
-	g.ij_b = (char *)p.ij_b + (size_t)view * p.V * 2 * es;
-	g.colors_b = (char *)p.colors_b + (size_t)view * p.V * p.C * es;
-	g.shade_b = (char *)p.shade_b + (size_t)view * p.V * es;
-	g.uv_b = p.uv_b;
 	const int P = s.P;
-	if (tri_role)
+	uint32_t flag = 0, f0 = 0, f1 = 0, f2 = 0;
+	if (k >= 0)
 	{
-		const int k = index * 64 + lane;
-		uint32_t flag = 0, f0 = 0, f1 = 0, f2 = 0;
-		if (k < p.T)
+		flag = w.tri_flag[k];
+		f0 = p.faces[3 * (size_t)k], f1 = p.faces[3 * (size_t)k + 1], f2 = p.faces[3 * (size_t)k + 2];
+	}
+	const bool live = k >= 0 && (flag & 4u) && (flag & 3u) == KIND_INTERP && (int32_t)(f0 | f1 | f2) >= 0 && P <= 4;
+	if (__ballot(live) == 0)
+		return;
+	double xa = 0, xb = 0, ya = 0, yb = 0;
+	double vx[3] = {0, 0, 0}, vy[3] = {0, 0, 0};
+	if (live)
+	{ // the pixel box of the triangle, two pixels wider than its vertices (fill rules, pixel-centre offset)
+		vx[0] = ldv(s.ij, 2 * (size_t)f0, s.vtx_f64), vy[0] = ldv(s.ij, 2 * (size_t)f0 + 1, s.vtx_f64);
+		vx[1] = ldv(s.ij, 2 * (size_t)f1, s.vtx_f64), vy[1] = ldv(s.ij, 2 * (size_t)f1 + 1, s.vtx_f64);
+		vx[2] = ldv(s.ij, 2 * (size_t)f2, s.vtx_f64), vy[2] = ldv(s.ij, 2 * (size_t)f2 + 1, s.vtx_f64);
+		xa = fmin(vx[0], fmin(vx[1], vx[2])) - 2, xb = fmax(vx[0], fmax(vx[1], vx[2])) + 2;
+		ya = fmin(vy[0], fmin(vy[1], vy[2])) - 2, yb = fmax(vy[0], fmax(vy[1], vy[2])) + 2;
+	}
+	run_when_ready(p, w, live, block_box(p, xa, xb, ya, yb), [&]() {
+		double *acc = w.tri_acc + (size_t)k * 3 * P;
+		FinMergeSink sink = {s, g, vt, {f0, f1, f2}, {fin_vertex_slot(vt, f0), fin_vertex_slot(vt, f1), fin_vertex_slot(vt, f2)}};
+		double T[9];
 		{
-			flag = w.tri_flag[k];
-			f0 = p.faces[3 * (size_t)k], f1 = p.faces[3 * (size_t)k + 1], f2 = p.faces[3 * (size_t)k + 2];
+			const double S[9] = {vx[0] - s.offset, vx[1] - s.offset, vx[2] - s.offset, vy[0] - s.offset, vy[1] - s.offset, vy[2] - s.offset, 1, 1, 1};
+			inv3(S, T);
 		}
-		// (a scene without texture draws KIND_INTERP triangles only: the set-up kernel drops the others with DEODR_HIP_ERR_NO_TEXTURE)
-		const bool live = k < p.T && (flag & 4u) && (flag & 3u) == KIND_INTERP && (int32_t)(f0 | f1 | f2) >= 0 && P <= 4;
-		if (__ballot(live) == 0)
-			return;
-		double xa = 0, xb = 0, ya = 0, yb = 0;
-		double vx[3] = {0, 0, 0}, vy[3] = {0, 0, 0};
-		if (live)
-		{ // the pixel box of the triangle, two pixels wider than its vertices (fill rules, pixel-centre offset)
-			vx[0] = ldv(s.ij, 2 * (size_t)f0, s.vtx_f64), vy[0] = ldv(s.ij, 2 * (size_t)f0 + 1, s.vtx_f64);
-			vx[1] = ldv(s.ij, 2 * (size_t)f1, s.vtx_f64), vy[1] = ldv(s.ij, 2 * (size_t)f1 + 1, s.vtx_f64);
-			vx[2] = ldv(s.ij, 2 * (size_t)f2, s.vtx_f64), vy[2] = ldv(s.ij, 2 * (size_t)f2 + 1, s.vtx_f64);
-			xa = fmin(vx[0], fmin(vx[1], vx[2])) - 2, xb = fmax(vx[0], fmax(vx[1], vx[2])) + 2;
-			ya = fmin(vy[0], fmin(vy[1], vy[2])) - 2, yb = fmax(vy[0], fmax(vy[1], vy[2])) + 2;
-		}
-		// Vertex colours interpolated linearly (the only kind a scene without texture draws), at most four channels, written for FEW
-		// REGISTERS: this code shares the register budget of the tile walkers (96), where finalize_triangle -- every input in flight at
-		// once, the reference's cofactor sweep for the adjoint of the 3 x 3 inverse -- spilled 280.  Same algebra (H.h:841-858) with the
-		// channels streamed two at a time and  S_B = -T^T T_B T^T  for the inverse's adjoint (T = S^-1; agrees with the sweep to rounding).
-		FinTable &vt = *(FinTable *)lds;
-		for (int i = lane; i < FinTable::SLOTS; i += 64)
-			vt.key[i] = 0xffffffffu;
-		for (int i = lane; i < FinTable::SLOTS * VT_ROW; i += 64)
-			(&vt.val[0][0])[i] = 0;
-		lds_sync();
-		run_when_ready(p, w, live, block_box(p, xa, xb, ya, yb), [&]() {
-			double *acc = w.tri_acc + (size_t)k * 3 * P;
-			FinMergeSink sink = {s, g, vt, {f0, f1, f2}, {fin_vertex_slot(vt, f0), fin_vertex_slot(vt, f1), fin_vertex_slot(vt, f2)}};
-			double T[9];
-			{
-				const double S[9] = {vx[0] - s.offset, vx[1] - s.offset, vx[2] - s.offset, vy[0] - s.offset, vy[1] - s.offset, vy[2] - s.offset, 1, 1, 1};
-				inv3(S, T);
-			}
-			double TB[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-			const uint32_t fk[3] = {f0, f1, f2};
+		double TB[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+		const uint32_t fk[3] = {f0, f1, f2};
 #pragma unroll 1
-			for (int c0 = 0; c0 < p.C; c0 += 2)
-			{
-				double M[2][3], a[2][3];
+		for (int c0 = 0; c0 < p.C; c0 += 2)
+		{
+			double M[2][3], a[2][3];
 #pragma unroll
-				for (int h = 0; h < 2; h++)
+			for (int h = 0; h < 2; h++)
+#pragma unroll
+				for (int j = 0; j < 3; j++)
+				{
+					const bool on = c0 + h < p.C;
+					M[h][j] = on ? sync_load(acc + 3 * (c0 + h) + j) : 0.0;
+					a[h][j] = on ? ldv(s.colors, (size_t)fk[j] * p.C + c0 + h, s.vtx_f64) : 0.0;
+				}
+#pragma unroll
+			for (int h = 0; h < 2; h++)
+#pragma unroll
+				for (int kk = 0; kk < 3; kk++)
+				{
+					double a_B = 0;
 #pragma unroll
 					for (int j = 0; j < 3; j++)
 					{
-						const bool on = c0 + h < p.C;
-						M[h][j] = on ? sync_load(acc + 3 * (c0 + h) + j) : 0.0;
-						a[h][j] = on ? ldv(s.colors, (size_t)fk[j] * p.C + c0 + h, s.vtx_f64) : 0.0;
+						a_B += M[h][j] * T[3 * kk + j];
+						TB[3 * kk + j] += a[h][kk] * M[h][j];
 					}
-#pragma unroll
-				for (int h = 0; h < 2; h++)
-#pragma unroll
-					for (int kk = 0; kk < 3; kk++)
-					{
-						double a_B = 0;
-#pragma unroll
-						for (int j = 0; j < 3; j++)
-						{
-							a_B += M[h][j] * T[3 * kk + j];
-							TB[3 * kk + j] += a[h][kk] * M[h][j];
-						}
-						if (c0 + h < p.C)
-							sink.color(kk, c0 + h, a_B);
-					}
-			}
-			double U[9]; // T_B T^T
-#pragma unroll
-			for (int kk = 0; kk < 3; kk++)
-#pragma unroll
-				for (int m = 0; m < 3; m++)
-					U[3 * kk + m] = TB[3 * kk] * T[3 * m] + TB[3 * kk + 1] * T[3 * m + 1] + TB[3 * kk + 2] * T[3 * m + 2];
-#pragma unroll
-			for (int d = 0; d < 2; d++)
-#pragma unroll
-				for (int v = 0; v < 3; v++)
-					sink.ij(v, d, -(T[d] * U[v] + T[3 + d] * U[3 + v] + T[6 + d] * U[6 + v]));
-			for (int i = 0; i < 3 * P; i++)
-				acc[i] = 0; // self-cleaning accumulators
-		});
-		DR_WAVE_PHASE(2); // every triangle of this wavefront finalized into the table
-		lds_sync();
-		for (int i = lane; i < FinTable::SLOTS * 8; i += 64)
-		{ // flush, vertex-major (see finalize_kernel)
-			const int row = i >> 3, col = i & 7;
-			const uint32_t v = vt.key[row];
-			if (col < 2 + p.C && v != 0xffffffffu)
-			{
-				const double x = vt.val[row][col];
-				if (col < 2)
-					DeviceAdd()(g.ij_b, 2 * (size_t)v + col, p.vtx_f64, x);
-				else
-					DeviceAdd()(g.colors_b, (size_t)v * p.C + (col - 2), p.vtx_f64, x);
-			}
+					if (c0 + h < p.C)
+						sink.color(kk, c0 + h, a_B);
+				}
 		}
-		DR_WAVE_PHASE(3);
-		return;
-	}
-	// edge workgroups: FIN_EDGE_WGS per view over the list of the edges the set-up kernel of this forward has drawn.  Vertex colours only,
-	// at most four channels (see above), and again written for few registers: the record already holds the inverse frame (x2b, sigma x2t =
-	// the three rows of x2e, H.h:1407-1435), the channels are streamed two at a time, and the adjoint of the inverse is -x2e^T x2e_B x2e^T.
-	const uint32_t n_drawn = sync_load(w.blk_sync + 2 * p.L.nblk + SYNC_DRAWN + (w.hdr->cur & 1u));
-#pragma unroll 1
-	for (uint32_t base = (uint32_t)index * 64u; base < n_drawn; base += FIN_EDGE_WGS * 64u)
+		double U[9]; // T_B T^T
+#pragma unroll
+		for (int kk = 0; kk < 3; kk++)
+#pragma unroll
+			for (int m = 0; m < 3; m++)
+				U[3 * kk + m] = TB[3 * kk] * T[3 * m] + TB[3 * kk + 1] * T[3 * m + 1] + TB[3 * kk + 2] * T[3 * m + 2];
+#pragma unroll
+		for (int d = 0; d < 2; d++)
+#pragma unroll
+			for (int v = 0; v < 3; v++)
+				sink.ij(v, d, -(T[d] * U[v] + T[3 + d] * U[3 + v] + T[6 + d] * U[6 + v]));
+		for (int i = 0; i < 3 * P; i++)
+			acc[i] = 0; // self-cleaning accumulators
+	});
+}
+
+// One drawn silhouette edge per lane (slot < 0: none).  Vertex colours only, at most four channels, and again written for few registers:
+// the record already holds the inverse frame (x2b, sigma x2t = the three rows of x2e, H.h:1407-1435), the channels are streamed two at a
+// time, and the adjoint of the inverse is -x2e^T x2e_B x2e^T.  Contributions go straight to the gradient arrays (a few hundred edges per view).
+__device__ __forceinline__ void fin_role_edges(const KParams &p, const SceneView &s, const ViewPtrs &w, const GradView &g, int slot)
+{
+	const int P = s.P;
+	const bool mine = slot >= 0;
+	const EdgeRec &er = w.edge_rec[mine ? slot : 0];
+	const EdgeFin &fin = w.edge_fin[mine ? slot : 0];
+	double *acc = w.edge_acc + (size_t)(mine ? slot : 0) * (3 * P + 3);
+	double V[2][2] = {{0, 0}, {0, 0}};
+	uint32_t vid[2] = {0, 0};
+	bool live = false;
+	double xa = 0, xb = 0, ya = 0, yb = 0;
+	if (mine)
 	{
-		const bool mine = base + lane < n_drawn;
-		const int slot = mine ? (int)w.drawn_edges[base + lane] : 0;
-		const EdgeRec &er = w.edge_rec[slot];
-		const EdgeFin &fin = w.edge_fin[slot];
-		double *acc = w.edge_acc + (size_t)slot * (3 * P + 3);
-		double V[2][2] = {{0, 0}, {0, 0}};
-		uint32_t vid[2] = {0, 0};
-		bool live = false;
-		double xa = 0, xb = 0, ya = 0, yb = 0;
-		if (mine)
-		{
-			live = er.kind == KIND_INTERP && fin.has_att && P <= 4;
-			V[0][0] = fin.V[0][0], V[0][1] = fin.V[0][1], V[1][0] = fin.V[1][0], V[1][1] = fin.V[1][1];
-			vid[0] = fin.vid[0], vid[1] = fin.vid[1];
-			const double m = p.sigma + 2 + p.offset;
-			xa = fmin(V[0][0], V[1][0]) - m, xb = fmax(V[0][0], V[1][0]) + m;
-			ya = fmin(V[0][1], V[1][1]) - m, yb = fmax(V[0][1], V[1][1]) + m;
-		}
-		run_when_ready(p, w, live, block_box(p, xa, xb, ya, yb), [&]() {
+		live = er.kind == KIND_INTERP && fin.has_att && P <= 4;
+		V[0][0] = fin.V[0][0], V[0][1] = fin.V[0][1], V[1][0] = fin.V[1][0], V[1][1] = fin.V[1][1];
+		vid[0] = fin.vid[0], vid[1] = fin.vid[1];
+		const double m = p.sigma + 2 + p.offset;
+		xa = fmin(V[0][0], V[1][0]) - m, xb = fmax(V[0][0], V[1][0]) + m;
+		ya = fmin(V[0][1], V[1][1]) - m, yb = fmax(V[0][1], V[1][1]) + m;
+	}
+	run_when_ready(p, w, live, block_box(p, xa, xb, ya, yb), [&]() {
 		double X[9], XB[9]; // x2e and its adjoint, row-major: rows 0, 1 = x2b, row 2 = sigma x2t
 #pragma unroll
 		for (int i = 0; i < 6; i++)
@@ -671,7 +594,107 @@ __device__ __forceinline__ void fin_in_fwd_role(const KParams &p0, char *lds, lo
 		DeviceAdd()(g.ij_b, 2 * (size_t)vid[1] + 1, p.vtx_f64, EB[1][1] - sgn * ntx_B);
 		for (int i = 0; i < 3 * P + 3; i++)
 			acc[i] = 0;
-		});
+	});
+}
+
+// Workgroup fi of the finalize workgroups of the forward raster: FIN_ROLES per view walk the view's list of WORK ITEMS (tile_scan_kernel:
+// up to 64 triangles, or 64 drawn edges, of ONE block of tiles -- the set-up kernel files every primitive under the block of the first tile
+// of its box --, or 64 entries of the overflow list), one more adds up the loss.
+template <bool VTX64>
+__device__ __forceinline__ void fin_in_fwd_role(const KParams &p0, char *lds, long long fi)
+{
+	KParams p = p0;
+	p.vtx_f64 = VTX64 ? 1 : 0;
+	DR_WAVE_TRACE_SCOPE(1); // (tools/wave_trace.py: these wavefronts take finalize_kernel's place in the trace)
+	DR_WAVE_PHASE(1);
+	const int lane = threadIdx.x & 63;
+	const int roles = fin_roles_per_view(p.L.nblk);
+	if (fi >= (long long)p.n_views * roles)
+	{ // the one workgroup behind them all: the loss, once every walker of every view has added its partial sums
+		if (!p.loss_out || fi > (long long)p.n_views * roles)
+			return;
+		uint32_t polls = 0;
+		while (true)
+		{
+			bool ready = true;
+			for (int v = lane; v < p.n_views; v += 64)
+				ready = ready && sync_load(view_ptrs(p, v).blk_sync + 2 * p.L.nblk + SYNC_WALKERS) >= (uint32_t)p.tile_blocks;
+			if (__ballot(!ready) == 0)
+				break;
+			__builtin_amdgcn_s_sleep(32);
+			if (++polls > (1u << 22))
+			{
+				atomicOr(&view_ptrs(p, 0).hdr->scene_errors, (uint32_t)DEODR_HIP_ERR_INTERNAL);
+				break;
+			}
+		}
+		__atomic_signal_fence(__ATOMIC_SEQ_CST);
+		double sum = 0;
+		for (int j = lane; j < p.n_views * LOSS_SLOTS; j += 64)
+			sum += sync_load(p.loss_wave + j);
+		sum = wave_sum(sum);
+		if (lane == 0)
+			p.loss_out[0] = p.loss_tile_bg[0] + sum;
+		return;
+	}
+	const int view = (int)(fi % p.n_views), role = (int)(fi / p.n_views);
+	const SceneView s = scene_view(p, view);
+	const ViewPtrs w = view_ptrs(p, view);
+	const size_t es = p.vtx_f64 ? 8 : 4;
+	GradView g;
+	g.ij_b = (char *)p.ij_b + (size_t)view * p.V * 2 * es;
+	g.colors_b = (char *)p.colors_b + (size_t)view * p.V * p.C * es;
+	g.shade_b = (char *)p.shade_b + (size_t)view * p.V * es;
+	g.uv_b = p.uv_b;
+	FinTable &vt = *(FinTable *)lds;
+	const uint32_t n_items = w.blk_sync[2 * p.L.nblk + SYNC_ITEMS]; // (written by the scan kernel, the launch before this one)
+#pragma unroll 1
+	for (uint32_t it = (uint32_t)role; it < n_items; it += (uint32_t)roles)
+	{
+		const uint2 item = w.fin_items[it];
+		const int kind = (int)(item.x >> 28), n = (int)((item.x >> 20) & 0x3fu) + 1, blk = (int)(item.x & 0xfffffu);
+		const bool has = lane < n;
+		int tri = -1, edge = -1;
+		if (kind == FIN_ITEM_TRI)
+			tri = has ? (int)w.blk_lists[(size_t)blk * (BLK_TRI_CAP + BLK_EDGE_CAP) + item.y + lane] : -1;
+		else if (kind == FIN_ITEM_EDGE)
+			edge = has ? (int)w.blk_lists[(size_t)blk * (BLK_TRI_CAP + BLK_EDGE_CAP) + BLK_TRI_CAP + item.y + lane] : -1;
+		else if (has)
+		{ // overflow list: a triangle, or (top bit) an edge slot
+			const uint32_t v = w.fin_overflow[item.y + lane];
+			if (v & 0x80000000u)
+				edge = (int)(v & 0x7fffffffu);
+			else
+				tri = (int)v;
+		}
+		if (__ballot(tri >= 0) != 0)
+		{
+			for (int i = lane; i < FinTable::SLOTS; i += 64)
+				vt.key[i] = 0xffffffffu;
+			for (int i = lane; i < FinTable::SLOTS * VT_ROW; i += 64)
+				(&vt.val[0][0])[i] = 0;
+			lds_sync();
+			fin_role_triangles(p, s, w, g, vt, tri);
+			DR_WAVE_PHASE(2); // every triangle of this item finalized into the table
+			lds_sync();
+			for (int i = lane; i < FinTable::SLOTS * 8; i += 64)
+			{ // flush, vertex-major (see finalize_kernel)
+				const int row = i >> 3, col = i & 7;
+				const uint32_t v = vt.key[row];
+				if (col < 2 + p.C && v != 0xffffffffu)
+				{
+					const double x = vt.val[row][col];
+					if (col < 2)
+						DeviceAdd()(g.ij_b, 2 * (size_t)v + col, p.vtx_f64, x);
+					else
+						DeviceAdd()(g.colors_b, (size_t)v * p.C + (col - 2), p.vtx_f64, x);
+				}
+			}
+			lds_sync();
+			DR_WAVE_PHASE(3);
+		}
+		if (__ballot(edge >= 0) != 0)
+			fin_role_edges(p, s, w, g, edge);
 	}
 }
 

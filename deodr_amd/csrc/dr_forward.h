@@ -478,6 +478,35 @@ __global__ __launch_bounds__(SCAN_BLOCK) void tile_scan_kernel(KParams p)
 		}
 		else if (work)
 			atomicAdd(expected, 1u);
+		// ... and their work items: the primitives the set-up kernel has filed under this block, 64 at a time (the thread of the block's
+		// first tile; the counters are left zero for the next forward)
+		if (valid && (tx & (BLK - 1)) == 0 && (ty & (BLK - 1)) == 0)
+		{
+			const int blk = (ty / BLK) * p.L.blk_x + tx / BLK;
+			uint32_t nt = w.blk_cnt[blk], ne = w.blk_cnt[p.L.nblk + blk];
+			if (nt | ne)
+			{
+				w.blk_cnt[blk] = 0, w.blk_cnt[p.L.nblk + blk] = 0;
+				nt = nt < (uint32_t)BLK_TRI_CAP ? nt : (uint32_t)BLK_TRI_CAP, ne = ne < (uint32_t)BLK_EDGE_CAP ? ne : (uint32_t)BLK_EDGE_CAP;
+				const uint32_t it = (nt + 63) / 64, ie = (ne + 63) / 64;
+				uint32_t at = atomicAdd(&w.blk_sync[2 * p.L.nblk + SYNC_ITEMS], it + ie);
+				for (uint32_t first = 0; first < nt; first += 64)
+					w.fin_items[at++] = make_uint2(FIN_ITEM_TRI << 28 | ((nt - first < 64 ? nt - first : 64u) - 1u) << 20 | (uint32_t)blk, first);
+				for (uint32_t first = 0; first < ne; first += 64)
+					w.fin_items[at++] = make_uint2(FIN_ITEM_EDGE << 28 | ((ne - first < 64 ? ne - first : 64u) - 1u) << 20 | (uint32_t)blk, first);
+			}
+		}
+		if (tile == 0)
+		{
+			uint32_t no = w.blk_sync[2 * p.L.nblk + SYNC_OVERFLOW + (w.hdr->cur & 1u)];
+			no = no < p.L.fin_overflow_cap ? no : p.L.fin_overflow_cap;
+			if (no)
+			{
+				uint32_t at = atomicAdd(&w.blk_sync[2 * p.L.nblk + SYNC_ITEMS], (no + 63) / 64);
+				for (uint32_t first = 0; first < no; first += 64)
+					w.fin_items[at++] = make_uint2(FIN_ITEM_OVERFLOW << 28 | ((no - first < 64 ? no - first : 64u) - 1u) << 20, first);
+			}
+		}
 	}
 	if (lane == 0 && valid)
 		w.tile_bits[tile >> 5] = (uint32_t)wm;
@@ -870,7 +899,6 @@ __device__ __forceinline__ void owner_adjoint_mfma(const KParams &p, const ViewP
 // (dr_finalize.h) the per-primitive adjoint algebra as workgroups of the forward raster: see raster_fwd_fast_kernel
 template <bool VTX64>
 __device__ __forceinline__ void fin_in_fwd_role(const KParams &p, char *lds, long long fi);
-constexpr int FIN_EDGE_WGS = 32;	   // workgroups per view that walk the list of drawn edges (persistent: the list's length is only known on the device)
 constexpr size_t FIN_LDS_BYTES = 128 * (4 + 6 * 8); // their vertex table (dr_finalize.h: FinTable), carved out of the walkers' staging area
 
 // A walker has finished `n` tiles of the block that holds `tile`: its accumulator atomics have been performed (vmcnt(0): returnless

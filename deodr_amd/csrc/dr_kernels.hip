@@ -390,8 +390,8 @@ int launch_forward_staged(const KParams &p, bool fused, hipStream_t stream, hipE
 		*join = ss.join;
 	}
 	// (+ the workgroups that stream this kernel's share of the background of the empty tiles, one bitmap word each)
-	// ... and, in a fit step that finalizes under the walkers, one per 64 triangles and FIN_EDGE_WGS per view for the drawn edges (+ the loss)
-	const unsigned fin_wgs = p.fin_in_fwd ? (unsigned)p.n_views * (unsigned)((p.T + 63) / 64 + FIN_EDGE_WGS) + (p.loss_out ? 1u : 0u) : 0u;
+	// ... and, in a fit step that finalizes under the walkers, the workgroups that walk the views' finalize work items (+ the loss)
+	const unsigned fin_wgs = p.fin_in_fwd ? (unsigned)p.n_views * (unsigned)fin_roles_per_view(p.L.nblk) + (p.loss_out ? 1u : 0u) : 0u;
 	const dim3 grid((unsigned)p.n_views * (unsigned)q.tile_blocks + (unsigned)p.n_views * (unsigned)fill_share(p.fill_mode, 2, p.L.nwords) + fin_wgs);
 	const bool tex = p.texture != nullptr; // (see launch_adjoint_raster)
 	const bool common = p.strict && p.W % TILE == 0 && p.H % TILE == 0;
