@@ -119,8 +119,7 @@ __device__ __forceinline__ void owner_adjoint(const KParams &p, const ViewPtrs &
 			if (v != 0)
 			{
 				const int texel = i / C, c = i - texel * C, jv = texel / win_w, ju = texel - jv * win_w;
-				if (!(DR_ABLATE & 1048576)) // (measurement build: no texture-gradient atomics)
-					unsafeAtomicAdd(texture_b + (size_t)C * ((win_u0 + ju) + (size_t)p.tex_w * (win_v0 + jv)) + c, (PixT)v);
+				unsafeAtomicAdd(texture_b + (size_t)C * ((win_u0 + ju) + (size_t)p.tex_w * (win_v0 + jv)) + c, (PixT)v);
 			}
 		}
 		lds_sync(); // tab is reused for the run totals below
@@ -227,10 +226,8 @@ __device__ __forceinline__ void owner_adjoint(const KParams &p, const ViewPtrs &
 				mask &= mask - 1;
 				acc += tab[r * NMOM + m];
 			}
-#if !(DR_ABLATE & 128)
 			if (m < nm && acc != 0)
 				atomic_add_f64(w.tri_acc + (size_t)o * nm + m, acc);
-#endif
 		}
 		emask &= ~__ballot(sel);
 	}
@@ -438,13 +435,6 @@ __device__ __forceinline__ void bwd_fast_tile(const KParams &p, const ViewPtrs &
 	if (EDGES && (chunked ? chunk >= nbatch_all : chunk > 0))
 		return; // nothing for this wavefront: the tile has fewer batches, or its sweep is not shared
 	const int b_hi = chunked ? chunk : nbatch_all - 1, b_lo = chunked ? chunk : 0;
-#ifdef DR_TILE_TRACE
-	uint32_t tr[8] = {0x7fc0beefu, (uint32_t)nedge, 0, 0, 0, 0, 0, 0};
-	const uint64_t tr0 = __builtin_readcyclecounter();
-#define DR_TRACE(i) tr[i] = (uint32_t)(__builtin_readcyclecounter() - tr0)
-#else
-#define DR_TRACE(i)
-#endif
 	int n_edges = 0;
 	if (EDGES && sweep_saved)
 	{ // the forward saved the blending order with its sweep
@@ -457,7 +447,6 @@ __device__ __forceinline__ void bwd_fast_tile(const KParams &p, const ViewPtrs &
 	}
 	else if (EDGES)
 		n_edges = gather_sorted_edges(*es, w, p, tile, nedge, lane);
-	DR_TRACE(2);
 	if (EDGES && n_edges < 0)
 	{ // more than EMAX edges in one tile (or pool overflow): the un-staged code, right here (pathological and slow, but no
 	  // queue and no extra launch for the tiles that never exist in a real scene)
@@ -583,7 +572,6 @@ __device__ __forceinline__ void bwd_fast_tile(const KParams &p, const ViewPtrs &
 			for (int bb = 0; bb < EMAX / TB; bb++)
 				tm[bb] = bb == b ? tmb : tm[bb];
 		}
-		DR_TRACE(3);
 		if (chunked && b_hi < nbatch - 1)
 		{ // the gradient that reaches batch b_hi has been attenuated by every nearer edge drawn over the pixel.  The transparency
 		  // planes of those edges are gathered into the (still idle) staging area with ONE round of loads: read from memory inside
@@ -620,22 +608,10 @@ __device__ __forceinline__ void bwd_fast_tile(const KParams &p, const ViewPtrs &
 		edge_reverse_sweep<PixT, TEX>(p, w, S, es, lane, x, y, n_edges, b_hi, b_lo, !sweep_saved && b_hi == nbatch - 1, tm, cur, g, base, have_base, pixel_base);
 	}
 
-	DR_TRACE(4);
 	if (EDGES && b_lo > 0)
 		return; // the wavefront that ran batch 0 (the farthest edges) holds the gradient that reaches pass 1
 	// ---- adjoint of pass 1: g now belongs to the triangle that owns the pixel
 	owner_adjoint<PixT, TEX>(p, w, lane, x, y, owner, kind, g, tap, L, (double *)&S.rec[0], (uint32_t *)&S.cover[0][0]);
-#ifdef DR_TILE_TRACE
-	DR_TRACE(5);
-	if (EDGES && lane < 8)
-	{
-		uint32_t v = 0;
-		for (int i = 0; i < 8; i++)
-			v = lane == i ? tr[i] : v;
-		((uint32_t *)p.image_in)[((size_t)view * H * W + (size_t)y0 * W + x0) * C + lane] = v; // C == 4: the first two pixels of the tile
-	}
-#endif
-#undef DR_TRACE
 }
 
 template <class PixT, bool TEX, int NC = 0> // NC: the channel count at compile time (0: the scene's), as for raster_fwd_fast_kernel
@@ -701,8 +677,7 @@ __global__ __launch_bounds__(64, TEX ? 2 : DR_EDGE_OCC) void raster_bwd_edge_ker
 			fill_share_word(p, 0, view, i, lane);
 		return;
 	}
-	const uint32_t n_short = w.edge_tile_cnt[0], n_long = (DR_ABLATE & 65536) ? 0u : w.edge_tile_cnt[CNT_STRIDE],
-				   n_multi = (DR_ABLATE & 32768) ? 0u : w.edge_tile_cnt[2 * CNT_STRIDE] * CHUNKS; // (measurement builds: without the multi-batch / the 9-16-edge tiles)
+	const uint32_t n_short = w.edge_tile_cnt[0], n_long = w.edge_tile_cnt[CNT_STRIDE], n_multi = w.edge_tile_cnt[2 * CNT_STRIDE] * CHUNKS;
 	const uint32_t *shorts = w.edge_tiles, *longs = w.edge_tiles + p.L.ntiles, *multi = w.edge_tiles + 2 * (size_t)p.L.ntiles;
 	// Work items: first the tiles with more than one batch of edges, each offered to CHUNKS wavefronts (one per batch of its
 	// reverse sweep; those the tile has no use for return at once), then the other tiles with more than PRIO_EDGES edges, then

@@ -123,21 +123,9 @@ __device__ __forceinline__ void stage_batch(WaveLds &S, const Rec *recs, const d
 		S.planes[a2 * 12 + c2] = v2;
 }
 
-#ifdef DR_FWD_TRACE
-#define DR_TRACE_ARGS , uint32_t *ftr, uint64_t ftr0
-#define DR_TRACE_PASS , ftr, ftr0
-#define DR_BTRACE(i)                                                                                                         \
-	if (ftr[i] == 0)                                                                                                         \
-	ftr[i] = (uint32_t)(__builtin_readcyclecounter() - ftr0)
-#else
-#define DR_TRACE_ARGS
-#define DR_TRACE_PASS
-#define DR_BTRACE(i)
-#endif
 template <bool TEX>
-__device__ __forceinline__ void tri_batch(const KParams &p, WaveLds &S, int nb, int lane, int x0, int y0, bool inb, PixState &st DR_TRACE_ARGS)
+__device__ __forceinline__ void tri_batch(const KParams &p, WaveLds &S, int nb, int lane, int x0, int y0, bool inb, PixState &st)
 {
-	DR_BTRACE(8); // records staged (first batch)
 	const int W = p.W, H = p.H, C = p.C;
 	const bool persp = p.persp, strict = p.strict;
 	// spans: lane = slot * 8 + row
@@ -149,9 +137,7 @@ __device__ __forceinline__ void tri_batch(const KParams &p, WaveLds &S, int nb, 
 		if (j < nb)
 		{
 			const TriRec &rec = S.rec[j].tri();
-			if (DR_ABLATE & 512)
-				m = 0xffu;
-			else if (rec.kind != KIND_NONE)
+			if (rec.kind != KIND_NONE)
 			{
 				// A row lies in one half of the triangle (above or below its middle vertex), so one span (two divisions, not
 				// four) per (triangle, row); only the non-strict fill rule puts the middle-vertex row in both halves.
@@ -160,14 +146,6 @@ __device__ __forceinline__ void tri_batch(const KParams &p, WaveLds &S, int nb, 
 				int xb, xe;
 				tri_half_span(rec, in0 ? 0 : 1, yy, W, H, strict, xb, xe);
 				m = column_mask(xb, xe, x0);
-				if (DR_ABLATE & 16384)
-				{ // measurement: the span arithmetic a second time (its cost = the difference in instruction counts)
-					int yy2 = yy;
-					asm volatile("" : "+v"(yy2));
-					int xb2, xe2;
-					tri_half_span(rec, in0 ? 0 : 1, yy2, W, H, strict, xb2, xe2);
-					m &= column_mask(xb2, xe2, x0);
-				}
 				if (__ballot(in0 && in1))
 				{
 					if (in0 && in1)
@@ -181,7 +159,6 @@ __device__ __forceinline__ void tri_batch(const KParams &p, WaveLds &S, int nb, 
 		if (j < TB)
 			S.cover[r][j] = (uint8_t)m;
 	}
-	DR_BTRACE(9); // spans computed
 	lds_sync();
 	const int lx = lane & 7, row = lane >> 3;
 	uint32_t mine = gather_column_bits(&S.cover[row][0], lx);
@@ -210,7 +187,6 @@ __device__ __forceinline__ void tri_batch(const KParams &p, WaveLds &S, int nb, 
 			jbest = j;
 		}
 	}
-	DR_BTRACE(10); // depth test done
 	if (jbest >= 0)
 	{ // per-lane reads of the winner's record and planes (LDS, a few distinct slots per tile)
 		st.slot = jbest;
@@ -830,72 +806,6 @@ __device__ __forceinline__ void fill_share_word(const KParams &p, int bit, int v
 		fill_word<float>(p, view, wi, lane, 0);
 }
 
-// Adjoint of pass 1 for a tile whose triangles are ONE staged batch (S.ids[0 .. ntri), the usual case), untextured: the moments
-//   M[owner][3 q + m] = sum over the owner's pixels of  g_q * {x, y, 1}[m]
-// are a small dense contraction over the 64 pixels of the tile -- (one-hot owner matrix)^T (64 x 16) times the 64 x 12 matrix of
-// per-pixel values -- and the forward raster is bound by vector-ALU issue while its matrix cores idle: sixteen
-// v_mfma_f64_16x16x4_f64 (K = 4 pixels each) can replace the segmented scans, run tables and merge loops of owner_adjoint
-// (about half of its vector instructions).  Operand layout (cdna_hip_programming.md, checked by tools/probes/mfma_f64_probe.hip): lane l
-// feeds A[l & 15][l >> 4] and B[l >> 4][l & 15], and receives D[(l >> 4) + 4 r][l & 15] in register r.  The per-pixel values
-// cross lanes through the (idle) staging area, 32 pixels at a time; the one-hot entries are exact, so only the order of the
-// additions differs from the scan (both differ from the reference's row-by-row sums; tolerance of the parity tests 1e-8).
-// MEASURED AND NOT USED (the product is built with DR_OWNER_MFMA = 0; tools/build_variants.sh can build the other): parity green
-// (all 205 GPU tests), 100 fewer vector instructions per tile -- and the forward raster 14 us SLOWER (85 -> 99 us per 8-view
-// launch): on MI355X the f64 matrix rate equals the f64 vector rate (78.6 TFLOP/s), a 16 x 16 x 4 f64 MFMA holds its SIMD for
-// ~64 cycles, and 16 of them (of whose 16 k multiply-adds ~2.5 k are useful: 3 - 4 owners x 12 moments x 64 pixels) cost more
-// issue time than the ~100 vector instructions they replace.
-#ifndef DR_OWNER_MFMA
-#define DR_OWNER_MFMA 0
-#endif
-typedef double mfma_f64x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void owner_adjoint_mfma(const KParams &p, const ViewPtrs &w, WaveLds &S, int lane, double x, double y, int slot, int ntri,
-												   const double *g)
-{
-	static_assert(sizeof(S.rec) + sizeof(S.planes) >= 32 * 12 * sizeof(double) && sizeof(S.cover) >= 64 && TB == 16, "LDS reuse");
-	const int C = p.C, nm = 3 * p.L.P;
-	double *bm = (double *)&S.rec[0]; // [32 pixels][12]: g_q x, g_q y, g_q of planes q = 0 .. 3
-	uint8_t *jb = &S.cover[0][0];	  // [64 pixels]: slot of the owner, 0xff: none
-	const int col = lane & 15, kq = lane >> 4;
-	jb[lane] = (uint8_t)(slot < 0 ? 0xff : slot);
-	mfma_f64x4 acc = {0, 0, 0, 0};
-#pragma unroll
-	for (int h = 0; h < 2; h++)
-	{
-		lds_sync();
-		if ((lane >> 5) == h)
-		{
-			double *row = bm + (lane & 31) * 12;
-#pragma unroll
-			for (int q = 0; q < CH; q++)
-			{
-				const double v = q < C ? g[q] : 0.0;
-				row[3 * q] = v * x;
-				row[3 * q + 1] = v * y;
-				row[3 * q + 2] = v;
-			}
-		}
-		lds_sync();
-#pragma unroll
-		for (int st = 0; st < 8; st++)
-		{
-			const int pl = 4 * st + kq; // pixel of this lane's A / B entries, inside the half
-			const double a = jb[32 * h + pl] == (uint8_t)col ? 1.0 : 0.0;
-			const double b = col < 12 ? bm[pl * 12 + col] : 0.0;
-			acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
-		}
-	}
-#pragma unroll
-	for (int r = 0; r < 4; r++)
-	{ // owner slot kq + 4 r, moment `col`: the 3P moments of an owner are contiguous (one atomic instruction per four owners)
-		const int i = kq + 4 * r;
-		const double v = acc[r];
-#if !(DR_ABLATE & 128)
-		if (i < ntri && col < nm && v != 0)
-			atomic_add_f64(w.tri_acc + (size_t)S.ids[i] * nm + col, v);
-#endif
-	}
-}
-
 // (dr_finalize.h) the per-primitive adjoint algebra as workgroups of the forward raster: see raster_fwd_fast_kernel
 template <bool VTX64>
 __device__ __forceinline__ void fin_in_fwd_role(const KParams &p, char *lds, long long fi);
@@ -1167,13 +1077,6 @@ template <class PixT, bool FUSED, bool TEX, int MODE, bool CLAMP>
 __device__ __forceinline__ void fwd_tiles(const KParams &p, WaveLds *s_lds, EdgeSort *s_es, const long long b)
 { // b: index of this walker among the walkers of the grid (the workgroup index, unless fill workgroups are dealt among them)
 	DR_WAVE_TRACE_SCOPE(2);
-#ifdef DR_FWD_TRACE
-	// per-tile phase timing (tools/fwd_trace.py): eight counters over the first row of the tile in the z buffer
-	uint32_t ftr[16] = {0x7fc0f00du, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-#define DR_FTRACE(i) ftr[i] = (uint32_t)(__builtin_readcyclecounter() - ftr0)
-#else
-#define DR_FTRACE(i)
-#endif
 	constexpr int wave = 0;
 	const int lane0 = threadIdx.x & 63;
 	const int G = p.tile_blocks;
@@ -1206,10 +1109,6 @@ __device__ __forceinline__ void fwd_tiles(const KParams &p, WaveLds *s_lds, Edge
 	const uint32_t n_work = w.hdr->work_count[heavy_list ? 0 : 1];
 	for (; rank < n_work; rank += (uint32_t)stride)
 	{
-#ifdef DR_FWD_TRACE
-		const uint64_t ftr0 = __builtin_readcyclecounter();
-		ftr[8] = ftr[9] = ftr[10] = ftr[11] = ftr[12] = 0;
-#endif
 		// (the lane index is made opaque per iteration: otherwise every lane-dependent address of the body is hoisted out of the
 		// loop and kept -- spilled -- in registers across it: + 150 VGPRs for a loop that usually runs once or twice)
 		int lane = lane0;
@@ -1256,10 +1155,6 @@ __device__ __forceinline__ void fwd_tiles(const KParams &p, WaveLds *s_lds, Edge
 #pragma unroll
 		for (int cc = 0; cc < CH; cc++)
 			st.v[cc] = 0;
-#ifdef DR_FWD_TRACE
-		ftr[1] = (uint32_t)ntri | ((uint32_t)nedge << 16);
-#endif
-		DR_FTRACE(2); // counters arrived
 		// ---- pass 1
 		if (ntri > 0)
 		{
@@ -1272,7 +1167,7 @@ __device__ __forceinline__ void fwd_tiles(const KParams &p, WaveLds *s_lds, Edge
 				lds_sync();
 				stage_batch(S, w.tri_rec, w.tri_planes, P, nb, lane);
 				lds_sync();
-				tri_batch<TEX>(p, S, nb, lane, x0, y0, inb, st DR_TRACE_PASS);
+				tri_batch<TEX>(p, S, nb, lane, x0, y0, inb, st);
 			}
 			if (ntri > K_TRI)
 			{ // spilled pairs of this tile: compact them out of the pool, TB at a time
@@ -1301,7 +1196,7 @@ __device__ __forceinline__ void fwd_tiles(const KParams &p, WaveLds *s_lds, Edge
 							lds_sync();
 							stage_batch(S, w.tri_rec, w.tri_planes, P, TB, lane);
 							lds_sync();
-							tri_batch<TEX>(p, S, TB, lane, x0, y0, inb, st DR_TRACE_PASS);
+							tri_batch<TEX>(p, S, TB, lane, x0, y0, inb, st);
 							fill = 0;
 						}
 					}
@@ -1311,11 +1206,10 @@ __device__ __forceinline__ void fwd_tiles(const KParams &p, WaveLds *s_lds, Edge
 					lds_sync();
 					stage_batch(S, w.tri_rec, w.tri_planes, P, fill, lane);
 					lds_sync();
-					tri_batch<TEX>(p, S, fill, lane, x0, y0, inb, st DR_TRACE_PASS);
+					tri_batch<TEX>(p, S, fill, lane, x0, y0, inb, st);
 				}
 			}
 		}
-		DR_FTRACE(3); // pass 1 done
 		// ---- resolve the winner's colour
 		double col[CH];
 #pragma unroll
@@ -1456,9 +1350,8 @@ __device__ __forceinline__ void fwd_tiles(const KParams &p, WaveLds *s_lds, Edge
 				}
 			}
 		}
-		DR_FTRACE(4); // colour resolved, edges blended
 		// ---- one write per pixel
-		if (inb && !(DR_ABLATE & 4))
+		if (inb)
 		{
 			if (p.image)
 			{
@@ -1486,7 +1379,6 @@ __device__ __forceinline__ void fwd_tiles(const KParams &p, WaveLds *s_lds, Edge
 			if (!FUSED || (nedge > 0 && (!fuse_edges || n_edges < 0)))
 				__builtin_nontemporal_store(pack_owner(st.kbest, st.kind), w.face_id + pix);
 		}
-		DR_FTRACE(5); // frame stores issued
 		if (FUSED && p.loss_wave)
 		{ // this tile's part of the loss sum (image - obs)^2, of the frame as stored (rounded to the pixel type), less what the tile would
 		  // contribute as pure background: the caller's table accounts for every tile as background, empty or not
@@ -1556,25 +1448,9 @@ __device__ __forceinline__ void fwd_tiles(const KParams &p, WaveLds *s_lds, Edge
 			for (int cc = 0; cc < CH; cc++)
 				g[cc] = (cc < C && inb) ? fit_residual<CLAMP>(p, (double)(PixT)col[cc], (double)ob[cc]) : 0.0;
 			lds_sync();
-			if (DR_ABLATE & 256)
-			{
-			}
-			else if (!TEX && DR_OWNER_MFMA && ntri <= TB)
-				owner_adjoint_mfma(p, w, S, lane, x, y, st.kbest >= 0 ? st.slot : -1, ntri, g);
-			else
-				owner_adjoint<PixT, TEX>(p, w, lane, x, y, st.kbest, st.kbest >= 0 ? st.kind : (int)KIND_NONE, g, tap, L, (double *)&S.rec[0],
+			owner_adjoint<PixT, TEX>(p, w, lane, x, y, st.kbest, st.kbest >= 0 ? st.kind : (int)KIND_NONE, g, tap, L, (double *)&S.rec[0],
 									(uint32_t *)&S.cover[0][0]);
 		}
-#ifdef DR_FWD_TRACE
-		DR_FTRACE(6); // adjoint of pass 1 issued
-		if (lane < 16 && p.zbuf)
-		{
-			uint32_t v = 0;
-			for (int i = 0; i < 16; i++)
-				v = lane == i ? ftr[i] : v;
-			((uint32_t *)p.zbuf)[(size_t)view * H * W + (size_t)(y0 + (lane >> 3)) * W + x0 + (lane & 7)] = v;
-		}
-#endif
 		}
 		}
 		if (FUSED)

@@ -428,7 +428,7 @@ __global__ __launch_bounds__(PRIM_BLOCK, DR_PRIM_WAVES) void setup_bin_kernel(KP
 					   // through the tile lists, the finalize kernel looks at tri_flag first
 			const int x0 = rec.x_min < 0 ? 0 : rec.x_min, x1 = rec.x_max > s.W - 1 ? s.W - 1 : rec.x_max;
 			const int y0 = rec.y_begin[0] < 0 ? 0 : rec.y_begin[0], y1 = rec.y_end[1] > s.H - 1 ? s.H - 1 : rec.y_end[1];
-			const bool on_screen = !(x0 > x1 || y0 > y1 || (DR_ABLATE & 2048));
+			const bool on_screen = !(x0 > x1 || y0 > y1);
 			const double eq[9] = {rec.eq[0][0], rec.eq[0][1], rec.eq[0][2], rec.eq[1][0], rec.eq[1][1], rec.eq[1][2], rec.eq[2][0], rec.eq[2][1], rec.eq[2][2]};
 			const int tx0 = x0 / TILE, ty0 = y0 / TILE, ntx = x1 / TILE - tx0 + 1, nty = y1 / TILE - ty0 + 1;
 			// Non-strict fill rule: get_xrange's ceil_div clamps the left end of a row to x_max (H.h:895), so a row whose span lies
@@ -462,8 +462,7 @@ __global__ __launch_bounds__(PRIM_BLOCK, DR_PRIM_WAVES) void setup_bin_kernel(KP
 			DR_WAVE_PHASE_T(2); // record computed
 			rec.pad0[0] = rec.pad0[1] = 0;
 			rec.pad1[0] = rec.pad1[1] = rec.pad1[2] = 0;
-			if (!(DR_ABLATE & 4096))
-				out = rec;
+			out = rec;
 			if (!on_screen)
 				break;
 			DR_WAVE_PHASE_T(3); // record stored

@@ -15,11 +15,6 @@ using namespace dr;
 namespace
 {
 
-#ifndef DR_ABLATE
-#define DR_ABLATE 0 // measurement builds only (tools/build_variants.sh): 4 no frame stores of non-empty tiles, 8 no fill waves'
-					// stores, 128 no accumulator atomics of the owner adjoint, 256 no owner adjoint in the fused forward, 512 no span
-					// arithmetic (every staged triangle covers its whole tile).  The product is always built with 0.
-#endif
 constexpr int TILE = 8;		// 8 x 8 pixels = one wavefront, lane = (y & 7) * 8 + (x & 7)
 constexpr int K_TRI = 32;	// inline triangle slots per tile; more spill to the pool
 constexpr int K_EDGE = 32;	// inline edge slots per tile (== TB: one staged batch)
@@ -478,7 +473,7 @@ struct DeviceAdd // accumulate a vertex gradient (the reference's `+=` into scen
 {
 	__device__ __forceinline__ void operator()(void *arr, size_t i, bool f64, double v) const
 	{
-		if (v == 0 || (DR_ABLATE & 1024))
+		if (v == 0)
 			return;
 		if (f64)
 			unsafeAtomicAdd((double *)arr + i, v);

@@ -1,24 +1,44 @@
 #!/bin/bash
 # Variants of libdeodr_hip.so for the measurement tools (built here, they travel to the GPU box with the tree; *.so is
 # git-ignored).  The product library is the one __graft_entry__.build() makes; nothing loads these unless a tool is given --lib.
-#   fwdtrace   -DDR_FWD_TRACE   per-tile phase counters of the fused forward   (tools/fwd_trace.py)
+#
+# The per-tile phase counters, the ablation masks and the matrix-core owner reduction are NOT in the product sources: they are
+# tools/variants/instrumentation.patch (a diff of deodr_amd/csrc against its instrumented twin), applied to a scratch copy of the
+# sources for the variants that need it.  After a change of the product sources that touches the patched places, re-create the
+# patch from a fixed-up copy (`diff -u a b` of the two directories) -- `patch` says which hunks no longer fit.
+#   fwdtrace   -DDR_FWD_TRACE   per-tile phase counters of the fused forward   (tools/fwd_trace.py)            [patched sources]
+#   tiletrace  -DDR_TILE_TRACE  per-tile counters of the adjoint's edge kernel  (tools/tile_trace.py)           [patched sources]
+#   ablM       -DDR_ABLATE=M    ablation masks: 4 no frame stores of non-empty tiles, 128 no accumulator atomics of the owner adjoint,
+#                               256 no owner adjoint in the fused forward, 512 no span arithmetic, 1024 no vertex-gradient atomics,
+#                               2048 no binning, 4096 no record stores, 16384 spans twice, 1048576 no texture-gradient atomics  [patched]
+#   mfma       -DDR_OWNER_MFMA=1 the owner reduction on the matrix cores (measured 14 us slower, round 2)        [patched sources]
 #   wavetrace  -DDR_WAVE_TRACE  start / end of every wave                       (tools/wave_trace.py)
-#   tiletrace  -DDR_TILE_TRACE  per-tile counters of the adjoint's edge kernel  (tools/tile_trace.py)
 #   fwdN       -DDR_FWD_WAVES=N the staged forward compiled for N waves / SIMD  (tools/step_time.py --lib)
-#   ablM       -DDR_ABLATE=M    ablation masks of the fused forward (4 no frame stores, 8 no fill stores, 128 no accumulator atomics)
-cd "$(dirname "$0")/../deodr_amd/csrc" || exit 1
-OUT=../../tools/variants
+#   <name>     EXTRA="-D..."    anything else: the product sources with the flags of $EXTRA
+ROOT="$(cd "$(dirname "$0")/.." && pwd)"
+OUT=$ROOT/tools/variants
 mkdir -p $OUT
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -ffp-contract=off -munsafe-fp-atomics"
-build() { /opt/rocm/bin/hipcc $FLAGS $2 -o $OUT/libdeodr_hip_$1.so dr_kernels.hip & }
+PATCHED=""
+patched_sources() { # a scratch copy of the sources with the instrumentation applied (once per invocation)
+  if [ -z "$PATCHED" ]; then
+    PATCHED=$(mktemp -d /tmp/deodr_instr.XXXXXX)
+    mkdir -p $PATCHED/deodr_amd/csrc $PATCHED/include
+    cp $ROOT/deodr_amd/csrc/*.h $ROOT/deodr_amd/csrc/*.hip $PATCHED/deodr_amd/csrc/
+    cp $ROOT/include/*.h $PATCHED/include/
+    (cd $PATCHED/deodr_amd/csrc && patch -p1 --no-backup-if-mismatch < $OUT/instrumentation.patch) || { echo "instrumentation.patch no longer fits the sources"; exit 1; }
+  fi
+}
+build() { (cd $1 && /opt/rocm/bin/hipcc $FLAGS $3 -o $OUT/libdeodr_hip_$2.so dr_kernels.hip) & }
 for v in ${@:-fwdtrace wavetrace tiletrace fwd4 fwd6}; do
   case $v in
-    fwdtrace) build $v -DDR_FWD_TRACE ;;
-    wavetrace) build $v -DDR_WAVE_TRACE ;;
-    tiletrace) build $v -DDR_TILE_TRACE ;;
-    fwd*) build $v -DDR_FWD_WAVES=${v#fwd} ;;
-    abl*) build $v "-DDR_ABLATE=${v#abl}" ;;
-    *) build $v "$EXTRA" ;;
+    fwdtrace) patched_sources; build $PATCHED/deodr_amd/csrc $v -DDR_FWD_TRACE ;;
+    tiletrace) patched_sources; build $PATCHED/deodr_amd/csrc $v -DDR_TILE_TRACE ;;
+    abl*) patched_sources; build $PATCHED/deodr_amd/csrc $v "-DDR_ABLATE=${v#abl}" ;;
+    mfma) patched_sources; build $PATCHED/deodr_amd/csrc $v -DDR_OWNER_MFMA=1 ;;
+    wavetrace) build $ROOT/deodr_amd/csrc $v -DDR_WAVE_TRACE ;;
+    fwd*) build $ROOT/deodr_amd/csrc $v -DDR_FWD_WAVES=${v#fwd} ;;
+    *) build $ROOT/deodr_amd/csrc $v "$EXTRA" ;;
   esac
 done
 wait
