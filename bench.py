@@ -25,6 +25,7 @@ The JSON line carries, besides the driver's contract:
                 again synchronously from that step's gradient arrays (relative error, asserted < 1e-12)
   hbm_probe     device-to-device copy / write-only / read-only bandwidth of this box (1 GiB buffers)
   single_view   the same fit step for ONE view (latency case): eager and replayed from a captured HIP graph
+  batch_sweep   the same fit step with 16 and 32 views per launch (where the library saturates; the headline stays at --views)
   other_configs fit-step time of BASELINE configs[1], [3], [4] (outside the timed headline; skipped with --no-other-configs)
   cpu_baseline  the reference's own CPU path (oracle/_ref = unmodified header, g++ -O2) on the host of the GPU box: one
                 thread, and one process per view on min(views, cores) cores; bounded samples (rank 0, N = 1 only)
@@ -274,6 +275,34 @@ def timed_steps(step, n):
         step()
     torch.cuda.synchronize()
     return (time.perf_counter() - t0) / n
+
+
+def batch_sweep(scenes_mod, DeviceScene, HipRasterizer, dev, S, sigma, batches=(16, 32)):
+    """The same fit step with more views per launch (the headline is quoted at `--views`, default 8): where the library saturates."""
+    out = []
+    for B in batches:
+        views = [scenes_mod.sphere_scene(size=S, angle=float(a)) for a in np.linspace(-0.5, 0.5, B)]
+        s0 = views[0]
+        stack = lambda n: np.stack([np.asarray(getattr(v, n)) for v in views])
+        ds = DeviceScene(
+            s0.faces, s0.faces_uv, s0.textured, s0.shaded, s0.uv, stack("ij"), stack("depths"), stack("colors"), stack("shade"), stack("edgeflags"),
+            S, S, texture=None, background_color=s0.background_color, clockwise=s0.clockwise, vertex_dtype=torch.float64, pixel_dtype=torch.float32, device=dev,
+        )  # fmt: skip
+        r = HipRasterizer.for_scene(ds)
+        Cc = ds.nb_colors
+        obs = torch.rand((B, S, S, Cc), dtype=torch.float32, device=dev)
+        image = torch.empty((B, S, S, Cc), dtype=torch.float32, device=dev)
+        z = torch.empty((B, S, S), dtype=torch.float32, device=dev)
+        grads = ds.zero_grads()
+        fit = lambda: r.render_fit(ds, obs, sigma, grads=grads, out=(image, z), check_overflow=False, clear_grads=True)
+        r.render(ds, sigma, out=(image, z), check_overflow=True)
+        for _ in range(5):
+            fit()
+        dt = min(timed_steps(fit, 20) for _ in range(3))
+        alg = sum(v for k, v in algorithmic_bytes(S, S, Cc, ds.nb_triangles, int(ds.depths.shape[1]), B, True).items() if k != "not_moved")
+        out.append({"views": B, "ms_per_step": dt * 1e3, "Mpixels_s": B * S * S / dt / 1e6, "whole_step_frac": alg / dt / 1e9 / HBM_PEAK_GBS})
+        del ds, r, obs, image, z, grads
+    return out
 
 
 def single_view_latency(scenes_mod, DeviceScene, HipRasterizer, dev, S, sigma, obs):
@@ -620,6 +649,7 @@ def main():
             out["other_configs"] = other_configs(dev)
         if world == 1 and not args.no_single_view:
             out["single_view"] = single_view_latency(scenes, DeviceScene, HipRasterizer, dev, S, args.sigma, obs)
+            out["batch_sweep"] = batch_sweep(scenes, DeviceScene, HipRasterizer, dev, S, args.sigma)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(views[0], 2 * (image[0] - obs).cpu().numpy().astype(np.float64), poses, S)
         result_line = json.dumps(out)
