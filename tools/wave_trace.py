@@ -34,6 +34,7 @@ for which, name in enumerate(("setup_bin_kernel", "finalize_kernel (or the final
     t = t[ok]
     if len(t) == 0:
         continue
+    t = t[t[:, 0] > t[:, 0].max() - 30000]  # (entries of earlier, larger grids stay in the buffer: keep the last launch -- 300 us)
     if which == 1 and (buf[2][:, 1] > 0).any():  # same clock: finalize workgroups inside the forward raster are shown on the walkers' time axis
         t0_fwd = buf[2].astype(np.int64)[buf[2][:, 1] > 0][:, 0].min()
         print(f"   (first of these wavefronts starts {(t[:, 0].min() - t0_fwd) * 0.01:.1f} us after the first walker, the last one ends {(t[:, 1].max() - t0_fwd) * 0.01:.1f} us after it)")
