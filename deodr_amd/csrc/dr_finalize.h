@@ -64,7 +64,9 @@ struct MergeSink // finalize_triangle's sink: corner i of the triangle adds into
 
 // DET: the deterministic mode (KParams::det): accumulators are read as int64 fixed point, contributions go to the int64 shadow arrays,
 // no vertex table (its LDS atomics are shared by four wavefronts: their order is not reproducible).
-template <bool VTX64, int NC, bool DET = false> // (the dtype of the vertex arrays and the channel count at compile time: see setup_bin_kernel)
+// TABLE: the instance with the per-workgroup vertex table (launches of >= DR_PRIM_TABLES_MIN triangles: KParams::prim_tables); the one
+// without keeps round 3's registers and LDS -- a single 20 k-triangle view is a chain of round trips and lost 1.7 us to the table's mere presence.
+template <bool VTX64, int NC, bool DET = false, bool TABLE = false> // (the dtype of the vertex arrays and the channel count at compile time: see setup_bin_kernel)
 #ifndef DR_FIN_WAVES
 #define DR_FIN_WAVES 4 // waves per SIMD finalize_kernel is compiled for (3: 144 registers with the vertex table, 21.4 -> 22.4 us)
 #endif
@@ -178,8 +180,9 @@ __global__ __launch_bounds__(PRIM_BLOCK, DR_FIN_WAVES) void finalize_kernel(KPar
 		// culled triangles own no accumulators
 		const bool live = k < p.T && (flag & 4u) && (flag & 3u) != KIND_NONE && (int32_t)(f0 | f1 | f2) >= 0;
 		// (the table's 26 KB are only touched by a block that has a triangle for it: half the blocks of a closed mesh are all back-facing)
-		__shared__ VertexTable s_vt;
-		const bool merge = DR_FIN_MERGE && p.prim_tables && P <= 4 && __syncthreads_or(live && (flag & 3u) == KIND_INTERP);
+		__shared__ __attribute__((aligned(16))) char s_vt_storage[TABLE ? sizeof(VertexTable) : 16]; // (no table, no LDS for it)
+		VertexTable &s_vt = *(VertexTable *)s_vt_storage;
+		const bool merge = TABLE && DR_FIN_MERGE && p.prim_tables && P <= 4 && __syncthreads_or(live && (flag & 3u) == KIND_INTERP);
 		if (merge)
 		{
 			for (int i = threadIdx.x; i < VT_SLOTS; i += PRIM_BLOCK)

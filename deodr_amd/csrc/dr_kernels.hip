@@ -512,6 +512,21 @@ int launch_adjoint(const DeodrHipScene *sc, KParams &p, hipStream_t st, bool own
 			hipLaunchKernelGGL((finalize_kernel<true, 0, true>), g2, dim3(PRIM_BLOCK), 0, st, p);
 		else if (p.det)
 			hipLaunchKernelGGL((finalize_kernel<false, 0, true>), g2, dim3(PRIM_BLOCK), 0, st, p);
+		else if (p.prim_tables && p.C <= CH)
+		{ // (the instances with the per-workgroup vertex table, for the channel counts that occur)
+			if (p.vtx_f64 && p.C == 4)
+				hipLaunchKernelGGL((finalize_kernel<true, 4, false, true>), g2, dim3(PRIM_BLOCK), 0, st, p);
+			else if (p.vtx_f64 && p.C == 3)
+				hipLaunchKernelGGL((finalize_kernel<true, 3, false, true>), g2, dim3(PRIM_BLOCK), 0, st, p);
+			else if (p.vtx_f64)
+				hipLaunchKernelGGL((finalize_kernel<true, 0, false, true>), g2, dim3(PRIM_BLOCK), 0, st, p);
+			else if (p.C == 4)
+				hipLaunchKernelGGL((finalize_kernel<false, 4, false, true>), g2, dim3(PRIM_BLOCK), 0, st, p);
+			else if (p.C == 3)
+				hipLaunchKernelGGL((finalize_kernel<false, 3, false, true>), g2, dim3(PRIM_BLOCK), 0, st, p);
+			else
+				hipLaunchKernelGGL((finalize_kernel<false, 0, false, true>), g2, dim3(PRIM_BLOCK), 0, st, p);
+		}
 		else
 			DR_LAUNCH_PRIM(finalize_kernel, g2, st);
 	}
