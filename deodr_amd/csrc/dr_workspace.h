@@ -16,8 +16,13 @@ namespace
 {
 
 constexpr int TILE = 8;		// 8 x 8 pixels = one wavefront, lane = (y & 7) * 8 + (x & 7)
-constexpr int K_TRI = 32;	// inline triangle slots per tile; more spill to the pool
-constexpr int K_EDGE = 32;	// inline edge slots per tile (== TB: one staged batch)
+#ifndef DR_K_LIST
+#define DR_K_LIST 64 // 32 until round 4: a tile with more primitives than inline slots scans the view's spill pool (two more round trips for the
+					 // long tiles, and every such walker reads the whole pool): 8 views 0.1211 -> 0.1175 ms, 1 view 0.0693 -> 0.0667 (profiles/r04t)
+#endif
+constexpr int K_TRI = DR_K_LIST;  // inline triangle slots per tile; more spill to the pool (at most 64: one per lane)
+constexpr int K_EDGE = DR_K_LIST; // inline edge slots per tile
+static_assert(K_TRI <= 64 && (K_TRI & (K_TRI - 1)) == 0, "a wavefront loads the inline list with one lane per slot");
 constexpr int CH = 4;		// colour channels kept in registers at a time
 constexpr int MAX_SORTED = 64; // edges of a tile whose blending order is cached in LDS
 constexpr int CNT_STRIDE = 32; // uint32 between two append counters (one 128-byte line each)

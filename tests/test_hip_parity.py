@@ -173,7 +173,7 @@ def test_spill_pool_regrows(oracle_api):
     """Many large overlapping triangles overflow the fixed per-tile lists and a deliberately tiny spill pool."""
     from hip_util import hip_render
 
-    s = scenes.soup_scene(n_tri=300, width=64, height=64, seed=9, min_area=600.0)
+    s = scenes.soup_scene(n_tri=700, width=64, height=64, seed=9, min_area=600.0)  # (~150 triangles per tile: inline lists hold 64)
     ref = checker(oracle_api).render(s, 1.0)
     ds, r, out = hip_render(s, 1.0, F64, pool_pairs=16)
     assert r.pool_pairs > 16  # regrown

@@ -481,7 +481,7 @@ def test_spill_pool_overflow_later_in_a_fit_is_detected(oracle_api):
 
     import copy
 
-    big = scenes.soup_scene(n_tri=300, width=64, height=64, seed=9, min_area=600.0)  # large triangles: every tile list spills
+    big = scenes.soup_scene(n_tri=700, width=64, height=64, seed=9, min_area=600.0)  # large triangles: every tile list (64 inline slots) spills
     small = copy.copy(big)  # the same triangles shrunk about their centroids, no silhouette edges: nothing spills
     tri = big.ij.reshape(-1, 3, 2)
     small.ij = (tri.mean(axis=1, keepdims=True) + 0.1 * (tri - tri.mean(axis=1, keepdims=True))).reshape(-1, 2)
