@@ -405,6 +405,11 @@ __host__ inline int heavy_share_for(int n_views, int tile_blocks, bool fuse_edge
 	return share;
 }
 
+#ifndef DR_SPLIT_EDGES
+#define DR_SPLIT_EDGES 1 // (measurement builds: 0 = a tile is one work item whatever its number of edges)
+#endif
+constexpr uint32_t SPLIT_FLAG = 0x80000000u; // in WorkEntry::nedge: bits 16 .. 18 = which batch of edges this copy of the tile back-propagates
+
 __global__ __launch_bounds__(SCAN_BLOCK) void tile_scan_kernel(KParams p)
 {
 	// classes compacted by this kernel: 0 many-primitive tiles (front of the work list), 1 the other non-empty tiles (back of it),
@@ -508,6 +513,14 @@ __global__ __launch_bounds__(SCAN_BLOCK) void tile_scan_kernel(KParams p)
 		pair_right = plain && (lane & 1) && n_prev > 0 && ntri + n_prev <= (uint32_t)ENTRY_IDS;
 		ntri_right = n_next;
 	}
+	// A fit step's tile with more than one batch of silhouette edges (17 .. EMAX) is listed once per batch: every copy ("part") runs
+	// pass 1 and the forward sweep over all the edges, but the reverse sweep -- 1.4 k cycles per edge, the long part -- of its own batch
+	// only (the first part also the adjoint of pass 1, the last one the frame stores).  One view of the benchmark scene waited 45 us
+	// for ONE wavefront with 43 triangles and 37 edges.
+	const uint32_t nparts = (DR_SPLIT_EDGES && heavy && p.fuse_edges && nedge > (uint32_t)TB && nedge <= (uint32_t)EMAX) ? (nedge + TB - 1) / TB : 1u;
+	const uint32_t extra = nparts - 1u; // 0 .. 7
+	const unsigned long long xb0 = __ballot(extra & 1u), xb1 = __ballot(extra & 2u), xb2 = __ballot(extra & 4u);
+	static_assert(EMAX / TB <= 8, "three bits of extra parts");
 	unsigned long long m[NCLS];
 	m[0] = __ballot(heavy);
 	m[1] = wm & ~m[0] & ~__ballot(pair_right);
@@ -522,7 +535,7 @@ __global__ __launch_bounds__(SCAN_BLOCK) void tile_scan_kernel(KParams p)
 #pragma unroll
 		for (int c = 0; c < NCLS; c++)
 			mine = lane == c ? m[c] : mine;
-		s_cnt[lane][wave] = (uint32_t)__popcll(mine);
+		s_cnt[lane][wave] = (uint32_t)__popcll(mine) + (lane == 0 ? (uint32_t)(__popcll(xb0) + 2 * __popcll(xb1) + 4 * __popcll(xb2)) : 0u);
 	}
 	__syncthreads();
 	if (threadIdx.x < NCLS)
@@ -591,12 +604,16 @@ __global__ __launch_bounds__(SCAN_BLOCK) void tile_scan_kernel(KParams p)
 	}
 	else if (work)
 	{
-		WorkEntry &e = heavy ? w.work_list[position(0, m[0])] : w.work_list[my_pos];
-		uint4 *out = (uint4 *)&e;
-		out[0] = make_uint4((uint32_t)tile, ntri, nedge, sweep_slot);
-		out[1] = ida;
-		out[2] = idb;
-		out[3] = idc;
+		const uint32_t head_pos = heavy ? position(0, m[0]) + (uint32_t)(__popcll(xb0 & below) + 2 * __popcll(xb1 & below) + 4 * __popcll(xb2 & below)) : 0u;
+		for (uint32_t part = 0; part < nparts; part++)
+		{
+			WorkEntry &e = heavy ? w.work_list[head_pos + part] : w.work_list[my_pos];
+			uint4 *out = (uint4 *)&e;
+			out[0] = make_uint4((uint32_t)tile, ntri, nparts > 1 ? (SPLIT_FLAG | part << 16 | nedge) : nedge, sweep_slot);
+			out[1] = ida;
+			out[2] = idb;
+			out[3] = idc;
+		}
 	}
 }
 
@@ -1124,7 +1141,11 @@ __device__ __forceinline__ void fwd_tiles(const KParams &p, WaveLds *s_lds, Edge
 			lds_sync();
 			continue;
 		}
-		const int tile = uniform((int)entry.tile), ntri = uniform((int)entry.ntri), nedge = MODE == FWD_NO_EDGES ? 0 : uniform((int)entry.nedge);
+		const uint32_t nedge_word = MODE == FWD_NO_EDGES ? 0u : (uint32_t)uniform((int)entry.nedge);
+		// (FWD_EDGE_ADJ: a tile of several batches of edges is listed once per batch, see tile_scan_kernel)
+		bool split = MODE == FWD_EDGE_ADJ && (nedge_word & SPLIT_FLAG);
+		const int part = split ? (int)((nedge_word >> 16) & 0xffu) : 0;
+		const int tile = uniform((int)entry.tile), ntri = uniform((int)entry.ntri), nedge = (int)(split ? (nedge_word & 0xffffu) : nedge_word);
 		const uint32_t sweep_slot = (uint32_t)uniform((int)entry.sweep_slot);
 		const int tx = tile % p.L.tiles_x, ty = tile / p.L.tiles_x;
 		const int x0 = tx * TILE, y0 = ty * TILE;
@@ -1236,6 +1257,17 @@ __device__ __forceinline__ void fwd_tiles(const KParams &p, WaveLds *s_lds, Edge
 		uint32_t tm[EMAX / TB] = {0, 0, 0, 0, 0, 0, 0, 0}; // (fused adjoint) bit j of tm[b]: edge 16 b + j of the blending order is drawn over this pixel
 		if (nedge > 0)
 			n_edges = gather_sorted_edges(s_es[wave], w, p, tile, nedge, lane);
+		if (split && n_edges < 0)
+		{ // (pairs of this tile lost to a pool overflow -- the call is repeated anyway: the first copy alone takes the un-staged path)
+			if (part > 0)
+			{
+				lds_sync();
+				continue;
+			}
+			split = false;
+		}
+		const int last_part = split ? (nedge + TB - 1) / TB - 1 : 0;
+		double colp[CH] = {0, 0, 0, 0}, trp = 1; // (split tile) the colour after this part's batch, the transparency of everything drawn later
 		if (n_edges > 0)
 		{
 			static_assert(EMAX == 128 && TB == 16, "layout of the saved masks: one 16-bit word per batch of 16 edges");
@@ -1287,6 +1319,8 @@ __device__ __forceinline__ void fwd_tiles(const KParams &p, WaveLds *s_lds, Edge
 								col[cc] *= Tr;
 								col[cc] += (1 - Tr) * A;
 							}
+						if (fuse_edges && split && first > part * TB)
+							trp *= Tr;
 					}
 				}
 				if (fuse_edges)
@@ -1294,6 +1328,12 @@ __device__ __forceinline__ void fwd_tiles(const KParams &p, WaveLds *s_lds, Edge
 #pragma unroll
 					for (int bb = 0; bb < EMAX / TB; bb++)
 						tm[bb] = bb == first / TB ? drawn_batch : tm[bb];
+					if (split && first == part * TB)
+					{
+#pragma unroll
+						for (int cc = 0; cc < CH; cc++)
+							colp[cc] = col[cc];
+					}
 				}
 				if (sweep_slot) // bit j: edge first + j of the blending order is drawn over this pixel
 					((uint16_t *)(w.edge_sweep + (size_t)(sweep_slot - 1) * SWEEP_BYTES + CH * 64 * sizeof(double)))[(first / TB) * 64 + lane] =
@@ -1351,7 +1391,7 @@ __device__ __forceinline__ void fwd_tiles(const KParams &p, WaveLds *s_lds, Edge
 			}
 		}
 		// ---- one write per pixel
-		if (inb)
+		if (inb && (!split || part == last_part))
 		{
 			if (p.image)
 			{
@@ -1379,7 +1419,7 @@ __device__ __forceinline__ void fwd_tiles(const KParams &p, WaveLds *s_lds, Edge
 			if (!FUSED || (nedge > 0 && (!fuse_edges || n_edges < 0)))
 				__builtin_nontemporal_store(pack_owner(st.kbest, st.kind), w.face_id + pix);
 		}
-		if (FUSED && p.loss_wave)
+		if (FUSED && p.loss_wave && (!split || part == last_part))
 		{ // this tile's part of the loss sum (image - obs)^2, of the frame as stored (rounded to the pixel type), less what the tile would
 		  // contribute as pure background: the caller's table accounts for every tile as background, empty or not
 			double r2 = 0;
@@ -1423,11 +1463,19 @@ __device__ __forceinline__ void fwd_tiles(const KParams &p, WaveLds *s_lds, Edge
 					}
 				};
 				const int nbatch = (n_edges + TB - 1) / TB;
+				if (split && part < last_part)
+				{ // where the reverse sweep stands when it reaches this part's batch
+#pragma unroll
+					for (int cc = 0; cc < CH; cc++)
+						g[cc] *= trp, col[cc] = colp[cc];
+				}
 				lds_sync();
-				edge_reverse_sweep<PixT, TEX>(p, w, S, &s_es[wave], lane, x, y, n_edges, nbatch - 1, 0, true, tm, col, g, base, have_base, pixel_base);
+				edge_reverse_sweep<PixT, TEX>(p, w, S, &s_es[wave], lane, x, y, n_edges, split ? part : nbatch - 1, split ? part : 0, !split || part == last_part,
+											  tm, col, g, base, have_base, pixel_base);
 				lds_sync();
-				owner_adjoint<PixT, TEX>(p, w, lane, x, y, st.kbest, st.kbest >= 0 ? st.kind : (int)KIND_NONE, g, tap, L, (double *)&S.rec[0],
-										(uint32_t *)&S.cover[0][0]);
+				if (!split || part == 0)
+					owner_adjoint<PixT, TEX>(p, w, lane, x, y, st.kbest, st.kbest >= 0 ? st.kind : (int)KIND_NONE, g, tap, L, (double *)&S.rec[0],
+											(uint32_t *)&S.cover[0][0]);
 			}
 			else if (n_edges < 0)
 			{ // more than EMAX edges in one tile: the un-staged adjoint reads the frame and the owner ids this wavefront has just written
