@@ -435,9 +435,8 @@ def main():
     grads = ds.zero_grads()
     # Multi-GPU: what the ranks share is the mesh -- 3-D vertex positions and vertex colours -- so the all-reduced buffer is
     # [vertices_b (V x 3), colors_b summed over the views (V x C)].  vertices_b = sum over the views of the adjoint of the view's
-    # camera projection (deodr's Camera.project_points_backward, dr.py:397-438) applied to ij_b: ONE launch of the library's
-    # pose-and-projection adjoint (deodr_hip_fit_pose_project_b with the identity pose: the kernel the device fitters use), which
-    # also adds the colour gradients up over the views.
+    # camera projection (deodr's Camera.project_points_backward, dr.py:397-438) applied to ij_b: ONE launch
+    # (deodr_hip_views_gradient_sum), which also adds the colour gradients up over the views.
     shared = torch.zeros(V * (3 + Cc), dtype=torch.float64, device=dev)  # packed shared-parameter gradient
     reduction = None
     if world > 1 or args.force_dist:
@@ -450,9 +449,12 @@ def main():
         camera = DeviceCamera(np.stack([c.extrinsic for c in cams]), np.stack([c.intrinsic for c in cams]), S, S, None, dev)
         world_vertices = torch.as_tensor(np.ascontiguousarray(verts, dtype=np.float64), device=dev)
         reduction = dict(
-            camera=camera, vertices=world_vertices, posed=world_vertices[None].expand(B, -1, -1).contiguous(),
-            identity=torch.tensor([[0.0, 0.0, 0.0, 1.0]] * B, dtype=torch.float64, device=dev),
-            pose_out=torch.zeros(3 + 7 * B, dtype=torch.float64, device=dev), scratch=fronthalf.fit_scratch(V, B, dev), call=fronthalf.fit_pose_project_b,
+            camera=camera, posed=world_vertices[None].expand(B, -1, -1).contiguous(), call=fronthalf.views_gradient_sum,
+            # the render stream tells the communication stream that a step's gradients are complete through a word of device memory
+            # (DeodrHipFitOptions::done_flag, stored by finalize_kernel's last wavefront; deodr_hip_wait_flag on the other side): an
+            # event recorded on the render stream and waited for by a second queue costs the render stream ~8 us per step
+            # (tools/dist_overhead_probe.py, profiles/r04v_*)
+            flag=torch.zeros(1, dtype=torch.int32, device=dev), wait_status=torch.zeros(1, dtype=torch.int32, device=dev),
         )  # fmt: skip
 
     obs_views = obs.expand(B, S, S, Cc).contiguous()  # one observation per view (here the same synthetic image)
@@ -481,22 +483,28 @@ def main():
         else:
             # same outputs in one call: the forward raster back-propagates through the tiles without silhouette edges itself
             # (and zeroes the gradient arrays of the previous step on the way)
-            r.render_fit(ds, obs_views, args.sigma, grads=g, out=(image, z), check_overflow=False, clear_grads=True)
+            done = None
+            if dist is not None:
+                done = (reduction["flag"], it[0])  # (the step number: increasing)
+            r.render_fit(ds, obs_views, args.sigma, grads=g, out=(image, z), check_overflow=False, clear_grads=True, done_flag=done)
         if dist is not None:
-            rendered = torch.cuda.Event()
-            rendered.record()
+            rd = reduction
+            rendered = None
+            if args.two_pass:  # (the two-call step has no done flag: an event)
+                rendered = torch.cuda.Event()
+                rendered.record()
             with torch.cuda.stream(comm):
-                comm.wait_event(rendered)
-                if pending[i] is not None:
-                    pending[i].wait()  # shared_pp[i] is free again
+                if rendered is not None:
+                    comm.wait_event(rendered)
+                else:
+                    hr.wait_flag(rd["flag"], it[0], status=rd["wait_status"], timeout=2.0)
                 # one kernel: the projection adjoint of every view applied to ij_b and summed over the views, the colour gradients
-                # summed over the views, both written straight into the packed buffer
-                rd = reduction
-                rd["call"](rd["vertices"], rd["identity"], rd["posed"], rd["camera"], None, g["ij_b"], None, shared_pp[i][: 3 * V].view(V, 3), rd["pose_out"],
-                           rd["scratch"], colors_b=g["colors_b"], colors_sum=shared_pp[i][3 * V :].view(V, Cc))  # fmt: skip
+                # summed over the views, both written straight into the packed buffer (which the collective of two steps ago, earlier
+                # on this stream, has left)
+                rd["call"](rd["posed"], rd["camera"], g["ij_b"], shared_pp[i][: 3 * V].view(V, 3), colors_b=g["colors_b"], colors_sum=shared_pp[i][3 * V :].view(V, Cc))
                 reads_done[i] = torch.cuda.Event()
                 reads_done[i].record()
-                pending[i] = dist.all_reduce(shared_pp[i], async_op=True)
+                dist.all_reduce(shared_pp[i])  # (issued under the communication stream: ordered on it)
 
     # first call checks the spill pool once (synchronises), then nothing in the loop does
     r.render(ds, args.sigma, out=(image, z), check_overflow=True)
@@ -566,13 +574,14 @@ def main():
     if dist is not None:
         last_i = (it[0] - 1) % len(grads_pp)
         g, rd, again = grads_pp[last_i], reduction, torch.zeros_like(shared)
-        rd["call"](rd["vertices"], rd["identity"], rd["posed"], rd["camera"], None, g["ij_b"], None, again[: 3 * V].view(V, 3), rd["pose_out"], rd["scratch"],
-                   colors_b=g["colors_b"], colors_sum=again[3 * V :].view(V, Cc))  # fmt: skip
+        rd["call"](rd["posed"], rd["camera"], g["ij_b"], again[: 3 * V].view(V, 3), colors_b=g["colors_b"], colors_sum=again[3 * V :].view(V, Cc))
         local_max = float(again.abs().max())
         dist.all_reduce(again)
         torch.cuda.synchronize()
         err = float((shared_pp[last_i] - again).abs().max() / again.abs().max())
-        reduction_check = {"ranks": world, "rel_err": err, "ok": bool(err < 1e-12 and local_max > 0), "values": int(again.numel())}
+        timed_out = int(reduction["wait_status"].item())
+        reduction_check = {"ranks": world, "rel_err": err, "ok": bool(err < 1e-12 and local_max > 0 and not timed_out), "values": int(again.numel()),
+                           "flag_wait_timed_out": bool(timed_out), "sync": "event" if args.two_pass else "done flag (deodr_hip_wait_flag)"}  # fmt: skip
         assert reduction_check["ok"], f"bench: the all-reduced shared gradient of the timed loop differs from a synchronous reduction: {reduction_check}"
 
     # spill pool never overflowed and the scene was valid during the run (deferred check, outside the timed region)

@@ -70,7 +70,7 @@ template <bool VTX64, int NC, bool DET = false, bool TABLE = false> // (the dtyp
 #ifndef DR_FIN_WAVES
 #define DR_FIN_WAVES 4 // waves per SIMD finalize_kernel is compiled for (3: 144 registers with the vertex table, 21.4 -> 22.4 us)
 #endif
-__global__ __launch_bounds__(PRIM_BLOCK, DR_FIN_WAVES) void finalize_kernel(KParams p)
+__device__ __forceinline__ void finalize_body(KParams &p)
 { // same split as setup_bin_kernel: triangle blocks, then edge-slot blocks compacted to the flagged slots.
   // (Lists of the front-facing triangles / drawn edges compacted by the set-up kernel were tried: a quarter as many wavefronts,
   // all lanes busy -- and 32 -> 41 us: the kernel is a chain of dependent round trips, fewer wavefronts overlap fewer of them.)
@@ -291,6 +291,74 @@ __global__ __launch_bounds__(PRIM_BLOCK, DR_FIN_WAVES) void finalize_kernel(KPar
 		DR_WAVE_PHASE(4);
 	}
 }
+
+// The step-done flag: every wavefront counts itself when its gradient contributions have been executed; the last one stores the flag.
+// The gradients leave this kernel as atomics, which are executed at the memory side: a wavefront whose vmcnt has
+// reached zero has them in memory, for every XCD to see, and nothing else is promised by the flag -- a release fence per wavefront
+// (= a write-back of its XCD's L2, 24 000 times per step) made the kernel 160 us longer.  Two levels of counters (DONE_SUBS of them a
+// cache line apart, then one): the returning atomics on ONE word are executed one after the other -- 24 000 of them, 55 us.
+// The counters are left zero: whoever completes one resets it.
+__device__ __forceinline__ void step_done_signal(const KParams &p)
+{
+	__atomic_signal_fence(__ATOMIC_SEQ_CST);
+	__builtin_amdgcn_s_waitcnt(0); // vmcnt(0) expcnt(0) lgkmcnt(0): this wavefront's atomics have been acknowledged
+	__atomic_signal_fence(__ATOMIC_SEQ_CST);
+	if ((threadIdx.x & 63) == 0)
+	{
+		uint32_t *counts = (uint32_t *)(p.ws + p.L.done_counts); // view 0's
+		const uint32_t waves = gridDim.x * (PRIM_BLOCK / 64), id = blockIdx.x * (PRIM_BLOCK / 64) + (threadIdx.x >> 6), sub = id % DONE_SUBS;
+		const uint32_t expected = (waves - sub + DONE_SUBS - 1) / DONE_SUBS; // wavefronts whose id is sub (mod DONE_SUBS)
+		if (__hip_atomic_fetch_add(&counts[sub * DONE_STRIDE], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == expected - 1u)
+		{
+			__hip_atomic_store(&counts[sub * DONE_STRIDE], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			const uint32_t subs = waves < (uint32_t)DONE_SUBS ? waves : (uint32_t)DONE_SUBS;
+			if (__hip_atomic_fetch_add(&counts[DONE_SUBS * DONE_STRIDE], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == subs - 1u)
+			{
+				__hip_atomic_store(&counts[DONE_SUBS * DONE_STRIDE], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				__hip_atomic_store(p.done_flag, p.done_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			}
+		}
+	}
+}
+
+template <bool VTX64, int NC, bool DET = false, bool TABLE = false>
+__global__ __launch_bounds__(PRIM_BLOCK, DR_FIN_WAVES) void finalize_kernel(KParams p)
+{
+	finalize_body<VTX64, NC, DET, TABLE>(p);
+	if (p.done_flag)
+		step_done_signal(p);
+}
+
+// ---- the step-done flag (DeodrHipFitOptions::done_flag) and its consumer's side
+__global__ void store_flag_kernel(uint32_t *flag, uint32_t value) { __hip_atomic_store(flag, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); }
+
+// one lane polls (agent scope: past the L2 of its XCD) until *flag has reached `value` (serial-number arithmetic), for at most `ticks` of
+// the 100 MHz counter; a wait that timed out leaves status[0] = 1 and every later wait on that status word returns at once
+__global__ void wait_flag_kernel(const uint32_t *flag, uint32_t value, uint32_t *status, unsigned long long ticks)
+{
+	if (threadIdx.x != 0)
+		return;
+	if (status && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)
+		return;
+	const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+	for (;;)
+	{
+		// RELAXED: an acquire load at agent scope invalidates the L2 of the XCD this wavefront sits on at every poll -- the forward raster that
+		// runs beside it lost 3 us per step to that (rocprofv3 trace, profiles/r04v_*); what is acquired here is acquired by the end of
+		// this kernel and the start of the next one on the stream
+		const uint32_t v = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		if ((int32_t)(v - value) >= 0)
+			return;
+		if (__builtin_amdgcn_s_memrealtime() - t0 > ticks)
+		{
+			if (status)
+				__hip_atomic_store(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			return;
+		}
+		__builtin_amdgcn_s_sleep(16); // (~0.5 us)
+	}
+}
+
 
 
 // Deterministic mode, last step: every element of a gradient array receives the integer sum of its shadow (one thread per element: a

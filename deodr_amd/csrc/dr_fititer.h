@@ -305,6 +305,51 @@ __global__ __launch_bounds__(FH_BLOCK) void fit_pose_project_b_kernel(const doub
 	}
 }
 
+// ---- what the views of a multi-view fit share (deodr/mesh_fitter.py:518-527: `vertices_b += ...` frame after frame): the adjoint of every
+// view's camera projection applied to its ij_b (and depths_b), summed over the views -> vertices_b [V,3]; the colour adjoints summed over the
+// views -> colors_sum [V,C].  No pose, no sum over the vertices: one round trip, as wide as the mesh (the L lanes of a vertex take its views) --
+// this is the buffer a sharded fit all-reduces, and as a tail of fit_pose_project_b_kernel (at most 64 workgroups, built to idle beside
+// the raster kernels) it took 30 us of the step it ran in.
+template <int L>
+__global__ __launch_bounds__(FH_BLOCK) void views_gradient_sum_kernel(const double *posed, const double *extrinsic, const double *intrinsic, const double *distortion,
+																	   const double *ij_b, const double *depths_b, double depths_b_scale, double *vertices_b, int V,
+																	   int n, const double *colors_b, int C, double *colors_sum)
+{
+	const int th = blockIdx.x * FH_BLOCK + threadIdx.x, v = th / L, sub = th % L;
+	const bool on = v < V;
+	Vec3 acc = {0, 0, 0};
+	double col_sum[4] = {0, 0, 0, 0};
+	for (int b = sub; b < n && on; b += L)
+	{
+		const size_t at = (size_t)b * V + v;
+		if (colors_sum)
+#pragma unroll
+			for (int cc = 0; cc < 4; cc++)
+				if (cc < C)
+					col_sum[cc] += colors_b[at * C + cc];
+		const CameraRow cam = load_camera(extrinsic, intrinsic, distortion, b);
+		acc = add3(acc, project_point_b(cam, load3(posed + 3 * at), ij_b[2 * at], ij_b[2 * at + 1], depths_b ? depths_b[at] * depths_b_scale : 0.0));
+	}
+	auto views_sum = [](double x) { // over the L lanes of a vertex (every lane of the wavefront takes part)
+#pragma unroll
+		for (int d = 1; d < L; d <<= 1)
+			x += __shfl_xor(x, d);
+		return x;
+	};
+	acc = {views_sum(acc.x), views_sum(acc.y), views_sum(acc.z)};
+	if (on && sub == 0)
+		store3(vertices_b + 3 * v, acc);
+	if (colors_sum)
+#pragma unroll
+		for (int cc = 0; cc < 4; cc++)
+			if (cc < C)
+			{
+				const double t = views_sum(col_sum[cc]);
+				if (on && sub == 0)
+					colors_sum[(size_t)v * C + cc] = t;
+			}
+}
+
 // ---- shading.  vf_offsets [V+1], vf_corners [3T]: for every vertex the (3 face + corner) slots it occupies (static per mesh)
 struct FaceNormal
 {

@@ -483,6 +483,12 @@ int launch_forward(const DeodrHipScene *sc, KParams &p, hipStream_t stream, hipE
 // the caller's stream waits for the side stream's work of this call
 int join_side(hipStream_t stream, hipEvent_t join) { return join ? check_hip(hipStreamWaitEvent(stream, join, 0), "join") : 0; }
 
+template <class Kernel>
+void launch_finalize(Kernel kernel, dim3 grid, hipStream_t st, const KParams &p)
+{
+	hipLaunchKernelGGL(kernel, grid, dim3(PRIM_BLOCK), 0, st, p);
+}
+
 // adjoint raster and the per-primitive finalize; owner_tiles = false after a fused forward
 int launch_adjoint(const DeodrHipScene *sc, KParams &p, hipStream_t st, bool owner_tiles)
 {
@@ -509,23 +515,23 @@ int launch_adjoint(const DeodrHipScene *sc, KParams &p, hipStream_t st, bool own
 				(p.loss_out ? 1u : 0u)); // (+ the workgroup that adds up the loss)
 		ScopedKernelTimer t(KID_FINALIZE, st);
 		if (p.det && p.vtx_f64)
-			hipLaunchKernelGGL((finalize_kernel<true, 0, true>), g2, dim3(PRIM_BLOCK), 0, st, p);
+			launch_finalize(finalize_kernel<true, 0, true>, g2, st, p);
 		else if (p.det)
-			hipLaunchKernelGGL((finalize_kernel<false, 0, true>), g2, dim3(PRIM_BLOCK), 0, st, p);
+			launch_finalize(finalize_kernel<false, 0, true>, g2, st, p);
 		else if (p.prim_tables && p.C <= CH)
 		{ // (the instances with the per-workgroup vertex table, for the channel counts that occur)
 			if (p.vtx_f64 && p.C == 4)
-				hipLaunchKernelGGL((finalize_kernel<true, 4, false, true>), g2, dim3(PRIM_BLOCK), 0, st, p);
+				launch_finalize(finalize_kernel<true, 4, false, true>, g2, st, p);
 			else if (p.vtx_f64 && p.C == 3)
-				hipLaunchKernelGGL((finalize_kernel<true, 3, false, true>), g2, dim3(PRIM_BLOCK), 0, st, p);
+				launch_finalize(finalize_kernel<true, 3, false, true>, g2, st, p);
 			else if (p.vtx_f64)
-				hipLaunchKernelGGL((finalize_kernel<true, 0, false, true>), g2, dim3(PRIM_BLOCK), 0, st, p);
+				launch_finalize(finalize_kernel<true, 0, false, true>, g2, st, p);
 			else if (p.C == 4)
-				hipLaunchKernelGGL((finalize_kernel<false, 4, false, true>), g2, dim3(PRIM_BLOCK), 0, st, p);
+				launch_finalize(finalize_kernel<false, 4, false, true>, g2, st, p);
 			else if (p.C == 3)
-				hipLaunchKernelGGL((finalize_kernel<false, 3, false, true>), g2, dim3(PRIM_BLOCK), 0, st, p);
+				launch_finalize(finalize_kernel<false, 3, false, true>, g2, st, p);
 			else
-				hipLaunchKernelGGL((finalize_kernel<false, 0, false, true>), g2, dim3(PRIM_BLOCK), 0, st, p);
+				launch_finalize(finalize_kernel<false, 0, false, true>, g2, st, p);
 		}
 		else
 			DR_LAUNCH_PRIM(finalize_kernel, g2, st);
@@ -777,6 +783,12 @@ static int render_scene_fit_impl(const DeodrHipScene *sc, void *image, void *z_b
 	hipEvent_t join = nullptr;
 	if (launch_forward(sc, p, st, &join, fused))
 		return 1;
+	// The step-done flag: stored by the last wavefront of finalize_kernel to finish when that kernel is the step's last (the usual fit
+	// step), by a one-thread kernel behind everything otherwise.
+	uint32_t *done_flag = opt ? opt->done_flag : nullptr;
+	const bool fin_signals = done_flag && p.T > 0 && !p.fin_in_fwd && !g_det && !join && !(loss_out && !loss_in_kernels);
+	if (fin_signals)
+		p.done_flag = done_flag, p.done_value = opt->done_value;
 	if (launch_adjoint(sc, p, st, !fused))
 		return 1;
 	if (join_side(st, join)) // the background fill has been overlapping the adjoint
@@ -785,8 +797,14 @@ static int render_scene_fit_impl(const DeodrHipScene *sc, void *image, void *z_b
 	{ // un-staged kernels (more than 4 channels) or a scene without triangles: one pass over the finished frame
 		if (check_hip(hipMemsetAsync(loss_scratch, 0, 64 + 8 * (size_t)L2_BLOCKS, st), "loss scratch"))
 			return 1;
-		return l2_loss_impl(image, obs, sc->pixel_dtype, (size_t)sc->n_views * sc->height * sc->width * sc->nb_colors, loss_out, loss_scratch,
-							64 + 8 * (size_t)L2_BLOCKS, stream, p.clamp, p.clamp_lo, p.clamp_hi);
+		if (l2_loss_impl(image, obs, sc->pixel_dtype, (size_t)sc->n_views * sc->height * sc->width * sc->nb_colors, loss_out, loss_scratch,
+						 64 + 8 * (size_t)L2_BLOCKS, stream, p.clamp, p.clamp_lo, p.clamp_hi))
+			return 1;
+	}
+	if (done_flag && !fin_signals)
+	{
+		hipLaunchKernelGGL(store_flag_kernel, dim3(1), dim3(1), 0, st, done_flag, opt->done_value);
+		return check_hip(hipGetLastError(), "done flag launch");
 	}
 	return 0;
 }
@@ -996,6 +1014,31 @@ int deodr_hip_fit_pose_project_b(const double *vertices, const double *quaternio
 		hipLaunchKernelGGL(fit_pose_project_b_kernel<GATHER_LANES>, pose_grid, dim3(FH_BLOCK), 0, (hipStream_t)stream, vertices, quaternions, posed, extrinsic, intrinsic,
 					   distortion, posed_b, ij_b, depths_b, depths_b_scale, vertices_b, out, (double *)((char *)scratch + 64), (unsigned *)scratch + FC_POSE_B, V, n, colors_b, nb_colors, colors_sum);
 	return check_hip(hipGetLastError(), "fit_pose_project_b launch");
+}
+
+int deodr_hip_views_gradient_sum(const double *posed, const double *extrinsic, const double *intrinsic, const double *distortion, const double *ij_b,
+								 const double *depths_b, double depths_b_scale, double *vertices_b, int V, int n, const double *colors_b, int nb_colors,
+								 double *colors_sum, void *stream)
+{
+	if (!posed || !extrinsic || !intrinsic || !ij_b || !vertices_b || V <= 0 || n <= 0)
+		return fail("views_gradient_sum: bad arguments");
+	if (colors_sum && (!colors_b || nb_colors <= 0 || nb_colors > 4))
+		return fail("views_gradient_sum: colors_sum needs colors_b with 1 - 4 channels");
+	if (n == 1)
+		hipLaunchKernelGGL(views_gradient_sum_kernel<1>, dim3(fh_blocks(V)), dim3(FH_BLOCK), 0, (hipStream_t)stream, posed, extrinsic, intrinsic, distortion, ij_b,
+						   depths_b, depths_b_scale, vertices_b, V, n, colors_b, nb_colors, colors_sum);
+	else
+		hipLaunchKernelGGL(views_gradient_sum_kernel<GATHER_LANES>, dim3(fh_blocks((long long)V * GATHER_LANES)), dim3(FH_BLOCK), 0, (hipStream_t)stream, posed,
+						   extrinsic, intrinsic, distortion, ij_b, depths_b, depths_b_scale, vertices_b, V, n, colors_b, nb_colors, colors_sum);
+	return check_hip(hipGetLastError(), "views_gradient_sum launch");
+}
+
+int deodr_hip_wait_flag(const uint32_t *flag, uint32_t value, uint32_t *status, double timeout_seconds, void *stream)
+{
+	if (!flag || !(timeout_seconds > 0))
+		return fail("wait_flag: bad arguments");
+	hipLaunchKernelGGL(wait_flag_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, flag, value, status, (unsigned long long)(timeout_seconds * 1e8));
+	return check_hip(hipGetLastError(), "wait_flag launch");
 }
 
 static int shade_args(ShadeArgs &a, const double *posed, const uint32_t *faces, const uint32_t *vf_offsets, const uint32_t *vf_corners, const double *light,

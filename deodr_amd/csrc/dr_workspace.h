@@ -105,6 +105,9 @@ static_assert(offsetof(WsHeader, all_needed_max) == 4 * DEODR_HIP_STATUS_WORD_NE
 				  (int)dr::SCENE_ERR_NO_TEXTURE == DEODR_HIP_ERR_NO_TEXTURE,
 			  "status block layout published in include/deodr_hip.h");
 
+// Step-done flag (KParams::done_flag): finalize_kernel's wavefronts count themselves on DONE_SUBS counters, a cache line apart -- on ONE word
+// the 24 000 returning atomics of an 8-view step are executed one after the other at the memory side: 55 us
+constexpr int DONE_SUBS = 256, DONE_STRIDE = 16;
 constexpr int LOSS_SLOTS = 256; // partial sums of the loss per view (one per walker was 32 768 values for ONE workgroup to add up: 20 us)
 
 struct Layout
@@ -113,7 +116,7 @@ struct Layout
 		edge_pool, face_id, tile_bits, tri_flag, work_list, edge_tile_cnt, edge_tiles, edge_slot, edge_sweep, edge_snap, view_bytes;
 	uint32_t tri_pool_cap, edge_pool_cap;
 	size_t edge_fin;
-	size_t blk_sync, blk_cnt, blk_lists, fin_overflow, fin_items;
+	size_t blk_sync, blk_cnt, blk_lists, fin_overflow, fin_items, done_counts;
 	uint32_t fin_overflow_cap;
 	int tiles_x, tiles_y, ntiles, nwords, P, sweep_cap;
 	int blk_x, blk_y, nblk; // blocks of BLK x BLK tiles: the grain at which the finalize workgroups of a fused forward wait for the tile walkers
@@ -184,6 +187,7 @@ Layout make_layout(int T, int H, int W, int C, size_t pool_pairs)
 	L.blk_lists = take(sizeof(uint32_t) * (size_t)L.nblk * (BLK_TRI_CAP + BLK_EDGE_CAP));
 	L.fin_overflow_cap = (uint32_t)(4 * (size_t)T < 0x7fffffffu ? 4 * (size_t)T : 0x7fffffffu);
 	L.fin_overflow = take(sizeof(uint32_t) * (size_t)L.fin_overflow_cap);
+	L.done_counts = take(sizeof(uint32_t) * (DONE_SUBS + 1) * DONE_STRIDE); // (view 0's are used: the step-done flag, dr_finalize.h)
 	L.fin_items = take(sizeof(uint2) * ((size_t)L.nblk * (BLK_TRI_CAP / 64 + BLK_EDGE_CAP / 64) + ((size_t)L.fin_overflow_cap + 63) / 64 + 8));
 	L.view_bytes = o;
 	return L;
@@ -233,6 +237,10 @@ struct KParams
 	// stamp[0 / 1 / 2] -- kernels of one stream run back to back, so the difference of two consecutive stamps IS the duration of the kernel(s)
 	// between them, with no event packet between the launches (a hipEvent pair per kernel costs the step it measures ~ 36 us)
 	unsigned long long *stamp;
+	// Step-done flag (DeodrHipFitOptions::done_flag): the last wavefront of finalize_kernel to finish stores done_value there once every
+	// wavefront's gradients are visible device-wide -- what a consumer on another stream waits for (deodr_hip_wait_flag) instead of an event
+	uint32_t *done_flag;
+	uint32_t done_value;
 	// loss of a fit step, sum (image - obs)^2 (deodr_hip_render_scene_fit_loss): loss_tile_bg[0] = the loss of a frame that is all
 	// background, [1 + view * ntiles + tile] = that of one tile; loss_wave[view * LOSS_SLOTS + q % LOSS_SLOTS]: walker q of the forward
 	// raster adds (loss of a tile - its background loss) for every tile it walks; one workgroup of finalize_kernel writes loss_out[0] =

@@ -37,13 +37,14 @@ def _lib():
         L.deodr_hip_fit_scratch_bytes.argtypes, L.deodr_hip_fit_scratch_bytes.restype = [i, i], C.c_size_t
         L.deodr_hip_fit_pose_project.argtypes = [vp] * 11 + [d, i, i, vp]
         L.deodr_hip_fit_pose_project_b.argtypes = [vp] * 9 + [d, vp, vp, vp, C.c_size_t, i, i, vp, i, vp, vp]
+        L.deodr_hip_views_gradient_sum.argtypes = [vp] * 6 + [d, vp, i, i, vp, i, vp, vp]
         L.deodr_hip_vertex_shade.argtypes = [vp] * 7 + [i, vp, vp, i, i, i, vp]
         L.deodr_hip_vertex_shade_b.argtypes = [vp] * 7 + [i, vp, vp, vp, vp, vp, C.c_size_t, i, i, i, vp]
         L.deodr_hip_rigid_energy.argtypes = [vp] * 5 + [d, vp, vp, vp, d, vp, C.c_size_t, i, vp]
         L.deodr_hip_l2_loss.argtypes = [vp, vp, i, C.c_size_t, vp, vp, C.c_size_t, vp]
         L.deodr_hip_depth_residual.argtypes = [vp, i, vp, d, C.c_size_t, vp, vp, vp, vp, vp, C.c_size_t, vp]
         for f in ("rigid_transform", "rigid_transform_b", "project_points", "project_points_b", "silhouette_flags", "momentum_update", "fit_pose_project",
-                  "fit_pose_project_b", "vertex_shade", "vertex_shade_b", "rigid_energy", "l2_loss", "depth_residual", "fit_front"):  # fmt: skip
+                  "fit_pose_project_b", "views_gradient_sum", "vertex_shade", "vertex_shade_b", "rigid_energy", "l2_loss", "depth_residual", "fit_front"):  # fmt: skip
             getattr(L, "deodr_hip_" + f).restype = i
         _bound = True
     return L
@@ -183,6 +184,18 @@ def fit_pose_project_b(vertices, quaternions, posed, camera, posed_b, ij_b, dept
         _check(_lib().deodr_hip_fit_pose_project_b(_p(vertices), _p(quaternions), _p(posed), _p(camera.extrinsic), _p(camera.intrinsic), _p(camera.distortion),
                                                    _p(posed_b), _p(ij_b), _p(depths_b), float(depths_b_scale), _p(vertices_b), _p(out), _p(scratch), scratch.numel(), V, n,
                                                    _p(colors_b), 0 if colors_b is None else int(colors_b.shape[-1]), _p(colors_sum), _stream(posed.device)))  # fmt: skip
+
+
+def views_gradient_sum(posed, camera, ij_b, vertices_b, depths_b=None, depths_b_scale=1.0, colors_b=None, colors_sum=None):
+    """What the views of a multi-view fit share (mesh_fitter.py:518-527): vertices_b [V,3] (written) = the adjoint of every view's camera
+    projection applied to ij_b [n,V,2] (and depths_b [n,V]), summed over the n views; colors_sum [V,C] (written, optional) = colors_b
+    [n,V,C] summed over the views.  One wide launch -- the packed buffer a sharded fit all-reduces."""
+    n, V = posed.shape[0], posed.shape[1]
+    _check_cameras(n, camera.extrinsic, camera.intrinsic, camera.distortion)
+    with torch.cuda.device(posed.device):
+        _check(_lib().deodr_hip_views_gradient_sum(_p(posed), _p(camera.extrinsic), _p(camera.intrinsic), _p(camera.distortion), _p(ij_b), _p(depths_b),
+                                                   float(depths_b_scale), _p(vertices_b), V, n, _p(colors_b), 0 if colors_b is None else int(colors_b.shape[-1]),
+                                                   _p(colors_sum), _stream(posed.device)))  # fmt: skip
 
 
 def vertex_shade(posed, topology, light, ambient, color=None, luminosity=None, colors=None):

@@ -20,7 +20,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libdeodr_hip.so")
-ABI_VERSION = 10
+ABI_VERSION = 11
 ERR_FACES, ERR_FACES_UV, ERR_NO_TEXTURE, ERR_INTERNAL = 1, 2, 4, 8  # include/deodr_hip.h DEODR_HIP_ERR_*
 _STATUS_NEEDED, _STATUS_ERRORS = 11, 12  # words of the 64-byte status block at the start of the workspace
 
@@ -43,7 +43,7 @@ class _FitOptionsC(C.Structure):
     """include/deodr_hip.h::DeodrHipFitOptions"""
 
     _fields_ = [("tile_loss", C.c_void_p), ("loss", C.c_void_p), ("loss_scratch", C.c_void_p), ("clamp", C.c_int), ("clamp_lo", C.c_double),
-                ("clamp_hi", C.c_double)]  # fmt: skip
+                ("clamp_hi", C.c_double), ("done_flag", C.c_void_p), ("done_value", C.c_uint32)]  # fmt: skip
 
 
 def lib():
@@ -77,6 +77,8 @@ def lib():
         L.deodr_hip_render_scene_fit_ex.restype = C.c_int
         L.deodr_hip_render_scene_fit_ex.argtypes = [C.POINTER(_SceneC), C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, C.c_int, C.POINTER(_FitOptionsC),
                                                     C.c_void_p, C.c_size_t, C.c_void_p]  # fmt: skip
+        L.deodr_hip_wait_flag.restype = C.c_int
+        L.deodr_hip_wait_flag.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_double, C.c_void_p]
         L.deodr_hip_workspace_status.restype = C.c_int
         L.deodr_hip_workspace_status.argtypes = [C.POINTER(_SceneC), C.c_void_p, C.c_size_t, C.c_void_p, C.POINTER(C.c_int),
                                                  C.POINTER(C.c_ulonglong), C.POINTER(C.c_int)]  # fmt: skip
@@ -96,6 +98,16 @@ def set_deterministic(on):
     """``deodr_hip_set_deterministic``: integer accumulation on the un-staged kernels -- gradients bit-identical from run to run (slow;
     for tests and for debugging an optimiser).  Process-wide."""
     lib().deodr_hip_set_deterministic(int(bool(on)))
+
+
+def wait_flag(flag, value, status=None, timeout=1.0, stream=None):
+    """``deodr_hip_wait_flag``: the current stream of ``flag``'s device (or ``stream``) waits until ``flag`` (a 4-byte integer tensor a fit step
+    was given as ``done_flag``) has reached ``value``.  The step must have been queued before this call.  ``status``: a 4-byte tensor set to 1 by a
+    wait that gave up after ``timeout`` seconds (check it where you synchronise)."""
+    dev = flag.device
+    with torch.cuda.device(dev):
+        _check(lib().deodr_hip_wait_flag(_ptr(flag), int(value) & 0xFFFFFFFF, _ptr(status), float(timeout),
+                                         C.c_void_p(stream.cuda_stream) if stream is not None else _stream(dev)))  # fmt: skip
 
 
 def force_generic(on):
@@ -445,7 +457,7 @@ class HipRasterizer:
             self._loss_cache = cache = (key, table, scratch, (obs_t, ds.background_color, ds.background_image))
         return cache[1], cache[2]
 
-    def render_fit(self, ds, obs, sigma=1.0, grads=None, out=None, check_overflow=None, clear_grads=False, loss_out=None, clamp=None):
+    def render_fit(self, ds, obs, sigma=1.0, grads=None, out=None, check_overflow=None, clear_grads=False, loss_out=None, clamp=None, done_flag=None):
         """One fit step in one call: render ``ds`` and back-propagate ``sum((image - obs)**2)``; -> (image, z_buffer, grads).
 
         Same results as :meth:`render` followed by ``render_backward(residual_obs=obs)`` (what the reference's
@@ -455,7 +467,9 @@ class HipRasterizer:
         tensor of one element that receives ``sum((image - obs)**2)`` -- from the same launches, without a pass over the frame
         (``deodr_hip_render_scene_fit_ex``; the table it needs is computed at the first call with this observation).  ``clamp`` =
         (lo, hi): the loss is ``sum((image.clamp(lo, hi) - obs)**2)``, the depth fitter's data term (deodr/mesh_fitter.py:108-123);
-        the returned image is the un-clamped rendering."""
+        the returned image is the un-clamped rendering.  ``done_flag`` = (int32 / uint32 device tensor of one element, value): the step
+        stores ``value`` there when its gradients are complete -- what a consumer on another stream waits for with :func:`wait_flag`
+        instead of an event (``DeodrHipFitOptions::done_flag``)."""
         self._check_scene(ds)
         n, H, W, Cc = ds.n_views, ds.height, ds.width, ds.nb_colors
         pd = ds.pixel_dtype
@@ -471,11 +485,15 @@ class HipRasterizer:
                 grads = ds.zero_grads()
             sc = ds.c_struct(grads)
             self._inspect_poll(sc)
-            if loss_out is None and clamp is None:
+            if done_flag is not None and (done_flag[0].element_size() != 4 or done_flag[0].numel() != 1 or done_flag[0].device != ds.device):
+                raise ValueError("done_flag must be (a 4-byte integer tensor of one element on the scene's device, value)")
+            if loss_out is None and clamp is None and done_flag is None:
                 _check(lib().deodr_hip_render_scene_fit(C.byref(sc), _ptr(image), _ptr(z), float(sigma), _ptr(obs_t), int(bool(clear_grads)),
                                                         _ptr(self.workspace), self.nbytes, _stream(self.device)))  # fmt: skip
             else:
                 options = _FitOptionsC()
+                if done_flag is not None:
+                    options.done_flag, options.done_value = done_flag[0].data_ptr(), int(done_flag[1]) & 0xFFFFFFFF
                 if clamp is not None:
                     options.clamp, options.clamp_lo, options.clamp_hi = 1, float(clamp[0]), float(clamp[1])
                 if loss_out is not None:

@@ -135,6 +135,13 @@ typedef struct DeodrHipFitOptions
 	void *loss_scratch;		 /* deodr_hip_fit_loss_bytes bytes, device */
 	int clamp;
 	double clamp_lo, clamp_hi;
+	/* Step-done flag, or NULL (a 4-byte word of device memory the caller owns): when the gradients of this step are complete and visible
+	 * device-wide, the step's last wavefront stores done_value there.  A consumer on ANOTHER stream -- the shared-gradient reduction of a
+	 * sharded fit -- waits for it with deodr_hip_wait_flag instead of a hipEvent: an event recorded on the render stream and waited for by
+	 * a second queue costs the render stream ~8 us per step on MI355X (tools/dist_overhead_probe.py), this flag nothing.  Use increasing
+	 * values (the step number): deodr_hip_wait_flag waits for *flag >= value in serial-number arithmetic. */
+	uint32_t *done_flag;
+	uint32_t done_value;
 } DeodrHipFitOptions;
 size_t deodr_hip_fit_loss_bytes(int height, int width, int n_views);
 int deodr_hip_background_loss(const DeodrHipScene *scene, const void *obs, const DeodrHipFitOptions *options, double *tile_loss, void *workspace,
@@ -304,12 +311,27 @@ int deodr_hip_force_generic(int on);
  * deodr_hip_force_generic. */
 int deodr_hip_set_deterministic(int on);
 
+/* A sharded multi-view fit (deodr/mesh_fitter.py:504-546 with the frames dealt to ranks): what the ranks all-reduce is the gradient of what
+ * the views share -- the mesh vertices and their colours.
+ * deodr_hip_views_gradient_sum   the adjoint of every view's camera projection (deodr_hip_project_points_b's formulas) applied to ij_b [n,V,2]
+ *                                (and depths_b_scale * depths_b [n,V], or NULL) and summed over the n views -> vertices_b [V,3]; colors_b
+ *                                [n,V,C] summed over the views -> colors_sum [V,C] (or NULL): `vertices_b += ...` of mesh_fitter.py:518-527 in
+ *                                one launch, straight into the packed buffer the collective runs on.
+ * deodr_hip_wait_flag            queues, on `stream`, a one-wavefront kernel that returns when *flag >= value (DeodrHipFitOptions::done_flag; the
+ *                                producer must have been queued BEFORE this call, on any stream of the device: the wait then never depends on
+ *                                work that does not exist yet).  After timeout_seconds it gives up and sets status[0] = 1 (device memory, or
+ *                                NULL); later waits on a status word that is set return at once -- the caller checks it where it synchronises. */
+int deodr_hip_views_gradient_sum(const double *posed, const double *extrinsic, const double *intrinsic, const double *distortion, const double *ij_b,
+								 const double *depths_b, double depths_b_scale, double *vertices_b, int V, int n, const double *colors_b, int nb_colors,
+								 double *colors_sum, void *stream);
+int deodr_hip_wait_flag(const uint32_t *flag, uint32_t value, uint32_t *status, double timeout_seconds, void *stream);
+
 /* Message of the last error returned on this host thread. */
 const char *deodr_hip_last_error(void);
 
 /* ABI version of this header; bumped on any incompatible change. */
 int deodr_hip_abi_version(void);
-#define DEODR_HIP_ABI_VERSION 10
+#define DEODR_HIP_ABI_VERSION 11
 
 #ifdef __cplusplus
 }

@@ -240,6 +240,8 @@ class FakeLib:
                 img, ob = _view(image, (n, H, W, Cc), pd).astype(np.float64), _view(obs, (n, H, W, Cc), pd).astype(np.float64)
                 image_b = np.where((img >= o.clamp_lo) & (img <= o.clamp_hi), 2 * (img - ob), 0.0).astype(pd)
                 self._adjoint(sc, a, pd, sigma, 0, image_b, None, None)
+        if not rc and o.done_flag:  # (the step-done flag: everything is synchronous here)
+            _view(o.done_flag, (1,), np.uint32)[0] = o.done_value
         if rc or not o.loss:
             return rc
         tx, ty = self._tiles(H, W)

@@ -171,3 +171,92 @@ def test_copy_probe_copies():
     torch.cuda.synchronize()
     assert torch.equal(a, b)
     assert hr.lib().deodr_hip_copy_probe(b.data_ptr(), a.data_ptr(), 24, 0, 1, st) != 0  # not a multiple of 16
+
+
+def _cameras(n, rng):
+    from deodr_amd.scene3d import DeviceCamera
+
+    K = np.array([[300.0, 0, 64], [0, 310.0, 48], [0, 0, 1]])
+    E = np.stack([np.column_stack((scenes.roty(0.2 * i) @ scenes.rotx(0.1), np.array([0.05 * i, 0.02, 4.0 + 0.1 * i]))) for i in range(n)])
+    dist = rng.randn(n, 5) * 0.01
+    return DeviceCamera(E, np.stack([K] * n), 96, 128, dist, torch.device("cuda"))
+
+
+@pytest.mark.parametrize("n", [1, 5, 8])
+def test_views_gradient_sum_is_the_sum_of_the_camera_adjoints(n, monkeypatch):
+    """deodr_hip_views_gradient_sum (what a sharded multi-view fit all-reduces: mesh_fitter.py:518-527's `vertices_b += ...` in one launch)
+    against autograd through the torch formulas of the projection, view by view, and against the pose adjoint with the identity pose"""
+    from deodr_amd import fronthalf
+
+    rng = np.random.RandomState(5)
+    V, Cc = 333, 3
+    cam = _cameras(n, rng)
+    posed = torch.as_tensor(rng.rand(n, V, 3) - 0.5, device="cuda")
+    ij_b = torch.as_tensor(rng.randn(n, V, 2), device="cuda")
+    depths_b = torch.as_tensor(rng.randn(n, V), device="cuda")
+    colors_b = torch.as_tensor(rng.randn(n, V, Cc), device="cuda")
+    vb, cs = torch.zeros(V, 3, dtype=F64, device="cuda"), torch.zeros(V, Cc, dtype=F64, device="cuda")
+    fronthalf.views_gradient_sum(posed, cam, ij_b, vb, depths_b=depths_b, depths_b_scale=0.7, colors_b=colors_b, colors_sum=cs)
+    p = posed.clone().requires_grad_(True)
+    monkeypatch.setattr(fronthalf, "usable", lambda *a: False)  # (DeviceCamera.project_points: the torch formulas, not the fused kernel)
+    ij, d = cam.project_points(p)
+    monkeypatch.undo()
+    ((ij * ij_b).sum() + 0.7 * (d * depths_b).sum()).backward()
+    assert torch.allclose(vb, p.grad.sum(0), rtol=1e-10, atol=1e-10)
+    assert torch.allclose(cs, colors_b.sum(0), rtol=1e-13, atol=1e-13)
+    # the pose adjoint with the identity pose computes the same sums (bit for bit: same formulas, same order over the views)
+    out, vb2, cs2 = torch.zeros(3 + 7 * n, dtype=F64, device="cuda"), torch.zeros_like(vb), torch.zeros_like(cs)
+    ident = torch.tensor([[0.0, 0.0, 0.0, 1.0]] * n, dtype=F64, device="cuda")
+    fronthalf.fit_pose_project_b(posed[0].contiguous(), ident, posed, cam, None, ij_b, depths_b, vb2, out, fronthalf.fit_scratch(V, n, torch.device("cuda")),
+                                 depths_b_scale=0.7, colors_b=colors_b, colors_sum=cs2)  # fmt: skip
+    assert torch.equal(vb, vb2) and torch.equal(cs, cs2)
+
+
+@pytest.mark.parametrize("n_views", [1, 8])
+def test_step_done_flag_and_wait_flag(n_views):
+    """DeodrHipFitOptions::done_flag: the step stores the value when its gradients are complete; a kernel on ANOTHER stream that was queued
+    behind deodr_hip_wait_flag then reads the finished gradients (no event between the streams).  One view: finalize_kernel without the vertex
+    table; eight: with it.  A wait for a value that never comes gives up and says so."""
+    from hip_util import device_scene
+    from deodr_amd import hip_renderer as hr
+    from deodr_amd.hip_renderer import HipRasterizer
+
+    views = [scenes.sphere_scene(size=512, angle=float(a)) for a in np.linspace(-0.3, 0.3, n_views)]
+    ds = device_scene(views, F64)
+    r = HipRasterizer.for_scene(ds)
+    obs = torch.as_tensor(np.random.RandomState(6).rand(n_views, 512, 512, 4), device=ds.device)
+    image, z, g_ref = r.render_fit(ds, obs, 1.0, check_overflow=True, clear_grads=True)
+    torch.cuda.synchronize()
+    ref = g_ref["ij_b"].clone()
+    flag = torch.zeros(1, dtype=torch.int32, device=ds.device)
+    status = torch.zeros(1, dtype=torch.int32, device=ds.device)
+    side = torch.cuda.Stream()
+    g = ds.zero_grads()
+    copies = []
+    for step in range(1, 21):
+        r.render_fit(ds, obs, 1.0, grads=g, clear_grads=True, check_overflow=False, done_flag=(flag, step))
+        with torch.cuda.stream(side):
+            hr.wait_flag(flag, step, status=status, timeout=5.0)
+            copies.append(g["ij_b"].clone())  # (on the side stream: ordered behind the wait only)
+        side.synchronize()  # (the next step clears the gradients: the copy must have been taken)
+    torch.cuda.synchronize()
+    assert int(flag.item()) == 20 and int(status.item()) == 0
+    for c in copies:  # every copy was taken from complete gradients (atomics: equal to rounding, run to run)
+        assert torch.allclose(c, ref, rtol=1e-9, atol=1e-9 * float(ref.abs().max()))
+    # the fallback (a one-thread kernel behind everything) where finalize_kernel is not the step's last kernel: the deterministic mode
+    hr.set_deterministic(True)
+    try:
+        r.render_fit(ds, obs, 1.0, grads=g, clear_grads=True, check_overflow=False, done_flag=(flag, 21))
+        with torch.cuda.stream(side):
+            hr.wait_flag(flag, 21, status=status, timeout=5.0)
+            det = g["ij_b"].clone()
+        torch.cuda.synchronize()
+    finally:
+        hr.set_deterministic(False)
+    assert int(flag.item()) == 21 and int(status.item()) == 0
+    assert float((det - ref).abs().max() / ref.abs().max()) < 1e-4  # (fixed point: 2^-32 per contribution, through the 3 x 3 inverses of finalize)
+    # a value nobody stores: the wait gives up after its timeout and raises the status word; later waits on that word return at once
+    hr.wait_flag(flag, 1000, status=status, timeout=0.05)
+    hr.wait_flag(flag, 1001, status=status, timeout=30.0)
+    torch.cuda.synchronize()
+    assert int(status.item()) == 1

@@ -11,7 +11,7 @@ from deodr_amd import scenes
 from deodr_amd.hip_renderer import DeviceScene, HipRasterizer
 
 dev = torch.device("cuda:0")
-S, B = 1024, 8
+S, B = 1024, (int(sys.argv[sys.argv.index('--views') + 1]) if '--views' in sys.argv else 8)
 views = [scenes.sphere_scene(size=S, angle=float(a)) for a in np.linspace(-0.5, 0.5, B)]
 s0 = views[0]
 stack = lambda name: np.stack([np.asarray(getattr(v, name)) for v in views])
