@@ -10,7 +10,10 @@
 #   tiletrace  -DDR_TILE_TRACE  per-tile counters of the adjoint's edge kernel  (tools/tile_trace.py)           [patched sources]
 #   ablM       -DDR_ABLATE=M    ablation masks: 4 no frame stores of non-empty tiles, 128 no accumulator atomics of the owner adjoint,
 #                               256 no owner adjoint in the fused forward, 512 no span arithmetic, 1024 no vertex-gradient atomics,
-#                               2048 no binning, 4096 no record stores, 16384 spans twice, 1048576 no texture-gradient atomics  [patched]
+#                               2048 no binning, 4096 no record stores, 16384 spans twice, 1048576 no texture-gradient atomics,
+#                               2097152 texture gradient dropped (no LDS adds, no scatter), 4194304 no texel loads / bilinear adjoint in the owner
+#                               adjoint, 8388608 no LDS window for the texture gradient, 16777216 one tap in four added to the window,
+#                               33554432 only the even lanes add to it  [patched]
 #   mfma       -DDR_OWNER_MFMA=1 the owner reduction on the matrix cores (measured 14 us slower, round 2)        [patched sources]
 #   wavetrace  -DDR_WAVE_TRACE  start / end of every wave                       (tools/wave_trace.py)
 #   fwdN       -DDR_FWD_WAVES=N the staged forward compiled for N waves / SIMD  (tools/step_time.py --lib)

@@ -12,11 +12,16 @@ from deodr_amd.hip_renderer import DeviceScene, HipRasterizer
 
 dev = torch.device("cuda:0")
 S, B = 1024, (int(sys.argv[sys.argv.index('--views') + 1]) if '--views' in sys.argv else 8)
-views = [scenes.sphere_scene(size=S, angle=float(a)) for a in np.linspace(-0.5, 0.5, B)]
+TEXTURED = "--textured" in sys.argv  # the shape of BASELINE configs[4]: 2048^2, 100 k triangles, 1024^2 texture, C = 3
+if TEXTURED:
+    S = 2048
+    views = [scenes.sphere_scene(size=S, nu=224, n_rings=224, nb_colors=3, textured=True, texture_size=1024, angle=float(a)) for a in np.linspace(-0.5, 0.5, B)]
+else:
+    views = [scenes.sphere_scene(size=S, angle=float(a)) for a in np.linspace(-0.5, 0.5, B)]
 s0 = views[0]
 stack = lambda name: np.stack([np.asarray(getattr(v, name)) for v in views])
 ds = DeviceScene(s0.faces, s0.faces_uv, s0.textured, s0.shaded, s0.uv, stack("ij"), stack("depths"), stack("colors"), stack("shade"),
-                 stack("edgeflags"), S, S, texture=None, background_color=s0.background_color, clockwise=s0.clockwise,
+                 stack("edgeflags"), S, S, texture=s0.texture if TEXTURED else None, background_color=s0.background_color, clockwise=s0.clockwise,
                  vertex_dtype=torch.float64, pixel_dtype=torch.float32, device=dev)
 r = HipRasterizer.for_scene(ds)
 obs = torch.rand((B, S, S, ds.nb_colors), dtype=torch.float32, device=dev)
