@@ -241,8 +241,8 @@ __device__ __forceinline__ void owner_adjoint(const KParams &p, const ViewPtrs &
 template <class PixT, bool TEX, class Lds, class BaseFn>
 __device__ __forceinline__ void edge_reverse_sweep(const KParams &p, const ViewPtrs &w, Lds &S, const EdgeSort *es, int lane, double x, double y, int n_edges,
 												   int b_hi, int b_lo, bool top_staged, const uint32_t (&tm)[EMAX / TB], double (&cur)[CH], double (&g)[CH],
-												   double (&base)[CH], bool &have_base, BaseFn pixel_base)
-{
+												   double (&base)[CH], bool &have_base, BaseFn pixel_base, int r_lo, int r_hi)
+{ // r_lo .. r_hi: the edges of each batch that are swept (a split tile of the fused forward: one part of one batch; everybody else: all)
 	const int C = p.C, P = p.L.P;
 	const PixT *texture = (const PixT *)p.texture;
 	PixT *texture_b = (PixT *)p.texture_b;
@@ -264,7 +264,7 @@ __device__ __forceinline__ void edge_reverse_sweep(const KParams &p, const ViewP
 #pragma unroll
 		for (int bb = 0; bb < EMAX / TB; bb++)
 			tmb = bb == b ? tm[bb] : tmb;
-		for (int r = nb - 1; r >= 0; r--)
+		for (int r = (nb - 1 < r_hi ? nb - 1 : r_hi); r >= r_lo; r--)
 		{
 			const bool hit = (tmb >> r) & 1u;
 			if (__ballot(hit) == 0)

@@ -315,7 +315,7 @@ __device__ __forceinline__ void owner_adjoint(const KParams &p, const ViewPtrs &
 template <class PixT, bool TEX, class Lds, class BaseFn>
 __device__ __forceinline__ void edge_reverse_sweep(const KParams &p, const ViewPtrs &w, Lds &S, const EdgeSort *es, int lane, double x, double y, int n_edges,
 												   int b_hi, int b_lo, bool top_staged, const uint32_t (&tm)[EMAX / TB], double (&cur)[CH], double (&g)[CH],
-												   double (&base)[CH], bool &have_base, BaseFn pixel_base);
+												   double (&base)[CH], bool &have_base, BaseFn pixel_base, int r_lo = 0, int r_hi = TB - 1);
 template <class PixT, bool LEAN, bool TEX>
 __device__ __forceinline__ void bwd_tile_generic_impl(const KParams &p, int view, int tx, int ty, int lane, volatile uint32_t *order);
 
@@ -408,7 +408,13 @@ __host__ inline int heavy_share_for(int n_views, int tile_blocks, bool fuse_edge
 #ifndef DR_SPLIT_EDGES
 #define DR_SPLIT_EDGES 1 // (measurement builds: 0 = a tile is one work item whatever its number of edges)
 #endif
-constexpr uint32_t SPLIT_FLAG = 0x80000000u; // in WorkEntry::nedge: bits 16 .. 18 = which batch of edges this copy of the tile back-propagates
+constexpr uint32_t SPLIT_FLAG = 0x80000000u; // in WorkEntry::nedge: bits 16 .. 19 = which part of the edges this copy of the tile back-propagates
+#ifndef DR_SPLIT_PART
+#define DR_SPLIT_PART 0 // (measurement builds: a fixed number of edges per part)
+#endif
+// Edges per part (KParams::split_part): 8 when the launch is about one dispatch round of walkers (one or two 1024^2 views: the longest
+// wavefront decides, 1 view 0.0607 -> 0.0585 ms), a whole batch of 16 otherwise (8 views: the repeated forward parts cost 1.5 us).
+__host__ inline int split_part_for(int n_views, int tile_blocks) { return DR_SPLIT_PART ? DR_SPLIT_PART : ((long long)n_views * tile_blocks <= 8192 ? 8 : 16); }
 
 __global__ __launch_bounds__(SCAN_BLOCK) void tile_scan_kernel(KParams p)
 {
@@ -513,14 +519,15 @@ __global__ __launch_bounds__(SCAN_BLOCK) void tile_scan_kernel(KParams p)
 		pair_right = plain && (lane & 1) && n_prev > 0 && ntri + n_prev <= (uint32_t)ENTRY_IDS;
 		ntri_right = n_next;
 	}
-	// A fit step's tile with more than one batch of silhouette edges (17 .. EMAX) is listed once per batch: every copy ("part") runs
-	// pass 1 and the forward sweep over all the edges, but the reverse sweep -- 1.4 k cycles per edge, the long part -- of its own batch
-	// only (the first part also the adjoint of pass 1, the last one the frame stores).  One view of the benchmark scene waited 45 us
+	// A fit step's tile with more than one batch of silhouette edges (17 .. EMAX) is listed once per KParams::split_part edges: every copy ("part")
+	// runs pass 1 and the forward sweep over all the edges, but the reverse sweep -- 1.4 k cycles per edge, the long part -- of its own
+	// edges only (the first part also the adjoint of pass 1, the last one the frame stores).  One view of the benchmark scene waited 45 us
 	// for ONE wavefront with 43 triangles and 37 edges.
-	const uint32_t nparts = (DR_SPLIT_EDGES && heavy && p.fuse_edges && nedge > (uint32_t)TB && nedge <= (uint32_t)EMAX) ? (nedge + TB - 1) / TB : 1u;
-	const uint32_t extra = nparts - 1u; // 0 .. 7
-	const unsigned long long xb0 = __ballot(extra & 1u), xb1 = __ballot(extra & 2u), xb2 = __ballot(extra & 4u);
-	static_assert(EMAX / TB <= 8, "three bits of extra parts");
+	const uint32_t nparts =
+		(DR_SPLIT_EDGES && heavy && p.fuse_edges && nedge > (uint32_t)TB && nedge <= (uint32_t)EMAX) ? (nedge + (uint32_t)p.split_part - 1) / (uint32_t)p.split_part : 1u;
+	const uint32_t extra = nparts - 1u; // 0 .. 15
+	const unsigned long long xb0 = __ballot(extra & 1u), xb1 = __ballot(extra & 2u), xb2 = __ballot(extra & 4u), xb3 = __ballot(extra & 8u);
+	static_assert(EMAX / 8 <= 16 && TB % 8 == 0, "split_part is 8 or 16: four bits of extra parts; a part lies in one batch");
 	unsigned long long m[NCLS];
 	m[0] = __ballot(heavy);
 	m[1] = wm & ~m[0] & ~__ballot(pair_right);
@@ -535,7 +542,7 @@ __global__ __launch_bounds__(SCAN_BLOCK) void tile_scan_kernel(KParams p)
 #pragma unroll
 		for (int c = 0; c < NCLS; c++)
 			mine = lane == c ? m[c] : mine;
-		s_cnt[lane][wave] = (uint32_t)__popcll(mine) + (lane == 0 ? (uint32_t)(__popcll(xb0) + 2 * __popcll(xb1) + 4 * __popcll(xb2)) : 0u);
+		s_cnt[lane][wave] = (uint32_t)__popcll(mine) + (lane == 0 ? (uint32_t)(__popcll(xb0) + 2 * __popcll(xb1) + 4 * __popcll(xb2) + 8 * __popcll(xb3)) : 0u);
 	}
 	__syncthreads();
 	if (threadIdx.x < NCLS)
@@ -604,7 +611,7 @@ __global__ __launch_bounds__(SCAN_BLOCK) void tile_scan_kernel(KParams p)
 	}
 	else if (work)
 	{
-		const uint32_t head_pos = heavy ? position(0, m[0]) + (uint32_t)(__popcll(xb0 & below) + 2 * __popcll(xb1 & below) + 4 * __popcll(xb2 & below)) : 0u;
+		const uint32_t head_pos = heavy ? position(0, m[0]) + (uint32_t)(__popcll(xb0 & below) + 2 * __popcll(xb1 & below) + 4 * __popcll(xb2 & below) + 8 * __popcll(xb3 & below)) : 0u;
 		for (uint32_t part = 0; part < nparts; part++)
 		{
 			WorkEntry &e = heavy ? w.work_list[head_pos + part] : w.work_list[my_pos];
@@ -1266,7 +1273,9 @@ __device__ __forceinline__ void fwd_tiles(const KParams &p, WaveLds *s_lds, Edge
 			}
 			split = false;
 		}
-		const int last_part = split ? (nedge + TB - 1) / TB - 1 : 0;
+		const int SPLIT_PART = p.split_part;
+		const int last_part = split ? (nedge + SPLIT_PART - 1) / SPLIT_PART - 1 : 0;
+		const int part_end = (part + 1) * SPLIT_PART; // (split tile) the first edge of the blending order behind this part's
 		double colp[CH] = {0, 0, 0, 0}, trp = 1; // (split tile) the colour after this part's batch, the transparency of everything drawn later
 		if (n_edges > 0)
 		{
@@ -1295,6 +1304,12 @@ __device__ __forceinline__ void fwd_tiles(const KParams &p, WaveLds *s_lds, Edge
 				uint32_t drawn_batch = 0;
 				for (int j = 0; j < nb; j++)
 				{
+					if (fuse_edges && split && first + j == part_end)
+					{ // the colour after this part's edges: where its reverse sweep starts
+#pragma unroll
+						for (int cc = 0; cc < CH; cc++)
+							colp[cc] = col[cc];
+					}
 					const bool c = (ecov >> j) & 1u;
 					if (__ballot(c) == 0)
 						continue;
@@ -1319,7 +1334,7 @@ __device__ __forceinline__ void fwd_tiles(const KParams &p, WaveLds *s_lds, Edge
 								col[cc] *= Tr;
 								col[cc] += (1 - Tr) * A;
 							}
-						if (fuse_edges && split && first > part * TB)
+						if (fuse_edges && split && first + j >= part_end)
 							trp *= Tr;
 					}
 				}
@@ -1328,12 +1343,6 @@ __device__ __forceinline__ void fwd_tiles(const KParams &p, WaveLds *s_lds, Edge
 #pragma unroll
 					for (int bb = 0; bb < EMAX / TB; bb++)
 						tm[bb] = bb == first / TB ? drawn_batch : tm[bb];
-					if (split && first == part * TB)
-					{
-#pragma unroll
-						for (int cc = 0; cc < CH; cc++)
-							colp[cc] = col[cc];
-					}
 				}
 				if (sweep_slot) // bit j: edge first + j of the blending order is drawn over this pixel
 					((uint16_t *)(w.edge_sweep + (size_t)(sweep_slot - 1) * SWEEP_BYTES + CH * 64 * sizeof(double)))[(first / TB) * 64 + lane] =
@@ -1470,8 +1479,9 @@ __device__ __forceinline__ void fwd_tiles(const KParams &p, WaveLds *s_lds, Edge
 						g[cc] *= trp, col[cc] = colp[cc];
 				}
 				lds_sync();
-				edge_reverse_sweep<PixT, TEX>(p, w, S, &s_es[wave], lane, x, y, n_edges, split ? part : nbatch - 1, split ? part : 0, !split || part == last_part,
-											  tm, col, g, base, have_base, pixel_base);
+				const int pb = part * SPLIT_PART / TB; // the batch this part's edges lie in
+				edge_reverse_sweep<PixT, TEX>(p, w, S, &s_es[wave], lane, x, y, n_edges, split ? pb : nbatch - 1, split ? pb : 0, !split || pb == nbatch - 1, tm,
+											  col, g, base, have_base, pixel_base, split ? part * SPLIT_PART % TB : 0, split ? part * SPLIT_PART % TB + SPLIT_PART - 1 : TB - 1);
 				lds_sync();
 				if (!split || part == 0)
 					owner_adjoint<PixT, TEX>(p, w, lane, x, y, st.kbest, st.kbest >= 0 ? st.kind : (int)KIND_NONE, g, tap, L, (double *)&S.rec[0],

@@ -276,6 +276,7 @@ void launch_adjoint_raster(const KParams &p, bool fast, bool owner_tiles, dim3 g
 		KParams q = p;
 		q.tile_blocks = fwd_tile_blocks(p.L.ntiles, p.n_views, false); // the grid of the forward that built the work list (never a fused one)
 		q.heavy_share = heavy_share_for(p.n_views, q.tile_blocks, false);
+		q.split_part = 16; // (no fit step here: nothing is split)
 		const dim3 grid((unsigned)p.n_views * (unsigned)q.tile_blocks);
 		// (instances for the channel counts that occur: RGB, RGB + depth -- see raster_fwd_fast_kernel)
 #define DR_LAUNCH_NC(kernel, tex_, grid_, q_)                                                        \
@@ -376,6 +377,7 @@ int launch_forward_staged(const KParams &p, bool fused, hipStream_t stream, hipE
 	KParams q = p;
 	q.tile_blocks = fwd_tile_blocks(p.L.ntiles, p.n_views, fused && p.fuse_edges);
 	q.heavy_share = heavy_share_for(p.n_views, q.tile_blocks, fused && p.fuse_edges);
+	q.split_part = split_part_for(p.n_views, q.tile_blocks);
 	hipLaunchKernelGGL(tile_scan_kernel, dim3((p.L.ntiles + SCAN_BLOCK - 1) / SCAN_BLOCK, p.n_views), dim3(SCAN_BLOCK), 0, stream, q);
 	if (p.fill_mode == 0)
 	{
