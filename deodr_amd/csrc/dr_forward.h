@@ -452,49 +452,6 @@ __global__ __launch_bounds__(SCAN_BLOCK) void tile_scan_kernel(KParams p)
 		w.edge_cnt[tile] = 0;
 	}
 	const unsigned long long wm = __ballot(work);
-	if (DR_FIN_IN_FWD && p.fin_in_fwd)
-	{ // how many walkers the finalize workgroups of the forward raster have to wait for, per block of BLK x BLK tiles
-		const int ty = tile / p.L.tiles_x, tx = tile - ty * p.L.tiles_x;
-		uint32_t *expected = w.blk_sync + (ty / BLK) * p.L.blk_x + tx / BLK;
-		static_assert(BLK == 8, "eight consecutive lanes = the eight tiles of one block row");
-		if ((p.L.tiles_x & 7) == 0)
-		{
-			const uint32_t cnt = (uint32_t)__popcll((wm >> (lane & ~7)) & 0xffull);
-			if ((lane & 7) == 0 && cnt)
-				atomicAdd(expected, cnt);
-		}
-		else if (work)
-			atomicAdd(expected, 1u);
-		// ... and their work items: the primitives the set-up kernel has filed under this block, 64 at a time (the thread of the block's
-		// first tile; the counters are left zero for the next forward)
-		if (valid && (tx & (BLK - 1)) == 0 && (ty & (BLK - 1)) == 0)
-		{
-			const int blk = (ty / BLK) * p.L.blk_x + tx / BLK;
-			uint32_t nt = w.blk_cnt[blk], ne = w.blk_cnt[p.L.nblk + blk];
-			if (nt | ne)
-			{
-				w.blk_cnt[blk] = 0, w.blk_cnt[p.L.nblk + blk] = 0;
-				nt = nt < (uint32_t)BLK_TRI_CAP ? nt : (uint32_t)BLK_TRI_CAP, ne = ne < (uint32_t)BLK_EDGE_CAP ? ne : (uint32_t)BLK_EDGE_CAP;
-				const uint32_t it = (nt + 63) / 64, ie = (ne + 63) / 64;
-				uint32_t at = atomicAdd(&w.blk_sync[2 * p.L.nblk + SYNC_ITEMS], it + ie);
-				for (uint32_t first = 0; first < nt; first += 64)
-					w.fin_items[at++] = make_uint2(FIN_ITEM_TRI << 28 | ((nt - first < 64 ? nt - first : 64u) - 1u) << 20 | (uint32_t)blk, first);
-				for (uint32_t first = 0; first < ne; first += 64)
-					w.fin_items[at++] = make_uint2(FIN_ITEM_EDGE << 28 | ((ne - first < 64 ? ne - first : 64u) - 1u) << 20 | (uint32_t)blk, first);
-			}
-		}
-		if (tile == 0)
-		{
-			uint32_t no = w.blk_sync[2 * p.L.nblk + SYNC_OVERFLOW + (w.hdr->cur & 1u)];
-			no = no < p.L.fin_overflow_cap ? no : p.L.fin_overflow_cap;
-			if (no)
-			{
-				uint32_t at = atomicAdd(&w.blk_sync[2 * p.L.nblk + SYNC_ITEMS], (no + 63) / 64);
-				for (uint32_t first = 0; first < no; first += 64)
-					w.fin_items[at++] = make_uint2(FIN_ITEM_OVERFLOW << 28 | ((no - first < 64 ? no - first : 64u) - 1u) << 20, first);
-			}
-		}
-	}
 	if (lane == 0 && valid)
 		w.tile_bits[tile >> 5] = (uint32_t)wm;
 	if (lane == 32 && valid)
@@ -830,32 +787,6 @@ __device__ __forceinline__ void fill_share_word(const KParams &p, int bit, int v
 		fill_word<float>(p, view, wi, lane, 0);
 }
 
-// (dr_finalize.h) the per-primitive adjoint algebra as workgroups of the forward raster: see raster_fwd_fast_kernel
-template <bool VTX64>
-__device__ __forceinline__ void fin_in_fwd_role(const KParams &p, char *lds, long long fi);
-constexpr size_t FIN_LDS_BYTES = 128 * (4 + 6 * 8); // their vertex table (dr_finalize.h: FinTable), carved out of the walkers' staging area
-
-// A walker has finished `n` tiles of the block that holds `tile`: its accumulator atomics have been performed (vmcnt(0): returnless
-// atomics are counted like stores; they are executed at the memory side, where the finalize workgroup's loads will find them), then
-// the block's counter goes up.  No cache write-back: nothing else the walker wrote is read before the kernel ends.
-__device__ __forceinline__ void signal_tiles_done(const KParams &p, const ViewPtrs &w, int tile, uint32_t n, int lane)
-{
-	if (!DR_FIN_IN_FWD || !p.fin_in_fwd)
-		return;
-#ifndef DR_FIN_PROBE
-#define DR_FIN_PROBE 0 // measurement builds (WRONG gradients): 1 = the finalize workgroups return at once, 2 = the walkers do not wait for their atomics
-#endif
-	__atomic_signal_fence(__ATOMIC_SEQ_CST);
-	if (DR_FIN_PROBE != 2)
-		__builtin_amdgcn_s_waitcnt(0);
-	__atomic_signal_fence(__ATOMIC_SEQ_CST);
-	if (lane == 0)
-	{
-		const int ty = tile / p.L.tiles_x, tx = tile - ty * p.L.tiles_x;
-		__hip_atomic_fetch_add(w.blk_sync + p.L.nblk + (ty / BLK) * p.L.blk_x + tx / BLK, n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-	}
-}
-
 // Grid of the staged forward (1-D, one wavefront per workgroup).  Workgroup b: view (b / 8) % n_views,
 // q = (b / 8 / n_views) * 8 + b % 8 in [0, p.tile_blocks); it walks the entries rank(q), rank(q) + tile_blocks, ... of the
 // view's work list (usually one or two).  rank() deals the list to the XCDs in chunks of 64 consecutive entries (workgroup b
@@ -1144,7 +1075,6 @@ __device__ __forceinline__ void fwd_tiles(const KParams &p, WaveLds *s_lds, Edge
 			const uint32_t nn = (uint32_t)uniform((int)entry.ntri);
 			fwd_pair_tiles<PixT, CLAMP>(p, w, S, view, lane, (int)((uint32_t)uniform((int)entry.tile) & ~PAIR_FLAG), (int)(nn & 0xffffu), (int)(nn >> 16), ids12,
 								 p.loss_wave ? p.loss_wave + (size_t)view * LOSS_SLOTS + q % LOSS_SLOTS : nullptr);
-			signal_tiles_done(p, w, (int)((uint32_t)uniform((int)entry.tile) & ~PAIR_FLAG), 2u, lane);
 			lds_sync();
 			continue;
 		}
@@ -1511,17 +1441,7 @@ __device__ __forceinline__ void fwd_tiles(const KParams &p, WaveLds *s_lds, Edge
 		}
 		}
 		}
-		if (FUSED)
-			signal_tiles_done(p, w, tile, 1u, lane);
 		lds_sync(); // the next tile of this wavefront reuses the staging area
-	}
-	if (DR_FIN_IN_FWD && FUSED && p.fin_in_fwd && p.loss_out)
-	{ // (the workgroup that adds up the loss waits for every walker of every view: their partial sums are complete)
-		__atomic_signal_fence(__ATOMIC_SEQ_CST);
-		__builtin_amdgcn_s_waitcnt(0);
-		__atomic_signal_fence(__ATOMIC_SEQ_CST);
-		if (lane0 == 0)
-			__hip_atomic_fetch_add(w.blk_sync + 2 * p.L.nblk + SYNC_WALKERS, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 	}
 	if (q == 0 && threadIdx.x == 0)
 		close_epoch(p, w, FUSED);
@@ -1548,13 +1468,12 @@ __global__ __launch_bounds__(64, DR_FWD_WAVES) void raster_fwd_fast_kernel(KPara
 	}
 	if (FUSED)
 		p.persp = 0; // (a fit step: fill_params refuses perspective_correct for anything with an adjoint, as the reference does, H.h:810)
-	// (one raw buffer: the finalize workgroups of a fit step reuse the walkers' staging area for their vertex table)
-	constexpr size_t LDS_BYTES = sizeof(WaveLds) + sizeof(EdgeSort) > FIN_LDS_BYTES ? sizeof(WaveLds) + sizeof(EdgeSort) : FIN_LDS_BYTES;
+	constexpr size_t LDS_BYTES = sizeof(WaveLds) + sizeof(EdgeSort);
 	__shared__ __attribute__((aligned(16))) char s_mem[LDS_BYTES];
 	WaveLds *const s_lds = (WaveLds *)s_mem;
 	EdgeSort *const s_es = (EdgeSort *)(s_mem + sizeof(WaveLds));
-	// Roles of the grid: the tile walkers, the workgroups that stream the background of this kernel's share of the empty tiles
-	// (fill_share), and -- DR_FIN_IN_FWD builds -- the per-primitive adjoint algebra (finalize_kernel's work) at the very end.
+	// Roles of the grid: the tile walkers and the workgroups that stream the background of this kernel's share of the empty tiles
+	// (fill_share).  (tools/variants/finalize_in_forward.patch adds a third: the per-primitive adjoint algebra, finalize_kernel's work.)
 	// In a fit step of an untextured scene the fill workgroups are DEALT among the walkers, eight (one per XCD) behind every 64:
 	// dispatched behind the last walker they START when the last walker has a slot, and the kernel then ends a fill later (73 MB of
 	// stores per 8-view step: same-box A/B 0.1279 / 0.1274 -> 0.1238 / 0.1232 ms, profiles/r04l).  (Round 3 measured "spread evenly:
@@ -1583,13 +1502,6 @@ __global__ __launch_bounds__(64, DR_FWD_WAVES) void raster_fwd_fast_kernel(KPara
 	{
 		if (fi < n_fill)
 			fill_share_word(p, 2, (int)(fi % p.n_views), (int)(fi / p.n_views), threadIdx.x & 63);
-		else if (DR_FIN_IN_FWD && FUSED && !TEX && DR_FIN_PROBE != 1)
-		{
-			if (p.vtx_f64)
-				fin_in_fwd_role<true>(p, s_mem, fi - n_fill);
-			else
-				fin_in_fwd_role<false>(p, s_mem, fi - n_fill);
-		}
 		return;
 	}
 	if (FUSED && DR_FUSE_EDGES && !TEX)

@@ -392,9 +392,7 @@ int launch_forward_staged(const KParams &p, bool fused, hipStream_t stream, hipE
 		*join = ss.join;
 	}
 	// (+ the workgroups that stream this kernel's share of the background of the empty tiles, one bitmap word each)
-	// ... and, in a fit step that finalizes under the walkers, the workgroups that walk the views' finalize work items (+ the loss)
-	const unsigned fin_wgs = p.fin_in_fwd ? (unsigned)p.n_views * (unsigned)fin_roles_per_view(p.L.nblk) + (p.loss_out ? 1u : 0u) : 0u;
-	const dim3 grid((unsigned)p.n_views * (unsigned)q.tile_blocks + (unsigned)p.n_views * (unsigned)fill_share(p.fill_mode, 2, p.L.nwords) + fin_wgs);
+	const dim3 grid((unsigned)p.n_views * (unsigned)q.tile_blocks + (unsigned)p.n_views * (unsigned)fill_share(p.fill_mode, 2, p.L.nwords));
 	const bool tex = p.texture != nullptr; // (see launch_adjoint_raster)
 	const bool common = p.strict && p.W % TILE == 0 && p.H % TILE == 0;
 	if (fused && p.clamp && tex) // (the clamped residual of the depth fitter: its own instances of the fused kernel)
@@ -510,7 +508,7 @@ int launch_adjoint(const DeodrHipScene *sc, KParams &p, hipStream_t st, bool own
 		else
 			launch_adjoint_raster<float>(p, fast, owner_tiles, generic_grid(p, sc->n_views), edge_grid, st);
 	}
-	if (p.T > 0 && !p.fin_in_fwd) // (fin_in_fwd: the forward raster has done it)
+	if (p.T > 0)
 	{
 		const int fill_words = fast ? sc->n_views * fill_share(p.fill_mode, 1, p.L.nwords) : 0;
 		dim3 g2((unsigned)prim_blocks(p.T) * (unsigned)sc->n_views + (unsigned)((fill_words + PRIM_BLOCK / 64 - 1) / (PRIM_BLOCK / 64)) +
@@ -778,9 +776,7 @@ static int render_scene_fit_impl(const DeodrHipScene *sc, void *image, void *z_b
 	// the reverse sweep (128 registers at four waves per SIMD, 400 spilled on the edge path; 2048^2 / 100 k triangles / 1 view:
 	// 0.264 -> 0.407 ms with fused edges), its tiles with edges wait for raster_bwd_edge_kernel.
 	p.fuse_edges = DR_FUSE_EDGES && fused && !p.texture;
-	// ... and then also runs the per-primitive adjoint algebra (extra workgroups that wait for the walkers block by block: dr_finalize.h)
-	p.fin_in_fwd = DR_FIN_IN_FWD && p.fuse_edges && p.T > 0;
-	p.fill_mode = fused ? ((((sigma > 0 && !p.fuse_edges) ? 1 : 0) | ((p.T > 0 && !p.fin_in_fwd) ? 2 : 0) | ((p.T > 0 && p.fuse_edges) ? 4 : 0)) & DR_FILL_MASK) : 0;
+	p.fill_mode = fused ? ((((sigma > 0 && !p.fuse_edges) ? 1 : 0) | (p.T > 0 ? 2 : 0) | ((p.T > 0 && p.fuse_edges) ? 4 : 0)) & DR_FILL_MASK) : 0;
 	note_forward(workspace, fused);
 	hipEvent_t join = nullptr;
 	if (launch_forward(sc, p, st, &join, fused))
@@ -788,7 +784,7 @@ static int render_scene_fit_impl(const DeodrHipScene *sc, void *image, void *z_b
 	// The step-done flag: stored by the last wavefront of finalize_kernel to finish when that kernel is the step's last (the usual fit
 	// step), by a one-thread kernel behind everything otherwise.
 	uint32_t *done_flag = opt ? opt->done_flag : nullptr;
-	const bool fin_signals = done_flag && p.T > 0 && !p.fin_in_fwd && !g_det && !join && !(loss_out && !loss_in_kernels);
+	const bool fin_signals = done_flag && p.T > 0 && !g_det && !join && !(loss_out && !loss_in_kernels);
 	if (fin_signals)
 		p.done_flag = done_flag, p.done_value = opt->done_value;
 	if (launch_adjoint(sc, p, st, !fused))

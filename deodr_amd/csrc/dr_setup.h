@@ -230,21 +230,6 @@ struct WaveTrace
 #define DR_WAVE_PHASE_T(i)
 #endif
 
-// Finalize under the forward raster: a drawn primitive is filed under the block of the first tile of its box (its finalize lane will wait
-// for that block and its neighbours only: dr_finalize.h).  An on-screen primitive only: the others receive no gradient.
-__device__ __forceinline__ void file_under_block(const KParams &p, const ViewPtrs &w, uint32_t cur, int blk, bool edge, uint32_t id)
-{
-	const uint32_t rank = atomicAdd(&w.blk_cnt[(edge ? p.L.nblk : 0) + blk], 1u);
-	if (rank < (uint32_t)(edge ? BLK_EDGE_CAP : BLK_TRI_CAP))
-		w.blk_lists[(size_t)blk * (BLK_TRI_CAP + BLK_EDGE_CAP) + (edge ? BLK_TRI_CAP : 0) + rank] = id;
-	else
-	{
-		const uint32_t o = atomicAdd(&w.blk_sync[2 * p.L.nblk + SYNC_OVERFLOW + cur], 1u);
-		if (o < p.L.fin_overflow_cap)
-			w.fin_overflow[o] = id | (edge ? 0x80000000u : 0u);
-	}
-}
-
 // VTX64: the dtype of the vertex arrays as a compile-time constant.  As a run-time flag every vertex value was loaded behind its own
 // branch, and a float32 value converted -- i.e. waited for -- right behind its load: 21 memory round trips one after the other for
 // the inputs of one triangle.
@@ -275,11 +260,6 @@ __global__ __launch_bounds__(PRIM_BLOCK, DR_PRIM_WAVES) void setup_bin_kernel(KP
 	}
 	if (item <= EDGE_LISTS) // appended to by tile_scan_kernel, the next kernel on the stream
 		w.edge_tile_cnt[item * CNT_STRIDE] = 0;
-	// (block counters of a forward that also finalizes: written by the scan kernel and the forward raster, both later on the stream)
-	for (int v = item; v < 2 * p.L.nblk + 2; v += n_items)
-		w.blk_sync[v] = 0;
-	if (item == 0)
-		w.blk_sync[2 * p.L.nblk + SYNC_OVERFLOW + (1 - cur)] = 0;
 	if (p.loss_wave) // (one partial per tile walker of the forward raster, two kernels later)
 		for (int v = item; v < LOSS_SLOTS; v += n_items)
 			p.loss_wave[(size_t)view * LOSS_SLOTS + v] = 0;
@@ -456,8 +436,6 @@ __global__ __launch_bounds__(PRIM_BLOCK, DR_PRIM_WAVES) void setup_bin_kernel(KP
 						slot0[q] = atomicAdd(&w.tri_cnt[(ty0 + dy) * p.L.tiles_x + tx0 + dx], 1u);
 				}
 			}
-			if (DR_FIN_IN_FWD && p.fin_in_fwd && on_screen && rec.front)
-				file_under_block(p, w, cur, (ty0 / BLK) * p.L.blk_x + tx0 / BLK, false, (uint32_t)k);
 			setup_tri_attributes(s, t, rec, x2b, w.tri_planes + (size_t)k * 3 * s.P);
 			DR_WAVE_PHASE_T(2); // record computed
 			rec.pad0[0] = rec.pad0[1] = 0;
@@ -523,8 +501,6 @@ __global__ __launch_bounds__(PRIM_BLOCK, DR_PRIM_WAVES) void setup_bin_kernel(KP
 			for (int i = 0; i < 7; i++)
 				e.pad0[i] = 0;
 			eout = e;
-			if (DR_FIN_IN_FWD && p.fin_in_fwd && !(e.x_begin > e.x_end || e.y_begin > e.y_end))
-				file_under_block(p, w, cur, (e.y_begin / TILE / BLK) * p.L.blk_x + e.x_begin / TILE / BLK, true, (uint32_t)slot);
 			DR_WAVE_PHASE(4); // record stored
 			if (e.x_begin > e.x_end || e.y_begin > e.y_end)
 				break;

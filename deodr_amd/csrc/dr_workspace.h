@@ -57,22 +57,6 @@ constexpr size_t SNAP_BYTES = (CHUNKS - 1) * CH * 64 * sizeof(double);
 // Entry of the staged forward's work list (one per non-empty tile, written by tile_scan_kernel): everything a wavefront needs to
 // start on the tile comes with ONE memory round trip -- the header with a scalar load, the first triangle ids with a vector
 // load issued at the same time (a tile with more triangles reads its inline list / the spill pool as well).
-#ifndef DR_FIN_IN_FWD
-#define DR_FIN_IN_FWD 0 // 1 = finalize under the forward raster (dr_finalize.h: parity-green, 244 GPU tests; NOT faster -- profiles/README.md, r04j).
-						// With 0 nothing of it is compiled into the kernels (KParams::fin_in_fwd is never set).
-#endif
-constexpr int BLK = 8; // tiles per side of a synchronisation block (64 x 64 pixels)
-constexpr int SYNC_WALKERS = 0, SYNC_ITEMS = 1, SYNC_OVERFLOW = 2; // words behind the two per-block arrays of ViewPtrs::blk_sync ([2], [3]: by forward parity)
-// Finalize under the forward raster: every drawn primitive is filed under the block of the first tile of its box (set-up kernel), up to
-// BLK_TRI_CAP triangles and BLK_EDGE_CAP edges per block, the rest on an overflow list; the scan kernel turns the counts into work items
-// of up to 64 primitives of one block: kind << 28 | (n - 1) << 20 | block, first index.
-constexpr int BLK_TRI_CAP = 256, BLK_EDGE_CAP = 64;
-constexpr uint32_t FIN_ITEM_TRI = 0, FIN_ITEM_EDGE = 1, FIN_ITEM_OVERFLOW = 2;
-__host__ __device__ inline int fin_roles_per_view(int nblk)
-{ // workgroups per view that walk the work items (about one item each on the benchmark scene: ~300 items per 1024^2 view)
-	const int r = 2 * nblk;
-	return r < 8 ? 8 : (r > 512 ? 512 : r);
-}
 constexpr int ENTRY_IDS = 12;
 struct alignas(64) WorkEntry
 {
@@ -116,10 +100,8 @@ struct Layout
 		edge_pool, face_id, tile_bits, tri_flag, work_list, edge_tile_cnt, edge_tiles, edge_slot, edge_sweep, edge_snap, view_bytes;
 	uint32_t tri_pool_cap, edge_pool_cap;
 	size_t edge_fin;
-	size_t blk_sync, blk_cnt, blk_lists, fin_overflow, fin_items, done_counts;
-	uint32_t fin_overflow_cap;
+	size_t done_counts;
 	int tiles_x, tiles_y, ntiles, nwords, P, sweep_cap;
-	int blk_x, blk_y, nblk; // blocks of BLK x BLK tiles: the grain at which the finalize workgroups of a fused forward wait for the tile walkers
 };
 
 size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -175,20 +157,7 @@ Layout make_layout(int T, int H, int W, int C, size_t pool_pairs)
 	// instead of three -- indices, vertices, record)
 	L.edge_fin = take(sizeof(EdgeFin) * 3 * (size_t)T);
 	L.edge_snap = take(SNAP_BYTES * SNAP_CAP);
-	// Finalize inside the forward raster (fit step of an untextured scene, round 4): [0, nblk) non-empty tiles per block of BLK x BLK tiles
-	// (tile_scan_kernel), [nblk, 2 nblk) tiles of the block whose walker has finished (raster_fwd_fast_kernel), [2 nblk] walkers that
-	// have left the kernel, [2 nblk + 1] work items of the finalize workgroups; all zeroed by the set-up kernel.  [2 nblk + 2 + parity of the
-	// forward]: entries of the overflow list (double-buffered like the spill counters: set-up counts into one, clears the other).
-	L.blk_x = (L.tiles_x + BLK - 1) / BLK;
-	L.blk_y = (L.tiles_y + BLK - 1) / BLK;
-	L.nblk = L.blk_x * L.blk_y;
-	L.blk_sync = take(sizeof(uint32_t) * (2 * (size_t)L.nblk + 16));
-	L.blk_cnt = take(sizeof(uint32_t) * 2 * (size_t)L.nblk); // triangles, then edges filed under each block (zeroed by the scan kernel)
-	L.blk_lists = take(sizeof(uint32_t) * (size_t)L.nblk * (BLK_TRI_CAP + BLK_EDGE_CAP));
-	L.fin_overflow_cap = (uint32_t)(4 * (size_t)T < 0x7fffffffu ? 4 * (size_t)T : 0x7fffffffu);
-	L.fin_overflow = take(sizeof(uint32_t) * (size_t)L.fin_overflow_cap);
 	L.done_counts = take(sizeof(uint32_t) * (DONE_SUBS + 1) * DONE_STRIDE); // (view 0's are used: the step-done flag, dr_finalize.h)
-	L.fin_items = take(sizeof(uint2) * ((size_t)L.nblk * (BLK_TRI_CAP / 64 + BLK_EDGE_CAP / 64) + ((size_t)L.fin_overflow_cap + 63) / 64 + 8));
 	L.view_bytes = o;
 	return L;
 }
@@ -225,7 +194,6 @@ struct KParams
 	// fit step of an untextured scene (round 4): the per-primitive adjoint algebra of finalize_kernel runs INSIDE the forward raster, by
 	// extra workgroups at the end of its grid that wait, block of tiles by block of tiles, for the walkers (set by the host; the
 	// set-up kernel then lists the edges it draws, the scan kernel counts the non-empty tiles of every block)
-	int fin_in_fwd;
 	// Deterministic accumulation (deodr_hip_set_deterministic; the un-staged kernels only): every gradient sum is an INTEGER sum of
 	// contributions rounded to multiples of 2^-32 -- integer addition is associative, so the order in which the memory system executes
 	// the atomics no longer shows in the result (the reference is bit-reproducible by construction: one thread, H.h:1029-1037).  The
@@ -275,8 +243,6 @@ struct ViewPtrs
 	WorkEntry *work_list;
 	uint32_t *edge_tile_cnt, *edge_tiles; // tiles with silhouette edges: EDGE_LISTS (+ 1) counters, EDGE_LISTS lists of ntiles entries
 	EdgeFin *edge_fin;
-	uint32_t *blk_sync, *blk_cnt, *blk_lists, *fin_overflow;
-	uint2 *fin_items;
 };
 
 // value whose squared distance to the observation is the loss, and d loss / d value, of a rendered value v (already rounded to the
@@ -324,11 +290,6 @@ __device__ __forceinline__ ViewPtrs view_ptrs(const KParams &p, int view)
 	v.edge_fin = (EdgeFin *)(b + p.L.edge_fin);
 	v.edge_sweep = b + p.L.edge_sweep;
 	v.edge_snap = b + p.L.edge_snap;
-	v.blk_sync = (uint32_t *)(b + p.L.blk_sync);
-	v.blk_cnt = (uint32_t *)(b + p.L.blk_cnt);
-	v.blk_lists = (uint32_t *)(b + p.L.blk_lists);
-	v.fin_overflow = (uint32_t *)(b + p.L.fin_overflow);
-	v.fin_items = (uint2 *)(b + p.L.fin_items);
 	return v;
 }
 

@@ -252,7 +252,8 @@ int deodr_hip_depth_residual(const void *image, int pixel_dtype, const double *o
 #define DEODR_HIP_ERR_FACES 1	   /* an entry of faces is >= nb_vertices */
 #define DEODR_HIP_ERR_FACES_UV 2   /* an entry of faces_uv is >= nb_uv */
 #define DEODR_HIP_ERR_NO_TEXTURE 4 /* textured[k] && shaded[k] for some k although scene.texture == NULL */
-#define DEODR_HIP_ERR_INTERNAL 8   /* a finalize workgroup of a fit step gave up waiting for the tile walkers (never expected; gradients incomplete) */
+#define DEODR_HIP_ERR_INTERNAL 8   /* reserved: raised by the experimental build that finalizes under the forward raster (tools/variants/finalize_in_forward.patch) when a
+                                      finalize workgroup gives up waiting for the tile walkers; the product never sets it */
 
 /* Synchronises `stream` and reports (1) whether any forward since the workspace was zero-filled overflowed the spill pool
  * (then that result was incomplete and the call must be repeated with a workspace sized for a larger `pool_pairs`):

@@ -15,6 +15,9 @@
 #                               adjoint, 8388608 no LDS window for the texture gradient, 16777216 one tap in four added to the window,
 #                               33554432 only the even lanes add to it  [patched]
 #   mfma       -DDR_OWNER_MFMA=1 the owner reduction on the matrix cores (measured 14 us slower, round 2)        [patched sources]
+#   fininfwd   -DDR_FIN_IN_FWD=1 finalize UNDER the forward raster (round 4: parity-green, not faster): the per-primitive adjoint algebra as
+#                               workgroups of raster_fwd_fast_kernel gated block by block by device-side counters -- tools/variants/finalize_in_forward.patch
+#                               (700 lines: set-up files primitives under screen blocks, the scan kernel builds work items, the walkers signal)  [its own patch]
 #   wavetrace  -DDR_WAVE_TRACE  start / end of every wave                       (tools/wave_trace.py)
 #   fwdN       -DDR_FWD_WAVES=N the staged forward compiled for N waves / SIMD  (tools/step_time.py --lib)
 #   <name>     EXTRA="-D..."    anything else: the product sources with the flags of $EXTRA
@@ -39,6 +42,11 @@ for v in ${@:-fwdtrace wavetrace tiletrace fwd4 fwd6}; do
     tiletrace) patched_sources; build $PATCHED/deodr_amd/csrc $v -DDR_TILE_TRACE ;;
     abl*) patched_sources; build $PATCHED/deodr_amd/csrc $v "-DDR_ABLATE=${v#abl}" ;;
     mfma) patched_sources; build $PATCHED/deodr_amd/csrc $v -DDR_OWNER_MFMA=1 ;;
+    fininfwd)
+      FIF=$(mktemp -d /tmp/deodr_fif.XXXXXX); mkdir -p $FIF/deodr_amd/csrc $FIF/include
+      cp $ROOT/deodr_amd/csrc/*.h $ROOT/deodr_amd/csrc/*.hip $FIF/deodr_amd/csrc/; cp $ROOT/include/*.h $FIF/include/
+      (cd $FIF/deodr_amd/csrc && patch -p1 --no-backup-if-mismatch < $OUT/finalize_in_forward.patch) || { echo "finalize_in_forward.patch no longer fits the sources"; exit 1; }
+      build $FIF/deodr_amd/csrc $v "-DDR_FIN_IN_FWD=1 -DDR_SPLIT_EDGES=0" ;; # (its block counters count one walker per tile: no split tiles)
     wavetrace) build $ROOT/deodr_amd/csrc $v -DDR_WAVE_TRACE ;;
     fwd*) build $ROOT/deodr_amd/csrc $v -DDR_FWD_WAVES=${v#fwd} ;;
     *) build $ROOT/deodr_amd/csrc $v "$EXTRA" ;;
