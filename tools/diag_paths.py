@@ -1,3 +1,6 @@
+"""Gradients of one fit step by the fused (staged) path, the un-staged path (deodr_hip_force_generic) and the deterministic mode against one
+another, for 1 / 8 views of the bumpy sphere at 512^2 / 256^2: which path is off when two disagree (e.g. a library variant given with --lib).
+Run on the GPU box:  python tools/diag_paths.py [--lib tools/variants/libdeodr_hip_x.so]"""
 import sys, os
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))

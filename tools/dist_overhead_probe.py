@@ -15,6 +15,7 @@ modes
   wide_main  the wide kernel on the render stream, event, all_reduce on the communication stream
   flagged    the fit step stores a step-done flag (DeodrHipFitOptions::done_flag: finalize_kernel's last wavefront); the communication stream
              waits for it with deodr_hip_wait_flag, then the wide kernel + all_reduce there: NO event on the render stream
+  flagged_sleepN   flagged, and the communication stream idles N us more before the reduction kernel
   flag_only  the fit step stores the flag, nothing waits for it (what the flag costs finalize_kernel)
   (measured once and removed from the library, profiles/r04v_*: a hipEvent recorded through finalize_kernel's completion signal --
    hipExtLaunchKernelGGL's stopEvent -- instead of hipEventRecord: 1.7 us alone, but 25 us once another stream waits for it)
@@ -115,12 +116,14 @@ def run(mode):
         it[0] += 1
         if reads_done[i] is not None:
             reads_done[i].synchronize()
-        if mode in ("flagged", "flag_only"):
+        if mode in ("flagged", "flag_only") or mode.startswith("flagged_sleep"):
             seq[0] += 1
             r.render_fit(ds, obs, 1.0, grads=grads_pp[i], out=(image, z), check_overflow=False, clear_grads=True, done_flag=(step_flag, seq[0]))
-            if mode == "flagged":
+            if mode != "flag_only":
                 with torch.cuda.stream(comm):
                     hr.wait_flag(step_flag, seq[0], status=wait_status, timeout=1.0)
+                    if mode.startswith("flagged_sleep"):  # flagged_sleepN: the reduction starts N us later (beside the forward raster, not beside set-up)
+                        torch.cuda._sleep(int(float(mode[len("flagged_sleep"):]) * 2100))
                     wide(i)
                     dist.all_reduce(shared_pp[i])
                     reads_done[i] = torch.cuda.Event()
@@ -209,7 +212,7 @@ def run(mode):
         t2 = time.perf_counter()
         if (t2 - t0) / steps < best:
             best, host = (t2 - t0) / steps, (t1 - t0) / steps
-    if mode == "flagged":  # the reduction of the last step against the same thing done synchronously
+    if mode.startswith("flagged"):  # the reduction of the last step against the same thing done synchronously
         last = (it[0] - 1) % NBUF
         got = shared_pp[last].clone()
         wide(last)
