@@ -4,6 +4,8 @@
   gradient -- texture gradient and loss included -- BIT-IDENTICAL from run to run, within the usual tolerance of the checker, on a
   textured soup, an 8-view mesh batch, the antialiase_error variant; a 30-iteration fit run twice, bit for bit;
 * finalize_kernel with and without its per-workgroup vertex table (launches on either side of the size threshold) against the checker;
+* a tile of many silhouette edges listed once per part of its edges (parts of 8 and of 16), against the checker and the two-call path;
+* the step-done flag + deodr_hip_wait_flag (a consumer on another stream), deodr_hip_views_gradient_sum against autograd and the pose adjoint;
 * a camera shared by several views (ADVICE r3: `DeviceCamera` expands every array per view);
 * the library's streaming-copy probe moves the bytes it says.
 """
@@ -260,3 +262,31 @@ def test_step_done_flag_and_wait_flag(n_views):
     hr.wait_flag(flag, 1001, status=status, timeout=30.0)
     torch.cuda.synchronize()
     assert int(status.item()) == 1
+
+
+@pytest.mark.parametrize("n_views", [1, 9])
+def test_tiles_of_many_edges_are_split_into_parts(oracle_api, n_views):
+    """A fit step lists a tile of 17 .. 128 silhouette edges once per part of its edges (8 per part for launches of about one dispatch round,
+    16 for larger ones), every copy back-propagating its own edges from a colour snapshot and the product of the later transparencies:
+    a 512^2 frame (a grid with a head of the list) with ~60 edges crowded into one tile, against the two-call path and the checker;
+    and the head of the work list really holds more entries per view with parts of 8 than with parts of 16."""
+    from test_hip_parity import compare_fit_step
+    from test_hip_parity2 import crowded_scene
+    from hip_util import device_scene
+    from deodr_amd.hip_renderer import HipRasterizer
+
+    views = [crowded_scene(20, seed=3 + i, size=512) for i in range(n_views)]
+    for v in views:
+        v.texture = np.zeros((0, 0))  # (an untextured scene: the forward raster of a fit step back-propagates the tiles with edges itself)
+    compare_fit_step(oracle_api, views, 1.0, F64)
+    if n_views == 1:
+        compare_fit_step(oracle_api, views, 2.5, F32)
+        heads = {}
+        for n in (1, 9):  # the same view n times: n = 9 makes the launch large enough for parts of 16
+            ds = device_scene([views[0]] * n, F64)
+            r = HipRasterizer.for_scene(ds)
+            obs = torch.zeros((n, 512, 512, views[0].nb_colors), dtype=F64, device=ds.device)
+            r.render_fit(ds, obs, 1.0, check_overflow=True, clear_grads=True)
+            torch.cuda.synchronize()
+            heads[n] = int(r.workspace[:64].view(torch.int32).cpu().numpy()[13])  # WsHeader::work_count[0] of view 0
+        assert heads[1] > heads[9] > 0, heads
