@@ -290,3 +290,17 @@ def test_tiles_of_many_edges_are_split_into_parts(oracle_api, n_views):
             torch.cuda.synchronize()
             heads[n] = int(r.workspace[:64].view(torch.int32).cpu().numpy()[13])  # WsHeader::work_count[0] of view 0
         assert heads[1] > heads[9] > 0, heads
+
+
+@pytest.mark.parametrize("n_tri,size", [(70, 512), (70, 24), (20, 24)])
+def test_crowded_tiles_of_an_untextured_fit_step(oracle_api, n_tri, size):
+    """the crowded tiles of test_many_edges_in_one_tile in an UNTEXTURED scene, where the forward raster of a fit step back-propagates them
+    itself: ~200 edges in a tile (more than the staged sweep orders: the un-staged tile code inside the forward raster) in a grid with a
+    head of the list and in a tiny frame, ~60 edges in a tiny frame (never split: one list)"""
+    from test_hip_parity import compare_fit_step
+    from test_hip_parity2 import crowded_scene
+
+    s = crowded_scene(n_tri, seed=5, size=size)
+    s.texture = np.zeros((0, 0))
+    compare_fit_step(oracle_api, s, 1.0, F64)
+    compare_fit_step(oracle_api, s, 1.0, F32)
