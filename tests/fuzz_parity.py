@@ -51,8 +51,10 @@ def draw_scene(it, rs, replay=False):
             background_color = colour if background_color is None else background_color
             s.background_image, s.background_color = None, background_color
         s.strict_edge, s.integer_pixel_centers, s.backface_culling = bool(strict), bool(it % 7 != 3), True
+        if textured == 0.0 and it % 2 == 0:
+            s.texture = np.zeros((0, 0))  # a scene WITHOUT a texture: the fit step's forward raster back-propagates the tiles with edges itself
         views.append(s)
-    desc = (f"H={H} W={W} n_tri={n_tri} views={n_views} sigma={sigma} dt={dt} textured={textured} tex={tex_size} min_area={min_area} round={rounded} "
+    desc = (f"H={H} W={W} n_tri={n_tri} views={n_views} sigma={sigma} dt={dt} textured={textured} no_texture={np.size(views[0].texture) == 0} tex={tex_size} min_area={min_area} round={rounded} "
             f"bgcolor={background_color is not None} strict={strict} intpix={views[0].integer_pixel_centers} cw={bool(it & 1)}")
     obs = rs.rand(n_views, H, W, 3)
     return views, sigma, dt, desc, obs
@@ -231,6 +233,9 @@ def draw_large_scene(it):
         for name in ("uv_b", "ij_b", "shade_b", "colors_b", "texture_b"):
             setattr(s, name, np.zeros(np.shape(getattr(s, name[:-2]))))
         views.append(s)
+    if textured == 0.0:
+        for s in views:
+            s.texture = s.texture_b = np.zeros((0, 0))  # (untextured: fused edge tiles, split tiles, tile pairs -- these frames have a head of the list)
     desc = f"large H={H} W={W} n_tri={n_tri} shrink={shrink} views={n_views} sigma={sigma} dt={dt} textured={textured} strict={strict} cw={bool(it & 1)}"
     return views, sigma, dt, desc
 
