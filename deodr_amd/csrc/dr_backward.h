@@ -638,7 +638,7 @@ __global__ __launch_bounds__(64, 6) void raster_bwd_fast_kernel(KParams p)
 	const uint32_t n_work = w.hdr->work_count[heavy_list ? 0 : 1];
 	for (; rank < n_work; rank += (uint32_t)stride)
 	{
-		const WorkEntry &entry = w.work_list[heavy_list ? rank : (uint32_t)p.L.ntiles - 1u - rank];
+		const WorkEntry &entry = w.work_list[heavy_list ? rank : (uint32_t)p.L.work_cap - 1u - rank];
 		const int tile = uniform((int)entry.tile);
 		if (uniform((int)entry.nedge) != 0)
 			continue;

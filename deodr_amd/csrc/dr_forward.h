@@ -373,7 +373,7 @@ __device__ __forceinline__ void fill_background_tile(const KParams &p, int view,
 #ifndef DR_WORK_CHUNK
 #define DR_WORK_CHUNK 64
 #endif
-constexpr int SCAN_BLOCK = 256, WORK_CHUNK = DR_WORK_CHUNK;
+constexpr int SCAN_BLOCK = SCAN_TILES, WORK_CHUNK = DR_WORK_CHUNK;
 #ifndef DR_PAIR_TILES
 #define DR_PAIR_TILES 1 // (measurement builds: 0 = one tile per wavefront everywhere, as in round 2)
 #endif
@@ -408,7 +408,6 @@ __host__ inline int heavy_share_for(int n_views, int tile_blocks, bool fuse_edge
 #ifndef DR_SPLIT_EDGES
 #define DR_SPLIT_EDGES 1 // (measurement builds: 0 = a tile is one work item whatever its number of edges)
 #endif
-constexpr uint32_t VOID_TILE = 0x7fffffffu;  // WorkEntry::tile of a void entry of the split list
 constexpr uint32_t SPLIT_FLAG = 0x80000000u; // in WorkEntry::nedge: bits 16 .. 19 = which part of the edges this copy of the tile back-propagates
 #ifndef DR_SPLIT_PART
 #define DR_SPLIT_PART 0 // (measurement builds: a fixed number of edges per part)
@@ -422,8 +421,9 @@ __global__ __launch_bounds__(SCAN_BLOCK) void tile_scan_kernel(KParams p)
 	// classes compacted by this kernel: 0 many-primitive tiles (front of the work list), 1 the other non-empty tiles (back of it),
 	// 2 .. 4 the three lists of edge tiles, 5 every edge tile (its rank is the tile's slot in edge_sweep)
 	constexpr int NCLS = 3 + EDGE_LISTS;
-	__shared__ uint32_t s_cnt[NCLS + 1][SCAN_BLOCK / 64]; // ([NCLS]: the extra copies of split tiles, which go to a list of their own)
-	__shared__ uint32_t s_base[NCLS + 1];
+	__shared__ uint32_t s_cnt[NCLS][SCAN_BLOCK / 64];
+	__shared__ uint32_t s_base[NCLS];
+	__shared__ uint32_t s_req[SCAN_BLOCK / 64]; // extra copies of split tiles the wavefronts of this block ask for
 	kernel_stamp(p, 1);
 	const int view = blockIdx.y;
 	const ViewPtrs w = view_ptrs(p, view);
@@ -481,9 +481,27 @@ __global__ __launch_bounds__(SCAN_BLOCK) void tile_scan_kernel(KParams p)
 	// runs pass 1 and the forward sweep over all the edges, but the reverse sweep -- 1.4 k cycles per edge, the long part -- of its own
 	// edges only (the first part also the adjoint of pass 1, the last one the frame stores).  One view of the benchmark scene waited 45 us
 	// for ONE wavefront with 43 triangles and 37 edges.
-	const uint32_t nparts =
-		(DR_SPLIT_EDGES && heavy && p.fuse_edges && nedge > (uint32_t)TB && nedge <= (uint32_t)EMAX) ? (nedge + (uint32_t)p.split_part - 1) / (uint32_t)p.split_part : 1u;
-	const uint32_t extra = nparts - 1u; // 0 .. 15
+	// The copies are entries of the work list, next to the tile's own (a walker finds them without another look at the counters, and they
+	// start with their tile, early).  Each block of SCAN_BLOCK tiles may add SPLIT_BUDGET of them, granted in tile order -- the list is laid
+	// out for that many and no more: a soup of 20 000 slivers at sigma = 3 has more tiles of 17+ edges than empty ones, and its copies,
+	// unbounded, ran into the entries that come from the other end of the list (memory fault found by tests/fuzz_parity.py).
+	const unsigned long long below = (1ull << lane) - 1ull;
+	uint32_t extra = (DR_SPLIT_EDGES && heavy && p.fuse_edges && nedge > (uint32_t)TB && nedge <= (uint32_t)EMAX)
+						 ? (nedge + (uint32_t)p.split_part - 1) / (uint32_t)p.split_part - 1u
+						 : 0u; // 0 .. 15 copies asked for
+	if (p.fuse_edges && DR_SPLIT_EDGES)
+	{ // (a condition of the launch: every thread of the block takes the barrier)
+		const unsigned long long r0 = __ballot(extra & 1u), r1 = __ballot(extra & 2u), r2 = __ballot(extra & 4u), r3 = __ballot(extra & 8u);
+		if (lane == 0)
+			s_req[wave] = (uint32_t)(__popcll(r0) + 2 * __popcll(r1) + 4 * __popcll(r2) + 8 * __popcll(r3));
+		__syncthreads();
+		uint32_t before = (uint32_t)(__popcll(r0 & below) + 2 * __popcll(r1 & below) + 4 * __popcll(r2 & below) + 8 * __popcll(r3 & below));
+		for (int i = 0; i < wave; i++)
+			before += s_req[i];
+		if (before + extra > (uint32_t)SPLIT_BUDGET)
+			extra = 0; // (not granted: the tile stays one work item)
+	}
+	const uint32_t nparts = extra + 1u;
 	const unsigned long long xb0 = __ballot(extra & 1u), xb1 = __ballot(extra & 2u), xb2 = __ballot(extra & 4u), xb3 = __ballot(extra & 8u);
 	static_assert(EMAX / 8 <= 16 && TB % 8 == 0, "split_part is 8 or 16: four bits of extra parts; a part lies in one batch");
 	unsigned long long m[NCLS];
@@ -493,26 +511,22 @@ __global__ __launch_bounds__(SCAN_BLOCK) void tile_scan_kernel(KParams p)
 	for (int c = 0; c < EDGE_LISTS; c++)
 		m[2 + c] = __ballot(elist == c);
 	m[2 + EDGE_LISTS] = __ballot(nedge > 0);
-	const unsigned long long below = (1ull << lane) - 1ull;
 	if (lane < NCLS)
 	{
 		unsigned long long mine = 0;
 #pragma unroll
 		for (int c = 0; c < NCLS; c++)
 			mine = lane == c ? m[c] : mine;
-		s_cnt[lane][wave] = (uint32_t)__popcll(mine);
+		s_cnt[lane][wave] = (uint32_t)__popcll(mine) + (lane == 0 ? (uint32_t)(__popcll(xb0) + 2 * __popcll(xb1) + 4 * __popcll(xb2) + 8 * __popcll(xb3)) : 0u);
 	}
-	if (lane == NCLS)
-		s_cnt[NCLS][wave] = (uint32_t)(__popcll(xb0) + 2 * __popcll(xb1) + 4 * __popcll(xb2) + 8 * __popcll(xb3));
 	__syncthreads();
-	if (threadIdx.x <= NCLS)
+	if (threadIdx.x < NCLS)
 	{
 		uint32_t total = 0;
 #pragma unroll
 		for (int i = 0; i < SCAN_BLOCK / 64; i++)
 			total += s_cnt[threadIdx.x][i];
-		uint32_t *counter = threadIdx.x < 2 ? &w.hdr->work_count[threadIdx.x]
-											: (threadIdx.x == NCLS ? &w.hdr->split_count : &w.edge_tile_cnt[(threadIdx.x - 2) * CNT_STRIDE]);
+		uint32_t *counter = threadIdx.x < 2 ? &w.hdr->work_count[threadIdx.x] : &w.edge_tile_cnt[(threadIdx.x - 2) * CNT_STRIDE];
 		s_base[threadIdx.x] = total ? atomicAdd(counter, total) : 0u;
 	}
 	__syncthreads();
@@ -536,7 +550,7 @@ __global__ __launch_bounds__(SCAN_BLOCK) void tile_scan_kernel(KParams p)
 	if (valid)
 		w.edge_saved[tile] = nedge | (sweep_slot ? SWEEP_SAVED : 0u);
 	// (every lane takes part in the exchange: the right tile of a pair needs the position of the left tile's entry)
-	const uint32_t my_pos = (work && !heavy && !pair_right) ? (uint32_t)p.L.ntiles - 1u - position(1, m[1]) : 0u;
+	const uint32_t my_pos = (work && !heavy && !pair_right) ? (uint32_t)p.L.work_cap - 1u - position(1, m[1]) : 0u;
 	const uint32_t left_pos = (uint32_t)__shfl_up((int)my_pos, 1, 64), left_ntri = (uint32_t)__shfl_up((int)ntri, 1, 64);
 	if (pair_right)
 	{ // this tile's ids behind the left tile's, in the left tile's entry
@@ -572,23 +586,13 @@ __global__ __launch_bounds__(SCAN_BLOCK) void tile_scan_kernel(KParams p)
 	}
 	else if (work)
 	{
-		// The extra copies of a split tile go to a list of their own (ViewPtrs::split_list, walked behind the head of the work list): the work
-		// list holds one entry per tile whatever the scene, the extra copies what fits their list -- a tile whose copies do not fit is not
-		// split (a soup of 20 000 slivers at sigma = 3 has more tiles of 17+ edges than empty ones: as entries of the work list the copies ran
-		// into the entries that come from its other end).
-		uint32_t split_pos = s_base[NCLS];
-		for (int i = 0; i < wave; i++)
-			split_pos += s_cnt[NCLS][i];
-		split_pos += (uint32_t)(__popcll(xb0 & below) + 2 * __popcll(xb1 & below) + 4 * __popcll(xb2 & below) + 8 * __popcll(xb3 & below));
-		const bool split = nparts > 1 && split_pos + extra <= (uint32_t)p.L.split_cap;
+		// (the copies of a split tile: the entries behind its own)
+		const uint32_t head_pos = heavy ? position(0, m[0]) + (uint32_t)(__popcll(xb0 & below) + 2 * __popcll(xb1 & below) + 4 * __popcll(xb2 & below) + 8 * __popcll(xb3 & below)) : 0u;
 		for (uint32_t part = 0; part < nparts; part++)
 		{
-			if (part > 0 && split_pos + part - 1u >= (uint32_t)p.L.split_cap)
-				break;
-			WorkEntry &e = part > 0 ? w.split_list[split_pos + part - 1u] : (heavy ? w.work_list[position(0, m[0])] : w.work_list[my_pos]);
+			WorkEntry &e = heavy ? w.work_list[head_pos + part] : w.work_list[my_pos];
 			uint4 *out = (uint4 *)&e;
-			// (the copies of a tile that is not split after all -- the one that straddles the end of their list -- are void entries)
-			out[0] = make_uint4(part > 0 && !split ? VOID_TILE : (uint32_t)tile, ntri, split ? (SPLIT_FLAG | part << 16 | nedge) : nedge, sweep_slot);
+			out[0] = make_uint4((uint32_t)tile, ntri, nparts > 1 ? (SPLIT_FLAG | part << 16 | nedge) : nedge, sweep_slot);
 			out[1] = ida;
 			out[2] = idb;
 			out[3] = idc;
@@ -1076,24 +1080,15 @@ __device__ __forceinline__ void fwd_tiles(const KParams &p, WaveLds *s_lds, Edge
 	const int qq = heavy_list ? q : q - Gh, stride = heavy_list ? Gh : G - Gh;
 	const bool chunk_here = chunked && stride % (8 * WORK_CHUNK) == 0;
 	uint32_t rank = chunk_here ? (uint32_t)((((qq >> 3) / WORK_CHUNK) * 8 + (qq & 7)) * WORK_CHUNK + (qq >> 3) % WORK_CHUNK) : (uint32_t)qq;
-	const uint32_t n_list = w.hdr->work_count[heavy_list ? 0 : 1];
-	uint32_t n_work = n_list;
-	if (MODE == FWD_EDGE_ADJ && heavy_list)
-	{ // behind the head of the list: the extra copies of its split tiles
-		const uint32_t n_split = w.hdr->split_count;
-		n_work += n_split < (uint32_t)p.L.split_cap ? n_split : (uint32_t)p.L.split_cap;
-	}
+	const uint32_t n_work = w.hdr->work_count[heavy_list ? 0 : 1];
 	for (; rank < n_work; rank += (uint32_t)stride)
 	{
 		// (the lane index is made opaque per iteration: otherwise every lane-dependent address of the body is hoisted out of the
 		// loop and kept -- spilled -- in registers across it: + 150 VGPRs for a loop that usually runs once or twice)
 		int lane = lane0;
 		asm volatile("" : "+v"(lane));
-		const WorkEntry &entry = (MODE == FWD_EDGE_ADJ && rank >= n_list) ? w.split_list[rank - n_list]
-																			   : w.work_list[heavy_list ? rank : (uint32_t)p.L.ntiles - 1u - rank];
+		const WorkEntry &entry = w.work_list[heavy_list ? rank : (uint32_t)p.L.work_cap - 1u - rank];
 		const uint32_t ids12 = entry.ids[lane < ENTRY_IDS ? lane : 0];
-		if (MODE == FWD_EDGE_ADJ && (uint32_t)uniform((int)entry.tile) == VOID_TILE)
-			continue;
 		if (FUSED && !TEX && MODE == FWD_NO_EDGES && ((uint32_t)uniform((int)entry.tile) & PAIR_FLAG))
 		{ // two adjacent tiles, two pixels per lane (the scan kernel pairs them up: fwd_pair_tiles)
 			const uint32_t nn = (uint32_t)uniform((int)entry.ntri);

@@ -256,7 +256,7 @@ __global__ __launch_bounds__(PRIM_BLOCK, DR_PRIM_WAVES) void setup_bin_kernel(KP
 		w.hdr->tri_spill[1 - cur] = 0;
 		w.hdr->edge_spill[1 - cur] = 0;
 		w.hdr->snap_count[1 - cur] = 0;
-		w.hdr->work_count[0] = w.hdr->work_count[1] = w.hdr->split_count = 0; // filled by tile_scan_kernel, read by the forward raster
+		w.hdr->work_count[0] = w.hdr->work_count[1] = 0; // filled by tile_scan_kernel, read by the forward raster
 	}
 	if (item <= EDGE_LISTS) // appended to by tile_scan_kernel, the next kernel on the stream
 		w.edge_tile_cnt[item * CNT_STRIDE] = 0;

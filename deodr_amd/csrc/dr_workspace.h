@@ -57,6 +57,8 @@ constexpr size_t SNAP_BYTES = (CHUNKS - 1) * CH * 64 * sizeof(double);
 // Entry of the staged forward's work list (one per non-empty tile, written by tile_scan_kernel): everything a wavefront needs to
 // start on the tile comes with ONE memory round trip -- the header with a scalar load, the first triangle ids with a vector
 // load issued at the same time (a tile with more triangles reads its inline list / the spill pool as well).
+constexpr int SCAN_TILES = 256;	 // tiles per workgroup of tile_scan_kernel
+constexpr int SPLIT_BUDGET = 32; // extra work-list entries (copies of tiles of many edges) such a workgroup may add
 constexpr int ENTRY_IDS = 12;
 struct alignas(64) WorkEntry
 {
@@ -80,7 +82,7 @@ struct WsHeader // 64 bytes per view at the start of the view's workspace (also 
 	// view 0 only: maximum / union of needed_max / scene_errors over the views, so that the host polls ONE 64-byte block
 	uint32_t all_needed_max, all_scene_errors;
 	uint32_t work_count[2]; // entries of the forward's work list: [0] many-primitive tiles (from the front), [1] the others (from the back)
-	uint32_t split_count; // extra copies of split tiles listed in ViewPtrs::split_list (may exceed its capacity: the readers clamp)
+	uint32_t pad[1];
 };
 static_assert(sizeof(WsHeader) == 64, "");
 static_assert(offsetof(WsHeader, all_needed_max) == 4 * DEODR_HIP_STATUS_WORD_NEEDED_PAIRS &&
@@ -100,8 +102,8 @@ struct Layout
 		edge_pool, face_id, tile_bits, tri_flag, work_list, edge_tile_cnt, edge_tiles, edge_slot, edge_sweep, edge_snap, view_bytes;
 	uint32_t tri_pool_cap, edge_pool_cap;
 	size_t edge_fin;
-	size_t done_counts, split_list;
-	int split_cap;
+	size_t done_counts;
+	int work_cap; // entries of work_list
 	int tiles_x, tiles_y, ntiles, nwords, P, sweep_cap;
 };
 
@@ -143,9 +145,10 @@ Layout make_layout(int T, int H, int W, int C, size_t pool_pairs)
 	// edges, sweep slot} per non-empty tile, both written by tile_scan_kernel between set-up and forward raster
 	L.nwords = (L.ntiles + 31) / 32;
 	L.tile_bits = take(sizeof(uint32_t) * L.nwords);
-	L.work_list = take(sizeof(WorkEntry) * (size_t)L.ntiles);
-	L.split_cap = L.ntiles / 8 > 512 ? L.ntiles / 8 : 512; // extra copies of the tiles of many edges (tile_scan_kernel); beyond: tiles are not split
-	L.split_list = take(sizeof(WorkEntry) * (size_t)L.split_cap);
+	// one entry per non-empty tile (many-primitive tiles from the front, the others from the back) + the extra copies of the tiles of many
+	// edges, at most SPLIT_BUDGET per block of the scan kernel (tile_scan_kernel)
+	L.work_cap = L.ntiles + ((L.ntiles + SCAN_TILES - 1) / SCAN_TILES) * SPLIT_BUDGET;
+	L.work_list = take(sizeof(WorkEntry) * (size_t)L.work_cap);
 	// kind | front << 2 of every triangle of the last forward: what finalize_kernel needs to know about a triangle before it
 	// touches anything else (one coalesced byte per thread instead of a 128-byte record line per triangle, two out of three
 	// of which are culled)
@@ -243,7 +246,7 @@ struct ViewPtrs
 	uint8_t *tri_flag;
 	uint32_t *edge_slot;
 	char *edge_sweep, *edge_snap;
-	WorkEntry *work_list, *split_list;
+	WorkEntry *work_list;
 	uint32_t *edge_tile_cnt, *edge_tiles; // tiles with silhouette edges: EDGE_LISTS (+ 1) counters, EDGE_LISTS lists of ntiles entries
 	EdgeFin *edge_fin;
 };
@@ -289,7 +292,6 @@ __device__ __forceinline__ ViewPtrs view_ptrs(const KParams &p, int view)
 	v.edge_tile_cnt = (uint32_t *)(b + p.L.edge_tile_cnt);
 	v.edge_tiles = (uint32_t *)(b + p.L.edge_tiles);
 	v.work_list = (WorkEntry *)(b + p.L.work_list);
-	v.split_list = (WorkEntry *)(b + p.L.split_list);
 	v.edge_slot = (uint32_t *)(b + p.L.edge_slot);
 	v.edge_fin = (EdgeFin *)(b + p.L.edge_fin);
 	v.edge_sweep = b + p.L.edge_sweep;

@@ -269,7 +269,7 @@ def test_tiles_of_many_edges_are_split_into_parts(oracle_api, n_views):
     """A fit step lists a tile of 17 .. 128 silhouette edges once per part of its edges (8 per part for launches of about one dispatch round,
     16 for larger ones), every copy back-propagating its own edges from a colour snapshot and the product of the later transparencies:
     a 512^2 frame (a grid with a head of the list) with ~60 edges crowded into one tile, against the two-call path and the checker;
-    and the list of extra copies really holds more entries per view with parts of 8 than with parts of 16."""
+    and the head of the work list really holds more entries per view with parts of 8 than with parts of 16."""
     from test_hip_parity import compare_fit_step
     from test_hip_parity2 import crowded_scene
     from hip_util import device_scene
@@ -288,7 +288,7 @@ def test_tiles_of_many_edges_are_split_into_parts(oracle_api, n_views):
             obs = torch.zeros((n, 512, 512, views[0].nb_colors), dtype=F64, device=ds.device)
             r.render_fit(ds, obs, 1.0, check_overflow=True, clear_grads=True)
             torch.cuda.synchronize()
-            heads[n] = int(r.workspace[:64].view(torch.int32).cpu().numpy()[15])  # WsHeader::split_count of view 0: the extra copies
+            heads[n] = int(r.workspace[:64].view(torch.int32).cpu().numpy()[13])  # WsHeader::work_count[0] of view 0: the head of the list, copies included
         assert heads[1] > heads[9] > 0, heads
 
 
