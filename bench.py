@@ -437,7 +437,6 @@ def main():
     # [vertices_b (V x 3), colors_b summed over the views (V x C)].  vertices_b = sum over the views of the adjoint of the view's
     # camera projection (deodr's Camera.project_points_backward, dr.py:397-438) applied to ij_b: ONE launch
     # (deodr_hip_views_gradient_sum), which also adds the colour gradients up over the views.
-    shared = torch.zeros(V * (3 + Cc), dtype=torch.float64, device=dev)  # packed shared-parameter gradient
     reduction = None
     if world > 1 or args.force_dist:
         from deodr_amd import fronthalf
@@ -448,32 +447,23 @@ def main():
         assert np.abs(scenes.project(cams[-1], verts)[0] - views[-1].ij).max() < 1e-9  # same cameras as the rendered views
         camera = DeviceCamera(np.stack([c.extrinsic for c in cams]), np.stack([c.intrinsic for c in cams]), S, S, None, dev)
         world_vertices = torch.as_tensor(np.ascontiguousarray(verts, dtype=np.float64), device=dev)
-        reduction = dict(
-            camera=camera, posed=world_vertices[None].expand(B, -1, -1).contiguous(), call=fronthalf.views_gradient_sum,
-            # the render stream tells the communication stream that a step's gradients are complete through a word of device memory
-            # (DeodrHipFitOptions::done_flag, stored by finalize_kernel's last wavefront; deodr_hip_wait_flag on the other side): an
-            # event recorded on the render stream and waited for by a second queue costs the render stream ~8 us per step
-            # (tools/dist_overhead_probe.py, profiles/r04v_*)
-            flag=torch.zeros(1, dtype=torch.int32, device=dev), wait_status=torch.zeros(1, dtype=torch.int32, device=dev),
-        )  # fmt: skip
+        # deodr_amd.distributed.OverlappedViewsReduction: a communication stream, two alternating sets of gradient buffers, the hand-over
+        # through a word of device memory (DeodrHipFitOptions::done_flag / deodr_hip_wait_flag: an event that a second queue waits for costs
+        # the render stream ~8 us per step, tools/dist_overhead_probe.py), deodr_hip_views_gradient_sum, the collective
+        from deodr_amd.distributed import OverlappedViewsReduction
+
+        reduction = OverlappedViewsReduction(ds, camera, world_vertices[None].expand(B, -1, -1).contiguous(), always_collective=True)
 
     obs_views = obs.expand(B, S, S, Cc).contiguous()  # one observation per view (here the same synthetic image)
     # The reduction of step k (camera adjoint, packing, RCCL all-reduce) runs on a communication stream while step k + 1 renders:
     # two sets of gradient buffers alternate, and a set is rendered into again only when the reduction that read it has finished.
-    comm = torch.cuda.Stream(device=dev) if dist is not None else None
-    grads_pp = [grads, ds.zero_grads()] if dist is not None else [grads]
-    shared_pp = [shared, torch.zeros_like(shared)]
-    reads_done, pending, it = [None, None], [None, None], [0]
+    it = [0]
+    last_slot = [None]
 
     def step():
-        i = it[0] % len(grads_pp)
         it[0] += 1
-        g = grads_pp[i]
-        if dist is not None and reads_done[i] is not None:
-            # the reduction of two steps ago has read this set of gradient buffers: the HOST waits for it (it runs at most two
-            # steps ahead of the GPU, which is enough to keep it fed) -- a stream-side wait would put one more event packet, i.e.
-            # one more ~7 us bubble, between two steps
-            reads_done[i].synchronize()
+        slot = reduction.begin() if reduction is not None else None
+        g = slot.grads if slot is not None else grads
         if args.two_pass:
             g["ij_b"].zero_()
             g["colors_b"].zero_()
@@ -483,28 +473,15 @@ def main():
         else:
             # same outputs in one call: the forward raster back-propagates through the tiles without silhouette edges itself
             # (and zeroes the gradient arrays of the previous step on the way)
-            done = None
-            if dist is not None:
-                done = (reduction["flag"], it[0])  # (the step number: increasing)
-            r.render_fit(ds, obs_views, args.sigma, grads=g, out=(image, z), check_overflow=False, clear_grads=True, done_flag=done)
-        if dist is not None:
-            rd = reduction
-            rendered = None
-            if args.two_pass:  # (the two-call step has no done flag: an event)
-                rendered = torch.cuda.Event()
-                rendered.record()
-            with torch.cuda.stream(comm):
-                if rendered is not None:
-                    comm.wait_event(rendered)
-                else:
-                    hr.wait_flag(rd["flag"], it[0], status=rd["wait_status"], timeout=2.0)
-                # one kernel: the projection adjoint of every view applied to ij_b and summed over the views, the colour gradients
-                # summed over the views, both written straight into the packed buffer (which the collective of two steps ago, earlier
-                # on this stream, has left)
-                rd["call"](rd["posed"], rd["camera"], g["ij_b"], shared_pp[i][: 3 * V].view(V, 3), colors_b=g["colors_b"], colors_sum=shared_pp[i][3 * V :].view(V, Cc))
-                reads_done[i] = torch.cuda.Event()
-                reads_done[i].record()
-                dist.all_reduce(shared_pp[i])  # (issued under the communication stream: ordered on it)
+            r.render_fit(ds, obs_views, args.sigma, grads=g, out=(image, z), check_overflow=False, clear_grads=True,
+                         done_flag=slot.done_flag if slot is not None else None)
+        if slot is not None:
+            event = None
+            if args.two_pass:  # (the two-call step stores no done flag: an event)
+                event = torch.cuda.Event()
+                event.record()
+            reduction.reduce(slot, event=event)
+            last_slot[0] = slot
 
     # first call checks the spill pool once (synchronises), then nothing in the loop does
     r.render(ds, args.sigma, out=(image, z), check_overflow=True)
@@ -515,12 +492,8 @@ def main():
         step()
 
     def barrier():
-        if dist is not None:
-            for k in range(2):
-                if pending[k] is not None:
-                    pending[k].wait()
-                    pending[k] = None
-            comm.synchronize()
+        if reduction is not None:
+            reduction.finish()
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -572,14 +545,16 @@ def main():
     # synchronously, from that step's gradient arrays (every rank takes part: it is a collective)
     reduction_check = None
     if dist is not None:
-        last_i = (it[0] - 1) % len(grads_pp)
-        g, rd, again = grads_pp[last_i], reduction, torch.zeros_like(shared)
-        rd["call"](rd["posed"], rd["camera"], g["ij_b"], again[: 3 * V].view(V, 3), colors_b=g["colors_b"], colors_sum=again[3 * V :].view(V, Cc))
+        from deodr_amd import fronthalf
+
+        slot = last_slot[0]
+        g, again = slot.grads, torch.zeros_like(slot.shared)
+        fronthalf.views_gradient_sum(reduction.posed, reduction.camera, g["ij_b"], again[: 3 * V].view(V, 3), colors_b=g["colors_b"], colors_sum=again[3 * V :].view(V, Cc))
         local_max = float(again.abs().max())
         dist.all_reduce(again)
         torch.cuda.synchronize()
-        err = float((shared_pp[last_i] - again).abs().max() / again.abs().max())
-        timed_out = int(reduction["wait_status"].item())
+        err = float((slot.shared - again).abs().max() / again.abs().max())
+        timed_out = int(reduction.wait_status.item())
         reduction_check = {"ranks": world, "rel_err": err, "ok": bool(err < 1e-12 and local_max > 0 and not timed_out), "values": int(again.numel()),
                            "flag_wait_timed_out": bool(timed_out), "sync": "event" if args.two_pass else "done flag (deodr_hip_wait_flag)"}  # fmt: skip
         assert reduction_check["ok"], f"bench: the all-reduced shared gradient of the timed loop differs from a synchronous reduction: {reduction_check}"
@@ -650,7 +625,7 @@ def main():
             out["reduction_check"] = reduction_check
         if not args.no_parity_check:
             # the launch that was timed (its last step's outputs are still in image / z / the gradient set it wrote), views 0 and last
-            last = grads_pp[(it[0] - 1) % len(grads_pp)]
+            last = last_slot[0].grads if last_slot[0] is not None else grads
             out["parity"] = parity_check(views, sorted({0, B - 1}), image, z, last, obs_views)
             out["parity_checked"] = out["parity"]["ok"]
             assert out["parity"]["ok"], f"bench: the timed launch does not match the checker: {out['parity']}"

@@ -304,3 +304,43 @@ def test_crowded_tiles_of_an_untextured_fit_step(oracle_api, n_tri, size):
     s.texture = np.zeros((0, 0))
     compare_fit_step(oracle_api, s, 1.0, F64)
     compare_fit_step(oracle_api, s, 1.0, F32)
+
+
+def test_overlapped_views_reduction_equals_a_synchronous_one():
+    """deodr_amd.distributed.OverlappedViewsReduction (what bench.py --gpus N drives): the shared gradient of every step, reduced on the
+    communication stream behind the step-done flag while the next step renders, equals the same sums formed synchronously from that
+    step's gradient arrays (one process: no collective; the two-rank collective is test_bench_two_ranks_on_one_gpu's)"""
+    from hip_util import device_scene
+    from deodr_amd import fronthalf
+    from deodr_amd.distributed import OverlappedViewsReduction
+    from deodr_amd.hip_renderer import HipRasterizer
+    from deodr_amd.scene3d import DeviceCamera
+
+    n, S = 4, 256
+    poses = np.linspace(-0.3, 0.3, n)
+    views = [scenes.sphere_scene(size=S, nu=40, n_rings=40, angle=float(a)) for a in poses]
+    verts, _f = scenes.bumpy_sphere(40, 40)
+    cams = [scenes.fit_camera(S, S, 60.0, verts, scenes.rotx(0.37) @ scenes.roty(0.23 + float(a))) for a in poses]
+    ds = device_scene(views, F64)
+    r = HipRasterizer.for_scene(ds)
+    camera = DeviceCamera(np.stack([c.extrinsic for c in cams]), np.stack([c.intrinsic for c in cams]), S, S, None, ds.device)
+    posed = torch.as_tensor(np.ascontiguousarray(verts), device=ds.device)[None].expand(n, -1, -1).contiguous()
+    V, C = posed.shape[1], ds.nb_colors
+    red = OverlappedViewsReduction(ds, camera, posed)
+    rng = np.random.RandomState(4)
+    r.render(ds, 1.0, check_overflow=True)
+    expected, slots = [], []
+    for step in range(6):
+        obs = torch.as_tensor(rng.rand(n, S, S, C), device=ds.device)
+        slot = red.begin()
+        r.render_fit(ds, obs, 1.0, grads=slot.grads, clear_grads=True, check_overflow=False, done_flag=slot.done_flag)
+        red.reduce(slot)
+        if step >= 4:  # the last two steps: their sets are not rendered into again
+            slots.append(slot)
+    red.finish()
+    for slot in slots:
+        vb, cs = torch.zeros(V, 3, dtype=F64, device=ds.device), torch.zeros(V, C, dtype=F64, device=ds.device)
+        fronthalf.views_gradient_sum(posed, camera, slot.grads["ij_b"], vb, colors_b=slot.grads["colors_b"], colors_sum=cs)
+        torch.cuda.synchronize()
+        assert float(vb.abs().max()) > 0
+        assert torch.equal(slot.vertices_b, vb) and torch.equal(slot.colors_b, cs)
