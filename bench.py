@@ -485,9 +485,10 @@ def main():
 
     # first call checks the spill pool once (synchronises), then nothing in the loop does
     r.render(ds, args.sigma, out=(image, z), check_overflow=True)
-    # the step time settles after a few dozen steps (clocks, caches, allocator): initialisation brings the untimed steps to at
-    # least 50 whatever --warmup says, so that a short timed region measures the steady state
-    warmup_run = max(args.warmup, 50)
+    # the step time settles slowly (clocks, caches, allocator): initialisation brings the untimed steps to at least 1 000 (0.12 s)
+    # whatever --warmup says, so that a short timed region measures the steady state -- same box, 20 timed steps: 0.1215 ms per step
+    # after 50 untimed ones, 0.1202 after 300, 0.1185 after 1 000 (200 timed steps: 0.1170); `warmup` in the line = steps executed
+    warmup_run = max(args.warmup, 1000)
     for _ in range(warmup_run):
         step()
 
