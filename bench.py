@@ -488,7 +488,7 @@ def main():
     # the step time settles slowly (clocks, caches, allocator): initialisation brings the untimed steps to at least 1 000 (0.12 s)
     # whatever --warmup says, so that a short timed region measures the steady state -- same box, 20 timed steps: 0.1215 ms per step
     # after 50 untimed ones, 0.1202 after 300, 0.1185 after 1 000 (200 timed steps: 0.1170); `warmup` in the line = steps executed
-    warmup_run = max(args.warmup, 1 if args.test_backend else 1000)  # (--test-backend: a functional test of the multi-rank path, not a measurement)
+    warmup_run = max(args.warmup, 1 if args.test_backend == "gloo" else 1000)  # (--test-backend gloo: a functional test of the multi-rank path, not a measurement)
     for _ in range(warmup_run):
         step()
 
