@@ -13,7 +13,7 @@ namespace
 
 // adds  sum over the wave of  v * [x, y, 1]  to acc[0..2]
 // (det: KParams::det, the deterministic mode of the un-staged kernels -- a compile-time false wherever this is inlined into a staged kernel)
-__device__ __forceinline__ void add_moments(double *acc, double v, double x, double y, int lane, bool det = false)
+__device__ __forceinline__ void add_moments(double *acc, double v, double x, double y, int lane, uint32_t *det = nullptr)
 {
 	double mx = wave_sum(v * x), my = wave_sum(v * y), m1 = wave_sum(v);
 	if (lane == 0)
@@ -28,14 +28,14 @@ __device__ __forceinline__ void add_moments(double *acc, double v, double x, dou
 }
 
 template <class PixT>
-__device__ __forceinline__ void texture_scatter(PixT *texture_b, const Tap &tap, int c, const double wgt[4], long long *det_texture = nullptr)
+__device__ __forceinline__ void texture_scatter(PixT *texture_b, const Tap &tap, int c, const double wgt[4], long long *det_texture = nullptr, uint32_t *det_err = nullptr)
 {
 #pragma unroll
 	for (int q = 0; q < 4; q++)
 		if (wgt[q] != 0)
 		{
 			if (det_texture)
-				det_add(det_texture + tap.idx[q] + c, wgt[q]);
+				det_add(det_texture + tap.idx[q] + c, wgt[q], det_err);
 			else
 				unsafeAtomicAdd(texture_b + tap.idx[q] + c, (PixT)wgt[q]);
 		}
@@ -50,7 +50,7 @@ __device__ __forceinline__ void bwd_tile_generic_impl(const KParams &p, int view
 	const ViewPtrs w = view_ptrs(p, view);
 	const int W = p.W, H = p.H, C = p.C, P = p.L.P;
 	const bool aa_err = !LEAN && p.aa_err;
-	const bool det = !LEAN && p.det; // (the deterministic mode runs on raster_bwd_kernel only)
+	uint32_t *const det = (!LEAN && p.det) ? p.det_err : nullptr; // (the deterministic mode runs on raster_bwd_kernel only)
 	long long *const det_tex = det ? p.det_texture : nullptr;
 	const PixT *texture = (const PixT *)p.texture;
 	PixT *texture_b = (PixT *)p.texture_b;
@@ -222,7 +222,7 @@ __device__ __forceinline__ void bwd_tile_generic_impl(const KParams &p, int view
 							double wgt[4];
 							bilinear_mix_adjoint(etap, diff_B * eL, i00, i10, i01, i11, wgt, e_B);
 							if (texture_b)
-								texture_scatter(texture_b, etap, c, wgt, det_tex);
+								texture_scatter(texture_b, etap, c, wgt, det_tex, det);
 						}
 						else // H.h:2579-2588, with the row fold the reference forgot (defect D2) restored
 							A_B = 2 * (interp_channel(ep, c, x, y, false, 0.0) - (double)obs[c]) * Err_B;
@@ -376,7 +376,7 @@ __device__ __forceinline__ void bwd_tile_generic_impl(const KParams &p, int view
 								double wgt[4];
 								bilinear_mix_adjoint(etap, a_b, i00, i10, i01, i11, wgt, e_B);
 								if (texture_b)
-									texture_scatter(texture_b, etap, c, wgt, det_tex);
+									texture_scatter(texture_b, etap, c, wgt, det_tex, det);
 							}
 							else
 							{ // H.h:1726-1746
@@ -414,7 +414,7 @@ __device__ __forceinline__ void bwd_tile_generic_impl(const KParams &p, int view
 					double wgt[4];
 					bilinear_mix_adjoint(tap, g[j] * L, i00, i10, i01, i11, wgt, own_e_B);
 					if (texture_b)
-						texture_scatter(texture_b, tap, c, wgt, det_tex);
+						texture_scatter(texture_b, tap, c, wgt, det_tex, det);
 				}
 			}
 			// segmented wave reduction over the distinct interpolated owners of the tile

@@ -128,7 +128,7 @@ __device__ __forceinline__ void finalize_body(KParams &p)
 	if constexpr (DET)
 	{ // the deterministic mode: plain and slow (one round trip after the other) -- it exists for tests, not for speed
 		const DetAdd dadd = {g.ij_b, g.colors_b, g.shade_b, p.det_ij + (size_t)view * p.V * 2, p.det_colors + (size_t)view * p.V * p.C,
-							 p.det_shade + (size_t)view * p.V, p.det_uv};
+							 p.det_shade + (size_t)view * p.V, p.det_uv, p.det_err};
 		double la[3 * DEODR_HIP_MAX_COLORS + 3];
 		if (tri_block)
 		{

@@ -232,6 +232,7 @@ int det_shadows(KParams &p, int n_views, hipStream_t st)
 		sc.words = need;
 	}
 	p.det = 1;
+	p.det_err = &((WsHeader *)(p.ws + p.L.hdr))->scene_errors; // (view 0: what deodr_hip_workspace_status reads; the next forward copies it to the polled word)
 	p.det_ij = sc.ptr;
 	p.det_colors = p.det_ij + n_ij;
 	p.det_shade = p.det_colors + n_col;

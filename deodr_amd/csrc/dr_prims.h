@@ -152,6 +152,7 @@ enum SceneError : uint32_t
 	SCENE_ERR_FACES = 1,	  // faces[k][i] >= nb_vertices
 	SCENE_ERR_FACES_UV = 2,	  // faces_uv[k][i] >= nb_uv
 	SCENE_ERR_NO_TEXTURE = 4, // textured[k] && shaded[k] but scene.texture == NULL
+	SCENE_ERR_DET_RANGE = 16, // deterministic mode: a contribution or a sum left the fixed-point range (det_add, dr_workspace.h)
 };
 
 // -> 0, or the SceneError bits of triangle k (then nothing was gathered through its indices and the caller must drop it)

@@ -88,7 +88,7 @@ static_assert(sizeof(WsHeader) == 64, "");
 static_assert(offsetof(WsHeader, all_needed_max) == 4 * DEODR_HIP_STATUS_WORD_NEEDED_PAIRS &&
 				  offsetof(WsHeader, all_scene_errors) == 4 * DEODR_HIP_STATUS_WORD_SCENE_ERRORS &&
 				  (int)dr::SCENE_ERR_FACES == DEODR_HIP_ERR_FACES && (int)dr::SCENE_ERR_FACES_UV == DEODR_HIP_ERR_FACES_UV &&
-				  (int)dr::SCENE_ERR_NO_TEXTURE == DEODR_HIP_ERR_NO_TEXTURE,
+				  (int)dr::SCENE_ERR_NO_TEXTURE == DEODR_HIP_ERR_NO_TEXTURE && (int)dr::SCENE_ERR_DET_RANGE == DEODR_HIP_ERR_DET_RANGE,
 			  "status block layout published in include/deodr_hip.h");
 
 // Step-done flag (KParams::done_flag): finalize_kernel's wavefronts count themselves on DONE_SUBS counters, a cache line apart -- on ONE word
@@ -207,6 +207,7 @@ struct KParams
 	// in int64 shadow arrays (det_*: library-owned scratch) and added to the caller's arrays by one thread per element afterwards.
 	int det;
 	long long *det_ij, *det_colors, *det_shade, *det_uv, *det_texture;
+	uint32_t *det_err; // sticky error word (view 0's WsHeader::scene_errors): SCENE_ERR_DET_RANGE when a contribution or a sum leaves +- 2^31
 	// Measurement (deodr_hip_profile_stamps): the first thread of set-up / tile scan / finalize writes the 100 MHz realtime counter into
 	// stamp[0 / 1 / 2] -- kernels of one stream run back to back, so the difference of two consecutive stamps IS the duration of the kernel(s)
 	// between them, with no event packet between the launches (a hipEvent pair per kernel costs the step it measures ~ 36 us)
@@ -359,16 +360,24 @@ __device__ __forceinline__ void atomic_add_f64(double *p, double v) { unsafeAtom
 
 // fixed point of the deterministic mode: |sum| < 2^31, resolution 2^-32
 constexpr double DET_SCALE = 4294967296.0, DET_INV_SCALE = 1.0 / 4294967296.0;
-__device__ __forceinline__ void det_add(void *slot, double v)
+// `err`: a sticky scene-error word of the workspace (view 0's WsHeader::scene_errors).  A contribution beyond the range saturates in the
+// conversion and a sum beyond it wraps: both raise SCENE_ERR_DET_RANGE instead of passing silently (the add returns the old value for that:
+// the mode is a test mode, several times slower than the default path anyway).
+__device__ __forceinline__ void det_add(void *slot, double v, uint32_t *err)
 {
-	atomicAdd((unsigned long long *)slot, (unsigned long long)__double2ll_rn(v * DET_SCALE));
+	const long long add = __double2ll_rn(v * DET_SCALE);
+	const long long old = (long long)atomicAdd((unsigned long long *)slot, (unsigned long long)add);
+	const long long sum = (long long)((unsigned long long)old + (unsigned long long)add);
+	if (!(fabs(v) < 2147483648.0) || (((old ^ sum) & (add ^ sum)) < 0)) // (NaN, saturated conversion, or signed overflow of the sum)
+		atomicOr(err, (uint32_t)SCENE_ERR_DET_RANGE);
 }
 __device__ __forceinline__ double det_value(const double *slot) { return (double)*(const long long *)slot * DET_INV_SCALE; }
 // accumulate into a moment accumulator of the workspace
-__device__ __forceinline__ void acc_add(double *slot, double v, bool det)
+// (det: nullptr, or the error word of the deterministic mode)
+__device__ __forceinline__ void acc_add(double *slot, double v, uint32_t *det)
 {
 	if (det)
-		det_add(slot, v);
+		det_add(slot, v, det);
 	else
 		unsafeAtomicAdd(slot, v);
 }
@@ -442,11 +451,12 @@ struct DetAdd // deterministic mode: the same contribution into the int64 shadow
 {
 	const void *ij_b, *colors_b, *shade_b; // the view's arrays as the caller of the functor names them
 	long long *ij, *colors, *shade, *uv;
+	uint32_t *err;
 	__device__ __forceinline__ void operator()(void *arr, size_t i, bool, double v) const
 	{
 		if (v == 0)
 			return;
-		det_add((arr == ij_b ? ij : (arr == colors_b ? colors : (arr == shade_b ? shade : uv))) + i, v);
+		det_add((arr == ij_b ? ij : (arr == colors_b ? colors : (arr == shade_b ? shade : uv))) + i, v, err);
 	}
 };
 

@@ -21,7 +21,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libdeodr_hip.so")
 ABI_VERSION = 11
-ERR_FACES, ERR_FACES_UV, ERR_NO_TEXTURE, ERR_INTERNAL = 1, 2, 4, 8  # include/deodr_hip.h DEODR_HIP_ERR_*
+ERR_FACES, ERR_FACES_UV, ERR_NO_TEXTURE, ERR_INTERNAL, ERR_DET_RANGE = 1, 2, 4, 8, 16  # include/deodr_hip.h DEODR_HIP_ERR_*
 _STATUS_NEEDED, _STATUS_ERRORS = 11, 12  # words of the 64-byte status block at the start of the workspace
 
 
@@ -135,6 +135,8 @@ def scene_error_message(bits):
         what.append("a triangle is textured and shaded but the scene has no texture")
     if bits & ERR_INTERNAL:
         what.append("internal: a finalize workgroup of a fit step gave up waiting for the tile walkers (gradients incomplete)")
+    if bits & ERR_DET_RANGE:
+        what.append("deterministic mode: a gradient contribution or running sum left the fixed-point range +- 2^31 (gradients of that call are wrong)")
     return "invalid scene (checkSceneValid): " + "; ".join(what)
 
 

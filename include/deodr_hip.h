@@ -254,6 +254,8 @@ int deodr_hip_depth_residual(const void *image, int pixel_dtype, const double *o
 #define DEODR_HIP_ERR_NO_TEXTURE 4 /* textured[k] && shaded[k] for some k although scene.texture == NULL */
 #define DEODR_HIP_ERR_INTERNAL 8   /* reserved: raised by the experimental build that finalizes under the forward raster (tools/variants/finalize_in_forward.patch) when a
                                       finalize workgroup gives up waiting for the tile walkers; the product never sets it */
+#define DEODR_HIP_ERR_DET_RANGE 16 /* deterministic mode (deodr_hip_set_deterministic): a contribution or a running sum left the fixed-point range
+                                      +- 2^31 (or was NaN) -- the gradients of that call are wrong; not a property of the scene's indices */
 
 /* Synchronises `stream` and reports (1) whether any forward since the workspace was zero-filled overflowed the spill pool
  * (then that result was incomplete and the call must be repeated with a workspace sized for a larger `pool_pairs`):
@@ -306,7 +308,8 @@ int deodr_hip_force_generic(int on);
  * DifferentiableRenderer.h:1029-1037).  Non-zero: every later call runs the un-staged kernels with INTEGER accumulation -- each
  * contribution to a moment accumulator, a vertex gradient or the texture gradient is rounded to a multiple of 2^-32 and added as a
  * 64-bit integer, so the order in which the memory system executes the atomics no longer shows: gradients (and, in a fit step, the
- * loss) are bit-identical from run to run.  Limits: |any gradient sum| < 2^31, resolution 2^-32 (~2.3e-10) per contribution;
+ * loss) are bit-identical from run to run.  Limits: |any gradient sum| < 2^31 (a contribution or a running sum beyond it raises the
+ * sticky bit DEODR_HIP_ERR_DET_RANGE of the status block instead of wrapping silently), resolution 2^-32 (~2.3e-10) per contribution;
  * several times slower than the default path (it is a mode for tests and for debugging an optimiser, default off); the library
  * allocates an int64 shadow of the gradient arrays the first time (hipMalloc: not under stream capture).  Process-wide, like
  * deodr_hip_force_generic. */

@@ -35,3 +35,13 @@ def oracle_api():
     from oracle import api
 
     return api
+
+
+@pytest.fixture(params=["staged", "generic"])
+def family(request):
+    """Run the test once per kernel family of the HIP library (LDS-staged / un-staged): deodr_hip_force_generic."""
+    from deodr_amd import hip_renderer as hr
+
+    hr.force_generic(request.param == "generic")
+    yield request.param
+    hr.force_generic(False)

@@ -51,10 +51,18 @@ def draw_scene(it, rs, replay=False):
             background_color = colour if background_color is None else background_color
             s.background_image, s.background_color = None, background_color
         s.strict_edge, s.integer_pixel_centers, s.backface_culling = bool(strict), bool(it % 7 != 3), True
+        if textured > 0.0 and it % 3 == 1:
+            # textured && !shaded triangles (H.h:2798, 2813, 2868-2895): out of pass 1, their silhouette edges drawn interpolated from
+            # the vertex colours (a generator of its own: the stream `rs` of the scenes drawn before round 5 stays what it was)
+            rs_mixed = np.random.RandomState(500000 + it)
+            unshaded = np.flatnonzero(s.textured)[rs_mixed.rand(int(s.textured.sum())) < 0.4]
+            s.shaded = s.shaded.copy()
+            s.shaded[unshaded] = False
+            s.colors[s.faces[unshaded].ravel()] = np.random.RandomState(600000 + 10 * it + v).rand(3 * unshaded.size, 3)
         if textured == 0.0 and it % 2 == 0:
             s.texture = np.zeros((0, 0))  # a scene WITHOUT a texture: the fit step's forward raster back-propagates the tiles with edges itself
         views.append(s)
-    desc = (f"H={H} W={W} n_tri={n_tri} views={n_views} sigma={sigma} dt={dt} textured={textured} no_texture={np.size(views[0].texture) == 0} tex={tex_size} min_area={min_area} round={rounded} "
+    desc = (f"H={H} W={W} n_tri={n_tri} views={n_views} sigma={sigma} dt={dt} textured={textured} unshaded={int((views[0].textured & ~views[0].shaded).sum())} no_texture={np.size(views[0].texture) == 0} tex={tex_size} min_area={min_area} round={rounded} "
             f"bgcolor={background_color is not None} strict={strict} intpix={views[0].integer_pixel_centers} cw={bool(it & 1)}")
     obs = rs.rand(n_views, H, W, 3)
     return views, sigma, dt, desc, obs
@@ -141,8 +149,12 @@ def draw_mesh_scene(it):
         s.integer_pixel_centers = bool(it % 3 != 1)
         s.perspective_correct = mode == "persp"
         s.backface_culling = mode != "noculling"
+        if textured and it % 3 == 2:  # a third of the textured meshes: bands of textured && !shaded triangles (H.h:2798, 2868-2895), coloured vertices
+            s.shaded = s.shaded.copy()
+            s.shaded[(np.arange(s.shaded.size) // 7) % 3 == 0] = False
+            s.colors = np.random.RandomState(800000 + 10 * it + v).rand(*s.colors.shape)
         views.append(s)
-    desc = (f"mesh H={H} W={W} sphere={nu}x{n_rings} C={nb_colors} textured={textured} views={n_views} sigma={sigma} dt={dt} mode={mode} zoom={zoom} "
+    desc = (f"mesh H={H} W={W} sphere={nu}x{n_rings} C={nb_colors} textured={textured} unshaded={int((views[0].textured & ~views[0].shaded).sum())} views={n_views} sigma={sigma} dt={dt} mode={mode} zoom={zoom} "
             f"fov={fov} intpix={views[0].integer_pixel_centers}")
     return views, sigma, dt, mode, desc
 

@@ -16,7 +16,7 @@ import torch
 
 from conftest import GOLDEN, golden_soup
 from deodr_amd import scenes
-from test_oracle import FLAG_CASES, random_scene
+from test_oracle import BACKWARD_CASES, FLAG_CASES, random_scene
 
 pytestmark = pytest.mark.gpu
 
@@ -77,7 +77,7 @@ def compare_backward(api, s, sigma, dt, seed=7):
 
 
 @pytest.mark.parametrize("dt", [F32, F64])
-@pytest.mark.parametrize("case", [0, 1, 3])
+@pytest.mark.parametrize("case", BACKWARD_CASES)
 @pytest.mark.parametrize("sigma", [0.0, 1.0, 2.5])
 def test_backward_parity_flag_space(oracle_api, case, sigma, dt):
     s = random_scene(200 + case, **FLAG_CASES[case])
@@ -86,7 +86,7 @@ def test_backward_parity_flag_space(oracle_api, case, sigma, dt):
 
 
 @pytest.mark.parametrize("dt", [F32, F64])
-@pytest.mark.parametrize("case", [0, 1, 3])
+@pytest.mark.parametrize("case", BACKWARD_CASES)
 @pytest.mark.parametrize("sigma", [0.0, 1.0, 2.5])
 def test_backward_parity_antialiase_error(oracle_api, case, sigma, dt):
     """renderScene_B with antialiaseError: every gradient against the REPAIRED reference (defects D1 + D2); uv_b / shade_b
@@ -360,7 +360,7 @@ def HipRasterizer_for(ds):
 
 
 @pytest.mark.parametrize("dt", [F32, F64])
-@pytest.mark.parametrize("case", [0, 1, 3])
+@pytest.mark.parametrize("case", BACKWARD_CASES)
 @pytest.mark.parametrize("sigma", [0.0, 1.0, 2.5])
 def test_fit_step_flag_space(oracle_api, case, sigma, dt):
     s = random_scene(300 + case, **FLAG_CASES[case])

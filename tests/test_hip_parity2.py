@@ -21,7 +21,7 @@ import torch
 
 from conftest import GOLDEN, golden_soup
 from deodr_amd import scenes
-from test_oracle import FLAG_CASES, random_scene
+from test_oracle import BACKWARD_CASES, FLAG_CASES, random_scene
 
 pytestmark = pytest.mark.gpu
 
@@ -31,16 +31,6 @@ TOL = {F32: (1e-5, 1e-4), F64: (1e-9, 1e-8)}
 
 def checker(api, fixed=False):
     return api.ref(fixed=fixed) or api.port(fixed=fixed)
-
-
-@pytest.fixture(params=["staged", "generic"])
-def family(request):
-    """Run the test once per kernel family."""
-    from deodr_amd import hip_renderer as hr
-
-    hr.force_generic(request.param == "generic")
-    yield request.param
-    hr.force_generic(False)
 
 
 def many_channel_scene(seed, nb_colors, **flags):
@@ -88,7 +78,7 @@ def compare_all(api, s, sigma, dt, fit=True):
 
 
 @pytest.mark.parametrize("dt", [F32, F64])
-@pytest.mark.parametrize("case", [0, 1, 3])
+@pytest.mark.parametrize("case", BACKWARD_CASES)
 @pytest.mark.parametrize("sigma", [0.0, 1.0, 2.5])
 def test_both_kernel_families_flag_space(oracle_api, family, case, sigma, dt):
     """The suite of test_hip_parity.py, reduced, on BOTH families (textured + untextured triangles, three channels)."""
@@ -100,7 +90,7 @@ def test_both_kernel_families_flag_space(oracle_api, family, case, sigma, dt):
     compare_fit_step(oracle_api, s, sigma, dt)
 
 
-@pytest.mark.parametrize("case", [4, 5, 6])
+@pytest.mark.parametrize("case", [4, 5, 6, 7, 8])
 def test_both_kernel_families_forward_only_flags(oracle_api, family, case):
     """perspective_correct and backface_culling=False are forward-only in the reference (H.h:2922, 810)."""
     from test_hip_parity import compare_forward

@@ -114,8 +114,15 @@ def random_scene(seed, **flags):
                           textured_ratio=0.5, flat=False, texture_size=16)  # fmt: skip
     s.depths = s.depths + 0.05 * rs.rand(s.depths.shape[0]) + 0.2  # slanted triangles, strictly positive depth
     for k, v in flags.items():
-        if k != "use_background_color":
+        if k not in ("use_background_color", "mixed_shading"):
             setattr(s, k, v)
+    if flags.get("mixed_shading"):
+        # textured && !shaded (H.h:2798, 2813: skipped by pass 1; H.h:2868-2895: its silhouette edges are drawn INTERPOLATED
+        # from the vertex colours; same branches in renderScene_B): every third textured triangle, with colours of its own
+        unshaded = np.flatnonzero(s.textured)[::3]
+        s.shaded = s.shaded.copy()
+        s.shaded[unshaded] = False
+        s.colors[s.faces[unshaded].ravel()] = rs.rand(3 * unshaded.size, s.colors.shape[1])
     if flags.get("use_background_color"):
         s.background_image, s.background_color = None, np.array([0.1, 0.2, 0.3])
     return s
@@ -129,7 +136,10 @@ FLAG_CASES = [
     dict(perspective_correct=True),
     dict(perspective_correct=True, strict_edge=False, clockwise=True),
     dict(backface_culling=False),
+    dict(mixed_shading=True),
+    dict(mixed_shading=True, clockwise=True, strict_edge=False),
 ]
+BACKWARD_CASES = [0, 1, 3, 7, 8]  # the adjoint refuses un-culled scenes (H.h:2922-2925) and perspective_correct
 
 
 @pytest.mark.parametrize("case", range(len(FLAG_CASES)))
@@ -150,7 +160,7 @@ def test_port_equals_reference_forward(oracle_api, case, sigma):
 
 
 @pytest.mark.parametrize("fixed", [False, True])
-@pytest.mark.parametrize("case", [0, 1, 3])
+@pytest.mark.parametrize("case", BACKWARD_CASES)
 @pytest.mark.parametrize("sigma", [0.0, 1.0, 2.5])
 def test_port_equals_reference_backward(oracle_api, case, sigma, fixed):
     ref = oracle_api.ref(fixed=fixed)
