@@ -186,16 +186,35 @@ def fit_pose_project_b(vertices, quaternions, posed, camera, posed_b, ij_b, dept
                                                    _p(colors_b), 0 if colors_b is None else int(colors_b.shape[-1]), _p(colors_sum), _stream(posed.device)))  # fmt: skip
 
 
-def views_gradient_sum(posed, camera, ij_b, vertices_b, depths_b=None, depths_b_scale=1.0, colors_b=None, colors_sum=None):
+def views_gradient_sum(posed, camera, ij_b, vertices_b, depths_b=None, depths_b_scale=1.0, colors_b=None, colors_sum=None, validate=True):
     """What the views of a multi-view fit share (mesh_fitter.py:518-527): vertices_b [V,3] (written) = the adjoint of every view's camera
     projection applied to ij_b [n,V,2] (and depths_b [n,V]), summed over the n views; colors_sum [V,C] (written, optional) = colors_b
     [n,V,C] summed over the views.  One wide launch -- the packed buffer a sharded fit all-reduces."""
     n, V = posed.shape[0], posed.shape[1]
-    _check_cameras(n, camera.extrinsic, camera.intrinsic, camera.distortion)
+    if validate:  # (validate=False: a caller that launches the same, already validated, tensors every step -- OverlappedViewsReduction)
+        _validate_views_gradient_sum(posed, camera, ij_b, vertices_b, depths_b, colors_b, colors_sum)
     with torch.cuda.device(posed.device):
         _check(_lib().deodr_hip_views_gradient_sum(_p(posed), _p(camera.extrinsic), _p(camera.intrinsic), _p(camera.distortion), _p(ij_b), _p(depths_b),
                                                    float(depths_b_scale), _p(vertices_b), V, n, _p(colors_b), 0 if colors_b is None else int(colors_b.shape[-1]),
                                                    _p(colors_sum), _stream(posed.device)))  # fmt: skip
+
+
+def _validate_views_gradient_sum(posed, camera, ij_b, vertices_b, depths_b, colors_b, colors_sum):
+    n, V = posed.shape[0], posed.shape[1]
+    _check_cameras(n, camera.extrinsic, camera.intrinsic, camera.distortion)
+    # the kernel reads every pointer as contiguous float64 of exactly these shapes: anything else (a float32 vertex_dtype, a strided
+    # view) would be read out of bounds and go into the collective as garbage without an error
+    expected = [("posed", posed, (n, V, 3)), ("ij_b", ij_b, (n, V, 2)), ("vertices_b", vertices_b, (V, 3))]
+    if depths_b is not None:
+        expected.append(("depths_b", depths_b, (n, V)))
+    if colors_b is not None or colors_sum is not None:
+        if colors_b is None or colors_sum is None:
+            raise ValueError("views_gradient_sum: colors_b and colors_sum go together")
+        expected += [("colors_b", colors_b, (n, V, int(colors_b.shape[-1]))), ("colors_sum", colors_sum, (V, int(colors_b.shape[-1])))]
+    for name, t, shape in expected:
+        if not usable(t) or not t.is_contiguous() or tuple(t.shape) != shape or t.device != posed.device:
+            raise ValueError(f"views_gradient_sum: {name} must be a contiguous float64 ROCm tensor of shape {shape} on {posed.device}, got "
+                             f"{tuple(t.shape)} {t.dtype} {t.device}{'' if t.is_contiguous() else ' (not contiguous)'}")
 
 
 def vertex_shade(posed, topology, light, ambient, color=None, luminosity=None, colors=None):

@@ -722,27 +722,44 @@ def test_float32_vertex_arrays_equal_float64_vertex_arrays_of_the_same_values():
                 assert rel(b[which][k].cpu(), a[which][k].cpu()) < 2e-6, (which, k)
 
 
-def test_bench_two_ranks_on_one_gpu():
-    """bench.py as the driver launches it for N > 1 (torch.distributed.run, one process per rank, views sharded, overlapped reduction of
-    the shared gradient, MAX over the ranks' times, ONE JSON line from rank 0) -- with two ranks that share this box's GPU and all-reduce
-    over gloo (`--test-backend gloo`: RCCL refuses two ranks on one device).  The line's own checks must hold: the timed launch against
-    the unmodified reference, the all-reduced gradient against a synchronous reduction."""
+def _run_bench(*args):
+    """plain `python bench.py ...` (for --gpus N > 1 bench.py becomes its own torch.distributed.run launcher) -> the parsed JSON line"""
     import json
     import subprocess
     import sys
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29547",
-           os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2", "--size", "256", "--views", "2", "--test-backend", "gloo"]  # fmt: skip
-    run = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    run = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + list(args), cwd=root, env=env, capture_output=True, text=True, timeout=900)
     assert run.returncode == 0, run.stderr[-3000:]
     lines = [ln for ln in run.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, run.stdout[-2000:]  # rank 0 alone prints
-    out = json.loads(lines[0])
-    assert out["n_gpus"] == 2 and out["steps"] == 6 and out["scaling"] == "weak" and out["value"] > 0
+    return json.loads(lines[0])
+
+
+def test_bench_two_ranks_on_one_gpu():
+    """bench.py --gpus 2 started WITHOUT a launcher, as the driver's N = 1 command is (round 4: AssertionError) -- it re-executes itself under
+    torch.distributed.run: one process per rank, views sharded, overlapped reduction of the shared gradient, MAX over the ranks' times, ONE
+    JSON line from rank 0 -- with two ranks that share this box's GPU and all-reduce over gloo (`--test-backend gloo`: RCCL refuses two
+    ranks on one device).  The line's own checks must hold: the timed launch against the unmodified reference, the all-reduced gradient
+    against a synchronous reduction."""
+    out = _run_bench("--gpus", "2", "--steps", "6", "--warmup", "2", "--size", "256", "--views", "2", "--test-backend", "gloo")
+    assert out["n_gpus"] == 2 and out["steps"] == 6 and out["warmup"] == 2 and out["scaling"] == "weak" and out["value"] > 0
     assert out["config"]["global_views"] == 4 and out["config"]["views_per_gpu"] == 2
     assert any("NOT a measurement" in o for o in out["config"]["env_overrides"])
     assert out["parity_checked"] is True
     assert out["reduction_check"]["ok"] and out["reduction_check"]["ranks"] == 2
     assert "cpu_baseline" not in out  # rank 0 at N = 1 only
+
+
+def test_bench_two_ranks_textured_batch_strong_scaling():
+    """--config 4 (BASELINE configs[4]'s shape at a small frame: 100k triangles, 1024^2 texture) --scaling strong: 4 views in all, two per rank;
+    texture_b and uv_b are part of the ONE all-reduced buffer (float32, 12.6 MB + the vertex sums), checked against a synchronous
+    reduction of the re-rendered step; the timed launch against the unmodified reference."""
+    out = _run_bench("--gpus", "2", "--config", "4", "--scaling", "strong", "--steps", "3", "--warmup", "1", "--size", "256", "--views", "4",
+                     "--test-backend", "gloo", "--time-every", "0")  # fmt: skip
+    assert out["n_gpus"] == 2 and out["scaling"] == "strong" and out["config"]["global_views"] == 4 and out["config"]["views_per_gpu"] == 2
+    assert "strong_scaling_floor" in out["config"] and "configs[4]" in out["config"]["workload"]
+    rc = out["reduction_check"]
+    assert rc["ok"] and rc["ranks"] == 2 and rc["dtype"] == "float32" and rc["parts"].startswith("texture_b") and rc["bytes"] > 4 * 1024 * 1024 * 3
+    assert out["parity_checked"] is True and out["parity"]["rel_err_shade_b"] < 1e-4

@@ -89,3 +89,85 @@ def test_deterministic_mode_reports_a_sum_beyond_its_range(oracle_api):
             assert ("fixed-point range" in hr.scene_error_message(errs)) == bool(expect)
     finally:
         hr.set_deterministic(False)
+
+
+@pytest.mark.parametrize("dt", [F32, F64])
+def test_overlapped_reduction_of_a_textured_scene(oracle_api, dt):
+    """OverlappedViewsReduction on a textured scene: texture_b and uv_b are part of the packed buffer (the library accumulates the views' taps
+    straight into it), next to the vertex / colour sums -- against the sum over the views of per-view calls of the checker, and against the
+    plain (unpacked) gradient arrays of the same step; float32 buffers pack in float32, float64 in float64."""
+    from hip_util import device_scene, rel_err
+    from deodr_amd import fronthalf
+    from deodr_amd.distributed import OverlappedViewsReduction
+    from deodr_amd.hip_renderer import HipRasterizer
+    from deodr_amd.scene3d import DeviceCamera
+
+    n, S = 3, 128
+    poses = np.linspace(-0.3, 0.3, n)
+    views = [scenes.sphere_scene(size=S, nu=24, n_rings=20, nb_colors=3, textured=True, texture_size=16, angle=float(a)) for a in poses]
+    verts, _f = scenes.bumpy_sphere(24, 20)
+    cams = [scenes.fit_camera(S, S, 60.0, verts, scenes.rotx(0.37) @ scenes.roty(0.23 + float(a))) for a in poses]
+    ds = device_scene(views, dt)
+    r = HipRasterizer.for_scene(ds)
+    camera = DeviceCamera(np.stack([c.extrinsic for c in cams]), np.stack([c.intrinsic for c in cams]), S, S, None, ds.device)
+    posed = torch.as_tensor(np.ascontiguousarray(verts), device=ds.device)[None].expand(n, -1, -1).contiguous()
+    V, C = posed.shape[1], ds.nb_colors
+    red = OverlappedViewsReduction(ds, camera, posed)
+    assert red.textured and red.slots[0].shared.dtype == dt and red.slots[0].grads["texture_b"].data_ptr() == red.slots[0].shared.data_ptr()
+    assert red.slots[0].shared.numel() == 16 * 16 * 3 + V * (3 + C) + 2 * ds.uv.shape[0]
+    rng = np.random.RandomState(4)
+    r.render(ds, 1.0, check_overflow=True)
+    kept = []
+    for step in range(5):
+        obs = torch.as_tensor(rng.rand(n, S, S, C), device=ds.device).to(dt)
+        slot = red.begin()
+        r.render_fit(ds, obs, 1.0, grads=slot.grads, clear_grads=True, check_overflow=False, done_flag=slot.done_flag)
+        red.reduce(slot)
+        kept.append((slot, obs))
+    red.finish()
+    slot, obs = kept[-1]
+    # the same step into plain arrays
+    image, _z, g = r.render_fit(ds, obs, 1.0, check_overflow=False, clear_grads=True)
+    vb, cs = torch.zeros(V, 3, dtype=F64, device=ds.device), torch.zeros(V, C, dtype=F64, device=ds.device)
+    fronthalf.views_gradient_sum(posed, camera, g["ij_b"], vb, colors_b=g["colors_b"], colors_sum=cs)
+    torch.cuda.synchronize()
+    tol = 1e-6 if dt == F32 else 1e-11  # (run-to-run order of the atomics; float32: the packed buffer's own rounding)
+    assert rel_err(slot.vertices_b.cpu().numpy(), vb.cpu().numpy()) < tol
+    assert rel_err(slot.uv_b.cpu().numpy(), g["uv_b"].cpu().numpy()) < tol
+    assert rel_err(slot.texture_b.cpu().numpy(), g["texture_b"].cpu().numpy()) < (1e-5 if dt == F32 else 1e-11)
+    # the checker, view by view
+    fixed = checker(oracle_api, fixed=True)
+    uv_ref = tex_ref = 0
+    for i, s in enumerate(views):
+        img_ref, z_ref = fixed.render(s, 1.0)
+        image_b = 2 * (image[i].cpu().numpy().astype(np.float64) - obs[i].cpu().numpy().astype(np.float64))
+        gr = fixed.grads(s, 1.0, img_ref, z_ref, image_b)
+        uv_ref, tex_ref = uv_ref + gr["uv_b"], tex_ref + gr["texture_b"]
+    tol = 1e-4 if dt == F32 else 1e-8
+    assert np.abs(tex_ref).max() > 0 and rel_err(slot.texture_b.cpu().numpy(), tex_ref) < tol and rel_err(slot.uv_b.cpu().numpy(), uv_ref) < tol
+
+
+def test_views_gradient_sum_refuses_what_it_cannot_read():
+    """the kernel reads contiguous float64 of fixed shapes -- a float32 vertex_dtype or a strided view used to be read out of bounds"""
+    from hip_util import device_scene
+    from deodr_amd import fronthalf
+    from deodr_amd.distributed import OverlappedViewsReduction
+    from deodr_amd.scene3d import DeviceCamera
+
+    n, S = 2, 64
+    poses = np.linspace(-0.2, 0.2, n)
+    views = [scenes.sphere_scene(size=S, nu=10, n_rings=8, angle=float(a)) for a in poses]
+    verts, _f = scenes.bumpy_sphere(10, 8)
+    cams = [scenes.fit_camera(S, S, 60.0, verts, scenes.rotx(0.37) @ scenes.roty(0.23 + float(a))) for a in poses]
+    ds32 = device_scene(views, F32, vertex_dtype=F32)
+    camera = DeviceCamera(np.stack([c.extrinsic for c in cams]), np.stack([c.intrinsic for c in cams]), S, S, None, ds32.device)
+    posed = torch.as_tensor(np.ascontiguousarray(verts), device=ds32.device)[None].expand(n, -1, -1).contiguous()
+    V = posed.shape[1]
+    with pytest.raises(ValueError, match="float64"):
+        OverlappedViewsReduction(ds32, camera, posed)
+    g = ds32.zero_grads()
+    vb = torch.zeros(V, 3, dtype=F64, device=ds32.device)
+    with pytest.raises(ValueError, match="ij_b"):
+        fronthalf.views_gradient_sum(posed, camera, g["ij_b"], vb)  # float32 ij_b
+    with pytest.raises(ValueError, match="vertices_b"):
+        fronthalf.views_gradient_sum(posed, camera, g["ij_b"].double(), torch.zeros(V, 6, dtype=F64, device=ds32.device)[:, ::2])  # strided

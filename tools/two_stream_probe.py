@@ -48,11 +48,11 @@ class Half:
         self.grads = self.ds.zero_grads()
         self.flag = torch.zeros(1, dtype=torch.int32, device=dev)
         self.status = torch.zeros(1, dtype=torch.int32, device=dev)
-        self.k = 0
+        self.k = 0  # flagged steps so far (= the value the flag holds once the last of them has finished)
         self.r.render(self.ds, 1.0, out=(self.image, self.z), check_overflow=True)
 
     def fit(self, flag=False):
-        self.k += 1
+        self.k += 1 if flag else 0
         self.r.render_fit(self.ds, self.obs, 1.0, grads=self.grads, out=(self.image, self.z), check_overflow=False, clear_grads=True,
                           done_flag=(self.flag, self.k) if flag else None)  # fmt: skip
 
@@ -80,6 +80,17 @@ def report(name, t):
     print(f"{name:9s} {t * 1e3:.4f} ms per {B} views = {B * S * S / t / 1e6:.0f} Mpixel/s   (8d fraction of 8 TB/s: {43.22e6 * B / t / 8e12:.3f})", flush=True)
 
 
+only = arg("--only", "")
+if only == "free2":  # (for a rocprofv3 --kernel-trace run: tools/trace_timeline.py reads the csv)
+    a, b = Half(views[: B // 2]), Half(views[B // 2 :])
+    sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+    for _ in range(steps):
+        with torch.cuda.stream(sa):
+            a.fit()
+        with torch.cuda.stream(sb):
+            b.fit()
+    torch.cuda.synchronize()
+    sys.exit(0)
 whole = Half(views)
 report("one", timed(whole.fit, steps, torch.cuda.synchronize))
 del whole
