@@ -33,6 +33,12 @@ __device__ __forceinline__ void lds_add(double *slot, double v)
 	if (v != 0)
 		unsafeAtomicAdd(slot, v);
 }
+// the native LDS float add of gfx950 (ds_add_f32, no return): through the address-space-3 builtin, so that the compiler cannot expand it
+// into a compare-and-swap loop (what round 4's atomicAdd on a generic float * became)
+__device__ __forceinline__ void lds_add_f32(float *slot, float v)
+{
+	__builtin_amdgcn_ds_faddf((__attribute__((address_space(3))) float *)slot, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP, false);
+}
 
 constexpr int RUNS = 32; // run totals flushed per pass: 32 x 12 doubles fit in the (by then idle) record staging area of the wave
 static_assert(RUNS * NMOM * sizeof(double) <= sizeof(WaveLds::rec) + sizeof(WaveLds::planes) && RUNS * 4 <= sizeof(WaveLds::cover), "LDS reuse");
@@ -232,6 +238,168 @@ __device__ __forceinline__ void owner_adjoint(const KParams &p, const ViewPtrs &
 		emask &= ~__ballot(sel);
 	}
 }
+
+// ---- round 5: the adjoint of pass 1 for the float32 instances of an UNTEXTURED fit step, keyed by the owner's SLOT in the staged batch
+//
+// owner_adjoint above knows an owner by its triangle index, so the run totals of a tile have to be grouped by owner before they can leave
+// (readlane / ballot rounds over the distinct owners, a loop over the runs of each), and it scans in double: two v_mov_dpp + one
+// v_add_f64 + the masking per value and step.  In a tile whose triangles all sit in ONE staged batch (every paired tile, nine single
+// tiles in ten) the owner of a pixel is a slot number below 16, which IS a table index:
+//   * per pixel and channel the two sums  g  and  g (x - x0)  -- coordinates relative to the tile, so that float32 carries them: the
+//     absolute moments are formed in double at the very end,  sum g x = x0 sum g + sum g (x - x0)  -- are scanned over the 8 lanes of a
+//     pixel row with ONE v_fmac_f32 row_shr per value and step (the segment mask is a float factor 0 / 1 that is scanned along);
+//   * the tail lane of every run STORES its 2 C run totals into entry [slot][row] of a float table in LDS (two 16-byte stores): a convex
+//     triangle meets a pixel row in one span, so an entry has one writer -- unless another triangle cuts the span in two (occlusion): a
+//     run whose owner already ended a run further left in the row is told apart by an OR-scan of the tails' slot bits and ADDS
+//     (ds_add_f32, the native instruction) after the stores.  (The table as [slot][moment] with every run added atomically was built
+//     first: 24 ds_add_f32 per pair of tiles cost the forward raster 9 us per step -- LDS float atomics are slow, plain stores are not.)
+//   * lane 4 j + c then sums the eight rows of slot j, channel c -- no grouping, no loop over runs --, makes the three moments absolute in
+//     double and issues the global atomics; the 3 P moments of an owner are contiguous, as before.
+// A pair of tiles (two pixels per lane) goes through ONE table, ONE zeroing and ONE flush.  Sums in float32: the contributions are
+// residuals of float32 pixels, a tile adds at most 64 of them per moment, and what leaves the tile is accumulated in double as before
+// (gradients within 1e-6 of the all-double path; the float64-pixel instances keep owner_adjoint).
+constexpr int SLOT_ROW = 2 * CH;				  // floats of an entry [slot][row]: (sum g (x - x0), sum g) per channel
+constexpr int SLOT_STRIDE = TILE * SLOT_ROW + 8; // floats per slot; + 8: the flush lanes of slots j, j + 1, ... start eight banks apart
+constexpr int SLOT_MOM = 12;					  // floats per slot of the moment table behind it: 3 per channel
+static_assert(TB * (SLOT_STRIDE + SLOT_MOM) * sizeof(float) <= sizeof(WaveLds) + sizeof(EdgeSort), "the slot table lives in the (by then idle) LDS of the wavefront");
+static_assert(CH == 4 && TILE == 8 && TB * CH == 64, "one flush lane per (slot, channel)");
+
+// One step of the segmented scan over 2 CH floats: v[i] += keep * v[i] of the lane `SHR` to the left, keep *= keep of that lane -- one
+// v_fmac_f32 with the DPP modifier per value (the compiler emits v_mov_b32_dpp + v_fmac_f32: its DPP combiner does not fold into an
+// instruction whose destination is also a source).  Hand-written, so the hazards are ours: a DPP read of a register needs two wait
+// states behind the VALU write of it -- s_nop 1 covers whatever the compiler placed in front; inside the block every register was
+// last written at least eight instructions earlier.  Lanes without a source lane in their 16-lane row read 0 (bound_ctrl).
+#define DR_DPP_F32_STEP(SHR)                                                                                                              \
+	asm("s_nop 1\n\t"                                                                                                                     \
+		"v_fmac_f32_dpp %0, %0, %8 " SHR " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"                                                    \
+		"v_fmac_f32_dpp %1, %1, %8 " SHR " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"                                                    \
+		"v_fmac_f32_dpp %2, %2, %8 " SHR " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"                                                    \
+		"v_fmac_f32_dpp %3, %3, %8 " SHR " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"                                                    \
+		"v_fmac_f32_dpp %4, %4, %8 " SHR " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"                                                    \
+		"v_fmac_f32_dpp %5, %5, %8 " SHR " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"                                                    \
+		"v_fmac_f32_dpp %6, %6, %8 " SHR " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"                                                    \
+		"v_fmac_f32_dpp %7, %7, %8 " SHR " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"                                                    \
+		"v_mul_f32_dpp %8, %8, %8 " SHR " row_mask:0xf bank_mask:0xf bound_ctrl:1"                                                          \
+		: "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]), "+v"(keep))
+
+// slot[k] / g[k][]: owner slot (-1: none) and dL/d(colour) of pixel k of this lane (pixel k lies 8 k columns right of lane & 7);
+// id_of_slot: lane j holds the triangle index of slot j; tab: TB * SLOT_STRIDE floats of LDS scratch.  All 64 lanes must call it.
+template <int NPIX>
+__device__ __forceinline__ void owner_adjoint_slots(const KParams &p, const ViewPtrs &w, int lane, int x0, int y0, const int (&slot)[NPIX],
+													const float (&g)[NPIX][CH], uint32_t id_of_slot, int nslots, float *tab)
+{
+	typedef float F4 __attribute__((ext_vector_type(4)));
+	const int C = p.C, nm = 3 * p.L.P;
+	const int lx = lane & 7, ly = lane >> 3;
+	lds_sync();
+	for (int i = lane * 4; i < nslots * SLOT_STRIDE; i += 256)
+		*(F4 *)(tab + i) = F4{0.0f, 0.0f, 0.0f, 0.0f};
+	lds_sync();
+	// which lanes may look 1 / 2 / 4 lanes to their left without leaving their pixel row (two pixel rows share a 16-lane DPP row)
+	const uint32_t in1 = lx >= 1 ? 0xffffffffu : 0u, in2 = lx >= 2 ? 0xffffffffu : 0u, in4 = lx >= 4 ? 0xffffffffu : 0u;
+#pragma unroll
+	for (int k = 0; k < NPIX; k++)
+	{
+		const int oid = slot[k];
+		const int left = dpp_i<0x111>(oid); // (all lanes: a DPP move reads 0 from a disabled lane)
+		const bool head = (lx == 0) | (left != oid);
+		float keep = head ? 0.0f : 1.0f; // 1 while the segment of this lane reaches further left than the scan has looked
+		const float xr = (float)(lx + 8 * k);
+		float v[2 * CH];
+#pragma unroll
+		for (int q = 0; q < CH; q++)
+		{
+			v[2 * q] = q < C ? g[k][q] * xr : 0.0f;
+			v[2 * q + 1] = q < C ? g[k][q] : 0.0f;
+		}
+		DR_DPP_F32_STEP("row_shr:1");
+		DR_DPP_F32_STEP("row_shr:2");
+		DR_DPP_F32_STEP("row_shr:4");
+		const int right_head = dpp_i<0x101>(head ? 1 : 0);
+		const bool tail = ((lx == 7) | (right_head != 0)) && oid >= 0;
+		// A span cut in two needs three runs in one pixel row (owner, occluder, owner): whether ANY row of the tile has three tails is
+		// a few scalar operations on the ballot (per-byte population counts); only then the vector unit looks which runs they are --
+		// slots whose run ended further left in the row: an exclusive OR-scan of the tails' slot bits
+		bool again = false;
+		{
+			unsigned long long t = __ballot(tail);
+			t = t - ((t >> 1) & 0x5555555555555555ull);
+			t = (t & 0x3333333333333333ull) + ((t >> 2) & 0x3333333333333333ull);
+			t = (t + (t >> 4)) & 0x0f0f0f0f0f0f0f0full; // tails per pixel row, one byte each
+			if ((t + 0x0505050505050505ull) & 0x0808080808080808ull)
+			{
+				const uint32_t bit = tail ? 1u << oid : 0u;
+				uint32_t seen = (uint32_t)dpp_i<0x111>((int)bit) & in1;
+				seen |= (uint32_t)dpp_i<0x111>((int)seen) & in1; // (bits of the lanes lx - 1, lx - 2; then - 3, - 4; then - 5 .. - 8)
+				seen |= (uint32_t)dpp_i<0x112>((int)seen) & in2;
+				seen |= (uint32_t)dpp_i<0x114>((int)seen) & in4;
+				again = tail && ((seen >> oid) & 1u);
+			}
+		}
+		float *entry = tab + oid * SLOT_STRIDE + ly * SLOT_ROW;
+		if (tail && !again)
+		{
+			*(F4 *)entry = F4{v[0], v[1], v[2], v[3]};
+			*(F4 *)(entry + 4) = F4{v[4], v[5], v[6], v[7]};
+		}
+		if (__ballot(again))
+		{ // a span cut in two by a nearer triangle: the later piece adds to the entry the first one has stored
+			if (again)
+			{
+#pragma unroll
+				for (int i = 0; i < 2 * CH; i++)
+					if (i < 2 * C)
+						lds_add_f32(entry + i, v[i]);
+			}
+		}
+	}
+	lds_sync();
+	// lane 4 j + c: the three moments of channel c of slot j
+	{
+		const int j = lane >> 2, c = lane & 3;
+		const bool live = j < nslots && c < C;
+		const float *col = tab + (live ? j : 0) * SLOT_STRIDE + 2 * c;
+		float T = 0.0f, S = 0.0f, Y = 0.0f;
+#pragma unroll
+		for (int r = 0; r < TILE; r++)
+		{
+			const float2 ts = *(const float2 *)(col + r * SLOT_ROW);
+			T += ts.x;
+			S += ts.y;
+			Y = fmaf(ts.y, (float)r, Y);
+		}
+		// The atomics leave MOMENT-major -- a memory-side atomic instruction is paid per cache line it touches, and the 3 P moments of an
+		// owner are 96 contiguous bytes: one instruction per 64 entries, not three per lane (measured: three instructions of 4 x 8 bytes
+		// per owner took the forward raster from 69 to 82 us per step, profiles/r05g_*) -- so the sums go through LDS once more:
+		// [slot][12] floats behind the table's last slot row (the table itself is being read by the other lanes).
+		float *const mom = tab + TB * SLOT_STRIDE;
+		lds_sync();
+		if (live)
+		{
+			mom[j * SLOT_MOM + 3 * c] = T;
+			mom[j * SLOT_MOM + 3 * c + 1] = Y;
+			mom[j * SLOT_MOM + 3 * c + 2] = S;
+		}
+		else if (j < nslots)
+			mom[j * SLOT_MOM + 3 * c] = mom[j * SLOT_MOM + 3 * c + 1] = mom[j * SLOT_MOM + 3 * c + 2] = 0.0f;
+	}
+	lds_sync();
+	const float *const mom = tab + TB * SLOT_STRIDE;
+	const int entries = nslots * SLOT_MOM;
+	for (int i0 = 0; i0 < entries; i0 += 64)
+	{
+		const int i = i0 + lane, j = i / SLOT_MOM, m = i - j * SLOT_MOM, k = m % 3;
+		const bool live = i < entries;
+		const float val = live ? mom[i] : 0.0f, sum = live ? mom[i + 2 - k] : 0.0f;
+		const uint32_t id = (uint32_t)__shfl((int)id_of_slot, live ? j : 0, 64); // (by every lane: not under the branch below)
+		if (live && m < nm && (val != 0.0f || sum != 0.0f))
+		{
+			const double origin = k == 0 ? (double)x0 : (k == 1 ? (double)y0 : 0.0);
+			atomic_add_f64(w.tri_acc + (size_t)id * nm + m, (double)val + origin * (double)sum);
+		}
+	}
+}
+#undef DR_DPP_F32_STEP
 
 // Adjoint of pass 2 for the batches b_hi .. b_lo of a tile's blending order (near -> far, H.h:2961-3052), shared by the edge-tile
 // kernel of the two-call path and by the fused forward of a fit step.  On entry: es.sorted = the blending order, tm[b] = mask of the

@@ -269,6 +269,15 @@ __device__ __forceinline__ double fit_residual(const KParams &p, double v, doubl
 	return 2 * (v - o);
 }
 
+// the same residual from float32 operands: 2 (v - o) rounded once -- what the double version gives when its result is rounded to float32
+template <bool CLAMP>
+__device__ __forceinline__ float fit_residual_f32(const KParams &p, float v, float o)
+{
+	if (CLAMP && p.clamp && ((double)v < p.clamp_lo || (double)v > p.clamp_hi))
+		return 0.0f;
+	return 2.0f * (v - o);
+}
+
 __device__ __forceinline__ ViewPtrs view_ptrs(const KParams &p, int view)
 {
 	char *b = p.ws + (size_t)view * p.L.view_bytes;

@@ -345,7 +345,9 @@ def compare_fit_step(api, views, sigma, dt, seed=11):
         g_fix = checker(api, fixed=True).grads(s, sigma, img_ref, z_ref, image_b)
         for k in ("ij_b", "colors_b", "shade_b"):
             assert rel_err(g[k][i].cpu().numpy(), g_ref[k]) < tol, (k, "vs checker")
-            assert rel_err(g[k][i].cpu().numpy(), g2[k][i].cpu().numpy()) < 1e-9, (k, "vs two calls")
+            # (float32 frames: the fit step of an untextured scene sums a tile's residuals in float32 -- owner_adjoint_slots --, the two-call
+            # path in double)
+            assert rel_err(g[k][i].cpu().numpy(), g2[k][i].cpu().numpy()) < (1e-9 if dt == F64 else 5e-6), (k, "vs two calls")
         if n == 1:
             assert rel_err(g["uv_b"].cpu().numpy(), g_ref["uv_b"]) < tol, "uv_b"
             if g["texture_b"] is not None and np.size(s.texture):
