@@ -1068,8 +1068,10 @@ enum FwdMode
 	FWD_NO_EDGES = 2, // fit step, rest of the list: no tile has an edge
 };
 template <class PixT, bool FUSED, bool TEX, int MODE, bool CLAMP>
-__device__ __forceinline__ void fwd_tiles(const KParams &p, WaveLds *s_lds, EdgeSort *s_es, const long long b)
-{ // b: index of this walker among the walkers of the grid (the workgroup index, unless fill workgroups are dealt among them)
+__device__ __forceinline__ void fwd_tiles(const KParams &p, WaveLds *s_lds, EdgeSort *s_es, const uint32_t b)
+{ // b: index of this walker among the walkers of the grid (the workgroup index, unless fill workgroups are dealt among them).
+  // (32-bit: a grid has fewer than 2^31 workgroups, and every wavefront pays for this arithmetic on the scalar unit before its first load --
+  // as `long long` the two divisions by the number of views alone were ~250 instructions of 64-bit division emulation)
 	DR_WAVE_TRACE_SCOPE(2);
 	constexpr int wave = 0;
 	const int lane0 = threadIdx.x & 63;
@@ -1078,13 +1080,15 @@ __device__ __forceinline__ void fwd_tiles(const KParams &p, WaveLds *s_lds, Edge
 	const bool chunked = G % (8 * WORK_CHUNK) == 0;
 	if (chunked)
 	{
-		view = (int)((b >> 3) % p.n_views);
-		q = (int)((b >> 3) / p.n_views) * 8 + (int)(b & 7);
+		const uint32_t g8 = b >> 3, gq = g8 / (uint32_t)p.n_views;
+		view = (int)(g8 - gq * (uint32_t)p.n_views);
+		q = (int)(gq * 8 + (b & 7));
 	}
 	else
 	{
-		view = (int)(b % p.n_views);
-		q = (int)(b / p.n_views);
+		const uint32_t gq = b / (uint32_t)p.n_views;
+		view = (int)(b - gq * (uint32_t)p.n_views);
+		q = (int)gq;
 	}
 	const ViewPtrs w = view_ptrs(p, view);
 	const int W = p.W, H = p.H, C = p.C, P = p.L.P;
@@ -1100,29 +1104,44 @@ __device__ __forceinline__ void fwd_tiles(const KParams &p, WaveLds *s_lds, Edge
 	const int qq = heavy_list ? q : q - Gh, stride = heavy_list ? Gh : G - Gh;
 	const bool chunk_here = chunked && stride % (8 * WORK_CHUNK) == 0;
 	uint32_t rank = chunk_here ? (uint32_t)((((qq >> 3) / WORK_CHUNK) * 8 + (qq & 7)) * WORK_CHUNK + (qq >> 3) % WORK_CHUNK) : (uint32_t)qq;
-	const uint32_t n_work = w.hdr->work_count[heavy_list ? 0 : 1];
-	for (; rank < n_work; rank += (uint32_t)stride)
+	// The first entry of a walker (usually its only one) is requested TOGETHER with the count it is checked against -- the position of the
+	// entry does not depend on the count and lies inside the list whatever the count is (rank < stride <= tiles <= work_cap).  As the first
+	// statement of the loop body the load sat behind the branch on the count: a third dependent round trip (count, entry, records) in the
+	// ~8 us life of a wavefront whose arithmetic is ~2 us.
+	auto entry_at = [&](uint32_t r) { return &w.work_list[heavy_list ? r : (uint32_t)p.L.work_cap - 1u - r]; };
+	// (The compiler sinks loads that only the loop body uses below the branch on the count, whatever their place in the source: the empty
+	// asm statement takes the three results as read-write operands, so all three loads are issued, and waited for ONCE, in front of it.)
+	uint4 head = *(const uint4 *)entry_at(rank); // {tile, ntri, nedge, sweep_slot}
+	uint32_t ids_first = entry_at(rank)->ids[lane0 < ENTRY_IDS ? lane0 : 0];
+	uint32_t n_work_v = w.hdr->work_count[heavy_list ? 0 : 1];
+	asm volatile("" : "+v"(head.x), "+v"(head.y), "+v"(head.z), "+v"(head.w), "+v"(ids_first), "+v"(n_work_v));
+	const uint32_t n_work = (uint32_t)uniform((int)n_work_v);
+	for (bool first = true; rank < n_work; rank += (uint32_t)stride, first = false)
 	{
 		// (the lane index is made opaque per iteration: otherwise every lane-dependent address of the body is hoisted out of the
 		// loop and kept -- spilled -- in registers across it: + 150 VGPRs for a loop that usually runs once or twice)
 		int lane = lane0;
 		asm volatile("" : "+v"(lane));
-		const WorkEntry &entry = w.work_list[heavy_list ? rank : (uint32_t)p.L.work_cap - 1u - rank];
-		const uint32_t ids12 = entry.ids[lane < ENTRY_IDS ? lane : 0];
-		if (FUSED && !TEX && MODE == FWD_NO_EDGES && ((uint32_t)uniform((int)entry.tile) & PAIR_FLAG))
+		if (!first)
+		{
+			head = *(const uint4 *)entry_at(rank);
+			ids_first = entry_at(rank)->ids[lane < ENTRY_IDS ? lane : 0];
+		}
+		const uint32_t ids12 = ids_first;
+		const uint32_t e_tile = (uint32_t)uniform((int)head.x), e_ntri = (uint32_t)uniform((int)head.y), e_nedge = (uint32_t)uniform((int)head.z);
+		if (FUSED && !TEX && MODE == FWD_NO_EDGES && (e_tile & PAIR_FLAG))
 		{ // two adjacent tiles, two pixels per lane (the scan kernel pairs them up: fwd_pair_tiles)
-			const uint32_t nn = (uint32_t)uniform((int)entry.ntri);
-			fwd_pair_tiles<PixT, CLAMP>(p, w, S, view, lane, (int)((uint32_t)uniform((int)entry.tile) & ~PAIR_FLAG), (int)(nn & 0xffffu), (int)(nn >> 16), ids12,
+			fwd_pair_tiles<PixT, CLAMP>(p, w, S, view, lane, (int)(e_tile & ~PAIR_FLAG), (int)(e_ntri & 0xffffu), (int)(e_ntri >> 16), ids12,
 								 p.loss_wave ? p.loss_wave + (size_t)view * LOSS_SLOTS + q % LOSS_SLOTS : nullptr);
 			lds_sync();
 			continue;
 		}
-		const uint32_t nedge_word = MODE == FWD_NO_EDGES ? 0u : (uint32_t)uniform((int)entry.nedge);
+		const uint32_t nedge_word = MODE == FWD_NO_EDGES ? 0u : e_nedge;
 		// (FWD_EDGE_ADJ: a tile of several batches of edges is listed once per batch, see tile_scan_kernel)
 		bool split = MODE == FWD_EDGE_ADJ && (nedge_word & SPLIT_FLAG);
 		const int part = split ? (int)((nedge_word >> 16) & 0xffu) : 0;
-		const int tile = uniform((int)entry.tile), ntri = uniform((int)entry.ntri), nedge = (int)(split ? (nedge_word & 0xffffu) : nedge_word);
-		const uint32_t sweep_slot = (uint32_t)uniform((int)entry.sweep_slot);
+		const int tile = (int)e_tile, ntri = (int)e_ntri, nedge = (int)(split ? (nedge_word & 0xffffu) : nedge_word);
+		const uint32_t sweep_slot = (uint32_t)uniform((int)head.w);
 		const int tx = tile % p.L.tiles_x, ty = tile / p.L.tiles_x;
 		const int x0 = tx * TILE, y0 = ty * TILE;
 		const int px = x0 + (lane & 7), py = y0 + (lane >> 3);
@@ -1520,30 +1539,31 @@ __global__ __launch_bounds__(64, DR_FWD_WAVES) void raster_fwd_fast_kernel(KPara
 	// dispatched behind the last walker they START when the last walker has a slot, and the kernel then ends a fill later (73 MB of
 	// stores per 8-view step: same-box A/B 0.1279 / 0.1274 -> 0.1238 / 0.1232 ms, profiles/r04l).  (Round 3 measured "spread evenly:
 	// nothing" -- with the heavy tiles still deciding when the kernel ends.)
-	const long long n_walk = (long long)p.n_views * p.tile_blocks, n_fill = (long long)p.n_views * fill_share(p.fill_mode, 2, p.L.nwords);
+	const uint32_t n_walk = (uint32_t)p.n_views * (uint32_t)p.tile_blocks, n_fill = (uint32_t)p.n_views * (uint32_t)fill_share(p.fill_mode, 2, p.L.nwords);
 #ifndef DR_FILL_DEAL
 #define DR_FILL_DEAL 1 // (measurement builds: 0 = the fill workgroups behind the walkers, as in round 3)
 #endif
-	const long long dealt = (DR_FILL_DEAL && FUSED && !TEX && p.fuse_edges && n_walk >= 8 * n_fill) ? n_fill / 8 : 0; // groups of 64 walkers + 8 fill workgroups
-	long long b = blockIdx.x, fi = -1;
+	const uint32_t dealt = (DR_FILL_DEAL && FUSED && !TEX && p.fuse_edges && n_walk >= 8 * n_fill) ? n_fill / 8 : 0; // groups of 64 walkers + 8 fill workgroups
+	uint32_t b = blockIdx.x; // (32-bit throughout: see fwd_tiles)
+	int fi = -1;
 	if (b < dealt * 72)
 	{
-		const long long grp = b / 72, r = b - grp * 72;
+		const uint32_t grp = b / 72, r = b - grp * 72;
 		if (r < 64)
 			b = grp * 64 + r;
 		else
-			fi = grp * 8 + (r - 64);
+			fi = (int)(grp * 8 + (r - 64));
 	}
 	else
 	{
 		b -= dealt * 8;
 		if (b >= n_walk)
-			fi = dealt * 8 + (b - n_walk);
+			fi = (int)(dealt * 8 + (b - n_walk));
 	}
 	if (fi >= 0)
 	{
-		if (fi < n_fill)
-			fill_share_word(p, 2, (int)(fi % p.n_views), (int)(fi / p.n_views), threadIdx.x & 63);
+		if ((uint32_t)fi < n_fill)
+			fill_share_word(p, 2, (int)((uint32_t)fi % (uint32_t)p.n_views), (int)((uint32_t)fi / (uint32_t)p.n_views), threadIdx.x & 63);
 		return;
 	}
 	if (FUSED && DR_FUSE_EDGES && !TEX)
