@@ -1116,19 +1116,23 @@ __device__ __forceinline__ void fwd_tiles(const KParams &p, WaveLds *s_lds, Edge
 	uint32_t n_work_v = w.hdr->work_count[heavy_list ? 0 : 1];
 	asm volatile("" : "+v"(head.x), "+v"(head.y), "+v"(head.z), "+v"(head.w), "+v"(ids_first), "+v"(n_work_v));
 	const uint32_t n_work = (uint32_t)uniform((int)n_work_v);
-	for (bool first = true; rank < n_work; rank += (uint32_t)stride, first = false)
+	while (rank < n_work)
 	{
 		// (the lane index is made opaque per iteration: otherwise every lane-dependent address of the body is hoisted out of the
 		// loop and kept -- spilled -- in registers across it: + 150 VGPRs for a loop that usually runs once or twice)
 		int lane = lane0;
 		asm volatile("" : "+v"(lane));
-		if (!first)
+		// this iteration's entry has been requested an iteration ago (or in front of the loop); the NEXT one of this walker is requested
+		// now, a whole tile ahead of its use: its position does not depend on anything this tile computes
+		const uint4 cur = head;
+		const uint32_t ids12 = ids_first;
+		rank += (uint32_t)stride;
+		if (rank < n_work)
 		{
 			head = *(const uint4 *)entry_at(rank);
 			ids_first = entry_at(rank)->ids[lane < ENTRY_IDS ? lane : 0];
 		}
-		const uint32_t ids12 = ids_first;
-		const uint32_t e_tile = (uint32_t)uniform((int)head.x), e_ntri = (uint32_t)uniform((int)head.y), e_nedge = (uint32_t)uniform((int)head.z);
+		const uint32_t e_tile = (uint32_t)uniform((int)cur.x), e_ntri = (uint32_t)uniform((int)cur.y), e_nedge = (uint32_t)uniform((int)cur.z);
 		if (FUSED && !TEX && MODE == FWD_NO_EDGES && (e_tile & PAIR_FLAG))
 		{ // two adjacent tiles, two pixels per lane (the scan kernel pairs them up: fwd_pair_tiles)
 			fwd_pair_tiles<PixT, CLAMP>(p, w, S, view, lane, (int)(e_tile & ~PAIR_FLAG), (int)(e_ntri & 0xffffu), (int)(e_ntri >> 16), ids12,
@@ -1141,7 +1145,7 @@ __device__ __forceinline__ void fwd_tiles(const KParams &p, WaveLds *s_lds, Edge
 		bool split = MODE == FWD_EDGE_ADJ && (nedge_word & SPLIT_FLAG);
 		const int part = split ? (int)((nedge_word >> 16) & 0xffu) : 0;
 		const int tile = (int)e_tile, ntri = (int)e_ntri, nedge = (int)(split ? (nedge_word & 0xffffu) : nedge_word);
-		const uint32_t sweep_slot = (uint32_t)uniform((int)head.w);
+		const uint32_t sweep_slot = (uint32_t)uniform((int)cur.w);
 		const int tx = tile % p.L.tiles_x, ty = tile / p.L.tiles_x;
 		const int x0 = tx * TILE, y0 = ty * TILE;
 		const int px = x0 + (lane & 7), py = y0 + (lane >> 3);
