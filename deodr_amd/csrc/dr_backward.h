@@ -29,9 +29,9 @@ struct alignas(16) BwdLds
 };
 
 __device__ __forceinline__ void lds_add(double *slot, double v)
-{
+{ // ds_add_f64 through the address-space-3 builtin (unsafeAtomicAdd on a generic pointer asks "is it shared?" first)
 	if (v != 0)
-		unsafeAtomicAdd(slot, v);
+		__builtin_amdgcn_ds_atomic_fadd_f64((__attribute__((address_space(3))) double *)slot, v);
 }
 // the native LDS float add of gfx950 (ds_add_f32, no return): through the address-space-3 builtin, so that the compiler cannot expand it
 // into a compare-and-swap loop (what round 4's atomicAdd on a generic float * became)
@@ -40,6 +40,12 @@ __device__ __forceinline__ void lds_add_f32(float *slot, float v)
 	__builtin_amdgcn_ds_faddf((__attribute__((address_space(3))) float *)slot, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP, false);
 }
 
+// The texture-gradient window of owner_adjoint holds doubles.  A float32 window for float32 frames (twice the texels in the same 3 KB)
+// was built twice -- round 4 through atomicAdd (a compare-and-swap loop), round 5 through the native ds_add_f32 -- and is slower both
+// times: BASELINE configs[4], forward raster 0.64 -> 0.97 / 0.99 ms.  LDS float32 adds are slow on this part where float64 adds are
+// not (the same showed in the slot table of owner_adjoint_slots: 24 ds_add_f32 per pair of tiles cost 17 us per step).
+__device__ __forceinline__ void win_add(double *slot, double v) { lds_add(slot, v); }
+
 constexpr int RUNS = 32; // run totals flushed per pass: 32 x 12 doubles fit in the (by then idle) record staging area of the wave
 static_assert(RUNS * NMOM * sizeof(double) <= sizeof(WaveLds::rec) + sizeof(WaveLds::planes) && RUNS * 4 <= sizeof(WaveLds::cover), "LDS reuse");
 
@@ -47,8 +53,8 @@ static_assert(RUNS * NMOM * sizeof(double) <= sizeof(WaveLds::rec) + sizeof(Wave
 // tab (RUNS * NMOM doubles) and own (RUNS words) are LDS scratch of this wave.  All 64 lanes must call it.
 template <class PixT, bool TEX>
 __device__ __forceinline__ void owner_adjoint(const KParams &p, const ViewPtrs &w, int lane, double x, double y, int owner, int kind, const double *g,
-											  const Tap &tap, double L, double *tab, uint32_t *own)
-{
+											  const Tap &tap, double L, double *tab, uint32_t *own, int win_cap)
+{ // win_cap: entries of `tab` the texture-gradient window may use (at least RUNS * NMOM: what the run totals need afterwards)
 	const int C = p.C, P = p.L.P;
 	const PixT *texture = (const PixT *)p.texture;
 	PixT *texture_b = (PixT *)p.texture_b;
@@ -57,11 +63,20 @@ __device__ __forceinline__ void owner_adjoint(const KParams &p, const ViewPtrs &
 	double val[CH] = {0, 0, 0, 0};
 	// Texture gradient.  The taps of the 64 pixels of a tile fall into a small window of texels (a magnified texture: a
 	// dozen texels for 768 contributions), and atomics to one address serialise in the L2 at ~80 ns each: when the window
-	// fits the LDS scratch, the contributions are summed there (ds_add_f64) and each touched texel leaves with ONE global
+	// fits the LDS scratch, the contributions are summed there (LDS adds) and each touched texel leaves with ONE global
 	// atomic -- "per-tile LDS partials before a single atomicAdd".
+	// Round 5: a tile whose window does not fit -- a MINIFIED texture: towards the limb of a curved surface the texels per pixel grow
+	// without bound; on BASELINE configs[4] a fifth of the tiles, and they scattered their 768 taps straight to memory -- is taken as
+	// four 4 x 4-pixel quadrants, each with a window of its own (quadrant bounds are the same butterfly stopped two steps early);
+	// only a quadrant whose own window does not fit scatters.
+	typedef double WinT;
+	const int WIN_CAP = win_cap;
+	WinT *const win = tab;
 	const bool textured = kind == KIND_TEXTURED && TEX;
-	int fu = 0, fv = 0, win_u0 = 0, win_v0 = 0, win_w = 0, win_h = 0;
-	bool windowed = false;
+	int fu = 0, fv = 0;
+	int mode = 0; // 0: no window (scatter, or no texture gradient asked for), 1: one window for the tile, 2: one per quadrant
+	int full_u0 = 0, full_v0 = 0, full_w = 0, full_h = 0;
+	uint32_t q_lo = 0xffffffffu, q_hi = 0; // this lane's quadrant: packed (u, v) bounds of the taps' first texels
 	if (texture_b && __ballot(textured))
 	{
 		if (textured)
@@ -70,65 +85,122 @@ __device__ __forceinline__ void owner_adjoint(const KParams &p, const ViewPtrs &
 			fv = t0 / p.tex_w;
 			fu = t0 - fv * p.tex_w;
 		}
-		int lo_u = textured ? fu : 0x7fffffff, lo_v = textured ? fv : 0x7fffffff, hi_u = textured ? fu : -1, hi_v = textured ? fv : -1;
-#pragma unroll
-		for (int d = 1; d < 64; d <<= 1)
-		{
-			lo_u = min(lo_u, __shfl_xor(lo_u, d, 64));
-			lo_v = min(lo_v, __shfl_xor(lo_v, d, 64));
-			hi_u = max(hi_u, __shfl_xor(hi_u, d, 64));
-			hi_v = max(hi_v, __shfl_xor(hi_v, d, 64));
+		if (p.tex_w <= 0xffff && p.tex_h <= 0xffff)
+		{ // (u, v) packed into one word: two exchanges per step (v_pk_min_u16 / v_pk_max_u16)
+			typedef unsigned short U2 __attribute__((ext_vector_type(2)));
+			U2 lo = textured ? U2{(unsigned short)fu, (unsigned short)fv} : U2{0xffff, 0xffff};
+			U2 hi = textured ? U2{(unsigned short)fu, (unsigned short)fv} : U2{0, 0};
+			auto step = [&](int d) {
+				const int lo_o = __shfl_xor(__builtin_bit_cast(int, lo), d, 64), hi_o = __shfl_xor(__builtin_bit_cast(int, hi), d, 64);
+				lo = __builtin_elementwise_min(lo, __builtin_bit_cast(U2, lo_o));
+				hi = __builtin_elementwise_max(hi, __builtin_bit_cast(U2, hi_o));
+			};
+			step(1), step(2), step(8), step(16); // lanes (x & 4, y & 4) alike: a 4 x 4-pixel quadrant
+			q_lo = __builtin_bit_cast(uint32_t, lo), q_hi = __builtin_bit_cast(uint32_t, hi);
+			step(4), step(32);
+			full_u0 = lo.x, full_v0 = lo.y, full_w = hi.x - lo.x + 2, full_h = hi.y - lo.y + 2;
+			mode = full_w * full_h * C <= WIN_CAP ? 1 : 2;
 		}
-		win_u0 = lo_u, win_v0 = lo_v, win_w = hi_u - lo_u + 2, win_h = hi_v - lo_v + 2;
-		windowed = win_w * win_h * C <= RUNS * NMOM;
-		if (windowed)
+		else
 		{
-			lds_sync();
-			for (int i = lane; i < win_w * win_h * C; i += 64)
-				tab[i] = 0;
-			lds_sync();
+			int lo_u = textured ? fu : 0x7fffffff, lo_v = textured ? fv : 0x7fffffff, hi_u = textured ? fu : -1, hi_v = textured ? fv : -1;
+#pragma unroll
+			for (int d = 1; d < 64; d <<= 1)
+			{
+				lo_u = min(lo_u, __shfl_xor(lo_u, d, 64));
+				lo_v = min(lo_v, __shfl_xor(lo_v, d, 64));
+				hi_u = max(hi_u, __shfl_xor(hi_u, d, 64));
+				hi_v = max(hi_v, __shfl_xor(hi_v, d, 64));
+			}
+			full_u0 = lo_u, full_v0 = lo_v, full_w = hi_u - lo_u + 2, full_h = hi_v - lo_v + 2;
+			mode = full_w * full_h * C <= WIN_CAP ? 1 : 0;
 		}
 	}
-	if (textured)
-	{ // H.h:1320-1353
-		double L_B = 0, e_B[2] = {0, 0};
-		const int wbase = ((fv - win_v0) * win_w + (fu - win_u0)) * C;
+	auto window_zero = [&](int ww, int wh) {
+		lds_sync();
+		for (int i = lane; i < ww * wh * C; i += 64)
+			win[i] = 0;
+		lds_sync();
+	};
+	// The window leaves row by row: a row of it is ww * C CONSECUTIVE elements of texture_b (x fastest, channels inside), so a lane
+	// needs no division to find its texel and the atomics of one instruction fall into one or two cache lines.  Several rows per pass
+	// when a row is shorter than half a wavefront (lane / row length once, by a float reciprocal: exact for these sizes).
+	auto window_flush = [&](int u0, int v0, int ww, int wh) {
+		lds_sync();
+		const int rowlen = ww * C;
+		const int per_pass = rowlen < 64 ? 64 / rowlen : 1; // rows per pass (uniform)
+		const int lr = rowlen < 64 ? (int)(((float)lane + 0.5f) * (1.0f / (float)rowlen)) : 0, li = lane - lr * rowlen;
+		for (int jv0 = 0; jv0 < wh; jv0 += per_pass)
+		{
+			const int jv = jv0 + lr;
+			if (lr < per_pass && jv < wh)
+				for (int i = li; i < rowlen; i += 64)
+				{
+					const WinT v = win[jv * rowlen + i];
+					if (v != 0)
+						unsafeAtomicAdd(texture_b + (size_t)C * (u0 + (size_t)p.tex_w * (v0 + jv)) + i, (PixT)v);
+				}
+		}
+		lds_sync(); // the table is reused
+	};
+	// the texels of this lane's four taps, channel by channel: the adjoint of the bilinear mix (H.h:1320-1353) and the texture gradient's
+	// four contributions per channel -- added to the window whose first texel is (u0, v0) (`add`), or scattered (`scatter`)
+	double L_B = 0, e_B[2] = {0, 0};
+	auto channels = [&](bool add, bool scatter, int u0, int v0, int ww, bool adjoint) {
+		const int wbase = ((fv - v0) * ww + (fu - u0)) * C;
 #pragma unroll
 		for (int cc = 0; cc < CH; cc++)
 			if (cc < C)
 			{
 				const double i00 = ldp(texture, tap.idx[0] + cc), i10 = ldp(texture, tap.idx[1] + cc);
 				const double i01 = ldp(texture, tap.idx[2] + cc), i11 = ldp(texture, tap.idx[3] + cc);
-				L_B += g[cc] * bilinear_mix(tap, i00, i10, i01, i11);
-				double wgt[4];
-				bilinear_mix_adjoint(tap, g[cc] * L, i00, i10, i01, i11, wgt, e_B);
-				if (windowed)
+				if (adjoint)
+					L_B += g[cc] * bilinear_mix(tap, i00, i10, i01, i11);
+				double wgt[4], e_tmp[2] = {0, 0};
+				bilinear_mix_adjoint(tap, g[cc] * L, i00, i10, i01, i11, wgt, adjoint ? e_B : e_tmp);
+				if (add)
 				{
-					lds_add(&tab[wbase + cc], wgt[0]);
-					lds_add(&tab[wbase + C + cc], wgt[1]);
-					lds_add(&tab[wbase + win_w * C + cc], wgt[2]);
-					lds_add(&tab[wbase + win_w * C + C + cc], wgt[3]);
+					win_add(&win[wbase + cc], wgt[0]);
+					win_add(&win[wbase + C + cc], wgt[1]);
+					win_add(&win[wbase + ww * C + cc], wgt[2]);
+					win_add(&win[wbase + ww * C + C + cc], wgt[3]);
 				}
-				else if (texture_b)
+				else if (scatter)
 					texture_scatter(texture_b, tap, cc, wgt);
 			}
+	};
+	if (mode == 1)
+		window_zero(full_w, full_h);
+	if (textured)
+		channels(mode == 1, mode == 0 && texture_b != nullptr, full_u0, full_v0, full_w, true);
+	if (mode == 1)
+		window_flush(full_u0, full_v0, full_w, full_h);
+	if (mode == 2)
+	{
+		const int my_q = ((lane >> 2) & 1) | ((lane >> 4) & 2); // (x & 4) | (y & 4): lane = y * 8 + x
+#pragma unroll 1
+		for (int qd = 0; qd < 4; qd++)
+		{
+			const int rep = (qd & 1) * 4 + (qd >> 1) * 32; // a lane of the quadrant
+			const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)q_lo, rep), hi = (uint32_t)__builtin_amdgcn_readlane((int)q_hi, rep);
+			if (lo == 0xffffffffu)
+				continue; // no textured pixel in this quadrant
+			const int u0 = (int)(lo & 0xffffu), v0 = (int)(lo >> 16), ww = (int)(hi & 0xffffu) - u0 + 2, wh = (int)(hi >> 16) - v0 + 2;
+			const bool fits = ww * wh * C <= WIN_CAP;
+			const bool mine = textured && my_q == qd;
+			if (fits)
+				window_zero(ww, wh);
+			if (mine)
+				channels(fits, !fits, u0, v0, ww, false);
+			if (fits)
+				window_flush(u0, v0, ww, wh);
+		}
+	}
+	if (textured)
+	{
 		val[0] = tap.out[0] ? 0.0 : e_B[0];
 		val[1] = tap.out[1] ? 0.0 : e_B[1];
 		val[2] = L_B;
-	}
-	if (windowed)
-	{
-		lds_sync();
-		for (int i = lane; i < win_w * win_h * C; i += 64)
-		{
-			const double v = tab[i];
-			if (v != 0)
-			{
-				const int texel = i / C, c = i - texel * C, jv = texel / win_w, ju = texel - jv * win_w;
-				unsafeAtomicAdd(texture_b + (size_t)C * ((win_u0 + ju) + (size_t)p.tex_w * (win_v0 + jv)) + c, (PixT)v);
-			}
-		}
-		lds_sync(); // tab is reused for the run totals below
 	}
 	if (kind == KIND_INTERP)
 	{ // H.h:1024-1037

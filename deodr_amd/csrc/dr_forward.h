@@ -309,7 +309,7 @@ __device__ __forceinline__ uint32_t stage_edge_batch(WaveLds &S, const EdgeSort 
 
 template <class PixT, bool TEX>
 __device__ __forceinline__ void owner_adjoint(const KParams &p, const ViewPtrs &w, int lane, double x, double y, int owner, int kind, const double *g,
-											  const Tap &tap, double L, double *tab, uint32_t *own);
+											  const Tap &tap, double L, double *tab, uint32_t *own, int win_cap = 384);
 
 template <int NPIX>
 __device__ __forceinline__ void owner_adjoint_slots(const KParams &p, const ViewPtrs &w, int lane, int x0, int y0, const int (&slot)[NPIX],
@@ -1501,8 +1501,9 @@ __device__ __forceinline__ void fwd_tiles(const KParams &p, WaveLds *s_lds, Edge
 			// (round 5: owner_adjoint_slots for the unpaired tiles -- and for the tiles with edges above -- was built and measured: with both
 			// adjoints in the walker the headline instance spills 123 registers instead of 98 and the step is 0.1140 - 0.1160 ms against
 			// 0.1130 with the pairs alone, profiles/r05g_*)
+			// (a tile without edges: the whole LDS of the wavefront -- staging area and edge order -- is idle: twice the window)
 			owner_adjoint<PixT, TEX>(p, w, lane, x, y, st.kbest, st.kbest >= 0 ? st.kind : (int)KIND_NONE, g, tap, L, (double *)&S.rec[0],
-									(uint32_t *)&S.cover[0][0]);
+									(uint32_t *)&S.cover[0][0], (int)((sizeof(WaveLds) + sizeof(EdgeSort)) / sizeof(double)));
 		}
 		}
 		}
