@@ -139,7 +139,11 @@ typedef struct DeodrHipFitOptions
 	 * device-wide, the step's last wavefront stores done_value there.  A consumer on ANOTHER stream -- the shared-gradient reduction of a
 	 * sharded fit -- waits for it with deodr_hip_wait_flag instead of a hipEvent: an event recorded on the render stream and waited for by
 	 * a second queue costs the render stream ~8 us per step on MI355X (tools/dist_overhead_probe.py), this flag nothing.  Use increasing
-	 * values (the step number): deodr_hip_wait_flag waits for *flag >= value in serial-number arithmetic. */
+	 * values (the step number): deodr_hip_wait_flag waits for *flag >= value in serial-number arithmetic.
+	 * WHAT THE FLAG COVERS: the gradient arrays (ij_b, colors_b, shade_b, uv_b, texture_b) -- they are written by memory-side atomics, which are
+	 * visible device-wide once acknowledged, and the flag is stored behind their acknowledgement.  NOT covered: *loss, the image and the
+	 * z-buffer of the step (plain stores, which may still sit in an XCD's L2 when the flag is seen): a consumer that reads those orders
+	 * itself behind the step's stream (an event, or stream order), as before. */
 	uint32_t *done_flag;
 	uint32_t done_value;
 } DeodrHipFitOptions;
