@@ -18,6 +18,8 @@
 #   fininfwd   -DDR_FIN_IN_FWD=1 finalize UNDER the forward raster (round 4: parity-green, not faster): the per-primitive adjoint algebra as
 #                               workgroups of raster_fwd_fast_kernel gated block by block by device-side counters -- tools/variants/finalize_in_forward.patch
 #                               (700 lines: set-up files primitives under screen blocks, the scan kernel builds work items, the walkers signal)  [its own patch]
+#   classtrace                   {start, end} of every workgroup of the forward raster by class (fill / head walker / other walker), plain stores into a device
+#                               table read by tools/wave_phase_probe.py -- tools/variants/forward_class_timeline.patch (round 5)                     [its own patch]
 #   wavetrace  -DDR_WAVE_TRACE  start / end of every wave                       (tools/wave_trace.py)
 #   fwdN       -DDR_FWD_WAVES=N the staged forward compiled for N waves / SIMD  (tools/step_time.py --lib)
 #   <name>     EXTRA="-D..."    anything else: the product sources with the flags of $EXTRA
@@ -47,6 +49,11 @@ for v in ${@:-fwdtrace wavetrace tiletrace fwd4 fwd6}; do
       cp $ROOT/deodr_amd/csrc/*.h $ROOT/deodr_amd/csrc/*.hip $FIF/deodr_amd/csrc/; cp $ROOT/include/*.h $FIF/include/
       (cd $FIF/deodr_amd/csrc && patch -p1 --no-backup-if-mismatch < $OUT/finalize_in_forward.patch) || { echo "finalize_in_forward.patch no longer fits the sources"; exit 1; }
       build $FIF/deodr_amd/csrc $v "-DDR_FIN_IN_FWD=1 -DDR_SPLIT_EDGES=0" ;; # (its block counters count one walker per tile: no split tiles)
+    classtrace)
+      CT=$(mktemp -d /tmp/deodr_ct.XXXXXX); mkdir -p $CT/deodr_amd/csrc $CT/include
+      cp $ROOT/deodr_amd/csrc/*.h $ROOT/deodr_amd/csrc/*.hip $CT/deodr_amd/csrc/; cp $ROOT/include/*.h $CT/include/
+      (cd $CT/deodr_amd/csrc && patch -p1 --no-backup-if-mismatch < $OUT/forward_class_timeline.patch) || { echo "forward_class_timeline.patch no longer fits the sources"; exit 1; }
+      build $CT/deodr_amd/csrc $v "" ;;
     wavetrace) build $ROOT/deodr_amd/csrc $v -DDR_WAVE_TRACE ;;
     fwd*) build $ROOT/deodr_amd/csrc $v -DDR_FWD_WAVES=${v#fwd} ;;
     *) build $ROOT/deodr_amd/csrc $v "$EXTRA" ;;
