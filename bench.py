@@ -346,7 +346,7 @@ def single_view_latency(scenes_mod, DeviceScene, HipRasterizer, dev, S, sigma, o
     with torch.cuda.stream(side):
         fit()
     torch.cuda.current_stream().wait_stream(side)
-    with torch.cuda.graph(graph):
+    with torch.cuda.graph(graph, capture_error_mode="thread_local"):  # (N > 1: RCCL's watchdog thread queries events while this thread captures)
         fit()
     for _ in range(5):
         graph.replay()

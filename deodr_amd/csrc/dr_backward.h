@@ -148,12 +148,14 @@ __device__ __forceinline__ void owner_adjoint(const KParams &p, const ViewPtrs &
 	double L_B = 0, e_B[2] = {0, 0};
 	auto channels = [&](bool add, bool scatter, int u0, int v0, int ww, bool adjoint) {
 		const int wbase = ((fv - v0) * ww + (fu - u0)) * C;
+		PixT tx[4][4];
+		tap_texels(texture, tap, C, tx);
 #pragma unroll
 		for (int cc = 0; cc < CH; cc++)
 			if (cc < C)
 			{
-				const double i00 = ldp(texture, tap.idx[0] + cc), i10 = ldp(texture, tap.idx[1] + cc);
-				const double i01 = ldp(texture, tap.idx[2] + cc), i11 = ldp(texture, tap.idx[3] + cc);
+				const double i00 = (double)tx[0][cc], i10 = (double)tx[1][cc];
+				const double i01 = (double)tx[2][cc], i11 = (double)tx[3][cc];
 				if (adjoint)
 					L_B += g[cc] * bilinear_mix(tap, i00, i10, i01, i11);
 				double wgt[4], e_tmp[2] = {0, 0};

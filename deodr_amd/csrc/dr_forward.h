@@ -1247,9 +1247,11 @@ __device__ __forceinline__ void fwd_tiles(const KParams &p, WaveLds *s_lds, Edge
 		{
 			bilinear_tap(p.tex_w, p.tex_h, st.v[0], st.v[1], C, tap);
 			L = st.v[2];
+			PixT tx[4][4];
+			tap_texels(texture, tap, C, tx);
 #pragma unroll
 			for (int cc = 0; cc < CH; cc++)
-				col[cc] = cc < C ? textured_channel(texture, tap, cc) * L : 0.0;
+				col[cc] = cc < C ? bilinear_mix(tap, (double)tx[0][cc], (double)tx[1][cc], (double)tx[2][cc], (double)tx[3][cc]) * L : 0.0;
 		}
 		// ---- pass 2: edges far -> near, TB at a time (H.h:2839-2900)
 		int n_edges = 0;

@@ -584,6 +584,32 @@ DR_HD void textured_tap(const double *planes, double x, double y, bool persp, do
 	bilinear_tap(tex_w, tex_h, UV[0], UV[1], nc, tap);
 }
 
+// The four texels of a footprint, every channel, in the pixel type.  Three float32 channels (RGB: the usual texture) are 12 consecutive
+// bytes: ONE load per texel instead of three -- the compiler merges the three single loads at one of the kernels' sites and not at the
+// others (a lane's 12 separate gathers per footprint were 768 requests per wavefront where 256 do).
+template <class PixT>
+DR_HD void tap_texels(const PixT *texture, const Tap &tap, int C, PixT (&t)[4][4])
+{
+#if defined(__HIPCC__)
+	if (C == 3 && sizeof(PixT) == 4)
+	{
+		typedef PixT V3 __attribute__((ext_vector_type(3), aligned(4)));
+#pragma unroll
+		for (int q = 0; q < 4; q++)
+		{
+			const V3 v = *(const V3 *)(texture + tap.idx[q]);
+			t[q][0] = v.x, t[q][1] = v.y, t[q][2] = v.z, t[q][3] = 0;
+		}
+		return;
+	}
+#endif
+#pragma unroll
+	for (int q = 0; q < 4; q++)
+#pragma unroll
+		for (int c = 0; c < 4; c++)
+			t[q][c] = c < C ? texture[tap.idx[q] + c] : (PixT)0;
+}
+
 template <class PixT>
 DR_HD double textured_channel(const PixT *texture, const Tap &tap, int c)
 {
