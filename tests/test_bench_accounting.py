@@ -38,3 +38,40 @@ def test_every_accounting_charges_the_survey_bytes():
 
 def test_cpu_model_string():
     assert isinstance(bench.cpu_model(), str) and bench.cpu_model()
+
+
+def test_gpus_n_without_a_launcher_becomes_the_launcher(monkeypatch):
+    """`python bench.py --gpus 2` with no WORLD_SIZE in the environment (the shape of the driver's N = 1 command; round 4: AssertionError)
+    re-executes itself under torch.distributed.run, one rank per GPU on 127.0.0.1, with its own arguments"""
+    seen = {}
+
+    class Stop(Exception):
+        pass
+
+    def fake_execv(path, argv):
+        seen["path"], seen["argv"] = path, list(argv)
+        raise Stop
+
+    monkeypatch.setattr(os, "execv", fake_execv)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        monkeypatch.delenv(k, raising=False)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "2", "--steps", "3", "--warmup", "1", "--config", "4", "--scaling", "strong"])
+    try:
+        bench.main()
+    except Stop:
+        pass
+    argv = seen["argv"]
+    assert seen["path"] == sys.executable and argv[1:3] == ["-m", "torch.distributed.run"]
+    assert "--nproc-per-node=2" in argv and "--nnodes=1" in argv and argv[argv.index("--master-addr") + 1] == "127.0.0.1"
+    script = argv.index(os.path.abspath(bench.__file__))
+    assert argv[script + 1 :] == ["--gpus", "2", "--steps", "3", "--warmup", "1", "--config", "4", "--scaling", "strong"]
+    assert 1024 < int(argv[argv.index("--master-port") + 1]) < 65536
+
+
+def test_textured_step_bytes_include_the_texture_terms():
+    """SURVEY 8d with a texture (configs[4]): the frame terms + per-view texture read twice and its gradient written once"""
+    H = W = 2048
+    plain = bench.survey_8d_bytes(H, W, 3, 100352, 50626, 8)
+    tex = bench.survey_8d_bytes(H, W, 3, 100352, 50626, 8, Vuv=50626, tex_hw=(1024, 1024))
+    extra_per_view = 4 * (3 * (3 * 100352 + 2 * 50626 + 50626 + 1024 * 1024 * 3) - 3 * 100352)  # fwd read + bwd read + gradient write (no faces_uv in the write)
+    assert tex - plain == 8 * extra_per_view
