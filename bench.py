@@ -38,6 +38,7 @@ The JSON line carries, besides the driver's contract:
 
 import argparse
 import ctypes as C
+import gc
 import json
 import os
 import sys
@@ -568,11 +569,14 @@ def main():
     barrier()
     if stamps is not None:
         hr.lib().deodr_hip_profile_stamps(stamps.data_ptr(), args.steps + 1)
+    gc.collect()
+    gc.disable()  # (no collector pause inside the timed region: its 22 ms of launches allocate nothing that needs one)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     barrier()
     dt = time.perf_counter() - t0
+    gc.enable()
     ms_sum = (C.c_double * 4)()
     launches = (C.c_ulonglong * 4)()
     stamp_ms = None
@@ -590,7 +594,10 @@ def main():
             tick = 1e-5  # ms per tick of the 100 MHz counter
             stamp_ms = {"setup_bin_kernel": float(((st[:K, 1] - st[:K, 0])[ok]).mean() * tick), "raster_fwd_kernel": float(((st[:K, 2] - st[:K, 1])[ok]).mean() * tick),
                         "raster_bwd_kernel": 0.0, "finalize_kernel": float(((nxt - st[:K, 2])[ok]).mean() * tick), "samples": int(ok.sum()),
-                        "step_ms_by_stamps": float(((nxt - st[:K, 0])[ok]).mean() * tick)}  # fmt: skip
+                        "step_ms_by_stamps": float(((nxt - st[:K, 0])[ok]).mean() * tick),
+                        # (the GPU's own view of the region: a step the host was late for -- the queue starts EMPTY behind the barrier, a host pause
+                        # longer than its lead shows as one long step -- moves the mean and the maximum, not the median)
+                        "step_ms_by_stamps_median": float(np.median((nxt - st[:K, 0])[ok]) * tick), "step_ms_by_stamps_max": float(((nxt - st[:K, 0])[ok]).max() * tick)}  # fmt: skip
         # cross-check with hipEvents on a few more steps (outside the timed region: they perturb what they measure)
         hr.lib().deodr_hip_profile_enable(1)
         for _ in range(6):
@@ -666,8 +673,9 @@ def main():
         alg_8d = algorithmic_bytes(S, S, Cc, T, V, B, fused)  # every frame byte of the step
         alg = algorithmic_bytes(S, S, Cc, T, V, B, fused, nonempty / ntiles if (fused and nonempty is not None) else None)
         if textured:
-            # configs[4]: SURVEY 8d's textured terms for the whole step; no split by kernel group (a textured fit step is five launches: the
-            # interval "raster_fwd_kernel" of the time stamps holds the tile scan, the forward raster AND the edge-tile kernel)
+            # configs[4]: SURVEY 8d's textured terms for the whole step; no split by kernel group (a textured fit step is four launches since round 5 -- the
+            # tiles with silhouette edges are back-propagated inside the forward raster, as in untextured scenes --, but the byte model of the groups
+            # has no texture terms)
             alg_8d = {"whole": survey_8d_bytes(S, S, Cc, T, V, B, Vuv=int(ds.uv.shape[0]), tex_hw=(int(ds.texture.shape[0]), int(ds.texture.shape[1])))}
             alg = dict(alg_8d, **{k: None for k in KERNELS})
         per_kernel = {}
@@ -716,13 +724,15 @@ def main():
             # duration, against the 8 TB/s of the data sheet; frac_of_measured: against the copy bandwidth measured on this box.
             # whole_step: all of SURVEY 8d's bytes / the step time (the north star's 40 % is about this number); frac_moved_bytes:
             # only the bytes somebody moves (the adjoint's frame term of the empty tiles is moved by nobody).
-            "roofline": {"bound": "hbm", "kernel": dom if not textured else "whole step (five launches; no per-group byte split for textured scenes)",
+            "roofline": {"bound": "hbm", "kernel": dom if not textured else "whole step (four launches; no per-group byte split for textured scenes)",
                          "achieved": dom_GBps, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": (dom_GBps or 0) / HBM_PEAK_GBS, "traffic": traffic if not textured else None,
                          "peak_measured": peak_meas, "frac_of_measured": (dom_GBps or 0) / peak_meas,
                          "timing": ("device time stamps of every step of the timed region (deodr_hip_profile_stamps); avg_ms_events = hipEvents on 6 steps after it"
                                     if stamp_ms is not None else "hipEvents on steps after the timed region"),
                          "step_ms_by_stamps": None if stamp_ms is None else stamp_ms["step_ms_by_stamps"],
+                         "step_ms_by_stamps_median": None if stamp_ms is None else stamp_ms["step_ms_by_stamps_median"],
+                         "step_ms_by_stamps_max": None if stamp_ms is None else stamp_ms["step_ms_by_stamps_max"],
                          "whole_step": {"alg_bytes": whole, "GBps": whole / step_s / 1e9, "frac": whole / step_s / 1e9 / HBM_PEAK_GBS,
                                         "frac_of_measured": whole / step_s / 1e9 / peak_meas,
                                         "frac_of_guide_copy": whole / step_s / 1e9 / GUIDE_COPY_GBS, "moved_bytes": moved,

@@ -834,10 +834,13 @@ __host__ __device__ inline int fwd_tile_blocks(int ntiles, int n_views, bool dea
 // resolved: tiles without silhouette edges back-propagate into their owners' accumulators right here (no second pass over the
 // frame, no owner buffer round trip -- the owner ids of those tiles are not even written); tiles with edges are left to
 // raster_bwd_edge_kernel.
-// Waves per SIMD the staged forward is compiled for: without texture code it fits five (96 registers), with it four
-// (tools/build_variants.sh builds the neighbours: -DDR_FWD_WAVES=n forces n for both).
+// Waves per SIMD the staged forward is compiled for: without texture code it fits five (96 registers), with it four -- three (168
+// registers) for the textured instances whose walkers also back-propagate the tiles with silhouette edges (TEXE: the reverse sweep with
+// texture taps; at four waves it spills 414 registers.  configs[4], 1 / 8 views: four waves 0.176 / 0.886 - 0.930 ms, three 0.168 / 0.868 -
+// 0.893, two 0.167 / 1.02; the instances WITHOUT the edge adjoint lose 6 - 9 % at three: profiles/r05y_ab_fused_textured_edge_tiles.txt)
+// (tools/build_variants.sh builds the neighbours: -DDR_FWD_WAVES=n forces n for all).
 #ifndef DR_FWD_WAVES
-#define DR_FWD_WAVES (TEX ? 4 : 5)
+#define DR_FWD_WAVES (TEX ? (TEXE ? 3 : 4) : 5)
 #endif
 // Two horizontally adjacent tiles in one wavefront, two pixels per lane (lane = row * 8 + column: pixel `column` of the left tile A
 // and pixel `column` of the right tile B).  For the pairs the scan kernel forms -- both tiles non-empty, no silhouette edge, at
@@ -1515,6 +1518,9 @@ __device__ __forceinline__ void fwd_tiles(const KParams &p, WaveLds *s_lds, Edge
 		close_epoch(p, w, FUSED);
 }
 
+#ifndef DR_FUSE_TEX_EDGES
+#define DR_FUSE_TEX_EDGES 1 // (measurement builds: 0 = the tiles with silhouette edges of a TEXTURED fit step wait for raster_bwd_edge_kernel, as until round 4)
+#endif
 #ifndef DR_FUSE_EDGES
 #define DR_FUSE_EDGES 1 // (measurement builds: 0 = the tiles with silhouette edges of a fit step wait for raster_bwd_edge_kernel, as in round 2)
 #endif
@@ -1523,7 +1529,8 @@ __device__ __forceinline__ void fwd_tiles(const KParams &p, WaveLds *s_lds, Edge
 // the 8-view benchmark step (C = 4) 0.160 -> 0.150 ms.  The host picks the instance (3 and 4 channels, the fit step's kernels).
 // COMMON: strict_edge = true and a frame whose sides are multiples of the tile (every pixel of every tile is inside it), the usual
 // case, at compile time as well: 0.144 -> 0.141 ms.
-template <class PixT, bool FUSED, bool TEX, bool CLAMP = false, int NC = 0, bool COMMON = false>
+// TEXE: (FUSED && TEX) the instance for KParams::fuse_edges -- its head walkers run the adjoint of the tiles with silhouette edges too.
+template <class PixT, bool FUSED, bool TEX, bool CLAMP = false, int NC = 0, bool COMMON = false, bool TEXE = false>
 __global__ __launch_bounds__(64, DR_FWD_WAVES) void raster_fwd_fast_kernel(KParams p)
 {
 	p.aligned = COMMON ? 1 : 0;
@@ -1573,7 +1580,7 @@ __global__ __launch_bounds__(64, DR_FWD_WAVES) void raster_fwd_fast_kernel(KPara
 			fill_share_word(p, 2, (int)((uint32_t)fi % (uint32_t)p.n_views), (int)((uint32_t)fi / (uint32_t)p.n_views), threadIdx.x & 63);
 		return;
 	}
-	if (FUSED && DR_FUSE_EDGES && !TEX)
+	if (FUSED && DR_FUSE_EDGES && (!TEX || TEXE))
 	{ // (p.fuse_edges is set: the host and the scan kernel follow the same rule -- fit step of an untextured scene)
 		const int G = p.tile_blocks;
 		const bool chunked = G % (8 * WORK_CHUNK) == 0;

@@ -396,7 +396,13 @@ int launch_forward_staged(const KParams &p, bool fused, hipStream_t stream, hipE
 	const dim3 grid((unsigned)p.n_views * (unsigned)q.tile_blocks + (unsigned)p.n_views * (unsigned)fill_share(p.fill_mode, 2, p.L.nwords));
 	const bool tex = p.texture != nullptr; // (see launch_adjoint_raster)
 	const bool common = p.strict && p.W % TILE == 0 && p.H % TILE == 0;
-	if (fused && p.clamp && tex) // (the clamped residual of the depth fitter: its own instances of the fused kernel)
+	if (fused && p.clamp && tex && p.fuse_edges) // (the clamped residual of the depth fitter: its own instances of the fused kernel)
+		hipLaunchKernelGGL((raster_fwd_fast_kernel<PixT, true, true, true, 0, false, true>), grid, dim3(64), 0, stream, q);
+	else if (fused && tex && p.fuse_edges && p.C == 3) // (textured fit step, sigma > 0: the instances with the edge adjoint)
+		hipLaunchKernelGGL((raster_fwd_fast_kernel<PixT, true, true, false, 3, false, true>), grid, dim3(64), 0, stream, q);
+	else if (fused && tex && p.fuse_edges)
+		hipLaunchKernelGGL((raster_fwd_fast_kernel<PixT, true, true, false, 0, false, true>), grid, dim3(64), 0, stream, q);
+	else if (fused && p.clamp && tex)
 		hipLaunchKernelGGL((raster_fwd_fast_kernel<PixT, true, true, true>), grid, dim3(64), 0, stream, q);
 	else if (fused && p.clamp && p.C == 1) // (a depth image)
 		hipLaunchKernelGGL((raster_fwd_fast_kernel<PixT, true, false, true, 1>), grid, dim3(64), 0, stream, q);
@@ -772,11 +778,12 @@ static int render_scene_fit_impl(const DeodrHipScene *sc, void *image, void *z_b
 #ifndef DR_FILL_MASK
 #define DR_FILL_MASK 7 // measurement builds: 0 side stream, 1 edge kernel only, 2 finalize only, 4 forward raster only
 #endif
-	// Untextured scenes: the forward raster also back-propagates the tiles with silhouette edges (no edge-tile kernel) and streams
-	// a share of the background.  Textured scenes keep round 2's structure: the textured tile walker has no registers to spare for
-	// the reverse sweep (128 registers at four waves per SIMD, 400 spilled on the edge path; 2048^2 / 100 k triangles / 1 view:
-	// 0.264 -> 0.407 ms with fused edges), its tiles with edges wait for raster_bwd_edge_kernel.
-	p.fuse_edges = DR_FUSE_EDGES && fused && !p.texture;
+	// The forward raster also back-propagates the tiles with silhouette edges (no edge-tile kernel, no saved sweeps) and streams a share
+	// of the background.  Textured scenes too since round 5 (round 2 measured 0.264 -> 0.407 ms for one 2048^2 view of 100 k triangles:
+	// 400 spilled registers on the edge path at four waves per SIMD; with the instances of their own at three waves, the many-edge tiles
+	// split into parts and the quadrant windows of the texture gradient it is 0.195 -> 0.168 ms, 2 / 4 / 8 views 0.257 -> 0.243 /
+	// 0.448 -> 0.451 / 0.890 -> 0.893: profiles/r05y_ab_fused_textured_edge_tiles.txt).  (sigma = 0: no edge anywhere, the lighter instances)
+	p.fuse_edges = DR_FUSE_EDGES && fused && (!p.texture || (DR_FUSE_TEX_EDGES && sigma > 0));
 	p.fill_mode = fused ? ((((sigma > 0 && !p.fuse_edges) ? 1 : 0) | (p.T > 0 ? 2 : 0) | ((p.T > 0 && p.fuse_edges) ? 4 : 0)) & DR_FILL_MASK) : 0;
 	note_forward(workspace, fused);
 	hipEvent_t join = nullptr;

@@ -278,7 +278,7 @@ int deodr_hip_workspace_pool_pairs(const DeodrHipScene *scene, size_t workspace_
 
 /* Measurement hooks (bench.py): deodr_hip_profile_enable(n), n > 0: the kernel launches of every n-th forward (and of the
  * adjoint that follows it) are bracketed by hipEvents recorded on the launch stream; 0: off.  An event pair costs ~3 us of
- * stream time on this part, i.e. ~10 % of a five-kernel step if every launch is timed, hence the sampling.
+ * stream time on this part, i.e. ~10 % of a four-kernel step if every launch is timed, hence the sampling.
  * deodr_hip_profile_read waits for the events and returns, per kernel
  *   [0] setup_bin_kernel  [1] raster_fwd_kernel  [2] raster_bwd_kernel (all adjoint raster kernels)  [3] finalize_kernel
  * the summed elapsed milliseconds and the number of timed launches since the previous read.  Not thread-safe. */

@@ -171,3 +171,68 @@ def test_views_gradient_sum_refuses_what_it_cannot_read():
         fronthalf.views_gradient_sum(posed, camera, g["ij_b"], vb)  # float32 ij_b
     with pytest.raises(ValueError, match="vertices_b"):
         fronthalf.views_gradient_sum(posed, camera, g["ij_b"].double(), torch.zeros(V, 6, dtype=F64, device=ds32.device)[:, ::2])  # strided
+
+
+@pytest.mark.parametrize("n_views", [1, 9])
+def test_textured_tiles_of_many_edges_in_the_fused_forward(oracle_api, n_views):
+    """Round 5: the forward raster of a TEXTURED fit step back-propagates its tiles with silhouette edges as well (no edge-tile kernel, no saved
+    sweep): ~60 textured edges crowded into one tile of a 512^2 frame (a grid with a head of the list: the tile is listed once per part of 8
+    edges for one view, 16 for nine), ~200 edges (more than the staged sweep orders: the un-staged tile code inside the forward raster) --
+    against the checker (uv_b, texture_b included) and the two-call path, which still runs raster_bwd_edge_kernel."""
+    from test_hip_parity import compare_fit_step
+    from test_hip_parity2 import crowded_scene
+
+    def textured_crowd(n_tri, seed):
+        s = crowded_scene(n_tri, seed=seed, size=512)
+        rs = np.random.RandomState(seed + 50)
+        t = rs.rand(n_tri) < 0.7  # (the others stay interpolated: both kinds of edges in the same tile)
+        t3 = np.repeat(t, 3)
+        s.textured, s.shaded = t, t.copy()
+        s.colors = np.where(t3[:, None], 0.0, s.colors)
+        s.shade = np.where(t3, rs.rand(3 * n_tri), 0.0)
+        s.uv = np.where(t3[:, None], rs.rand(3 * n_tri, 2) * (min(s.texture.shape[:2]) - 1), 0.0)
+        return s
+
+    views = [textured_crowd(20, 3 + i) for i in range(n_views)]
+    for v in views[1:]:  # (one mesh, one texture: which triangles are textured, and their uv, are shared by the views; positions, colours, shade are per view)
+        t3 = np.repeat(views[0].textured, 3)
+        v.textured, v.shaded, v.uv, v.texture = views[0].textured, views[0].shaded, views[0].uv, views[0].texture
+        v.colors = np.where(t3[:, None], 0.0, np.random.RandomState(9).rand(*v.colors.shape))
+        v.shade = np.where(t3, np.abs(v.shade) + 0.25, 0.0)
+    assert np.size(views[0].texture) > 0 and views[0].textured.sum() > 8
+    compare_fit_step(oracle_api, views, 1.0, F64)
+    if n_views == 1:
+        compare_fit_step(oracle_api, views, 2.5, F32)
+        compare_fit_step(oracle_api, textured_crowd(70, 5), 1.0, F64)
+
+
+def test_textured_fit_step_launches_no_edge_tile_kernel(oracle_api):
+    """the structure itself: with sigma > 0 a textured fit step is set-up, scan + forward raster, finalize -- the edge-tile kernel of the two-call
+    path is not launched (per-kernel launch counts of the profiling hook); and the frame and gradients do not depend on the kernel family"""
+    import ctypes
+
+    from hip_util import device_scene
+    from deodr_amd import hip_renderer as hr
+
+    s = scenes.sphere_scene(size=256, nu=40, n_rings=30, nb_colors=3, textured=True, texture_size=32)
+    ds = device_scene(s, F32)
+    r = hr.HipRasterizer.for_scene(ds)
+    obs = torch.rand((1, 256, 256, 3), dtype=F32, device=ds.device)
+    r.render_fit(ds, obs, 1.0, check_overflow=True, clear_grads=True)
+    torch.cuda.synchronize()
+    ms, launches = (ctypes.c_double * 4)(), (ctypes.c_ulonglong * 4)()
+    hr.lib().deodr_hip_profile_enable(1)
+    try:
+        hr.lib().deodr_hip_profile_read(ms, launches)  # (reset)
+        for _ in range(3):
+            r.render_fit(ds, obs, 1.0, check_overflow=False, clear_grads=True)
+        torch.cuda.synchronize()
+        hr.lib().deodr_hip_profile_read(ms, launches)
+        assert launches[1] == 3 and launches[3] == 3 and launches[2] == 0, list(launches)
+        r.render(ds, 1.0)
+        r.render_backward(ds, residual_obs=obs)
+        torch.cuda.synchronize()
+        hr.lib().deodr_hip_profile_read(ms, launches)
+        assert launches[2] >= 1, list(launches)  # (the two-call path: the edge-tile kernel)
+    finally:
+        hr.lib().deodr_hip_profile_enable(0)

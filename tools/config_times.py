@@ -61,4 +61,6 @@ run("configs[3] hand, 8 views", lambda: [scenes.hand_scene(GOLD, size=1024, angl
 run("configs[2] sphere 20k", lambda: [scenes.sphere_scene(size=1024, angle=float(a)) for a in np.linspace(-0.5, 0.5, 8)])
 big = dict(size=2048, nu=224, n_rings=224, nb_colors=3, textured=True, texture_size=1024)
 run("configs[4] shape, 1 view", lambda: [scenes.sphere_scene(**big)])
+for nv in (2, 4):
+    run(f"configs[4] shape, {nv} views", lambda: [scenes.sphere_scene(angle=float(a), **big) for a in np.linspace(-0.5, 0.5, nv)], steps=10)
 run("configs[4] shape, 8 views", lambda: [scenes.sphere_scene(angle=float(a), **big) for a in np.linspace(-0.5, 0.5, 8)], steps=10)
