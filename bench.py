@@ -38,7 +38,6 @@ The JSON line carries, besides the driver's contract:
 
 import argparse
 import ctypes as C
-import gc
 import json
 import os
 import sys
@@ -569,14 +568,13 @@ def main():
     barrier()
     if stamps is not None:
         hr.lib().deodr_hip_profile_stamps(stamps.data_ptr(), args.steps + 1)
-    gc.collect()
-    gc.disable()  # (no collector pause inside the timed region: its 22 ms of launches allocate nothing that needs one)
+    # (no gc.collect() / gc.disable() here: tried at the end of round 5 -- the collection idles the GPU for some tens of milliseconds right before the
+    # timed region, the core clock falls back and the 200 steps read 0.1136 - 0.1144 ms instead of 0.1101 - 0.1102, profiles/r05z3_ab_bench_gc.txt)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     barrier()
     dt = time.perf_counter() - t0
-    gc.enable()
     ms_sum = (C.c_double * 4)()
     launches = (C.c_ulonglong * 4)()
     stamp_ms = None
@@ -588,6 +586,8 @@ def main():
         K = args.steps
         nxt = st[1 : K + 1, 0]
         ok = (st[:K, 0] > 0) & (st[:K, 1] > 0) & (st[:K, 2] > 0) & (nxt > 0)
+        if K > 1:
+            ok[K - 1] = False  # (the end of the last step is the set-up stamp of the extra step, launched behind the barrier: host time, not finalize's)
         if args.two_pass or not ok.any():
             stamp_ms = None  # (the two-call step runs set-up twice per step: the rows do not line up with steps; hipEvents below)
         else:
@@ -597,7 +597,9 @@ def main():
                         "step_ms_by_stamps": float(((nxt - st[:K, 0])[ok]).mean() * tick),
                         # (the GPU's own view of the region: a step the host was late for -- the queue starts EMPTY behind the barrier, a host pause
                         # longer than its lead shows as one long step -- moves the mean and the maximum, not the median)
-                        "step_ms_by_stamps_median": float(np.median((nxt - st[:K, 0])[ok]) * tick), "step_ms_by_stamps_max": float(((nxt - st[:K, 0])[ok]).max() * tick)}  # fmt: skip
+                        "step_ms_by_stamps_median": float(np.median((nxt - st[:K, 0])[ok]) * tick), "step_ms_by_stamps_max": float(((nxt - st[:K, 0])[ok]).max() * tick),
+                        # [step, ms] of the steps that took more than 1.25 x the median (at most 12 of them): where in the region the GPU waited for the host
+                        "late_steps": [[int(i), round(float((nxt - st[:K, 0])[i] * tick), 4)] for i in np.nonzero(ok & ((nxt - st[:K, 0]) > 1.25 * np.median((nxt - st[:K, 0])[ok])))[0][:12]]}  # fmt: skip
         # cross-check with hipEvents on a few more steps (outside the timed region: they perturb what they measure)
         hr.lib().deodr_hip_profile_enable(1)
         for _ in range(6):
@@ -733,6 +735,7 @@ def main():
                          "step_ms_by_stamps": None if stamp_ms is None else stamp_ms["step_ms_by_stamps"],
                          "step_ms_by_stamps_median": None if stamp_ms is None else stamp_ms["step_ms_by_stamps_median"],
                          "step_ms_by_stamps_max": None if stamp_ms is None else stamp_ms["step_ms_by_stamps_max"],
+                         "late_steps": None if stamp_ms is None else stamp_ms["late_steps"],
                          "whole_step": {"alg_bytes": whole, "GBps": whole / step_s / 1e9, "frac": whole / step_s / 1e9 / HBM_PEAK_GBS,
                                         "frac_of_measured": whole / step_s / 1e9 / peak_meas,
                                         "frac_of_guide_copy": whole / step_s / 1e9 / GUIDE_COPY_GBS, "moved_bytes": moved,
