@@ -196,10 +196,14 @@ unsigned g_stamp_calls = 0;
 bool g_force_generic = false; // deodr_hip_force_generic(1): run the un-staged kernels (the parity suite covers both families)
 bool g_det = false;			  // deodr_hip_set_deterministic(1): un-staged kernels + integer accumulation (KParams::det)
 
-// int64 shadows of the gradient arrays in the deterministic mode: ONE library-owned buffer per device, grown on demand (the only
-// allocation the library ever makes, and only in this mode: a test mode), zero between calls (det_convert_kernel clears what it reads)
+// int64 shadows of the gradient arrays in the deterministic mode: one library-owned buffer per (device, stream), grown on demand (the only
+// allocation the library ever makes, and only in this mode: a test mode), zero between calls (det_convert clears what it reads).  Per
+// STREAM: calls on one stream are ordered, so they may share the shadows; two fit steps on two streams (or threads) of one device each
+// get their own -- with one buffer per device their sums mixed.  Never freed (a handful of streams per process).
 struct DetScratch
 {
+	int dev = -1;
+	hipStream_t stream = nullptr;
 	long long *ptr = nullptr;
 	size_t words = 0;
 };
@@ -213,9 +217,15 @@ int det_shadows(KParams &p, int n_views, hipStream_t st)
 	if (check_hip(hipGetDevice(&dev), "hipGetDevice"))
 		return 1;
 	std::lock_guard<std::mutex> lock(g_det_mutex);
-	if ((size_t)dev >= g_det_scratch.size())
-		g_det_scratch.resize(dev + 1);
-	DetScratch &sc = g_det_scratch[dev];
+	size_t at = 0;
+	while (at < g_det_scratch.size() && !(g_det_scratch[at].dev == dev && g_det_scratch[at].stream == st))
+		at++;
+	if (at == g_det_scratch.size())
+	{
+		g_det_scratch.emplace_back();
+		g_det_scratch[at].dev = dev, g_det_scratch[at].stream = st;
+	}
+	DetScratch &sc = g_det_scratch[at];
 	if (sc.words < need)
 	{
 		hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
@@ -247,6 +257,8 @@ void det_convert(const KParams &p, int n_views, hipStream_t st)
 	auto run = [&](long long *shadow, void *out, size_t n, int f64) {
 		if (n && out)
 			hipLaunchKernelGGL(det_convert_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, shadow, out, n, f64);
+		else if (n && shadow) // (an array the caller did not ask for: whatever the kernels added to its shadow must not reach the next call)
+			(void)hipMemsetAsync(shadow, 0, 8 * n, st);
 	};
 	run(p.det_ij, p.ij_b, n_ij, p.vtx_f64);
 	run(p.det_colors, p.colors_b, n_col, p.vtx_f64);

@@ -315,7 +315,8 @@ int deodr_hip_force_generic(int on);
  * loss) are bit-identical from run to run.  Limits: |any gradient sum| < 2^31 (a contribution or a running sum beyond it raises the
  * sticky bit DEODR_HIP_ERR_DET_RANGE of the status block instead of wrapping silently), resolution 2^-32 (~2.3e-10) per contribution;
  * several times slower than the default path (it is a mode for tests and for debugging an optimiser, default off); the library
- * allocates an int64 shadow of the gradient arrays the first time (hipMalloc: not under stream capture).  Process-wide, like
+ * allocates an int64 shadow of the gradient arrays the first time a (device, stream) pair is used in this mode (hipMalloc: not under
+ * stream capture; calls on different streams or host threads never share a shadow).  The switch itself is process-wide, like
  * deodr_hip_force_generic. */
 int deodr_hip_set_deterministic(int on);
 

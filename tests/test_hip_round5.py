@@ -236,3 +236,41 @@ def test_textured_fit_step_launches_no_edge_tile_kernel(oracle_api):
         assert launches[2] >= 1, list(launches)  # (the two-call path: the edge-tile kernel)
     finally:
         hr.lib().deodr_hip_profile_enable(0)
+
+
+def test_deterministic_steps_on_two_streams_do_not_share_their_shadows(oracle_api):
+    """the int64 shadows of the deterministic mode were one buffer per device -- two fit steps in flight on two streams added into,
+    converted and cleared the same words.  One per (device, stream) now: two different scenes stepped concurrently on two streams give, bit for bit,
+    what each gives alone."""
+    from hip_util import device_scene
+    from deodr_amd import hip_renderer as hr
+    from test_oracle import random_scene
+
+    hr.set_deterministic(True)
+    try:
+        jobs = []
+        for seed in (4200, 4201):
+            s = random_scene(seed)
+            s.backface_culling = True
+            ds = device_scene(s, F64)
+            r = hr.HipRasterizer.for_scene(ds)
+            obs = torch.as_tensor(np.random.RandomState(seed).rand(1, s.height, s.width, s.nb_colors), device=ds.device)
+            r.render_fit(ds, obs, 1.0, check_overflow=True, clear_grads=True)  # (pools sized, shadows of the default stream allocated)
+            alone = {k: v.clone() for k, v in r.render_fit(ds, obs, 1.0, check_overflow=False, clear_grads=True)[2].items() if v is not None}
+            jobs.append((ds, r, obs, alone, torch.cuda.Stream()))
+        torch.cuda.synchronize()
+        for ds, r, obs, _alone, st in jobs:  # (first use of each stream: its shadows are allocated, which synchronises)
+            with torch.cuda.stream(st):
+                r.render_fit(ds, obs, 1.0, check_overflow=False, clear_grads=True)
+        torch.cuda.synchronize()
+        for _rep in range(20):
+            got = []
+            for ds, r, obs, _alone, st in jobs:
+                with torch.cuda.stream(st):
+                    got.append(r.render_fit(ds, obs, 1.0, check_overflow=False, clear_grads=True)[2])
+            torch.cuda.synchronize()
+            for (_ds, _r, _obs, alone, _st), g in zip(jobs, got):
+                for k, v in alone.items():
+                    assert torch.equal(g[k], v), k
+    finally:
+        hr.set_deterministic(False)
