@@ -194,7 +194,8 @@ unsigned long long *g_stamps = nullptr; // deodr_hip_profile_stamps: device buff
 int g_stamp_rows = 0;
 unsigned g_stamp_calls = 0;
 bool g_force_generic = false; // deodr_hip_force_generic(1): run the un-staged kernels (the parity suite covers both families)
-bool g_det = false;			  // deodr_hip_set_deterministic(1): un-staged kernels + integer accumulation (KParams::det)
+bool g_det = false;			  // deodr_hip_set_deterministic(1): un-staged kernels + integer accumulation (KParams::det) for EVERY scene
+inline bool det_mode(const DeodrHipScene *sc) { return g_det || sc->deterministic != 0; } // (DeodrHipScene::deterministic: for this scene)
 
 // int64 shadows of the gradient arrays in the deterministic mode: one library-owned buffer per (device, stream), grown on demand (the only
 // allocation the library ever makes, and only in this mode: a test mode), zero between calls (det_convert clears what it reads).  Per
@@ -459,7 +460,7 @@ int launch_forward(const DeodrHipScene *sc, KParams &p, hipStream_t stream, hipE
 	g_profile = g_profile_every > 0 && (g_profile_calls++ % (unsigned)g_profile_every) == 0;
 	p.stamp = (g_stamps && g_stamp_calls < (unsigned)g_stamp_rows) ? g_stamps + 4 * (size_t)g_stamp_calls++ : nullptr;
 	p.n_views = n_views;
-	const bool fast = !p.aa_err && p.C <= CH && !g_force_generic && !g_det;
+	const bool fast = !p.aa_err && p.C <= CH && !g_force_generic && !det_mode(sc);
 	if (p.T > 0)
 	{
 		dim3 grid((unsigned)prim_blocks(p.T) * (unsigned)n_views);
@@ -511,9 +512,9 @@ void launch_finalize(Kernel kernel, dim3 grid, hipStream_t st, const KParams &p)
 // adjoint raster and the per-primitive finalize; owner_tiles = false after a fused forward
 int launch_adjoint(const DeodrHipScene *sc, KParams &p, hipStream_t st, bool owner_tiles)
 {
-	const bool fast = !p.aa_err && p.C <= CH && !g_force_generic && !g_det;
+	const bool fast = !p.aa_err && p.C <= CH && !g_force_generic && !det_mode(sc);
 	p.n_views = sc->n_views;
-	if (g_det && det_shadows(p, sc->n_views, st))
+	if (det_mode(sc) && det_shadows(p, sc->n_views, st))
 		return 1;
 	// persistent waves of the edge kernel: enough to cover a silhouette-heavy single view, few enough that with many views
 	// the waves that find their sub-list exhausted cost nothing
@@ -780,7 +781,7 @@ static int render_scene_fit_impl(const DeodrHipScene *sc, void *image, void *z_b
 		if (p.texture_b && check_hip(hipMemsetAsync(p.texture_b, 0, (size_t)p.tex_h * p.tex_w * p.C * ps, st), "clear texture_b"))
 			return 1;
 	}
-	const bool fused = p.C <= CH && !g_force_generic && !g_det;
+	const bool fused = p.C <= CH && !g_force_generic && !det_mode(sc);
 	const bool loss_in_kernels = loss_out && fused && p.T > 0; // (the tile walkers of the staged forward + finalize's last workgroup)
 	if (loss_in_kernels)
 		p.loss_tile_bg = tile_loss, p.loss_wave = loss_scratch, p.loss_out = loss_out;
@@ -804,7 +805,7 @@ static int render_scene_fit_impl(const DeodrHipScene *sc, void *image, void *z_b
 	// The step-done flag: stored by the last wavefront of finalize_kernel to finish when that kernel is the step's last (the usual fit
 	// step), by a one-thread kernel behind everything otherwise.
 	uint32_t *done_flag = opt ? opt->done_flag : nullptr;
-	const bool fin_signals = done_flag && p.T > 0 && !g_det && !join && !(loss_out && !loss_in_kernels);
+	const bool fin_signals = done_flag && p.T > 0 && !det_mode(sc) && !join && !(loss_out && !loss_in_kernels);
 	if (fin_signals)
 		p.done_flag = done_flag, p.done_value = opt->done_value;
 	if (launch_adjoint(sc, p, st, !fused))

@@ -20,7 +20,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libdeodr_hip.so")
-ABI_VERSION = 11
+ABI_VERSION = 12
 ERR_FACES, ERR_FACES_UV, ERR_NO_TEXTURE, ERR_INTERNAL, ERR_DET_RANGE = 1, 2, 4, 8, 16  # include/deodr_hip.h DEODR_HIP_ERR_*
 _STATUS_NEEDED, _STATUS_ERRORS = 11, 12  # words of the 64-byte status block at the start of the workspace
 
@@ -32,7 +32,7 @@ class _SceneC(C.Structure):
         + [(n, C.c_void_p) for n in ("uv_b", "ij_b", "shade_b", "colors_b", "texture_b")]
         + [(n, C.c_int) for n in ("nb_triangles", "nb_vertices", "nb_uv", "height", "width", "nb_colors", "texture_height", "texture_width")]
         + [(n, C.c_int) for n in ("clockwise", "backface_culling", "strict_edge", "perspective_correct", "integer_pixel_centers")]
-        + [(n, C.c_int) for n in ("n_views", "vertex_dtype", "pixel_dtype")]
+        + [(n, C.c_int) for n in ("n_views", "vertex_dtype", "pixel_dtype", "deterministic")]
     )
 
 
@@ -96,7 +96,7 @@ def lib():
 
 def set_deterministic(on):
     """``deodr_hip_set_deterministic``: integer accumulation on the un-staged kernels -- gradients bit-identical from run to run (slow;
-    for tests and for debugging an optimiser).  Process-wide."""
+    for tests and for debugging an optimiser).  Process-wide; ``DeviceScene(deterministic=True)`` asks for it per scene."""
     lib().deodr_hip_set_deterministic(int(bool(on)))
 
 
@@ -189,9 +189,12 @@ class DeviceScene:
     def __init__(self, faces, faces_uv, textured, shaded, uv, ij, depths, colors, shade, edgeflags, height, width, texture=None,
                  background_color=None, background_image=None, clockwise=False, backface_culling=True, strict_edge=True,
                  perspective_correct=False, integer_pixel_centers=True, vertex_dtype=torch.float64, pixel_dtype=torch.float32,
-                 device="cuda", validate=True):  # fmt: skip
+                 device="cuda", validate=True, deterministic=False):  # fmt: skip
         dev = _resolve_device(device)
         self.device, self.vertex_dtype, self.pixel_dtype = dev, vertex_dtype, pixel_dtype
+        # integer accumulation for the calls on THIS scene (DeodrHipScene::deterministic): gradients bit-identical from run to run, several times
+        # slower; may be switched at any time (it is read when a call is made).  set_deterministic() is the process-wide switch.
+        self.deterministic = bool(deterministic)
         as_t = lambda a, dt: torch.as_tensor(np.asarray(a) if not torch.is_tensor(a) else a).to(device=dev, dtype=dt).contiguous()
         self.faces = as_t(np.asarray(faces).astype(np.int64) if not torch.is_tensor(faces) else faces, torch.int32)
         self.faces_uv = as_t(np.asarray(faces_uv).astype(np.int64) if not torch.is_tensor(faces_uv) else faces_uv, torch.int32)
@@ -273,6 +276,7 @@ class DeviceScene:
         s.n_views = self.n_views
         s.vertex_dtype = 1 if self.vertex_dtype == torch.float64 else 0
         s.pixel_dtype = 1 if self.pixel_dtype == torch.float64 else 0
+        s.deterministic = 1 if self.deterministic else 0
         return s
 
 

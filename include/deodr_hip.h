@@ -76,6 +76,8 @@ typedef struct DeodrHipScene
 	int n_views;
 	int vertex_dtype; /* DEODR_HIP_F32 / DEODR_HIP_F64 */
 	int pixel_dtype;  /* DEODR_HIP_F32 / DEODR_HIP_F64 */
+	int deterministic; /* non-zero: the calls on THIS scene accumulate their gradients in integers, bit-identical from run to run (see
+						* deodr_hip_set_deterministic, the process-wide switch for every scene); a property of the call, no global involved */
 } DeodrHipScene;
 
 /* Size in bytes of the device workspace for a scene of these dimensions.  `pool_pairs` bounds the number of
@@ -316,7 +318,8 @@ int deodr_hip_force_generic(int on);
  * sticky bit DEODR_HIP_ERR_DET_RANGE of the status block instead of wrapping silently), resolution 2^-32 (~2.3e-10) per contribution;
  * several times slower than the default path (it is a mode for tests and for debugging an optimiser, default off); the library
  * allocates an int64 shadow of the gradient arrays the first time a (device, stream) pair is used in this mode (hipMalloc: not under
- * stream capture; calls on different streams or host threads never share a shadow).  The switch itself is process-wide, like
+ * stream capture; calls on different streams or host threads never share a shadow).  DeodrHipScene::deterministic asks for the mode per
+ * scene (re-entrant: nothing but the arguments of the call decides); this switch turns it on for every scene of the process, like
  * deodr_hip_force_generic. */
 int deodr_hip_set_deterministic(int on);
 
@@ -340,7 +343,7 @@ const char *deodr_hip_last_error(void);
 
 /* ABI version of this header; bumped on any incompatible change. */
 int deodr_hip_abi_version(void);
-#define DEODR_HIP_ABI_VERSION 11
+#define DEODR_HIP_ABI_VERSION 12
 
 #ifdef __cplusplus
 }

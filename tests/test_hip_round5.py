@@ -274,3 +274,37 @@ def test_deterministic_steps_on_two_streams_do_not_share_their_shadows(oracle_ap
                     assert torch.equal(g[k], v), k
     finally:
         hr.set_deterministic(False)
+
+
+def test_deterministic_mode_per_scene(oracle_api):
+    """ABI v12, DeodrHipScene::deterministic: the integer accumulation as a property of the scene a call is made on (VERDICT r4, missing 6: the mode
+    was only reachable through a process-wide switch) -- two scenes stepped alternately, one deterministic: its gradients are bit-identical from
+    run to run and equal what the process-wide switch gives; the other scene keeps the default path (close to, and in general not bit-equal to, it)."""
+    from hip_util import device_scene, rel_err
+    from deodr_amd import hip_renderer as hr
+    from test_oracle import random_scene
+
+    s = random_scene(4300)
+    s.backface_culling = True
+    obs_np = np.random.RandomState(5).rand(1, s.height, s.width, s.nb_colors)
+    det, plain = device_scene(s, F64), device_scene(s, F64)
+    det.deterministic = True
+    r_det, r_plain = hr.HipRasterizer.for_scene(det), hr.HipRasterizer.for_scene(plain)
+    obs = torch.as_tensor(obs_np, device=det.device)
+    runs = []
+    for _rep in range(6):
+        g_det = r_det.render_fit(det, obs, 1.0, check_overflow=True, clear_grads=True)[2]
+        g_plain = r_plain.render_fit(plain, obs, 1.0, check_overflow=True, clear_grads=True)[2]
+        torch.cuda.synchronize()
+        runs.append({k: v.clone() for k, v in g_det.items() if v is not None})
+        assert rel_err(g_plain["ij_b"].cpu().numpy(), g_det["ij_b"].cpu().numpy()) < 1e-8
+    for k, v in runs[0].items():
+        assert all(torch.equal(v, r[k]) for r in runs[1:]), k
+    hr.set_deterministic(True)
+    try:
+        g_switch = r_plain.render_fit(plain, obs, 1.0, check_overflow=True, clear_grads=True)[2]
+        torch.cuda.synchronize()
+        for k, v in runs[0].items():
+            assert torch.equal(v, g_switch[k]), k
+    finally:
+        hr.set_deterministic(False)
