@@ -18,10 +18,14 @@
 #   fininfwd   -DDR_FIN_IN_FWD=1 finalize UNDER the forward raster (round 4: parity-green, not faster): the per-primitive adjoint algebra as
 #                               workgroups of raster_fwd_fast_kernel gated block by block by device-side counters -- tools/variants/finalize_in_forward.patch
 #                               (700 lines: set-up files primitives under screen blocks, the scan kernel builds work items, the walkers signal)  [its own patch]
+#                               (an archived experiment: the patch fits the sources of commit 8628d5e, end of round 4 -- `git worktree add /tmp/r4 8628d5e` and
+#                               run that tree's build_variants.sh; round 5 rewrote the places it touches)
 #   classtrace                   {start, end} of every workgroup of the forward raster by class (fill / head walker / other walker), plain stores into a device
 #                               table read by tools/wave_phase_probe.py -- tools/variants/forward_class_timeline.patch (round 5)                     [its own patch]
 #   wavetrace  -DDR_WAVE_TRACE  start / end of every wave                       (tools/wave_trace.py)
 #   fwdN       -DDR_FWD_WAVES=N the staged forward compiled for N waves / SIMD  (tools/step_time.py --lib)
+#   (tools/variants/lean_many_walkers.patch, one_batch_body.patch: round 5's two walker experiments as `git diff`s against commit 824e91e^ -- apply from the
+#    repository root with `patch -p1`; measured and not adopted, profiles/r05y_ab_*.txt)
 #   <name>     EXTRA="-D..."    anything else: the product sources with the flags of $EXTRA
 ROOT="$(cd "$(dirname "$0")/.." && pwd)"
 OUT=$ROOT/tools/variants
