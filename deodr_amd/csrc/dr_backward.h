@@ -480,9 +480,9 @@ __device__ __forceinline__ void owner_adjoint_slots(const KParams &p, const View
 // edges of batch b drawn over this lane's pixel, cur = the pixel's colour after batch b_hi, g = dL/d(that colour); on exit g is the
 // gradient that reaches the colour before batch b_lo, cur that colour.  top_staged: the records of batch b_hi are still in S.
 // pixel_base(base) fills the un-antialiased colour of the pixel when a replay needs it (have_base says whether it already did).
-template <class PixT, bool TEX, class Lds, class BaseFn>
+template <class PixT, bool TEX, int NBATCH, class Lds, class BaseFn>
 __device__ __forceinline__ void edge_reverse_sweep(const KParams &p, const ViewPtrs &w, Lds &S, const EdgeSort *es, int lane, double x, double y, int n_edges,
-												   int b_hi, int b_lo, bool top_staged, const uint32_t (&tm)[EMAX / TB], double (&cur)[CH], double (&g)[CH],
+												   int b_hi, int b_lo, bool top_staged, const uint32_t (&tm)[NBATCH], double (&cur)[CH], double (&g)[CH],
 												   double (&base)[CH], bool &have_base, BaseFn pixel_base, int r_lo, int r_hi)
 { // r_lo .. r_hi: the edges of each batch that are swept (a split tile of the fused forward: one part of one batch; everybody else: all)
 	const int C = p.C, P = p.L.P;
@@ -504,7 +504,7 @@ __device__ __forceinline__ void edge_reverse_sweep(const KParams &p, const ViewP
 		}
 		uint32_t tmb = 0;
 #pragma unroll
-		for (int bb = 0; bb < EMAX / TB; bb++)
+		for (int bb = 0; bb < NBATCH; bb++)
 			tmb = bb == b ? tm[bb] : tmb;
 		for (int r = (nb - 1 < r_hi ? nb - 1 : r_hi); r >= r_lo; r--)
 		{
@@ -551,7 +551,7 @@ __device__ __forceinline__ void edge_reverse_sweep(const KParams &p, const ViewP
 				{
 					uint32_t tq = 0;
 #pragma unroll
-					for (int bb = 0; bb < EMAX / TB; bb++)
+					for (int bb = 0; bb < NBATCH; bb++)
 						tq = bb == (q / TB) ? tm[bb] : tq;
 					if (!need_replay || !((tq >> (q % TB)) & 1u))
 						continue;

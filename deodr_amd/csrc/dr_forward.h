@@ -316,9 +316,9 @@ __device__ __forceinline__ void owner_adjoint_slots(const KParams &p, const View
 													const float (&g)[NPIX][CH], uint32_t id_of_slot, int nslots, float *tab);
 
 // (dr_backward.h) adjoint of pass 2 for batches b_hi .. b_lo of a tile's blending order; (dr_backward_generic.h) the un-staged adjoint
-template <class PixT, bool TEX, class Lds, class BaseFn>
+template <class PixT, bool TEX, int NBATCH, class Lds, class BaseFn> // (NBATCH: batches of TB edges the caller's masks cover)
 __device__ __forceinline__ void edge_reverse_sweep(const KParams &p, const ViewPtrs &w, Lds &S, const EdgeSort *es, int lane, double x, double y, int n_edges,
-												   int b_hi, int b_lo, bool top_staged, const uint32_t (&tm)[EMAX / TB], double (&cur)[CH], double (&g)[CH],
+												   int b_hi, int b_lo, bool top_staged, const uint32_t (&tm)[NBATCH], double (&cur)[CH], double (&g)[CH],
 												   double (&base)[CH], bool &have_base, BaseFn pixel_base, int r_lo = 0, int r_hi = TB - 1);
 template <class PixT, bool LEAN, bool TEX>
 __device__ __forceinline__ void bwd_tile_generic_impl(const KParams &p, int view, int tx, int ty, int lane, volatile uint32_t *order);
@@ -1064,6 +1064,9 @@ __device__ __forceinline__ void fwd_pair_tiles(const KParams &p, const ViewPtrs 
 // loop: the edge adjoint needs ~40 registers more than the rest, and as a branch of the common loop (or as a function called from
 // it) it cost EVERY tile spills on its path (forward 83 -> 90 us before the first edge tile was fused); as a disjoint path its
 // spills stay with the one workgroup in sixteen that walks the head.
+#ifndef DR_ONE_BATCH_BODY
+#define DR_ONE_BATCH_BODY 1 // (measurement builds: 0 = one body for every head tile, as until the end of round 5)
+#endif
 enum FwdMode
 {
 	FWD_PLAIN = 0,	  // forward only (or adjoint left to the two-call path): pass 2 saves its sweep for raster_bwd_edge_kernel
@@ -1143,9 +1146,20 @@ __device__ __forceinline__ void fwd_tiles(const KParams &p, WaveLds *s_lds, Edge
 			lds_sync();
 			continue;
 		}
+		// The rest of the body twice in the FWD_EDGE_ADJ instance: for the tiles of at most ONE batch of TB edges (one_batch: most of the head)
+		// without the state of a tile of several -- eight masks instead of one, the colour and transparency a split part starts from, the
+		// un-staged fallback -- that every head tile used to carry (and spill) through its pass 2 and reverse sweep.  It pays in the TEXTURED
+		// instance (250 spilled registers at 168 -> 197): configs[4], 8 views 0.874 - 0.877 -> 0.833 - 0.835 ms, 4 views 0.451 -> 0.433, 2 views
+		// 0.242 -> 0.235, one view level; the untextured instance is level (forward 68.2 / 68.5 against 68.8 / 68.6 us, 69.9 / 68.2 against
+		// 70.0 / 67.1).  Both as a generic lambda called twice -- code generation is touchy here: the same body as text included three times left the
+		// textured instance where it was (382 spilled registers, 0.870 - 0.880 ms), and the lambda with ONE call in the untextured instance cost
+		// it 15 spilled registers and 11 us (profiles/r05y_ab_one_batch_body.txt, r05z4_ab_one_batch_body_textured.txt).
+		auto tile_body = [&](auto one_batch_tag) __attribute__((always_inline)) {
+		constexpr bool one_batch = decltype(one_batch_tag)::value;
+		constexpr int NBATCH = one_batch ? 1 : EMAX / TB;
 		const uint32_t nedge_word = MODE == FWD_NO_EDGES ? 0u : e_nedge;
 		// (FWD_EDGE_ADJ: a tile of several batches of edges is listed once per batch, see tile_scan_kernel)
-		bool split = MODE == FWD_EDGE_ADJ && (nedge_word & SPLIT_FLAG);
+		bool split = MODE == FWD_EDGE_ADJ && !one_batch && (nedge_word & SPLIT_FLAG);
 		const int part = split ? (int)((nedge_word >> 16) & 0xffu) : 0;
 		const int tile = (int)e_tile, ntri = (int)e_ntri, nedge = (int)(split ? (nedge_word & 0xffffu) : nedge_word);
 		const uint32_t sweep_slot = (uint32_t)uniform((int)cur.w);
@@ -1258,16 +1272,15 @@ __device__ __forceinline__ void fwd_tiles(const KParams &p, WaveLds *s_lds, Edge
 		}
 		// ---- pass 2: edges far -> near, TB at a time (H.h:2839-2900)
 		int n_edges = 0;
-		uint32_t tm[EMAX / TB] = {0, 0, 0, 0, 0, 0, 0, 0}; // (fused adjoint) bit j of tm[b]: edge 16 b + j of the blending order is drawn over this pixel
+		uint32_t tm[NBATCH] = {}; // (fused adjoint) bit j of tm[b]: edge 16 b + j of the blending order is drawn over this pixel
 		if (nedge > 0)
 			n_edges = gather_sorted_edges(s_es[wave], w, p, tile, nedge, lane);
+		if (one_batch) // (at most TB <= K_EDGE edges: all of them in the tile's inline list)
+			n_edges = n_edges < 0 ? 0 : n_edges > TB ? TB : n_edges;
 		if (split && n_edges < 0)
 		{ // (pairs of this tile lost to a pool overflow -- the call is repeated anyway: the first copy alone takes the un-staged path)
 			if (part > 0)
-			{
-				lds_sync();
-				continue;
-			}
+				return;
 			split = false;
 		}
 		const int SPLIT_PART = p.split_part;
@@ -1338,7 +1351,7 @@ __device__ __forceinline__ void fwd_tiles(const KParams &p, WaveLds *s_lds, Edge
 				if (fuse_edges)
 				{
 #pragma unroll
-					for (int bb = 0; bb < EMAX / TB; bb++)
+					for (int bb = 0; bb < NBATCH; bb++)
 						tm[bb] = bb == first / TB ? drawn_batch : tm[bb];
 				}
 				if (sweep_slot) // bit j: edge first + j of the blending order is drawn over this pixel
@@ -1360,7 +1373,7 @@ __device__ __forceinline__ void fwd_tiles(const KParams &p, WaveLds *s_lds, Edge
 					slot[cc * 64 + lane] = col[cc];
 			}
 		}
-		else if (n_edges < 0)
+		else if (!one_batch && n_edges < 0)
 		{ // more than EMAX edges in one tile: ordered search through list + pool, records straight from memory
 			uint32_t edge_spill_n = w.hdr->edge_spill[w.hdr->cur];
 			if (edge_spill_n > p.L.edge_pool_cap)
@@ -1484,7 +1497,7 @@ __device__ __forceinline__ void fwd_tiles(const KParams &p, WaveLds *s_lds, Edge
 					owner_adjoint<PixT, TEX>(p, w, lane, x, y, st.kbest, st.kbest >= 0 ? st.kind : (int)KIND_NONE, g, tap, L, (double *)&S.rec[0],
 											(uint32_t *)&S.cover[0][0]);
 			}
-			else if (n_edges < 0)
+			else if (!one_batch && n_edges < 0)
 			{ // more than EMAX edges in one tile: the un-staged adjoint reads the frame and the owner ids this wavefront has just written
 				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
 				__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
@@ -1512,6 +1525,11 @@ __device__ __forceinline__ void fwd_tiles(const KParams &p, WaveLds *s_lds, Edge
 		}
 		}
 		}
+		};
+		if (MODE == FWD_EDGE_ADJ && DR_ONE_BATCH_BODY && !(e_nedge & SPLIT_FLAG) && e_nedge <= (uint32_t)TB)
+			tile_body(std::true_type{});
+		else
+			tile_body(std::false_type{});
 		lds_sync(); // the next tile of this wavefront reuses the staging area
 	}
 	if (q == 0 && threadIdx.x == 0)

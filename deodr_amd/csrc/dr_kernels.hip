@@ -48,6 +48,7 @@
 #include <string.h>
 
 #include <mutex>
+#include <type_traits>
 #include <unordered_set>
 #include <utility>
 #include <vector>
