@@ -24,8 +24,9 @@
 #                               table read by tools/wave_phase_probe.py -- tools/variants/forward_class_timeline.patch (round 5)                     [its own patch]
 #   wavetrace  -DDR_WAVE_TRACE  start / end of every wave                       (tools/wave_trace.py)
 #   fwdN       -DDR_FWD_WAVES=N the staged forward compiled for N waves / SIMD  (tools/step_time.py --lib)
-#   (tools/variants/lean_many_walkers.patch, one_batch_body.patch: round 5's two walker experiments as `git diff`s against commit 824e91e^ -- apply from the
-#    repository root with `patch -p1`; measured and not adopted, profiles/r05y_ab_*.txt)
+#   (tools/variants/lean_many_walkers.patch: a round-5 walker experiment as a `git diff` against the sources of commit 824e91e -- apply from the root of a
+#    checkout of that commit with `patch -p1`; measured and not adopted, profiles/r05y_ab_lean_and_many_edge_walkers.txt.  Its sibling, the tile body
+#    compiled twice, is in the product since commit 3de053c: -DDR_ONE_BATCH_BODY=0 builds the neighbour)
 #   <name>     EXTRA="-D..."    anything else: the product sources with the flags of $EXTRA
 ROOT="$(cd "$(dirname "$0")/.." && pwd)"
 OUT=$ROOT/tools/variants
