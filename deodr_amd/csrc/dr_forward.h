@@ -839,8 +839,11 @@ __host__ __device__ inline int fwd_tile_blocks(int ntiles, int n_views, bool dea
 // texture taps; at four waves it spills 414 registers.  configs[4], 1 / 8 views: four waves 0.176 / 0.886 - 0.930 ms, three 0.168 / 0.868 -
 // 0.893, two 0.167 / 1.02; the instances WITHOUT the edge adjoint lose 6 - 9 % at three: profiles/r05y_ab_fused_textured_edge_tiles.txt)
 // (tools/build_variants.sh builds the neighbours: -DDR_FWD_WAVES=n forces n for all).
+#ifndef DR_TEXE_HEAD_WAVES
+#define DR_TEXE_HEAD_WAVES 3 // waves per SIMD of the kernel of the head walkers alone (TEXE = 2)
+#endif
 #ifndef DR_FWD_WAVES
-#define DR_FWD_WAVES (TEX ? (TEXE ? 3 : 4) : 5)
+#define DR_FWD_WAVES (TEX ? (TEXE == 1 ? 3 : (TEXE == 2 ? DR_TEXE_HEAD_WAVES : 4)) : 5)
 #endif
 // Two horizontally adjacent tiles in one wavefront, two pixels per lane (lane = row * 8 + column: pixel `column` of the left tile A
 // and pixel `column` of the right tile B).  For the pairs the scan kernel forms -- both tiles non-empty, no silhouette edge, at
@@ -1539,6 +1542,15 @@ __device__ __forceinline__ void fwd_tiles(const KParams &p, WaveLds *s_lds, Edge
 #ifndef DR_FUSE_TEX_EDGES
 #define DR_FUSE_TEX_EDGES 1 // (measurement builds: 0 = the tiles with silhouette edges of a TEXTURED fit step wait for raster_bwd_edge_kernel, as until round 4)
 #endif
+// The forward raster of a textured fit step of DR_TEX_TWO_KERNELS views or more as TWO kernels on two streams -- the head walkers (edge adjoint: 168
+// registers, three waves per SIMD) on the library's side stream, everybody else (128 registers, four waves again) on the caller's, both behind the scan
+// kernel, joined in front of finalize.  As one kernel the 95 % of the tiles that hold no edge run at the occupancy the edge adjoint dictates.
+// configs[4]: 8 views 0.839 - 0.841 -> 0.800 - 0.810 ms; 4 views level (0.436 / 0.434); 2 views 0.235 -> 0.275, one view 0.166 -> 0.21 (the fork and the
+// join cost more than the occupancy returns), hence the threshold; head walkers at two waves: worse everywhere (profiles/r05z6_ab_two_kernels.txt).
+// 0: never.  Not while the stream is being captured (the single kernel then).
+#ifndef DR_TEX_TWO_KERNELS
+#define DR_TEX_TWO_KERNELS 8
+#endif
 #ifndef DR_FUSE_EDGES
 #define DR_FUSE_EDGES 1 // (measurement builds: 0 = the tiles with silhouette edges of a fit step wait for raster_bwd_edge_kernel, as in round 2)
 #endif
@@ -1547,8 +1559,9 @@ __device__ __forceinline__ void fwd_tiles(const KParams &p, WaveLds *s_lds, Edge
 // the 8-view benchmark step (C = 4) 0.160 -> 0.150 ms.  The host picks the instance (3 and 4 channels, the fit step's kernels).
 // COMMON: strict_edge = true and a frame whose sides are multiples of the tile (every pixel of every tile is inside it), the usual
 // case, at compile time as well: 0.144 -> 0.141 ms.
-// TEXE: (FUSED && TEX) the instance for KParams::fuse_edges -- its head walkers run the adjoint of the tiles with silhouette edges too.
-template <class PixT, bool FUSED, bool TEX, bool CLAMP = false, int NC = 0, bool COMMON = false, bool TEXE = false>
+// TEXE: (FUSED && TEX) 1: the instance for KParams::fuse_edges -- its head walkers run the adjoint of the tiles with silhouette edges too;
+// 2 / 3: the same grid as TWO kernels for two streams, the head walkers (2) and everybody else (3: four waves per SIMD again) -- KParams::block_base.
+template <class PixT, bool FUSED, bool TEX, bool CLAMP = false, int NC = 0, bool COMMON = false, int TEXE = 0>
 __global__ __launch_bounds__(64, DR_FWD_WAVES) void raster_fwd_fast_kernel(KParams p)
 {
 	p.aligned = COMMON ? 1 : 0;
@@ -1576,7 +1589,7 @@ __global__ __launch_bounds__(64, DR_FWD_WAVES) void raster_fwd_fast_kernel(KPara
 #define DR_FILL_DEAL 1 // (measurement builds: 0 = the fill workgroups behind the walkers, as in round 3)
 #endif
 	const uint32_t dealt = (DR_FILL_DEAL && FUSED && !TEX && p.fuse_edges && n_walk >= 8 * n_fill) ? n_fill / 8 : 0; // groups of 64 walkers + 8 fill workgroups
-	uint32_t b = blockIdx.x; // (32-bit throughout: see fwd_tiles)
+	uint32_t b = blockIdx.x + p.block_base; // (32-bit throughout: see fwd_tiles)
 	int fi = -1;
 	if (b < dealt * 72)
 	{
@@ -1598,7 +1611,11 @@ __global__ __launch_bounds__(64, DR_FWD_WAVES) void raster_fwd_fast_kernel(KPara
 			fill_share_word(p, 2, (int)((uint32_t)fi % (uint32_t)p.n_views), (int)((uint32_t)fi / (uint32_t)p.n_views), threadIdx.x & 63);
 		return;
 	}
-	if (FUSED && DR_FUSE_EDGES && (!TEX || TEXE))
+	if constexpr (TEXE == 2)
+		fwd_tiles<PixT, FUSED, TEX, FWD_EDGE_ADJ, CLAMP>(p, s_lds, s_es, b); // (this launch: the head walkers, nobody else)
+	else if constexpr (TEXE == 3)
+		fwd_tiles<PixT, FUSED, TEX, FWD_NO_EDGES, CLAMP>(p, s_lds, s_es, b); // (this launch: everybody else)
+	else if (FUSED && DR_FUSE_EDGES && (!TEX || TEXE))
 	{ // (p.fuse_edges is set: the host and the scan kernel follow the same rule -- fit step of an untextured scene)
 		const int G = p.tile_blocks;
 		const bool chunked = G % (8 * WORK_CHUNK) == 0;

@@ -410,12 +410,39 @@ int launch_forward_staged(const KParams &p, bool fused, hipStream_t stream, hipE
 	const dim3 grid((unsigned)p.n_views * (unsigned)q.tile_blocks + (unsigned)p.n_views * (unsigned)fill_share(p.fill_mode, 2, p.L.nwords));
 	const bool tex = p.texture != nullptr; // (see launch_adjoint_raster)
 	const bool common = p.strict && p.W % TILE == 0 && p.H % TILE == 0;
+	hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
+	if (DR_TEX_TWO_KERNELS && fused && tex && p.fuse_edges)
+		(void)hipStreamIsCapturing(stream, &capturing);
+	if (DR_TEX_TWO_KERNELS && fused && tex && p.fuse_edges && !p.clamp && p.n_views >= DR_TEX_TWO_KERNELS && q.tile_blocks % (8 * WORK_CHUNK) == 0 &&
+		capturing == hipStreamCaptureStatusNone)
+	{ // the head walkers (edge adjoint: many registers) on the side stream, everybody else (+ the fill workgroups) on the caller's, both behind the scan
+		const unsigned head = (unsigned)p.n_views * (unsigned)(q.tile_blocks / q.heavy_share);
+		std::lock_guard<std::mutex> lock(g_side_mutex);
+		SideStream ss;
+		if (side_stream(ss) || check_hip(hipEventRecord(ss.fork, stream), "fork") || check_hip(hipStreamWaitEvent(ss.stream, ss.fork, 0), "fork"))
+			return 1;
+		KParams rest = q;
+		rest.block_base = head;
+		if (p.C == 3)
+		{
+			hipLaunchKernelGGL((raster_fwd_fast_kernel<PixT, true, true, false, 3, false, 2>), dim3(head), dim3(64), 0, ss.stream, q);
+			hipLaunchKernelGGL((raster_fwd_fast_kernel<PixT, true, true, false, 3, false, 3>), dim3(grid.x - head), dim3(64), 0, stream, rest);
+		}
+		else
+		{
+			hipLaunchKernelGGL((raster_fwd_fast_kernel<PixT, true, true, false, 0, false, 2>), dim3(head), dim3(64), 0, ss.stream, q);
+			hipLaunchKernelGGL((raster_fwd_fast_kernel<PixT, true, true, false, 0, false, 3>), dim3(grid.x - head), dim3(64), 0, stream, rest);
+		}
+		if (check_hip(hipEventRecord(ss.join, ss.stream), "join") || check_hip(hipStreamWaitEvent(stream, ss.join, 0), "join"))
+			return 1;
+		return 0;
+	}
 	if (fused && p.clamp && tex && p.fuse_edges) // (the clamped residual of the depth fitter: its own instances of the fused kernel)
-		hipLaunchKernelGGL((raster_fwd_fast_kernel<PixT, true, true, true, 0, false, true>), grid, dim3(64), 0, stream, q);
+		hipLaunchKernelGGL((raster_fwd_fast_kernel<PixT, true, true, true, 0, false, 1>), grid, dim3(64), 0, stream, q);
 	else if (fused && tex && p.fuse_edges && p.C == 3) // (textured fit step, sigma > 0: the instances with the edge adjoint)
-		hipLaunchKernelGGL((raster_fwd_fast_kernel<PixT, true, true, false, 3, false, true>), grid, dim3(64), 0, stream, q);
+		hipLaunchKernelGGL((raster_fwd_fast_kernel<PixT, true, true, false, 3, false, 1>), grid, dim3(64), 0, stream, q);
 	else if (fused && tex && p.fuse_edges)
-		hipLaunchKernelGGL((raster_fwd_fast_kernel<PixT, true, true, false, 0, false, true>), grid, dim3(64), 0, stream, q);
+		hipLaunchKernelGGL((raster_fwd_fast_kernel<PixT, true, true, false, 0, false, 1>), grid, dim3(64), 0, stream, q);
 	else if (fused && p.clamp && tex)
 		hipLaunchKernelGGL((raster_fwd_fast_kernel<PixT, true, true, true>), grid, dim3(64), 0, stream, q);
 	else if (fused && p.clamp && p.C == 1) // (a depth image)

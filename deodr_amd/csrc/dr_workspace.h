@@ -217,6 +217,7 @@ struct KParams
 	uint32_t *done_flag;
 	uint32_t done_value;
 	int split_part; // edges per copy of a tile with several batches of silhouette edges (fused forward: dr_forward.h)
+	uint32_t block_base; // staged forward launched as two kernels (textured fit step): index of this launch's first workgroup in the one-kernel grid
 	// loss of a fit step, sum (image - obs)^2 (deodr_hip_render_scene_fit_loss): loss_tile_bg[0] = the loss of a frame that is all
 	// background, [1 + view * ntiles + tile] = that of one tile; loss_wave[view * LOSS_SLOTS + q % LOSS_SLOTS]: walker q of the forward
 	// raster adds (loss of a tile - its background loss) for every tile it walks; one workgroup of finalize_kernel writes loss_out[0] =

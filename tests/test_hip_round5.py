@@ -308,3 +308,35 @@ def test_deterministic_mode_per_scene(oracle_api):
             assert torch.equal(v, g_switch[k]), k
     finally:
         hr.set_deterministic(False)
+
+
+def test_textured_fit_step_of_eight_views_as_two_kernels(oracle_api):
+    """From 8 views per launch on the forward raster of a textured fit step runs as two kernels on two streams (the head walkers with the edge
+    adjoint on the library's side stream, the others on the caller's; joined in front of finalize): 8 views of a textured sphere against the checker,
+    view by view, and against the two-call path; the same step captured in a HIP graph (capture takes the one-kernel form) gives the eager result."""
+    from hip_util import device_scene, rel_err
+    from deodr_amd.hip_renderer import HipRasterizer
+    from test_hip_parity import compare_fit_step
+
+    views = [scenes.sphere_scene(size=256, nu=40, n_rings=30, nb_colors=3, textured=True, texture_size=32, angle=float(a)) for a in np.linspace(-0.4, 0.4, 8)]
+    compare_fit_step(oracle_api, views, 1.0, F32)
+    compare_fit_step(oracle_api, views, 2.0, F64)
+    ds = device_scene(views, F32)
+    r = HipRasterizer.for_scene(ds)
+    obs = torch.rand((8, 256, 256, 3), dtype=F32, device=ds.device)
+    image, z = torch.empty((8, 256, 256, 3), dtype=F32, device=ds.device), torch.empty((8, 256, 256), dtype=F32, device=ds.device)
+    grads = ds.zero_grads()
+    for _ in range(3):  # (two kernels; also back to back: the side stream's events are re-recorded every step)
+        r.render_fit(ds, obs, 1.0, grads=grads, out=(image, z), check_overflow=True, clear_grads=True)
+    torch.cuda.synchronize()
+    eager = (image.clone(), {k: v.clone() for k, v in grads.items() if v is not None})
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        r.render_fit(ds, obs, 1.0, grads=grads, out=(image, z), check_overflow=False, clear_grads=True)
+    for _ in range(2):
+        image.zero_()
+        graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(image, eager[0])
+    for k, v in eager[1].items():
+        assert rel_err(grads[k].cpu().numpy(), v.cpu().numpy()) < (1e-5 if k == "texture_b" else 1e-9), k
