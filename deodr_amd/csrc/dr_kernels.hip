@@ -14,15 +14,16 @@
 //   raster_fwd_fast_kernel  1 wavefront / work-list entry, lane = pixel.  Pass 1 (z-buffered triangles staged 16 at a time
 //                           through LDS, exact scanline spans, winner = min (Z, index)), shading of the winner, pass 2 (ordered
 //                           edge overdraw) fused in registers, ONE write of image / z (/ owner) per pixel.  FUSED
-//                           (deodr_hip_render_scene_fit): also the adjoint for the sum-of-squares residual -- of every tile of an
-//                           untextured scene (tiles with silhouette edges: reverse sweep + pass 1 by a second instance of the
-//                           walker on the head of the work list; pairs of adjacent edge-free tiles share a wavefront), of the
-//                           edge-free tiles of a textured one
+//                           (deodr_hip_render_scene_fit): also the adjoint for the sum-of-squares residual of EVERY tile (tiles with
+//                           silhouette edges: reverse sweep + pass 1 by a second instance of the walker on the head of the work
+//                           list; untextured scenes: pairs of adjacent edge-free tiles share a wavefront; textured scenes, round 5:
+//                           instances of their own at three waves per SIMD, from 8 views per launch on as two kernels on two
+//                           streams -- the head walkers / everybody else)
 //   fill_kernel / fill_word background + depth = inf of the empty tiles, runs of tiles written as contiguous 16-byte pieces:
 //                           a kernel on a forked stream (forward-only calls) or extra workgroups of the forward raster and of
 //                           finalize, dealt 2 : 1 (fit step)
 //   raster_bwd_fast_kernel  (two-call path) adjoint of pass 1 in every non-empty tile without edges
-//   raster_bwd_edge_kernel  (two-call path, textured fit steps) persistent waves over the listed edge tiles: adjoint of pass 2 (un-blend in reverse order, moments
+//   raster_bwd_edge_kernel  (two-call path) persistent waves over the listed edge tiles: adjoint of pass 2 (un-blend in reverse order, moments
 //                           by a transposing butterfly, one 15-lane atomic per edge and tile), then of pass 1
 //   finalize_kernel         per primitive: moments -> plane adjoints -> 3x3-inverse adjoint -> vertex gradients
 //   raster_fwd_kernel / raster_bwd_kernel   the same algorithm without LDS staging: nb_colors > 4, antialiase_error
