@@ -17,7 +17,10 @@
  * Differences from the reference interface, all forced by the device:
  *   - every array pointer is a device pointer (HBM); nothing is copied to or from the host by this library;
  *   - the caller passes a `stream` (hipStream_t as void*) and a device workspace (size from deodr_hip_workspace_bytes);
- *     calls are asynchronous on that stream and never allocate;
+ *     calls are asynchronous on that stream and never allocate (a call may run part of its kernels on ONE stream the library owns per
+ *     device -- the background fill of a forward-only call, the head walkers of a textured fit step of 8 views or more -- forked from and
+ *     joined back to `stream` by events inside the call: to the caller the call is ordered on `stream` alone; under stream capture the
+ *     fork and join are edges of the captured graph);
  *   - errors are returned (0 = ok), never thrown (the reference's `throw "literal"` terminates the process through the
  *     Cython shim); deodr_hip_last_error() gives the message;
  *   - the adjoint never mutates `image` / `image_b` / `err_buffer` / `err_buffer_b` (the reference un-antialiases
