@@ -131,11 +131,11 @@ def hbm_probe(dev, nbytes=1 << 30, reps=10):
     return out
 
 
-def parity_check(views, which, image, z, grads, obs, sigma=1.0):
+def parity_check(views, which, image, z, grads, obs, sigma=1.0, sum_views=False):
     """Views `which` of the timed launch against oracle/_ref (the reference's own code): max |image - ref|, gradients relative to the
     largest reference entry -- the tolerances of the north star (1e-5 / 1e-4, float32 pixel buffers).  Per-view gradients: ij_b, colors_b
     (untextured triangles), shade_b (textured ones); uv_b / texture_b are sums over the views of a launch and are compared when the launch
-    has ONE view (the 8-view sums are the GPU suite's: tests/test_hip_round3.py, test_hip_round5.py)."""
+    has ONE view, or -- `sum_views` -- against the sum of per-view checker calls over every view of the launch (a few seconds of CPU per 2048^2 view)."""
     from oracle import api
 
     ref = api.ref() or api.port()
@@ -159,6 +159,18 @@ def parity_check(views, which, image, z, grads, obs, sigma=1.0):
         if single and grads.get("texture_b") is not None and np.size(s.texture):
             worst["uv_b"] = rel(grads["uv_b"].cpu().numpy(), g_ref["uv_b"])
             worst["texture_b"] = rel(grads["texture_b"].cpu().numpy(), fixed.grads(s, sigma, im_ref, z_ref, image_b)["texture_b"])
+    if sum_views and not single and grads.get("texture_b") is not None and np.size(views[0].texture):
+        # uv_b / texture_b of a multi-view launch are SUMS over its views (one array per scene, H.h:56-90): against the sum of per-view checker
+        # calls over ALL views of the timed launch, each with the residual of that view's own frame of the launch
+        uv_sum, tex_sum = 0.0, 0.0
+        for i, s in enumerate(views):
+            im_ref, z_ref = ref.render(s, sigma)
+            image_b = 2 * (image[i].cpu().numpy().astype(np.float64) - obs[i].cpu().numpy().astype(np.float64))
+            uv_sum = uv_sum + ref.grads(s, sigma, im_ref, z_ref, image_b)["uv_b"]
+            tex_sum = tex_sum + fixed.grads(s, sigma, im_ref, z_ref, image_b)["texture_b"]
+        worst["uv_b"] = rel(grads["uv_b"].cpu().numpy(), uv_sum)
+        worst["texture_b"] = rel(grads["texture_b"].cpu().numpy(), tex_sum)
+        out["summed_over_views"] = {"arrays": ["uv_b", "texture_b"], "views": len(views)}
     out.update({"max_abs_err_image": worst["image"], "max_abs_err_z": worst["z"], "tolerances": {"image": 1e-5, "gradients": 1e-4}})
     out.update({"rel_err_" + k: v for k, v in worst.items() if k not in ("image", "z")})
     out["ok"] = bool(worst["image"] < 1e-5 and worst["z"] < 1e-3 and all(v < 1e-4 for k, v in worst.items() if k not in ("image", "z")))
@@ -203,12 +215,131 @@ def other_configs(dev):
         alg = survey_8d_bytes(H, W, Cc, ds.nb_triangles, int(ds.depths.shape[1]), n, Vuv=int(ds.uv.shape[0]), tex_hw=tex_hw,
                               bg_image=ds.background_image is not None)  # fmt: skip
         # the timed launch against the checker (view 0; a one-view launch: uv_b and texture_b too)
-        parity = parity_check(views, [0], image, z, grads, obs)
+        parity = parity_check(views, [0], image, z, grads, obs, sum_views=True)
         assert parity["ok"], f"bench: {name}: the timed launch does not match the checker: {parity}"
         out.append({"config": name, "views": n, "ms_per_step": dt * 1e3, "Mpixels_s": n * H * W / dt / 1e6, "parity": parity, "parity_checked": parity["ok"],
                     "roofline": {"alg_bytes": alg, "GBps": alg / dt / 1e9, "frac": alg / dt / 1e9 / HBM_PEAK_GBS, "peak": HBM_PEAK_GBS,
                                  "note": "SURVEY 8d bytes of the whole step / step time (whole-step fraction, as roofline.whole_step)"}})  # fmt: skip
         del ds, r, obs, image, z, grads
+    return out
+
+
+def slow_family(dev, fused_one_view_ms=None):
+    """What has no LDS-staged kernel, timed and checked: `antialiase_error` (rasterize_edge_*_error[_B], H.h:2067-2618: the mode of two
+    of the reference's four soup-fit goldens, tests/test_triangle_soup_fitting.py:50-67) and more than four channels (Scene3D.render_deferred's
+    15-channel frame, dr.py:1053-1174) run on the un-staged raster_fwd_kernel / raster_bwd_kernel; and the NumPy drop-ins renderSceneCpp /
+    renderSceneBCpp (pyx:50-57, 206-215; float64 host arrays over PCIe, stateless adjoint), SURVEY.md section 8d's "report separately"."""
+    from deodr_amd import scenes
+    from deodr_amd.hip_renderer import DeviceScene, HipRasterizer, renderSceneBCpp, renderSceneCpp
+    from oracle import api
+
+    ref, fixed = api.ref() or api.port(), api.ref(fixed=True) or api.port(fixed=True)
+    rel = lambda a, r: float(np.abs(a - r).max() / max(np.abs(r).max(), 1e-30))
+    out = []
+
+    def device_scene(s):
+        return DeviceScene(s.faces, s.faces_uv, s.textured, s.shaded, s.uv, s.ij[None], s.depths[None], s.colors[None], s.shade[None], s.edgeflags[None],
+                           s.height, s.width, texture=None, background_color=getattr(s, "background_color", None),
+                           background_image=None if getattr(s, "background_image", None) is None else s.background_image[None], clockwise=s.clockwise,
+                           vertex_dtype=torch.float64, pixel_dtype=torch.float32, device=dev)  # fmt: skip
+
+    def entry(name, s, dt, parity, extra_frame_terms, note):
+        H, W, Cc, T, V = s.height, s.width, s.nb_colors, len(s.faces), len(s.depths)
+        alg = survey_8d_bytes(H, W, Cc, T, V, 1, bg_image=getattr(s, "background_image", None) is not None) + 4 * H * W * extra_frame_terms
+        e = {"config": name, "views": 1, "ms_per_step": dt * 1e3, "Mpixels_s": H * W / dt / 1e6, "parity": parity, "parity_checked": parity["ok"],
+             "roofline": {"alg_bytes": alg, "GBps": alg / dt / 1e9, "frac": alg / dt / 1e9 / HBM_PEAK_GBS, "peak": HBM_PEAK_GBS, "note": note}}  # fmt: skip
+        if fused_one_view_ms and (H, W) == (1024, 1024):
+            e["times_the_fused_one_view_step"] = dt * 1e3 / fused_one_view_ms
+        assert parity["ok"], f"bench: {name}: the timed launch does not match the checker: {parity}"
+        out.append(e)
+
+    # ---- antialiase_error = True: Scene2D.render_compare_and_backward's other branch (dr.py:700-724): render with err_buffer, adjoint of sum(err_buffer)
+    soup = scenes.soup_scene(n_tri=200, width=256, height=256, seed=2)
+    sphere = scenes.sphere_scene(size=1024, angle=0.0)
+    for name, s, steps in (("configs[0] 256^2 200-triangle soup, antialiase_error=True (un-staged kernels)", soup, 50),
+                           ("configs[2] scene, 1 view, antialiase_error=True (un-staged kernels)", sphere, 30)):  # fmt: skip
+        ds = device_scene(s)
+        r = HipRasterizer.for_scene(ds)
+        H, W, Cc = s.height, s.width, s.nb_colors
+        obs = torch.rand((1, H, W, Cc), dtype=torch.float32, device=dev)
+        ones = torch.ones((1, H, W), dtype=torch.float32, device=dev)
+        grads = ds.zero_grads()
+        image = torch.empty((1, H, W, Cc), dtype=torch.float32, device=dev)
+        z = torch.empty((1, H, W), dtype=torch.float32, device=dev)
+        state = {}
+
+        def step():
+            for g in ("ij_b", "colors_b"):
+                grads[g].zero_()
+            state["out"] = r.render(ds, 1.0, antialiase_error=True, obs=obs, out=(image, z), check_overflow=False)
+            r.render_backward(ds, err_buffer_b=ones, grads=grads)
+
+        r.render(ds, 1.0, out=(image, z), check_overflow=True)
+        for _ in range(3):
+            step()
+        dt = min(timed_steps(step, steps) for _ in range(2))
+        o = obs[0].cpu().numpy().astype(np.float64)
+        im_ref, z_ref, err_ref = ref.render(s, 1.0, True, o)
+        # (the adjoint of the error buffer: against the REPAIRED reference -- defect D2 of DESIGN.md section 6, H.h:2595)
+        g_ref = fixed.grads(s, 1.0, im_ref, z_ref, None, True, o, err_ref, np.ones((H, W)))
+        err = state["out"][2][0].cpu().numpy().astype(np.float64)
+        worst = {"max_abs_err_image": float(np.abs(image[0].cpu().numpy() - im_ref).max()), "rel_err_err_buffer": rel(err, err_ref),
+                 "rel_err_ij_b": rel(grads["ij_b"][0].cpu().numpy(), g_ref["ij_b"]), "rel_err_colors_b": rel(grads["colors_b"][0].cpu().numpy(), g_ref["colors_b"])}  # fmt: skip
+        worst["ok"] = bool(worst["max_abs_err_image"] < 1e-5 and worst["rel_err_err_buffer"] < 1e-5 and worst["rel_err_ij_b"] < 1e-4 and worst["rel_err_colors_b"] < 1e-4)
+        worst["checker"] = "oracle/_ref (adjoint: the build with defect D2 repaired)"
+        entry(name, s, dt, worst, Cc + 2, "SURVEY 8d bytes of forward + adjoint + the observation (read) and the error buffer (written, its adjoint read) / step time")
+        del ds, r, obs, ones, grads, image, z
+    # ---- 15 channels: the frame of Scene3D.render_deferred (dr.py:1053-1174: colours, normals, depth, uv, barycentrics ... in one render)
+    s = scenes.sphere_scene(size=1024, angle=0.0, nb_colors=15, depth_channel=True)
+    ds = device_scene(s)
+    r = HipRasterizer.for_scene(ds)
+    H, W, Cc = s.height, s.width, s.nb_colors
+    image_b = torch.randn((1, H, W, Cc), dtype=torch.float32, device=dev)
+    grads = ds.zero_grads()
+    image = torch.empty((1, H, W, Cc), dtype=torch.float32, device=dev)
+    z = torch.empty((1, H, W), dtype=torch.float32, device=dev)
+
+    def step15():
+        for g in ("ij_b", "colors_b"):
+            grads[g].zero_()
+        r.render(ds, 1.0, out=(image, z), check_overflow=False)
+        r.render_backward(ds, image_b=image_b, grads=grads)
+
+    r.render(ds, 1.0, out=(image, z), check_overflow=True)
+    for _ in range(3):
+        step15()
+    dt = min(timed_steps(step15, 20) for _ in range(2))
+    im_ref, z_ref = ref.render(s, 1.0)
+    g_ref = ref.grads(s, 1.0, im_ref, z_ref, image_b[0].cpu().numpy().astype(np.float64))
+    worst = {"max_abs_err_image": float(np.abs(image[0].cpu().numpy() - im_ref).max()), "rel_err_ij_b": rel(grads["ij_b"][0].cpu().numpy(), g_ref["ij_b"]),
+             "rel_err_colors_b": rel(grads["colors_b"][0].cpu().numpy(), g_ref["colors_b"]), "checker": "oracle/_ref"}  # fmt: skip
+    worst["ok"] = bool(worst["max_abs_err_image"] < 1e-5 and worst["rel_err_ij_b"] < 1e-4 and worst["rel_err_colors_b"] < 1e-4)
+    entry("configs[2] mesh with 15 channels (the frame of Scene3D.render_deferred), 1 view, render + render_backward (un-staged kernels)", s, dt, worst, 0,
+          "SURVEY 8d bytes of forward + adjoint (C = 15) / step time")
+    del ds, r, image_b, grads, image, z
+    # ---- the NumPy drop-ins of the reference's entry points: float64 host arrays in and out, everything over PCIe, the adjoint stateless
+    s = scenes.sphere_scene(size=1024, angle=0.0)
+    H, W, Cc = s.height, s.width, s.nb_colors
+    image, zb = np.zeros((H, W, Cc)), np.zeros((H, W))
+    image_b = np.random.RandomState(5).rand(H, W, Cc) - 0.5
+    best = 1e9
+    for rep in range(4):
+        s.clear_gradients()
+        t0 = time.perf_counter()
+        renderSceneCpp(s, 1.0, image, zb)
+        renderSceneBCpp(s, 1.0, image, zb, image_b)
+        if rep:  # (the first pair allocates the workspace)
+            best = min(best, time.perf_counter() - t0)
+    im_ref, z_ref = ref.render(s, 1.0)
+    g_ref = ref.grads(s, 1.0, im_ref, z_ref, image_b)
+    worst = {"max_abs_err_image": float(np.abs(image - im_ref).max()), "rel_err_ij_b": rel(s.ij_b, g_ref["ij_b"]), "rel_err_colors_b": rel(s.colors_b, g_ref["colors_b"]),
+             "checker": "oracle/_ref", "tolerances": {"image": 1e-9, "gradients": 1e-8, "note": "float64 buffers"}}  # fmt: skip
+    worst["ok"] = bool(worst["max_abs_err_image"] < 1e-9 and worst["rel_err_ij_b"] < 1e-8 and worst["rel_err_colors_b"] < 1e-8)
+    host_bytes = 8 * (2 * H * W * Cc + 2 * H * W + H * W * Cc)  # frame out, frame + image_b in, z out and in (float64)
+    entry("configs[2] scene, 1 view, NumPy drop-ins renderSceneCpp + renderSceneBCpp (float64 host arrays, PCIe included, wall clock)", s, best, worst, 0,
+          "SURVEY 8d bytes / wall time of the two calls: PCIe-bound by construction -- never part of `value`")
+    out[-1]["host_bytes_over_pcie"] = host_bytes
+    out[-1]["pcie_GBps_if_nothing_else"] = host_bytes / best / 1e9
     return out
 
 
@@ -688,10 +819,13 @@ def main():
             per_kernel[k] = {"avg_ms": avg_ms, "launches": samples, "alg_bytes": alg.get(k), "GBps": alg[k] / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 and alg.get(k) else None,
                              "avg_ms_events": ev_ms, "event_launches": int(launches[i])}  # fmt: skip
         dom = max(KERNELS, key=lambda k: per_kernel[k]["avg_ms"])
-        traffic = None
+        traffic = traffic_source = None
         tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
         if os.path.exists(tpath):  # HBM bytes per launch from the last PMC run (tools/profile_round.sh), gfx950 correction applied
-            traffic = (json.load(open(tpath)).get(dom) or {}).get("bytes_per_launch")
+            tjson = json.load(open(tpath))
+            traffic = (tjson.get(dom) or {}).get("bytes_per_launch")
+            # NOT measured in this run (PMC passes need rocprofv3 around the process): which profile the figure is from
+            traffic_source = dict(tjson.get("_source") or {}, file="profiles/traffic_latest.json", measured_in_this_run=False)
         kernel_ms = sum(v["avg_ms"] for v in per_kernel.values())
         step_s = dt / args.steps
         whole = sum(v for k, v in alg_8d.items() if k != "not_moved")
@@ -729,6 +863,7 @@ def main():
             "roofline": {"bound": "hbm", "kernel": dom if not textured else "whole step (four launches; no per-group byte split for textured scenes)",
                          "achieved": dom_GBps, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": (dom_GBps or 0) / HBM_PEAK_GBS, "traffic": traffic if not textured else None,
+                         "traffic_source": traffic_source if not textured else None,
                          "peak_measured": peak_meas, "frac_of_measured": (dom_GBps or 0) / peak_meas,
                          "timing": ("device time stamps of every step of the timed region (deodr_hip_profile_stamps); avg_ms_events = hipEvents on 6 steps after it"
                                     if stamp_ms is not None else "hipEvents on steps after the timed region"),
@@ -754,6 +889,7 @@ def main():
             assert out["parity"]["ok"], f"bench: the timed launch does not match the checker: {out['parity']}"
         if world == 1 and not args.no_other_configs and not textured:
             out["other_configs"] = other_configs(dev)
+            out["other_configs"] += slow_family(dev, single_view["ms_eager"] if single_view is not None else None)
         if single_view is not None:
             out["single_view"], out["batch_sweep"] = single_view, sweep
             # (the north star's 40 % is asked of the forward + backward pass of this scene: where more views per launch take the same code)

@@ -547,7 +547,8 @@ __global__ __launch_bounds__(SCAN_BLOCK) void tile_scan_kernel(KParams p)
 		const uint32_t at = position(2 + EDGE_LISTS, m[2 + EDGE_LISTS]);
 		const uint32_t slot_word = at < (uint32_t)p.L.sweep_cap ? at + 1u : 0u;
 		w.edge_slot[tile] = slot_word; // always written: a stale value must never be read
-		sweep_slot = (nedge <= (uint32_t)EMAX && !p.persp && !p.fuse_edges) ? slot_word : 0u; // (fused: nothing is saved for a later kernel)
+		sweep_slot = (nedge <= (uint32_t)EMAX && !p.persp && !p.fuse_edges && !p.aa_err) ? slot_word : 0u; // (fused: nothing is saved for a later kernel;
+		// antialiase_error: the sweep runs over the error buffer, its adjoint over the un-staged code)
 		static_assert(EDGE_LISTS == 3, "select below");
 		w.edge_tiles[(size_t)elist * p.L.ntiles + position(2 + elist, elist == 0 ? m[2] : (elist == 1 ? m[3] : m[4]))] = (uint32_t)tile;
 	}
@@ -718,6 +719,25 @@ __device__ __forceinline__ void fill_word(const KParams &p, int view, int wi, in
 	if (!empty)
 		return;
 	const int C = p.C;
+	if (p.aa_err && p.err)
+	{ // antialiase_error: the error buffer of a background pixel, sum_c (background - obs)^2 (H.h:2824-2837), tile by tile (lane = pixel)
+		for (uint32_t rest = empty; rest; rest &= rest - 1)
+		{
+			const int t = base + __ffs((int)rest) - 1, ty = t / p.L.tiles_x, tx = t - ty * p.L.tiles_x;
+			const int px = tx * TILE + (lane & 7), py = ty * TILE + (lane >> 3);
+			if (px < p.W && py < p.H)
+			{
+				const size_t pix = (size_t)py * p.W + px, vpix = (size_t)view * p.H * p.W + pix;
+				double e = 0;
+				for (int c = 0; c < C; c++)
+				{
+					const double d = background_channel<PixT>(p, view, pix, c) - (double)((const PixT *)p.obs)[vpix * C + c];
+					e += d * d;
+				}
+				__builtin_nontemporal_store((PixT)e, (PixT *)p.err + vpix);
+			}
+		}
+	}
 	double bgc[CH] = {0, 0, 0, 0};
 	if (!p.bg_image)
 	{
@@ -1076,7 +1096,9 @@ enum FwdMode
 	FWD_EDGE_ADJ = 1, // fit step, head of the list: tiles with edges are back-propagated here as well
 	FWD_NO_EDGES = 2, // fit step, rest of the list: no tile has an edge
 };
-template <class PixT, bool FUSED, bool TEX, int MODE, bool CLAMP>
+// AA (round 6): antialiase_error -- the image stays un-antialiased, err_buffer = sum_c (image - obs)^2 (H.h:2824-2837) is what the edges blend
+// (rasterize_edge_*_error, H.h:2067-2197, 2371-2478).  Forward-only instances (FUSED = false: the adjoint of this mode is the two-call path's).
+template <class PixT, bool FUSED, bool TEX, int MODE, bool CLAMP, bool AA = false>
 __device__ __forceinline__ void fwd_tiles(const KParams &p, WaveLds *s_lds, EdgeSort *s_es, const uint32_t b)
 { // b: index of this walker among the walkers of the grid (the workgroup index, unless fill workgroups are dealt among them).
   // (32-bit: a grid has fewer than 2^31 workgroups, and every wavefront pays for this arithmetic on the scalar unit before its first load --
@@ -1165,7 +1187,7 @@ __device__ __forceinline__ void fwd_tiles(const KParams &p, WaveLds *s_lds, Edge
 		bool split = MODE == FWD_EDGE_ADJ && !one_batch && (nedge_word & SPLIT_FLAG);
 		const int part = split ? (int)((nedge_word >> 16) & 0xffu) : 0;
 		const int tile = (int)e_tile, ntri = (int)e_ntri, nedge = (int)(split ? (nedge_word & 0xffffu) : nedge_word);
-		const uint32_t sweep_slot = (uint32_t)uniform((int)cur.w);
+		const uint32_t sweep_slot = AA ? 0u : (uint32_t)uniform((int)cur.w);
 		const int tx = tile % p.L.tiles_x, ty = tile / p.L.tiles_x;
 		const int x0 = tx * TILE, y0 = ty * TILE;
 		const int px = x0 + (lane & 7), py = y0 + (lane >> 3);
@@ -1179,7 +1201,7 @@ __device__ __forceinline__ void fwd_tiles(const KParams &p, WaveLds *s_lds, Edge
 		{
 		PixT ob[CH] = {0, 0, 0, 0};
 		constexpr bool fuse_edges = MODE == FWD_EDGE_ADJ; // tiles with silhouette edges are back-propagated right here as well
-		if (FUSED && inb && ((nedge == 0 ? ntri > 0 : fuse_edges) || p.loss_wave))
+		if ((AA && inb) || (FUSED && inb && ((nedge == 0 ? ntri > 0 : fuse_edges) || p.loss_wave)))
 		{ // requested now, used after the last triangle
 			const PixT *o = (const PixT *)p.obs + vpix * C;
 #pragma unroll
@@ -1273,6 +1295,17 @@ __device__ __forceinline__ void fwd_tiles(const KParams &p, WaveLds *s_lds, Edge
 			for (int cc = 0; cc < CH; cc++)
 				col[cc] = cc < C ? bilinear_mix(tap, (double)tx[0][cc], (double)tx[1][cc], (double)tx[2][cc], (double)tx[3][cc]) * L : 0.0;
 		}
+		double err = 0; // (AA) the squared residual of the un-antialiased pixel, then blended by the edges in place of the colour
+		if (AA)
+		{
+#pragma unroll
+			for (int cc = 0; cc < CH; cc++)
+				if (cc < C && inb)
+				{
+					const double d = col[cc] - (double)ob[cc];
+					err += d * d;
+				}
+		}
 		// ---- pass 2: edges far -> near, TB at a time (H.h:2839-2900)
 		int n_edges = 0;
 		uint32_t tm[NBATCH] = {}; // (fused adjoint) bit j of tm[b]: edge 16 b + j of the blending order is drawn over this pixel
@@ -1339,6 +1372,21 @@ __device__ __forceinline__ void fwd_tiles(const KParams &p, WaveLds *s_lds, Edge
 						double eL = 0, eUV[2];
 						if (e.kind == KIND_TEXTURED && TEX)
 							textured_tap(ep, x, y, persp, Ze, p.tex_w, p.tex_h, C, etap, eL, eUV);
+						if (AA)
+						{ // H.h:2154-2193, 2441-2472: the edge paints its squared distance to the observation over the error buffer
+							double Err = 0;
+#pragma unroll
+							for (int cc = 0; cc < CH; cc++)
+								if (cc < C)
+								{
+									const double d = edge_channel<PixT, TEX>(e, ep, texture, etap, eL, cc, x, y, persp, Ze) - (double)ob[cc];
+									Err += d * d;
+								}
+							err *= Tr;
+							err += (1 - Tr) * Err;
+						}
+						else
+						{
 #pragma unroll
 						for (int cc = 0; cc < CH; cc++)
 							if (cc < C)
@@ -1347,6 +1395,7 @@ __device__ __forceinline__ void fwd_tiles(const KParams &p, WaveLds *s_lds, Edge
 								col[cc] *= Tr;
 								col[cc] += (1 - Tr) * A;
 							}
+						}
 						if (fuse_edges && split && first + j >= part_end)
 							trp *= Tr;
 					}
@@ -1401,14 +1450,25 @@ __device__ __forceinline__ void fwd_tiles(const KParams &p, WaveLds *s_lds, Edge
 					double eL = 0, eUV[2];
 					if (e.kind == KIND_TEXTURED && TEX)
 						textured_tap(ep, x, y, persp, Ze, p.tex_w, p.tex_h, C, etap, eL, eUV);
+					double Err = 0;
 #pragma unroll
 					for (int cc = 0; cc < CH; cc++)
 						if (cc < C)
 						{
 							const double A = edge_channel<PixT, TEX>(e, ep, texture, etap, eL, cc, x, y, persp, Ze);
-							col[cc] *= Tr;
-							col[cc] += (1 - Tr) * A;
+							if (AA)
+								Err += (A - (double)ob[cc]) * (A - (double)ob[cc]);
+							else
+							{
+								col[cc] *= Tr;
+								col[cc] += (1 - Tr) * A;
+							}
 						}
+					if (AA)
+					{
+						err *= Tr;
+						err += (1 - Tr) * Err;
+					}
 				}
 			}
 		}
@@ -1435,6 +1495,8 @@ __device__ __forceinline__ void fwd_tiles(const KParams &p, WaveLds *s_lds, Edge
 			}
 			if (p.zbuf)
 				__builtin_nontemporal_store((PixT)st.zbest, (PixT *)p.zbuf + vpix);
+			if (AA && p.err)
+				__builtin_nontemporal_store((PixT)err, (PixT *)p.err + vpix);
 			// a fused forward back-propagates through a tile without edges right below: nobody reads its owner ids again
 			// (nor those of a tile with edges when its adjoint is fused too -- except the pathological tile of more than EMAX edges,
 			// whose adjoint runs on the un-staged code and reads them)
@@ -1561,7 +1623,7 @@ __device__ __forceinline__ void fwd_tiles(const KParams &p, WaveLds *s_lds, Edge
 // case, at compile time as well: 0.144 -> 0.141 ms.
 // TEXE: (FUSED && TEX) 1: the instance for KParams::fuse_edges -- its head walkers run the adjoint of the tiles with silhouette edges too;
 // 2 / 3: the same grid as TWO kernels for two streams, the head walkers (2) and everybody else (3: four waves per SIMD again) -- KParams::block_base.
-template <class PixT, bool FUSED, bool TEX, bool CLAMP = false, int NC = 0, bool COMMON = false, int TEXE = 0>
+template <class PixT, bool FUSED, bool TEX, bool CLAMP = false, int NC = 0, bool COMMON = false, int TEXE = 0, bool AA = false>
 __global__ __launch_bounds__(64, DR_FWD_WAVES) void raster_fwd_fast_kernel(KParams p)
 {
 	p.aligned = COMMON ? 1 : 0;
@@ -1626,7 +1688,7 @@ __global__ __launch_bounds__(64, DR_FWD_WAVES) void raster_fwd_fast_kernel(KPara
 			fwd_tiles<PixT, FUSED, TEX, FWD_EDGE_ADJ, CLAMP>(p, s_lds, s_es, b); // the head (tiny frames: the whole list)
 	}
 	else
-		fwd_tiles<PixT, FUSED, TEX, FWD_PLAIN, CLAMP>(p, s_lds, s_es, b);
+		fwd_tiles<PixT, FUSED, TEX, FWD_PLAIN, CLAMP, AA>(p, s_lds, s_es, b);
 }
 
 } // namespace

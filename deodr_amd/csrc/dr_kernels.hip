@@ -320,7 +320,15 @@ void launch_adjoint_raster(const KParams &p, bool fast, bool owner_tiles, dim3 g
 		DR_LAUNCH_NC(raster_bwd_fast_kernel, tex, grid, q);
 	}
 	// (running the two kernels side by side on a forked stream was measured: no gain, the edge kernel just stretches)
-	if (p.sigma > 0 && !p.fuse_edges) // (a fit step back-propagates the tiles with edges inside its forward raster)
+	if (p.sigma > 0 && p.aa_err)
+	{ // antialiase_error: the sweep ran over the error buffer, and so does its adjoint (bwd_err_tile, dr_backward.h)
+		const dim3 grid(edge_grid.x, edge_grid.y);
+		if (tex)
+			hipLaunchKernelGGL((raster_bwd_edge_err_kernel<PixT, true>), grid, dim3(64), 0, st, p);
+		else
+			hipLaunchKernelGGL((raster_bwd_edge_err_kernel<PixT, false>), grid, dim3(64), 0, st, p);
+	}
+	else if (p.sigma > 0 && !p.fuse_edges) // (a fit step back-propagates the tiles with edges inside its forward raster)
 	{
 		DR_LAUNCH_NC(raster_bwd_edge_kernel, tex, edge_grid, p);
 	}
@@ -446,7 +454,11 @@ int launch_forward_staged(const KParams &p, bool fused, hipStream_t stream, hipE
 			return 1;
 		return 0;
 	}
-	if (fused && p.clamp && tex && p.fuse_edges) // (the clamped residual of the depth fitter: its own instances of the fused kernel)
+	if (p.aa_err && !fused && tex) // (antialiase_error: the edges blend the error buffer, the image stays un-antialiased)
+		hipLaunchKernelGGL((raster_fwd_fast_kernel<PixT, false, true, false, 0, false, 0, true>), grid, dim3(64), 0, stream, q);
+	else if (p.aa_err && !fused)
+		hipLaunchKernelGGL((raster_fwd_fast_kernel<PixT, false, false, false, 0, false, 0, true>), grid, dim3(64), 0, stream, q);
+	else if (fused && p.clamp && tex && p.fuse_edges) // (the clamped residual of the depth fitter: its own instances of the fused kernel)
 		hipLaunchKernelGGL((raster_fwd_fast_kernel<PixT, true, true, true, 0, false, 1>), grid, dim3(64), 0, stream, q);
 	else if (fused && tex && p.fuse_edges && p.C == 3) // (textured fit step, sigma > 0: the instances with the edge adjoint)
 		hipLaunchKernelGGL((raster_fwd_fast_kernel<PixT, true, true, false, nc_for<PixT, 3>, false, 1>), grid, dim3(64), 0, stream, q);
@@ -497,7 +509,7 @@ int launch_forward(const DeodrHipScene *sc, KParams &p, hipStream_t stream, hipE
 	g_profile = g_profile_every > 0 && (g_profile_calls++ % (unsigned)g_profile_every) == 0;
 	p.stamp = (g_stamps && g_stamp_calls < (unsigned)g_stamp_rows) ? g_stamps + 4 * (size_t)g_stamp_calls++ : nullptr;
 	p.n_views = n_views;
-	const bool fast = !p.aa_err && p.C <= CH && !g_force_generic && !det_mode(sc);
+	const bool fast = p.C <= CH && !g_force_generic && !det_mode(sc); // (antialiase_error: staged since round 6, the AA instances of the forward raster)
 	if (p.T > 0)
 	{
 		dim3 grid((unsigned)prim_blocks(p.T) * (unsigned)n_views);
@@ -549,7 +561,9 @@ void launch_finalize(Kernel kernel, dim3 grid, hipStream_t st, const KParams &p)
 // adjoint raster and the per-primitive finalize; owner_tiles = false after a fused forward
 int launch_adjoint(const DeodrHipScene *sc, KParams &p, hipStream_t st, bool owner_tiles)
 {
-	const bool fast = !p.aa_err && p.C <= CH && !g_force_generic && !det_mode(sc);
+	// (antialiase_error, round 6: the tiles without silhouette edges through raster_bwd_fast_kernel -- their gradient is -2 (obs - image) err_buffer_b,
+	// H.h:3054-3060 --, the tiles with edges through the un-staged tile code, called tile by tile from raster_bwd_edge_kernel's work lists)
+	const bool fast = p.C <= CH && !g_force_generic && !det_mode(sc);
 	p.n_views = sc->n_views;
 	if (det_mode(sc) && det_shadows(p, sc->n_views, st))
 		return 1;

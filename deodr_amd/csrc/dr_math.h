@@ -215,6 +215,39 @@ DR_HD int ceil_div(double a, double b, int x_min, int x_max) // H.h:481-519
 	return x;
 }
 
+// floor_div / ceil_div WITHOUT the IEEE division, for the usual quotient (round 6): branch-free, and `ok` is cleared when the result is
+// not PROVEN equal to the exact function's -- the caller then repeats the whole span pass with the exact functions (a wave-uniform
+// branch around a second copy of the pass: a per-call fallback inside these functions put a division behind a branch at every one of
+// the ~40 inlined call sites of the forward raster, whose edge-free walkers then spilled registers: 0.1119 -> 0.1175 ms per step).
+// q~ = a * r with r = 1 / b from the hardware reciprocal (v_rcp_f64: relative error < 2^-24, tools/probes/rcp_probe.hip; 2^-20 is
+// assumed here) and ONE Newton step, so r is good to 2^-39 and, as |a / b| < 2^15 behind the reference's own guard,
+// |q~ - a / b| < 2^-23.  fl(a / b) is within half an ulp (< 2^-38) of a / b.  When q~ lies at least 2^-20 away from both neighbouring
+// integers, a / b and fl(a / b) lie strictly between the same two integers: floor(fl(a / b)) = floor(q~) and ceil(fl(a / b)) =
+// floor(q~) + 1, bit for bit.  Otherwise (integer vertex coordinates do that: the quotient IS an integer, and fl() of a quotient just
+// below one may round up to it), or when the guard fails (the reference's slow walk), or with a NaN / infinite intermediate (both
+// comparisons fail): ok = false.  On the device a division is ~14 double instructions behind a quarter-rate reciprocal, twice per
+// (triangle, row) lane of a span pass and four times per (edge, row).
+DR_HD double quick_floor_quotient(double a, double b, bool &ok)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+	double r = __builtin_amdgcn_rcp(b); // v_rcp_f64
+#else
+	double r = 1.0 / b;
+#endif
+	r = __builtin_fma(__builtin_fma(-b, r, 1.0), r, r);
+	const double q = a * r, fl = floor(q), d = q - fl; // (d: exact)
+	ok = ok & (fabs(b) * DR_SHRT_MAX > fabs(a) + fabs(b)) & (d > 0x1p-20) & (d < 1.0 - 0x1p-20);
+	return fl;
+}
+DR_HD int clamp_i16(double v, int x_min, int x_max)
+{ // (the conversions of the reference's fast path; a garbage v of a lane whose `ok` is false is never used)
+	int x = (int)(int16_t)(int)v;
+	x = x < x_min ? x_min : x;
+	return x > x_max ? x_max : x;
+}
+DR_HD int floor_div_quick(double a, double b, int x_min, int x_max, bool &ok) { return clamp_i16(quick_floor_quotient(a, b, ok), x_min, x_max); }
+DR_HD int ceil_div_quick(double a, double b, int x_min, int x_max, bool &ok) { return clamp_i16(quick_floor_quotient(a, b, ok) + 1, x_min, x_max); }
+
 // ------------------------------------------------------------------------------------------------- triangle stencil
 
 DR_HD double signed_area(const double V[3][2], bool clockwise) // H.h:391-398
@@ -320,7 +353,9 @@ DR_HD void tri_stencil(const double V[3][2], bool strict, TriRec &r, double x2b[
 
 // Columns [xb, xe] of scanline y covered by one half of the triangle: get_xrange, H.h:864-906 (left edge exclusive
 // when strict, right edge inclusive).  Returns an empty span (xb > xe) when the row is outside the half.
-DR_HD void tri_half_span(const TriRec &r, int half, int y, int width, int height, bool strict, int &xb, int &xe)
+// QUICK: the divisions by reciprocal (floor_div_quick); *ok is cleared when a result is not proven exact -- the caller repeats the pass.
+template <bool QUICK = false>
+DR_HD void tri_half_span(const TriRec &r, int half, int y, int width, int height, bool strict, int &xb, int &xe, bool *ok = nullptr)
 {
 	int yb = r.y_begin[half] < 0 ? 0 : r.y_begin[half];
 	int ye = r.y_end[half] > height - 1 ? height - 1 : r.y_end[half];
@@ -334,11 +369,15 @@ DR_HD void tri_half_span(const TriRec &r, int half, int y, int width, int height
 	xb = x_min;
 	xe = x_max;
 	double num = -(left[1] * y + left[2]);
-	int t = strict ? 1 + floor_div(num, left[0], x_min - 1, x_max) : ceil_div(num, left[0], x_min - 1, x_max);
+	int t;
+	if (QUICK)
+		t = strict ? 1 + floor_div_quick(num, left[0], x_min - 1, x_max, *ok) : ceil_div_quick(num, left[0], x_min - 1, x_max, *ok);
+	else
+		t = strict ? 1 + floor_div(num, left[0], x_min - 1, x_max) : ceil_div(num, left[0], x_min - 1, x_max);
 	if (t > xb)
 		xb = t;
 	num = -(right[1] * y + right[2]);
-	t = floor_div(num, right[0], x_min - 1, x_max);
+	t = QUICK ? floor_div_quick(num, right[0], x_min - 1, x_max, *ok) : floor_div(num, right[0], x_min - 1, x_max);
 	if (t < xe)
 		xe = t;
 }
@@ -422,7 +461,8 @@ DR_HD void edge_stencil(const double V[2][2], int height, int width, double sigm
 
 // get_edge_xrange_from_ineq, H.h:2620-2648.  The four half-planes are bary0 > 0, bary1 > 0, T > 0, 1 - T > 0
 // (rows built at H.h:1418-1435).
-DR_HD void edge_row_span(const EdgeRec &r, int y, int width, int &xb, int &xe)
+template <bool QUICK = false> // (see tri_half_span)
+DR_HD void edge_row_span(const EdgeRec &r, int y, int width, int &xb, int &xe, bool *ok = nullptr)
 {
 	xb = 0;
 	xe = width - 1;
@@ -449,7 +489,8 @@ DR_HD void edge_row_span(const EdgeRec &r, int y, int width, int &xb, int &xe)
 			c = (1 - r.x2t[2]);
 		}
 		const double num = -(b * y + c);
-		const int t = floor_div(num, a, xb - 1, xe + 1); // one division whatever the sign of a (on the GPU both sides of a branch run)
+		// one division whatever the sign of a (on the GPU both sides of a branch run)
+		const int t = QUICK ? floor_div_quick(num, a, xb - 1, xe + 1, *ok) : floor_div(num, a, xb - 1, xe + 1);
 		if (a < 0)
 			xe = t < xe ? t : xe;
 		else

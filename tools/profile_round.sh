@@ -37,6 +37,10 @@ for (g, k), d in acc.items():
     part = (2 * fetch_kb + write_kb) * 1024
     t["parts"][k] = {"bytes_per_launch": part, "FETCH_SIZE_KB_raw": fetch_kb, "WRITE_SIZE_KB": write_kb}
     t["bytes_per_launch"] += part
+# where the figures are from: bench.py copies this into roofline.traffic_source (the commit: tools/gpu_round.sh leaves it in .profile_commit)
+import os
+commit = open("$GRAFT_REPO_ROOT/.profile_commit").read().strip() if os.path.exists("$GRAFT_REPO_ROOT/.profile_commit") else None
+traffic["_source"] = {"profile": "$TAG", "commit": commit, "command": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) -- python bench.py --steps 4 --warmup 1", "workload": "the headline workload of bench.py"}
 json.dump(traffic, open(f"{out}/traffic.json", "w"), indent=1)
 print(json.dumps(traffic))
 PY
