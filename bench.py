@@ -227,7 +227,8 @@ def other_configs(dev):
 def slow_family(dev, fused_one_view_ms=None):
     """What has no LDS-staged kernel, timed and checked: `antialiase_error` (rasterize_edge_*_error[_B], H.h:2067-2618: the mode of two
     of the reference's four soup-fit goldens, tests/test_triangle_soup_fitting.py:50-67) and more than four channels (Scene3D.render_deferred's
-    15-channel frame, dr.py:1053-1174) run on the un-staged raster_fwd_kernel / raster_bwd_kernel; and the NumPy drop-ins renderSceneCpp /
+    15-channel frame, dr.py:1053-1174) ran on the un-staged raster_fwd_kernel / raster_bwd_kernel until round 6 (now: the AA instances of the staged
+    forward + raster_bwd_edge_err_kernel, and fwd_manyc_tile for a many-channel frame without edges); and the NumPy drop-ins renderSceneCpp /
     renderSceneBCpp (pyx:50-57, 206-215; float64 host arrays over PCIe, stateless adjoint), SURVEY.md section 8d's "report separately"."""
     from deodr_amd import scenes
     from deodr_amd.hip_renderer import DeviceScene, HipRasterizer, renderSceneBCpp, renderSceneCpp
@@ -256,8 +257,8 @@ def slow_family(dev, fused_one_view_ms=None):
     # ---- antialiase_error = True: Scene2D.render_compare_and_backward's other branch (dr.py:700-724): render with err_buffer, adjoint of sum(err_buffer)
     soup = scenes.soup_scene(n_tri=200, width=256, height=256, seed=2)
     sphere = scenes.sphere_scene(size=1024, angle=0.0)
-    for name, s, steps in (("configs[0] 256^2 200-triangle soup, antialiase_error=True (un-staged kernels)", soup, 50),
-                           ("configs[2] scene, 1 view, antialiase_error=True (un-staged kernels)", sphere, 30)):  # fmt: skip
+    for name, s, steps in (("configs[0] 256^2 200-triangle soup, antialiase_error=True (render + render_backward)", soup, 50),
+                           ("configs[2] scene, 1 view, antialiase_error=True (render + render_backward)", sphere, 30)):  # fmt: skip
         ds = device_scene(s)
         r = HipRasterizer.for_scene(ds)
         H, W, Cc = s.height, s.width, s.nb_colors
@@ -289,34 +290,32 @@ def slow_family(dev, fused_one_view_ms=None):
         worst["checker"] = "oracle/_ref (adjoint: the build with defect D2 repaired)"
         entry(name, s, dt, worst, Cc + 2, "SURVEY 8d bytes of forward + adjoint + the observation (read) and the error buffer (written, its adjoint read) / step time")
         del ds, r, obs, ones, grads, image, z
-    # ---- 15 channels: the frame of Scene3D.render_deferred (dr.py:1053-1174: colours, normals, depth, uv, barycentrics ... in one render)
-    s = scenes.sphere_scene(size=1024, angle=0.0, nb_colors=15, depth_channel=True)
+    # ---- 15 channels: the frame of Scene3D.render_deferred (dr.py:1053-1174: depth, face ids, barycentrics, normals, luminosity, xyz, colours in ONE
+    # forward render of the mesh's triangle soup, sigma = 0 by its own assert, a background image; there is no adjoint of it in the reference)
+    s = scenes.deferred_scene(size=1024, channels=15)
     ds = device_scene(s)
     r = HipRasterizer.for_scene(ds)
     H, W, Cc = s.height, s.width, s.nb_colors
-    image_b = torch.randn((1, H, W, Cc), dtype=torch.float32, device=dev)
-    grads = ds.zero_grads()
     image = torch.empty((1, H, W, Cc), dtype=torch.float32, device=dev)
     z = torch.empty((1, H, W), dtype=torch.float32, device=dev)
-
-    def step15():
-        for g in ("ij_b", "colors_b"):
-            grads[g].zero_()
-        r.render(ds, 1.0, out=(image, z), check_overflow=False)
-        r.render_backward(ds, image_b=image_b, grads=grads)
-
-    r.render(ds, 1.0, out=(image, z), check_overflow=True)
+    r.render(ds, 0.0, out=(image, z), check_overflow=True)
+    fwd15 = lambda: r.render(ds, 0.0, out=(image, z), check_overflow=False)
     for _ in range(3):
-        step15()
-    dt = min(timed_steps(step15, 20) for _ in range(2))
-    im_ref, z_ref = ref.render(s, 1.0)
-    g_ref = ref.grads(s, 1.0, im_ref, z_ref, image_b[0].cpu().numpy().astype(np.float64))
-    worst = {"max_abs_err_image": float(np.abs(image[0].cpu().numpy() - im_ref).max()), "rel_err_ij_b": rel(grads["ij_b"][0].cpu().numpy(), g_ref["ij_b"]),
-             "rel_err_colors_b": rel(grads["colors_b"][0].cpu().numpy(), g_ref["colors_b"]), "checker": "oracle/_ref"}  # fmt: skip
-    worst["ok"] = bool(worst["max_abs_err_image"] < 1e-5 and worst["rel_err_ij_b"] < 1e-4 and worst["rel_err_colors_b"] < 1e-4)
-    entry("configs[2] mesh with 15 channels (the frame of Scene3D.render_deferred), 1 view, render + render_backward (un-staged kernels)", s, dt, worst, 0,
-          "SURVEY 8d bytes of forward + adjoint (C = 15) / step time")
-    del ds, r, image_b, grads, image, z
+        fwd15()
+    dt = min(timed_steps(fwd15, 30) for _ in range(2))
+    im_ref, z_ref = ref.render(s, 0.0)
+    fin = np.isfinite(z_ref)
+    worst = {"max_abs_err_image": float(np.abs(image[0].cpu().numpy() - im_ref).max()), "max_abs_err_z": float(np.abs(z[0].cpu().numpy()[fin] - z_ref[fin]).max()),
+             "pixels_with_another_owner": int((np.isfinite(z[0].cpu().numpy()) != fin).sum()), "checker": "oracle/_ref"}  # fmt: skip
+    worst["ok"] = bool(worst["max_abs_err_image"] < 1e-5 and worst["max_abs_err_z"] < 1e-5 and worst["pixels_with_another_owner"] == 0)
+    T, V = len(s.faces), len(s.depths)
+    fwd_bytes = 4 * (H * W * (Cc + 1) + H * W * Cc + V * (3 + Cc) + 3 * T)  # SURVEY 8d's forward term with a background image
+    out.append({"config": "the frame of Scene3D.render_deferred: 1024^2, the 20 000-triangle mesh as a triangle soup, 15 channels, sigma = 0, background image, FORWARD only (staged forward, fwd_manyc_tile)",
+                "views": 1, "ms_per_step": dt * 1e3, "Mpixels_s": H * W / dt / 1e6, "parity": worst, "parity_checked": worst["ok"],
+                "roofline": {"alg_bytes": fwd_bytes, "GBps": fwd_bytes / dt / 1e9, "frac": fwd_bytes / dt / 1e9 / HBM_PEAK_GBS, "peak": HBM_PEAK_GBS,
+                             "note": "SURVEY 8d forward bytes (C = 15, background image read) / time of the forward call"}})  # fmt: skip
+    assert worst["ok"], f"bench: render_deferred frame: the timed launch does not match the checker: {worst}"
+    del ds, r, image, z
     # ---- the NumPy drop-ins of the reference's entry points: float64 host arrays in and out, everything over PCIe, the adjoint stateless
     s = scenes.sphere_scene(size=1024, angle=0.0)
     H, W, Cc = s.height, s.width, s.nb_colors

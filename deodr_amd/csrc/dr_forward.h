@@ -89,12 +89,12 @@ __device__ __forceinline__ uint32_t gather_column_bits(const uint8_t *row_bytes,
 // stage `nb` primitives whose ids are in S.ids: records (128 B each, 8 lanes x 16 B) and planes (3P doubles each).
 // Every global load is issued before the first LDS store: ONE memory round trip per batch (a rolled loop over the planes
 // paid one per 64 doubles, i.e. two or three for a batch of more than five primitives).
-template <class Rec>
+template <class Rec, bool PLANES = true> // PLANES = false: records only (the many-channel forward shades its winner from memory)
 __device__ __forceinline__ void stage_batch(WaveLds &S, const Rec *recs, const double *planes, int P, int nb, int lane)
 {
 	static_assert(TB == 16, "two record pieces and three plane doubles per lane");
 	const int piece = lane & 7;
-	const int np = 3 * P, total = nb * np; // np = 9 or 12
+	const int np = 3 * P, total = PLANES ? nb * np : 0; // np = 9 or 12
 	const int j0 = lane >> 3, j1 = 8 + (lane >> 3);
 	const int i0 = lane, i1 = lane + 64, i2 = lane + 128;
 	const int a0 = np == 12 ? i0 / 12 : i0 / 9, a1 = np == 12 ? i1 / 12 : i1 / 9, a2 = np == 12 ? i2 / 12 : i2 / 9;
@@ -123,7 +123,7 @@ __device__ __forceinline__ void stage_batch(WaveLds &S, const Rec *recs, const d
 		S.planes[a2 * 12 + c2] = v2;
 }
 
-template <bool TEX>
+template <bool TEX, bool SHADE = true> // SHADE = false: the winner is only remembered (index, depth, kind), not shaded
 __device__ __forceinline__ void tri_batch(const KParams &p, WaveLds &S, int nb, int lane, int x0, int y0, bool inb, PixState &st)
 {
 	const int W = p.W, H = p.H, C = p.C;
@@ -187,7 +187,12 @@ __device__ __forceinline__ void tri_batch(const KParams &p, WaveLds &S, int nb, 
 			jbest = j;
 		}
 	}
-	if (jbest >= 0)
+	if (!SHADE && jbest >= 0)
+	{
+		st.slot = jbest;
+		st.kind = S.rec[jbest].tri().kind;
+	}
+	if (SHADE && jbest >= 0)
 	{ // per-lane reads of the winner's record and planes (LDS, a few distinct slots per tile)
 		st.slot = jbest;
 		const int kind = S.rec[jbest].tri().kind;
@@ -657,16 +662,16 @@ __device__ __forceinline__ void fill_run(const KParams &p, int view, int32_t *fa
 		const int n = npx * C / E; // pieces per pixel row (npx is a multiple of 8: whole pieces)
 		auto pattern = [&](int piece) { // the background colour as it falls on piece `piece` of a row
 			VE v;
-			int ph = C == 3 ? (piece * E) % 3 : ((piece * E) & (C - 1)); // channel of the piece's first element
+			int ph = (C == 3 || C > CH) ? (piece * E) % C : ((piece * E) & (C - 1)); // channel of the piece's first element
 #pragma unroll
 			for (int j = 0; j < E; j++)
 			{
-				v[j] = (PixT)(ph == 0 ? bgc[0] : (ph == 1 ? bgc[1] : (ph == 2 ? bgc[2] : bgc[3])));
+				v[j] = C > CH ? ((const PixT *)p.bg_color)[ph] : (PixT)(ph == 0 ? bgc[0] : (ph == 1 ? bgc[1] : (ph == 2 ? bgc[2] : bgc[3])));
 				ph = ph + 1 == C ? 0 : ph + 1;
 			}
 			return v;
 		};
-		if (n >= 64 && !bgi)
+		if (n >= 64 && !bgi && C <= CH)
 		{ // the usual long run of a colour background: a lane's pieces lane, lane + 64, ... of a row see the pattern with period 3
 		  // (period 1 unless C = 3), so the three vectors are formed once and the loop is a store and a pointer increment
 			const VE v0 = pattern(lane), v1 = pattern(lane + 64), v2 = pattern(lane + 128);
@@ -737,6 +742,26 @@ __device__ __forceinline__ void fill_word(const KParams &p, int view, int wi, in
 				__builtin_nontemporal_store((PixT)e, (PixT *)p.err + vpix);
 			}
 		}
+	}
+	if (C > CH && (p.W & 7) != 0)
+	{ // more than CH channels (the staged forward of a many-channel frame, fwd_manyc_tile) AND a ragged frame width: pixel by pixel, channel by
+	  // channel (the usual width goes through fill_run below, whose 16-byte pieces do not care about the channel count)
+		for (uint32_t rest = empty; rest; rest &= rest - 1)
+		{
+			const int t = base + __ffs((int)rest) - 1, ty = t / p.L.tiles_x, tx = t - ty * p.L.tiles_x;
+			const int px = tx * TILE + (lane & 7), py = ty * TILE + (lane >> 3);
+			if (px >= p.W || py >= p.H)
+				continue;
+			const size_t pix = (size_t)py * p.W + px, vpix = (size_t)view * p.H * p.W + pix;
+			if (p.image)
+				for (int c = 0; c < C; c++)
+					__builtin_nontemporal_store((PixT)background_channel<PixT>(p, view, pix, c), (PixT *)p.image + vpix * C + c);
+			if (p.zbuf)
+				__builtin_nontemporal_store((PixT)INFINITY, (PixT *)p.zbuf + vpix);
+			if (owners)
+				__builtin_nontemporal_store((int32_t)-1, w.face_id + pix);
+		}
+		return;
 	}
 	double bgc[CH] = {0, 0, 0, 0};
 	if (!p.bg_image)
@@ -1080,6 +1105,140 @@ __device__ __forceinline__ void fwd_pair_tiles(const KParams &p, const ViewPtrs 
 	}
 }
 
+// More than CH channels, forward only, no silhouette edge anywhere (sigma = 0), no texture: the frame of Scene3D.render_deferred (dr.py:1053-1174:
+// depth, face ids, barycentrics, normals, luminosity, xyz, colours or uv -- 15 channels of a triangle soup in ONE render, sigma = 0 by its own assert).
+// Pass 1 as everywhere (staged records, exact spans, winner = min (Z, index)); the planes of a triangle are 3 C doubles, too many to stage, and only the
+// WINNER's are needed: each lane reads them from memory once the tile is resolved (lanes with the same winner read the same lines).  The un-staged
+// kernel walked the tile's list once per chunk of four channels, a dependent record load per triangle each time: 138 -> ?? us for one 1024^2 view.
+template <class PixT>
+__device__ __forceinline__ void fwd_manyc_tile(const KParams &p, const ViewPtrs &w, WaveLds &S, int view, int lane, int tile, int ntri, uint32_t ids12)
+{
+	const int W = p.W, H = p.H, C = p.C, P = p.L.P;
+	const bool persp = p.persp;
+	const int tx = tile % p.L.tiles_x, ty = tile / p.L.tiles_x;
+	const int x0 = tx * TILE, y0 = ty * TILE;
+	const int px = x0 + (lane & 7), py = y0 + (lane >> 3);
+	const bool inb = px < W && py < H;
+	const size_t pix = (size_t)py * W + px;
+	const size_t vpix = (size_t)view * H * W + pix;
+	const double x = px, y = py;
+	const uint32_t list_entry = ntri <= ENTRY_IDS ? ids12 : w.tri_list[(size_t)tile * K_TRI + (lane & (K_TRI - 1))];
+	PixState st;
+	st.zbest = INFINITY;
+	st.kbest = -1;
+	st.kind = KIND_NONE;
+	st.slot = 0;
+	const int n_inline = ntri < K_TRI ? ntri : K_TRI;
+	for (int base = 0; base < n_inline; base += TB)
+	{
+		const int nb = n_inline - base < TB ? n_inline - base : TB;
+		if (lane >= base && lane < base + nb)
+			S.ids[lane - base] = list_entry;
+		lds_sync();
+		stage_batch<TriRec, false>(S, w.tri_rec, w.tri_planes, P, nb, lane);
+		lds_sync();
+		tri_batch<false, false>(p, S, nb, lane, x0, y0, inb, st);
+	}
+	if (ntri > K_TRI)
+	{ // spilled pairs of this tile: compact them out of the pool, TB at a time
+		uint32_t spill_n = w.hdr->tri_spill[w.hdr->cur];
+		if (spill_n > p.L.tri_pool_cap)
+			spill_n = p.L.tri_pool_cap;
+		int fill = 0;
+		for (uint32_t i0 = 0; i0 < spill_n; i0 += 64)
+		{
+			const uint2 pr = (i0 + lane < spill_n) ? w.tri_pool[i0 + lane] : make_uint2(0xffffffffu, 0u);
+			unsigned long long m = __ballot((int)pr.x == tile);
+			while (m)
+			{
+				const int room = TB - fill, cnt = __popcll(m);
+				const int rank = __popcll(m & ((1ull << lane) - 1ull));
+				const bool sel = ((m >> lane) & 1ull) && rank < room;
+				if (sel)
+					S.ids[fill + rank] = pr.y;
+				m &= ~__ballot(sel);
+				fill += cnt < room ? cnt : room;
+				if (fill == TB)
+				{
+					lds_sync();
+					stage_batch<TriRec, false>(S, w.tri_rec, w.tri_planes, P, TB, lane);
+					lds_sync();
+					tri_batch<false, false>(p, S, TB, lane, x0, y0, inb, st);
+					fill = 0;
+				}
+			}
+		}
+		if (fill > 0)
+		{
+			lds_sync();
+			stage_batch<TriRec, false>(S, w.tri_rec, w.tri_planes, P, fill, lane);
+			lds_sync();
+			tri_batch<false, false>(p, S, fill, lane, x0, y0, inb, st);
+		}
+	}
+	if (p.image)
+	{
+		const double *planes = w.tri_planes + (size_t)(st.kbest < 0 ? 0 : st.kbest) * 3 * P;
+		const bool drawn = st.kbest >= 0 && st.kind == KIND_INTERP;
+		// A pixel's C values are C consecutive elements of the frame, a tile row 8 C of them: written by the pixel's lane they are 4-byte stores
+		// 4 C bytes apart (15 channels: every store instruction touches 64 partial lines).  Through LDS instead -- the wavefront's whole
+		// allotment, staging area and edge order, idle by now -- and out as 16-byte pieces of contiguous tile rows, as many rows per pass as fit.
+		// (A frame whose width is not a multiple of the tile keeps the direct stores: its last tile column has shorter rows.)
+		constexpr int LDS_ELEMS = (int)((sizeof(WaveLds) + sizeof(EdgeSort)) / sizeof(PixT)), E = 16 / (int)sizeof(PixT);
+		const int row_elems = TILE * C;
+		const bool via_lds = (W & (TILE - 1)) == 0 && row_elems <= LDS_ELEMS;
+		const int rows_pp = via_lds ? (LDS_ELEMS / row_elems < TILE ? LDS_ELEMS / row_elems : TILE) : TILE;
+		PixT *const stage = (PixT *)&S;
+		for (int r0 = 0; r0 < TILE; r0 += rows_pp)
+		{
+			const int my_row = (lane >> 3) - r0;
+			const bool mine = inb && my_row >= 0 && my_row < rows_pp;
+			if (via_lds)
+				lds_sync();
+			if (mine)
+			{
+				PixT *out = via_lds ? stage + (my_row * TILE + (lane & 7)) * C : (PixT *)p.image + vpix * C;
+				for (int c0 = 0; c0 < C; c0 += CH)
+				{ // four channels at a time: their twelve plane coefficients are requested together
+					double v[CH];
+#pragma unroll
+					for (int j = 0; j < CH; j++)
+						v[j] = c0 + j < C ? (drawn ? interp_channel(planes, c0 + j, x, y, persp, st.zbest) : background_channel<PixT>(p, view, pix, c0 + j)) : 0.0;
+#pragma unroll
+					for (int j = 0; j < CH; j++)
+						if (c0 + j < C)
+						{
+							if (via_lds)
+								out[c0 + j] = (PixT)v[j];
+							else
+								__builtin_nontemporal_store((PixT)v[j], out + c0 + j);
+						}
+				}
+			}
+			if (via_lds)
+			{
+				lds_sync();
+				typedef PixT VE __attribute__((ext_vector_type(E)));
+				const int ppr = row_elems / E; // 16-byte pieces per tile row (8 C elements: a whole number of pieces)
+				for (int i = lane; i < rows_pp * ppr; i += 64)
+				{
+					const int row = i / ppr, piece = i - row * ppr, yy = y0 + r0 + row;
+					if (r0 + row < TILE && yy < H)
+						__builtin_nontemporal_store(*(const VE *)(stage + row * row_elems + piece * E),
+													(VE *)((PixT *)p.image + ((size_t)view * H * W + (size_t)yy * W + x0) * C + piece * E));
+				}
+			}
+		}
+		if (via_lds)
+			lds_sync(); // (the next tile of this wavefront stages its records here)
+	}
+	if (!inb)
+		return;
+	if (p.zbuf)
+		__builtin_nontemporal_store((PixT)st.zbest, (PixT *)p.zbuf + vpix);
+	__builtin_nontemporal_store(pack_owner(st.kbest, st.kind), w.face_id + pix);
+}
+
 // Code-generation modes of the tile walker.  A fit step (FUSED) back-propagates EVERY tile in the forward launch: the scan kernel puts
 // the tiles that hold silhouette edges at the head of the work list, and the workgroups that walk the head run the instance that
 // can do their adjoint too (FWD_EDGE_ADJ: reverse sweep over the tile's edges, then pass 1) while all the other workgroups run an
@@ -1098,7 +1257,7 @@ enum FwdMode
 };
 // AA (round 6): antialiase_error -- the image stays un-antialiased, err_buffer = sum_c (image - obs)^2 (H.h:2824-2837) is what the edges blend
 // (rasterize_edge_*_error, H.h:2067-2197, 2371-2478).  Forward-only instances (FUSED = false: the adjoint of this mode is the two-call path's).
-template <class PixT, bool FUSED, bool TEX, int MODE, bool CLAMP, bool AA = false>
+template <class PixT, bool FUSED, bool TEX, int MODE, bool CLAMP, bool AA = false, bool MANYC = false>
 __device__ __forceinline__ void fwd_tiles(const KParams &p, WaveLds *s_lds, EdgeSort *s_es, const uint32_t b)
 { // b: index of this walker among the walkers of the grid (the workgroup index, unless fill workgroups are dealt among them).
   // (32-bit: a grid has fewer than 2^31 workgroups, and every wavefront pays for this arithmetic on the scalar unit before its first load --
@@ -1168,6 +1327,12 @@ __device__ __forceinline__ void fwd_tiles(const KParams &p, WaveLds *s_lds, Edge
 		{ // two adjacent tiles, two pixels per lane (the scan kernel pairs them up: fwd_pair_tiles)
 			fwd_pair_tiles<PixT, CLAMP>(p, w, S, view, lane, (int)(e_tile & ~PAIR_FLAG), (int)(e_ntri & 0xffffu), (int)(e_ntri >> 16), ids12,
 								 p.loss_wave ? p.loss_wave + (size_t)view * LOSS_SLOTS + q % LOSS_SLOTS : nullptr);
+			lds_sync();
+			continue;
+		}
+		if (MANYC)
+		{ // more than CH channels (forward only, no edges, no texture: the host's rule)
+			fwd_manyc_tile<PixT>(p, w, S, view, lane, (int)e_tile, (int)e_ntri, ids12);
 			lds_sync();
 			continue;
 		}
@@ -1623,7 +1788,8 @@ __device__ __forceinline__ void fwd_tiles(const KParams &p, WaveLds *s_lds, Edge
 // case, at compile time as well: 0.144 -> 0.141 ms.
 // TEXE: (FUSED && TEX) 1: the instance for KParams::fuse_edges -- its head walkers run the adjoint of the tiles with silhouette edges too;
 // 2 / 3: the same grid as TWO kernels for two streams, the head walkers (2) and everybody else (3: four waves per SIMD again) -- KParams::block_base.
-template <class PixT, bool FUSED, bool TEX, bool CLAMP = false, int NC = 0, bool COMMON = false, int TEXE = 0, bool AA = false>
+// VAR (round 6, forward-only instances): 1 = antialiase_error (the edges blend the error buffer), 2 = more than CH channels (fwd_manyc_tile).
+template <class PixT, bool FUSED, bool TEX, bool CLAMP = false, int NC = 0, bool COMMON = false, int TEXE = 0, int VAR = 0>
 __global__ __launch_bounds__(64, DR_FWD_WAVES) void raster_fwd_fast_kernel(KParams p)
 {
 	p.aligned = COMMON ? 1 : 0;
@@ -1688,7 +1854,7 @@ __global__ __launch_bounds__(64, DR_FWD_WAVES) void raster_fwd_fast_kernel(KPara
 			fwd_tiles<PixT, FUSED, TEX, FWD_EDGE_ADJ, CLAMP>(p, s_lds, s_es, b); // the head (tiny frames: the whole list)
 	}
 	else
-		fwd_tiles<PixT, FUSED, TEX, FWD_PLAIN, CLAMP, AA>(p, s_lds, s_es, b);
+		fwd_tiles<PixT, FUSED, TEX, FWD_PLAIN, CLAMP, VAR == 1, VAR == 2>(p, s_lds, s_es, b);
 }
 
 } // namespace

@@ -454,10 +454,12 @@ int launch_forward_staged(const KParams &p, bool fused, hipStream_t stream, hipE
 			return 1;
 		return 0;
 	}
-	if (p.aa_err && !fused && tex) // (antialiase_error: the edges blend the error buffer, the image stays un-antialiased)
-		hipLaunchKernelGGL((raster_fwd_fast_kernel<PixT, false, true, false, 0, false, 0, true>), grid, dim3(64), 0, stream, q);
+	if (p.C > CH) // (more than CH channels: launch_forward sends only forward-only calls without edges and without texture here)
+		hipLaunchKernelGGL((raster_fwd_fast_kernel<PixT, false, false, false, 0, false, 0, 2>), grid, dim3(64), 0, stream, q);
+	else if (p.aa_err && !fused && tex) // (antialiase_error: the edges blend the error buffer, the image stays un-antialiased)
+		hipLaunchKernelGGL((raster_fwd_fast_kernel<PixT, false, true, false, 0, false, 0, 1>), grid, dim3(64), 0, stream, q);
 	else if (p.aa_err && !fused)
-		hipLaunchKernelGGL((raster_fwd_fast_kernel<PixT, false, false, false, 0, false, 0, true>), grid, dim3(64), 0, stream, q);
+		hipLaunchKernelGGL((raster_fwd_fast_kernel<PixT, false, false, false, 0, false, 0, 1>), grid, dim3(64), 0, stream, q);
 	else if (fused && p.clamp && tex && p.fuse_edges) // (the clamped residual of the depth fitter: its own instances of the fused kernel)
 		hipLaunchKernelGGL((raster_fwd_fast_kernel<PixT, true, true, true, 0, false, 1>), grid, dim3(64), 0, stream, q);
 	else if (fused && tex && p.fuse_edges && p.C == 3) // (textured fit step, sigma > 0: the instances with the edge adjoint)
@@ -509,7 +511,10 @@ int launch_forward(const DeodrHipScene *sc, KParams &p, hipStream_t stream, hipE
 	g_profile = g_profile_every > 0 && (g_profile_calls++ % (unsigned)g_profile_every) == 0;
 	p.stamp = (g_stamps && g_stamp_calls < (unsigned)g_stamp_rows) ? g_stamps + 4 * (size_t)g_stamp_calls++ : nullptr;
 	p.n_views = n_views;
-	const bool fast = p.C <= CH && !g_force_generic && !det_mode(sc); // (antialiase_error: staged since round 6, the AA instances of the forward raster)
+	// (antialiase_error: staged since round 6, the AA instances of the forward raster; more than CH channels: staged when the frame has no silhouette
+	// edge and no texture and nothing is fused -- Scene3D.render_deferred's frame, sigma = 0 -- through fwd_manyc_tile)
+	const bool many_channels = p.C > CH && !(p.sigma > 0) && !p.aa_err && !p.texture && !fused;
+	const bool fast = (p.C <= CH || many_channels) && !g_force_generic && !det_mode(sc);
 	if (p.T > 0)
 	{
 		dim3 grid((unsigned)prim_blocks(p.T) * (unsigned)n_views);

@@ -7,6 +7,7 @@ inputs* for tests and benchmarks -- the rasterizer never depends on it.
 
   soup_scene      configs[0]: 256x256, 200 flat-colour soup triangles (generator modelled on
                   deodr/examples/triangle_soup_fitting.py:18-97, own RNG stream)
+  deferred_scene  the frame of Scene3D.render_deferred: the soup of the sphere mesh, 15 channels, no silhouette edge, background image
   sphere_scene    configs[2] / configs[4]: bumpy UV sphere, 2*nu*n_rings triangles (100x100 -> 20 000 tris /
                   10 002 verts; 224x224 -> 100 352 tris / 50 178 verts), perspective camera, Gouraud colours
                   (+ depth channel) or planar-UV texture
@@ -188,6 +189,25 @@ def sphere_scene(size=1024, nu=100, n_rings=100, nb_colors=4, depth_channel=True
     return mesh_scene(
         vertices, faces, size, size, nb_colors=nb_colors, rot=rotx(0.37) @ roty(0.23 + angle), seed=seed, depth_channel=depth_channel and not textured,
         textured=textured, texture_size=texture_size,
+    )  # fmt: skip
+
+
+def deferred_scene(size=1024, channels=15, nu=100, n_rings=100, angle=0.0, width=None, height=None, background_image=True, seed=2):
+    """The 2.5-D scene `Scene3D.render_deferred` hands to renderScene (deodr/differentiable_renderer.py:1053-1174): the triangle SOUP of a mesh (three
+    vertices per face, so that face ids / barycentrics / discontinuous uv can ride in the colour channels), `channels` interpolated channels (the
+    reference's default set is 15: depth, face id, 3 barycentrics, 3 normal, luminosity, 3 xyz, 3 colour), no silhouette edge (it asserts sigma = 0),
+    a background image (depth channel = far), back-face culling.  Here: the bumpy sphere of configs[2] with random channel values."""
+    width, height = width or size, height or size
+    m = sphere_scene(size=width, nu=nu, n_rings=n_rings, nb_colors=channels, depth_channel=True, angle=angle)
+    f = m.faces.astype(np.int64).reshape(-1)
+    rs = np.random.RandomState(seed)
+    return Scene2D(
+        faces=np.arange(f.size, dtype=np.uint32).reshape(-1, 3), faces_uv=np.arange(f.size, dtype=np.uint32).reshape(-1, 3),
+        ij=m.ij[f] * [1.0, height / width], depths=m.depths[f], textured=m.textured, uv=np.zeros((f.size, 2)), shade=np.zeros(f.size),
+        colors=np.ascontiguousarray(m.colors[f]), shaded=m.shaded, edgeflags=np.zeros_like(m.edgeflags), height=height, width=width, nb_colors=channels,
+        texture=np.zeros((0, 0)), background_image=rs.rand(height, width, channels) if background_image else None,
+        background_color=None if background_image else rs.rand(channels), clockwise=m.clockwise, backface_culling=True, strict_edge=True,
+        perspective_correct=False, integer_pixel_centers=True,
     )  # fmt: skip
 
 

@@ -75,17 +75,14 @@ for name, s in (("sphere 1024^2 1 view", sphere), ("soup 256^2 200 triangles", s
     hr.force_generic(False)
 
 # the frame of Scene3D.render_deferred (dr.py:1053-1174): triangle soup of the mesh (3 vertices per face), 15 channels, sigma = 0, background image, forward only
-s = scenes.sphere_scene(size=1024, angle=0.0, nb_colors=15, depth_channel=True)
-f = s.faces.astype(np.int64).reshape(-1)
-soup_s = type(s)(faces=np.arange(f.size, dtype=np.uint32).reshape(-1, 3), faces_uv=np.arange(f.size, dtype=np.uint32).reshape(-1, 3), ij=s.ij[f], depths=s.depths[f],
-                 textured=s.textured, uv=np.zeros((f.size, 2)), shade=np.zeros(f.size), colors=np.ascontiguousarray(s.colors[f]), shaded=s.shaded,
-                 edgeflags=np.zeros_like(s.edgeflags), height=s.height, width=s.width, nb_colors=15, texture=np.zeros((0, 0)),
-                 background_image=np.zeros((s.height, s.width, 15)), clockwise=s.clockwise, backface_culling=True)  # fmt: skip
 for C in (15, 4):
-    if C == 4:
-        soup_s.colors = np.ascontiguousarray(soup_s.colors[:, :4]); soup_s.nb_colors = 4; soup_s.background_image = np.zeros((s.height, s.width, 4))
-    ds = dscene(soup_s)
+    s = scenes.deferred_scene(size=1024, channels=C)
+    ds = dscene(s)
     r = HipRasterizer.for_scene(ds)
     image, z = torch.empty((1, s.height, s.width, C), dtype=torch.float32, device=dev), torch.empty((1, s.height, s.width), dtype=torch.float32, device=dev)
     r.render(ds, 0.0, out=(image, z), check_overflow=True)
     report(f"render_deferred shape, C = {C}, sigma = 0, forward only", *timed(lambda: r.render(ds, 0.0, out=(image, z), check_overflow=False)))
+    if C == 15:
+        hr.force_generic(True)
+        report(f"render_deferred shape, C = {C}, sigma = 0, forward only (un-staged)", *timed(lambda: r.render(ds, 0.0, out=(image, z), check_overflow=False)))
+        hr.force_generic(False)
