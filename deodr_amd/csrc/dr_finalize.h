@@ -361,6 +361,20 @@ __global__ void wait_flag_kernel(const uint32_t *flag, uint32_t value, uint32_t 
 
 
 
+// Deterministic mode: DEODR_HIP_ERR_DET_RANGE speaks about ONE adjoint ("the gradients of that call are wrong"), so the bit is cleared when a
+// deterministic adjoint starts (begin = 1: in view 0's sticky word, where det_add raises it, and in the polled word) and copied to the polled
+// word when it ends (begin = 0) -- an asynchronous poller sees it in the same step, and a later, good call does not inherit it.
+__global__ void det_status_kernel(WsHeader *view0, int begin)
+{
+	if (begin)
+	{
+		atomicAnd(&view0->scene_errors, ~(uint32_t)SCENE_ERR_DET_RANGE);
+		atomicAnd(&view0->all_scene_errors, ~(uint32_t)SCENE_ERR_DET_RANGE);
+	}
+	else if (__hip_atomic_load(&view0->scene_errors, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & (uint32_t)SCENE_ERR_DET_RANGE)
+		atomicOr(&view0->all_scene_errors, (uint32_t)SCENE_ERR_DET_RANGE);
+}
+
 // Deterministic mode, last step: every element of a gradient array receives the integer sum of its shadow (one thread per element: a
 // fixed order of two operands) and the shadow is cleared for the next call.
 __global__ __launch_bounds__(256) void det_convert_kernel(long long *shadow, void *out, size_t n, int f64)

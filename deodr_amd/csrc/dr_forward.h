@@ -1476,7 +1476,8 @@ __device__ __forceinline__ void fwd_tiles(const KParams &p, WaveLds *s_lds, Edge
 		uint32_t tm[NBATCH] = {}; // (fused adjoint) bit j of tm[b]: edge 16 b + j of the blending order is drawn over this pixel
 		if (nedge > 0)
 			n_edges = gather_sorted_edges(s_es[wave], w, p, tile, nedge, lane);
-		if (one_batch) // (at most TB <= K_EDGE edges: all of them in the tile's inline list)
+		static_assert(TB <= K_EDGE && TB <= EMAX, "a tile of at most one batch of edges has them all in its inline list: gather_sorted_edges cannot fail there");
+		if (one_batch) // (at most TB <= K_EDGE edges: all of them in the tile's inline list, so n_edges is the tile's count: 1 .. TB)
 			n_edges = n_edges < 0 ? 0 : n_edges > TB ? TB : n_edges;
 		if (split && n_edges < 0)
 		{ // (pairs of this tile lost to a pool overflow -- the call is repeated anyway: the first copy alone takes the un-staged path)

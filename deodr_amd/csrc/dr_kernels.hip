@@ -245,7 +245,8 @@ int det_shadows(KParams &p, int n_views, hipStream_t st)
 		sc.words = need;
 	}
 	p.det = 1;
-	p.det_err = &((WsHeader *)(p.ws + p.L.hdr))->scene_errors; // (view 0: what deodr_hip_workspace_status reads; the next forward copies it to the polled word)
+	p.det_err = &((WsHeader *)(p.ws + p.L.hdr))->scene_errors; // (view 0: what deodr_hip_workspace_status reads; det_convert copies it to the polled word)
+	hipLaunchKernelGGL(det_status_kernel, dim3(1), dim3(1), 0, st, (WsHeader *)(p.ws + p.L.hdr), 1); // (the range bit of the PREVIOUS deterministic adjoint goes)
 	p.det_ij = sc.ptr;
 	p.det_colors = p.det_ij + n_ij;
 	p.det_shade = p.det_colors + n_col;
@@ -268,6 +269,7 @@ void det_convert(const KParams &p, int n_views, hipStream_t st)
 	run(p.det_shade, p.shade_b, n_sh, p.vtx_f64);
 	run(p.det_uv, p.uv_b, n_uv, p.vtx_f64);
 	run(p.det_texture, p.texture_b, n_tex, p.pix_f64);
+	hipLaunchKernelGGL(det_status_kernel, dim3(1), dim3(1), 0, st, (WsHeader *)(p.ws + p.L.hdr), 0);
 }
 // Tuning constants (measured in round 1, profiles/README.md); deliberately NOT read from the environment: nothing outside the
 // arguments of a call may change what the call launches.
@@ -430,8 +432,10 @@ int launch_forward_staged(const KParams &p, bool fused, hipStream_t stream, hipE
 	hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
 	if (DR_TEX_TWO_KERNELS && fused && tex && p.fuse_edges)
 		(void)hipStreamIsCapturing(stream, &capturing);
+	// (the split point must fall between two groups of eight workgroups -- a walker's list and XCD follow from its index in the one-kernel grid
+	// (KParams::block_base) --: true for the shares heavy_share_for returns, checked here for measurement builds with another DR_HEAVY_SHARE)
 	if (DR_TEX_TWO_KERNELS && fused && tex && p.fuse_edges && !p.clamp && p.n_views >= DR_TEX_TWO_KERNELS && q.tile_blocks % (8 * WORK_CHUNK) == 0 &&
-		capturing == hipStreamCaptureStatusNone)
+		q.tile_blocks % q.heavy_share == 0 && (q.tile_blocks / q.heavy_share) % 8 == 0 && capturing == hipStreamCaptureStatusNone)
 	{ // the head walkers (edge adjoint: many registers) on the side stream, everybody else (+ the fill workgroups) on the caller's, both behind the scan
 		const unsigned head = (unsigned)p.n_views * (unsigned)(q.tile_blocks / q.heavy_share);
 		std::lock_guard<std::mutex> lock(g_side_mutex);

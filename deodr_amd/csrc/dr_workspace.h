@@ -373,6 +373,10 @@ constexpr double DET_SCALE = 4294967296.0, DET_INV_SCALE = 1.0 / 4294967296.0;
 // `err`: a sticky scene-error word of the workspace (view 0's WsHeader::scene_errors).  A contribution beyond the range saturates in the
 // conversion and a sum beyond it wraps: both raise SCENE_ERR_DET_RANGE instead of passing silently (the add returns the old value for that:
 // the mode is a test mode, several times slower than the default path anyway).
+// (ADVICE r5 proposed to look at the FINAL sum once per element instead -- order-independent, and the atomic need not return.  Not taken: a sum
+// that wrapped is a valid int64 again, the final value cannot tell; what the returning add buys is that EVERY wrap is seen.  The price is the one
+// the advice names: a sum that leaves the range and comes back -- harmless in two's complement -- raises the bit in the runs whose order of
+// execution takes it out, and not in the others.  The GRADIENTS are bit-identical either way; the bit then says "too close to the range".)
 __device__ __forceinline__ void det_add(void *slot, double v, uint32_t *err)
 {
 	const long long add = __double2ll_rn(v * DET_SCALE);

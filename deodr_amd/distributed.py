@@ -100,7 +100,8 @@ class OverlappedViewsReduction:
     (``DeodrHipFitOptions::done_flag``) and a one-lane kernel on the communication stream that waits for it (``deodr_hip_wait_flag``): an
     event recorded on the render stream and waited for by a second hardware queue costs the render stream ~8 us per step on MI355X, the flag
     1.6.  ``reduce(slot, event=...)`` takes an event instead, for steps that cannot store the flag (the two-call path).
-    The collective is issued under the communication stream; with one rank it is skipped unless ``always_collective``.
+    The collective is issued under the communication stream; with one rank it is skipped unless ``always_collective``.  ``status_every``: steps
+    between two looks at the time-out word of the flag waits (``begin()`` raises at the next look; 64 by default, 1 = every step: see ``__init__``).
 
     Textured scenes (``texture`` = None: when the scene has one): the library adds every local view's texture taps and uv adjoints into ONE
     array each (they are per-scene fields of the reference's struct), so ``slot.grads["texture_b"]`` IS the texture part of the packed buffer
@@ -113,7 +114,7 @@ class OverlappedViewsReduction:
         __slots__ = ("index", "grads", "buffer", "shared", "stage", "stage_parts", "vertices_b", "colors_b", "uv_b", "texture_b", "done_flag", "read", "step",
                      "status_host")
 
-    def __init__(self, ds, camera, posed, group=None, sets=2, always_collective=False, wait_timeout=2.0, texture=None):
+    def __init__(self, ds, camera, posed, group=None, sets=2, always_collective=False, wait_timeout=2.0, texture=None, status_every=64):
         from . import fronthalf
 
         self.device = ds.device
@@ -130,7 +131,12 @@ class OverlappedViewsReduction:
         self.flag = torch.zeros(1, dtype=torch.int32, device=self.device)
         self.wait_status = torch.zeros(1, dtype=torch.int32, device=self.device)
         self.wait_timeout = float(wait_timeout)
-        self.status_every = 64  # steps between two looks at the time-out word of the flag waits (begin() raises at the next look)
+        # Steps between two looks at the time-out word of the flag waits.  A wait that timed out lets every later wait return at once, so between the
+        # time-out and the next look begin() keeps handing out sets whose reductions read INCOMPLETE gradients -- for up to `status_every` steps.
+        # 64: the copy of the word to pinned memory costs the communication stream ~10 us of host time per look, more than the kernels it follows;
+        # 1: every step is checked (a fit loop that cannot afford a bad step; finish() always checks).  The word only changes when a flag wait gives
+        # up after `wait_timeout` seconds, i.e. when the render stream has hung or died.
+        self.status_every = max(1, int(status_every))
         self.collective = always_collective or (dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1)
         self.steps = 0
         self.slots = []

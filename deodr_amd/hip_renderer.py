@@ -135,8 +135,12 @@ def scene_error_message(bits):
         what.append("a triangle is textured and shaded but the scene has no texture")
     if bits & ERR_INTERNAL:
         what.append("internal: a finalize workgroup of a fit step gave up waiting for the tile walkers (gradients incomplete)")
+    det = ("deterministic mode: a gradient contribution or running sum of the last deterministic adjoint left the fixed-point range +- 2^31 "
+           "(the gradients of that call are wrong; the bit is cleared when the next deterministic adjoint starts)")
+    if bits & ERR_DET_RANGE and not what:
+        return det  # (not a statement about the scene)
     if bits & ERR_DET_RANGE:
-        what.append("deterministic mode: a gradient contribution or running sum left the fixed-point range +- 2^31 (gradients of that call are wrong)")
+        what.append(det)
     return "invalid scene (checkSceneValid): " + "; ".join(what)
 
 

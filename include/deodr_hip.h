@@ -99,6 +99,9 @@ int deodr_hip_render_scene(const DeodrHipScene *scene, void *image, void *z_buff
  * sum-of-squares loss L = sum (image - obs)^2 is propagated, i.e. image_b = 2 (image - obs) is formed inside the kernel
  * from the rendered image (what Scene2D.render_compare_and_backward does on the host, dr.py:728-732) instead of being
  * written to and read back from HBM.
+ * antialiase_error != 0 (`image` = the frame deodr_hip_render_scene wrote in this mode, `obs`, `err_buffer_b`): nb_colors <= 4 runs on
+ * the LDS-staged kernels since round 6 (tiles without silhouette edges: image_b = -2 (obs - image) err_buffer_b, H.h:3054-3060; tiles with:
+ * a staged sweep over the error buffer, H.h:2200-2368, 2481-2618); more channels, and the deterministic mode, on the un-staged ones.
  * have_forward_state != 0: the workspace still holds the state of the matching deodr_hip_render_scene call (same scene
  * arrays, same sigma) and is reused; 0: the forward state is recomputed first (stateless use, as the reference).  After a
  * deodr_hip_render_scene_fit on the same workspace the state is always recomputed (the fused forward does not keep the
@@ -115,7 +118,15 @@ int deodr_hip_render_scene_b(const DeodrHipScene *scene, const void *image, cons
  * is known as soon as the pixel is resolved, the forward raster back-propagates through the tiles that have no silhouette
  * edge in the same pass; only the tiles with edges are visited again.  Same preconditions as deodr_hip_render_scene_b.
  * clear_gradients != 0: the scene's *_b arrays are zeroed first (Scene2D.clear_gradients, dr.py) inside the same launches,
- * so that a fit loop needs no separate fills; 0: they are accumulated into, as renderScene_B does. */
+ * so that a fit loop needs no separate fills; 0: they are accumulated into, as renderScene_B does.
+ * STREAMS.  Everything is queued on `stream`, with two exceptions that go through ONE library-owned side stream per device (forked from and
+ * joined back to `stream` by events, so that the call still looks ordered on `stream` to the caller): the background fill of a forward-only
+ * deodr_hip_render_scene, and -- a TEXTURED fit step of 8 views or more -- the head walkers of the forward raster (a kernel of their own at
+ * three waves per SIMD; everybody else runs beside it at four).  Callers that drive ONE device from several host threads or streams are
+ * therefore serialised through that side stream (and a mutex held across its two launches) for those calls; results are unaffected.  Under
+ * stream capture the textured fit step takes its ONE-kernel form (a captured graph has no second stream to fork to), so eager and
+ * captured runs of such a step launch different kernel instances: equal results up to the order of the float atomics, different timings
+ * -- compare eager with eager, replay with replay. */
 int deodr_hip_render_scene_fit(const DeodrHipScene *scene, void *image, void *z_buffer, double sigma, const void *obs,
 							   int clear_gradients, void *workspace, size_t workspace_bytes, void *stream);
 
