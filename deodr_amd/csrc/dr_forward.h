@@ -860,6 +860,17 @@ __device__ __forceinline__ void fill_share_word(const KParams &p, int bit, int v
 // view's work list (usually one or two).  rank() deals the list to the XCDs in chunks of 64 consecutive entries (workgroup b
 // runs on XCD b % 8; consecutive entries are neighbouring tiles, which share triangle records and should share an L2).
 
+// x / n_views without the division (KParams::views_magic = floor(2^32 / n) + 1, or 2^32 - 1 for one view): the estimate mulhi(x, magic) is off by at
+// most one either way (n >= 2: exact or one too large, as magic * n exceeds 2^32 by at most n; n = 1: one too small), two compares settle it
+__device__ __forceinline__ uint32_t div_views(const KParams &p, uint32_t x)
+{
+	const uint32_t n = (uint32_t)p.n_views;
+	uint32_t qv = __umulhi(x, p.views_magic);
+	qv -= qv * n > x ? 1u : 0u;
+	qv += (qv + 1u) * n <= x ? 1u : 0u;
+	return qv;
+}
+
 __host__ __device__ inline int fwd_tile_blocks(int ntiles, int n_views, bool dealt_fill)
 { // workgroups per view that walk the work list: a quarter of the tiles (about a third of a frame's tiles hold primitives, and most
   // of those pair up: about one entry per walker) -- a sixth from 8 views up in a fit step of an untextured scene (dealt_fill): with the
@@ -1270,13 +1281,13 @@ __device__ __forceinline__ void fwd_tiles(const KParams &p, WaveLds *s_lds, Edge
 	const bool chunked = G % (8 * WORK_CHUNK) == 0;
 	if (chunked)
 	{
-		const uint32_t g8 = b >> 3, gq = g8 / (uint32_t)p.n_views;
+		const uint32_t g8 = b >> 3, gq = div_views(p, g8);
 		view = (int)(g8 - gq * (uint32_t)p.n_views);
 		q = (int)(gq * 8 + (b & 7));
 	}
 	else
 	{
-		const uint32_t gq = b / (uint32_t)p.n_views;
+		const uint32_t gq = div_views(p, b);
 		view = (int)(b - gq * (uint32_t)p.n_views);
 		q = (int)gq;
 	}
@@ -1289,7 +1300,7 @@ __device__ __forceinline__ void fwd_tiles(const KParams &p, WaveLds *s_lds, Edge
 	// the back): the index of a workgroup's entry does not depend on the counts, so the counts, the entry header and the
 	// entry's triangle ids are all requested at once.
 	// (tiny frames -- G not a multiple of 512 -- have one class only: the scan kernel lists every tile as "other")
-	const int Gh = chunked ? G / p.heavy_share : 0;
+	const int Gh = chunked ? (int)p.fwd_heads : 0; // (= G / p.heavy_share, from the host)
 	const bool heavy_list = q < Gh;
 	const int qq = heavy_list ? q : q - Gh, stride = heavy_list ? Gh : G - Gh;
 	const bool chunk_here = chunked && stride % (8 * WORK_CHUNK) == 0;
@@ -1813,11 +1824,11 @@ __global__ __launch_bounds__(64, DR_FWD_WAVES) void raster_fwd_fast_kernel(KPara
 	// dispatched behind the last walker they START when the last walker has a slot, and the kernel then ends a fill later (73 MB of
 	// stores per 8-view step: same-box A/B 0.1279 / 0.1274 -> 0.1238 / 0.1232 ms, profiles/r04l).  (Round 3 measured "spread evenly:
 	// nothing" -- with the heavy tiles still deciding when the kernel ends.)
-	const uint32_t n_walk = (uint32_t)p.n_views * (uint32_t)p.tile_blocks, n_fill = (uint32_t)p.n_views * (uint32_t)fill_share(p.fill_mode, 2, p.L.nwords);
+	const uint32_t n_walk = (uint32_t)p.n_views * (uint32_t)p.tile_blocks, n_fill = p.fwd_n_fill; // (= n_views * fill_share(fill_mode, 2, nwords), from the host)
 #ifndef DR_FILL_DEAL
 #define DR_FILL_DEAL 1 // (measurement builds: 0 = the fill workgroups behind the walkers, as in round 3)
 #endif
-	const uint32_t dealt = (DR_FILL_DEAL && FUSED && !TEX && p.fuse_edges && n_walk >= 8 * n_fill) ? n_fill / 8 : 0; // groups of 64 walkers + 8 fill workgroups
+	const uint32_t dealt = (DR_FILL_DEAL && FUSED && !TEX) ? p.fwd_dealt : 0; // groups of 64 walkers + 8 fill workgroups (the host: fuse_edges && n_walk >= 8 n_fill ? n_fill / 8 : 0)
 	uint32_t b = blockIdx.x + p.block_base; // (32-bit throughout: see fwd_tiles)
 	int fi = -1;
 	if (b < dealt * 72)
@@ -1848,8 +1859,8 @@ __global__ __launch_bounds__(64, DR_FWD_WAVES) void raster_fwd_fast_kernel(KPara
 	{ // (p.fuse_edges is set: the host and the scan kernel follow the same rule -- fit step of an untextured scene)
 		const int G = p.tile_blocks;
 		const bool chunked = G % (8 * WORK_CHUNK) == 0;
-		const int q = chunked ? (int)((b >> 3) / p.n_views) * 8 + (int)(b & 7) : 0;
-		if (chunked && q >= G / p.heavy_share)
+		const int q = chunked ? (int)div_views(p, b >> 3) * 8 + (int)(b & 7) : 0;
+		if (chunked && q >= (int)p.fwd_heads)
 			fwd_tiles<PixT, FUSED, TEX, FWD_NO_EDGES, CLAMP>(p, s_lds, s_es, b); // the rest of the list: no tile with edges
 		else
 			fwd_tiles<PixT, FUSED, TEX, FWD_EDGE_ADJ, CLAMP>(p, s_lds, s_es, b); // the head (tiny frames: the whole list)

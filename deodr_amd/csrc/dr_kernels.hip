@@ -402,6 +402,18 @@ int side_stream(SideStream &out)
 	return 0;
 }
 
+// KParams::fwd_* / views_magic: what every workgroup of the staged forward (and of raster_bwd_fast_kernel, which walks the same list) would otherwise
+// derive for itself (tile_blocks, heavy_share, fill_mode, n_views are set)
+void forward_launch_constants(KParams &q)
+{
+	const bool chunked = q.tile_blocks % (8 * WORK_CHUNK) == 0;
+	q.fwd_heads = chunked ? (uint32_t)(q.tile_blocks / q.heavy_share) : 0u;
+	const uint32_t n_walk = (uint32_t)q.n_views * (uint32_t)q.tile_blocks;
+	q.fwd_n_fill = (uint32_t)q.n_views * (uint32_t)fill_share(q.fill_mode, 2, q.L.nwords);
+	q.fwd_dealt = (q.fuse_edges && n_walk >= 8 * q.fwd_n_fill) ? q.fwd_n_fill / 8 : 0u;
+	q.views_magic = q.n_views == 1 ? 0xffffffffu : (uint32_t)(0x100000000ull / (unsigned long long)q.n_views) + 1u; // (see div_views)
+}
+
 // Staged forward: counters -> work list + tile bitmap (scan), then the raster on the caller's stream and, forked from it, the
 // background fill on the side stream.  *join receives the event the caller's stream has to wait for before the call returns
 // control to it (the fill overlaps whatever the call launches in between).
@@ -412,6 +424,7 @@ int launch_forward_staged(const KParams &p, bool fused, hipStream_t stream, hipE
 	q.tile_blocks = fwd_tile_blocks(p.L.ntiles, p.n_views, fused && p.fuse_edges);
 	q.heavy_share = heavy_share_for(p.n_views, q.tile_blocks, fused && p.fuse_edges);
 	q.split_part = split_part_for(p.n_views, q.tile_blocks);
+	forward_launch_constants(q);
 	hipLaunchKernelGGL(tile_scan_kernel, dim3((p.L.ntiles + SCAN_BLOCK - 1) / SCAN_BLOCK, p.n_views), dim3(SCAN_BLOCK), 0, stream, q);
 	if (p.fill_mode == 0)
 	{

@@ -217,6 +217,13 @@ struct KParams
 	uint32_t *done_flag;
 	uint32_t done_value;
 	int split_part; // edges per copy of a tile with several batches of silhouette edges (fused forward: dr_forward.h)
+	// Launch constants of the staged forward raster, formed ONCE on the host (round 6): every one of its 27 000 one-wave workgroups used to derive them
+	// on the scalar unit before its first load -- four integer divisions (by the number of views, by the head share, inside fill_share) among the ~420
+	// instructions in front of a walker's first tile, on a scalar unit that twenty wavefronts of a CU share.
+	uint32_t fwd_heads;	  // walkers per view on the head of the work list: tile_blocks / heavy_share (0: the list has one class)
+	uint32_t fwd_n_fill;  // workgroups of this launch that stream the background of the forward's share of the empty tiles
+	uint32_t fwd_dealt;	  // of those, groups of eight dealt among the walkers (behind every 64), see raster_fwd_fast_kernel
+	uint32_t views_magic; // floor(2^32 / n_views) + 1: x / n_views = mulhi(x, magic) for x < 2^32 / n_views (every workgroup index >> 3 is)
 	uint32_t block_base; // staged forward launched as two kernels (textured fit step): index of this launch's first workgroup in the one-kernel grid
 	// loss of a fit step, sum (image - obs)^2 (deodr_hip_render_scene_fit_loss): loss_tile_bg[0] = the loss of a frame that is all
 	// background, [1 + view * ntiles + tile] = that of one tile; loss_wave[view * LOSS_SLOTS + q % LOSS_SLOTS]: walker q of the forward
