@@ -1275,7 +1275,7 @@ __device__ __forceinline__ void fwd_tiles(const KParams &p, WaveLds *s_lds, Edge
   // as `long long` the two divisions by the number of views alone were ~250 instructions of 64-bit division emulation)
 	DR_WAVE_TRACE_SCOPE(2);
 	constexpr int wave = 0;
-	const int lane0 = threadIdx.x & 63;
+	const int lane0 = wave_lane(); // (= threadIdx.x: one-wave workgroups; see wave_lane)
 	const int G = p.tile_blocks;
 	int view, q;
 	const bool chunked = G % (8 * WORK_CHUNK) == 0;
@@ -1321,7 +1321,7 @@ __device__ __forceinline__ void fwd_tiles(const KParams &p, WaveLds *s_lds, Edge
 	{
 		// (the lane index is made opaque per iteration: otherwise every lane-dependent address of the body is hoisted out of the
 		// loop and kept -- spilled -- in registers across it: + 150 VGPRs for a loop that usually runs once or twice)
-		int lane = lane0;
+		int lane = wave_lane();
 		asm volatile("" : "+v"(lane));
 		// this iteration's entry has been requested an iteration ago (or in front of the loop); the NEXT one of this walker is requested
 		// now, a whole tile ahead of its use: its position does not depend on anything this tile computes
@@ -1774,7 +1774,7 @@ __device__ __forceinline__ void fwd_tiles(const KParams &p, WaveLds *s_lds, Edge
 			tile_body(std::false_type{});
 		lds_sync(); // the next tile of this wavefront reuses the staging area
 	}
-	if (q == 0 && threadIdx.x == 0)
+	if (q == 0 && wave_lane() == 0)
 		close_epoch(p, w, FUSED);
 }
 
@@ -1848,7 +1848,7 @@ __global__ __launch_bounds__(64, DR_FWD_WAVES) void raster_fwd_fast_kernel(KPara
 	if (fi >= 0)
 	{
 		if ((uint32_t)fi < n_fill)
-			fill_share_word(p, 2, (int)((uint32_t)fi % (uint32_t)p.n_views), (int)((uint32_t)fi / (uint32_t)p.n_views), threadIdx.x & 63);
+			fill_share_word(p, 2, (int)((uint32_t)fi % (uint32_t)p.n_views), (int)((uint32_t)fi / (uint32_t)p.n_views), wave_lane());
 		return;
 	}
 	if constexpr (TEXE == 2)

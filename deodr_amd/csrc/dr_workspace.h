@@ -373,6 +373,12 @@ __device__ __forceinline__ void kernel_stamp(const KParams &p, int id)
 
 __device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
+// The lane's index in its wavefront, from the execution mask (v_mbcnt) instead of threadIdx.x: in a one-wave workgroup the two are the same number,
+// but threadIdx.x is a live-in of the kernel -- register v0 from the first instruction to the last use -- and the register allocator of the forward
+// raster (96 registers, spilling) chose to send it to scratch memory at the kernel's first instruction and to reload it right in front of a walker's
+// first load: a memory round trip in the prologue of every wavefront.  This one is two instructions wherever it is needed.  All lanes must be enabled.
+__device__ __forceinline__ int wave_lane() { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+
 __device__ __forceinline__ void atomic_add_f64(double *p, double v) { unsafeAtomicAdd(p, v); }
 
 // fixed point of the deterministic mode: |sum| < 2^31, resolution 2^-32
