@@ -534,7 +534,11 @@ int launch_forward(const DeodrHipScene *sc, KParams &p, hipStream_t stream, hipE
 	const bool fast = (p.C <= CH || many_channels) && !g_force_generic && !det_mode(sc);
 	if (p.T > 0)
 	{
-		dim3 grid((unsigned)prim_blocks(p.T) * (unsigned)n_views);
+#ifndef DR_SPARSE_MAX
+#define DR_SPARSE_MAX 16384 // triangles (all views) up to which the set-up kernel spreads them over four times the wavefronts (KParams::setup_sparse)
+#endif
+		p.setup_sparse = (long long)p.T * n_views <= DR_SPARSE_MAX ? 4 : 1;
+		dim3 grid((unsigned)(prim_tri_blocks(p.T * p.setup_sparse) + prim_edge_blocks(p.T, p.setup_sparse > 1 ? 1 : EDGE_SLOTS)) * (unsigned)n_views);
 		ScopedKernelTimer t(KID_SETUP, stream);
 		// (instances for the vertex dtype and for the channel counts that occur -- RGB, RGB + depth --; other counts: the run-time one)
 #define DR_LAUNCH_PRIM(kernel, grid_, stream_)                                                                              \

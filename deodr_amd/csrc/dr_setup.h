@@ -118,9 +118,12 @@ struct PrimWork
 	bool tri;
 	int view_block; // a block id in [0, prim_blocks(T)) inside the view (housekeeping loops)
 };
-__device__ __forceinline__ PrimWork prim_work(const KParams &p, bool edge_first = DR_EDGE_FIRST, int skip = 0)
+// tri_slots: triangle slots of a view (p.T, or p.T * KParams::setup_sparse in the set-up kernel of a small scene: see setup_bin_kernel)
+__host__ __device__ inline int prim_edge_blocks(int T, int slots_per_thread) { return (3 * T + PRIM_BLOCK * slots_per_thread - 1) / (PRIM_BLOCK * slots_per_thread); }
+// edge_slots: edge slots an edge-slot block looks at per thread (EDGE_SLOTS, or 1 in the set-up kernel of a small scene)
+__device__ __forceinline__ PrimWork prim_work(const KParams &p, bool edge_first = DR_EDGE_FIRST, int skip = 0, int tri_slots = -1, int edge_slots = EDGE_SLOTS)
 {
-	const int TBk = prim_tri_blocks(p.T), EB = prim_blocks(p.T) - TBk, nv = p.n_views;
+	const int TBk = prim_tri_blocks(tri_slots < 0 ? p.T : tri_slots), EB = prim_edge_blocks(p.T, edge_slots), nv = p.n_views;
 	int b = (int)blockIdx.x - skip;
 	PrimWork w;
 	const int first = (edge_first ? EB : TBk) * nv;
@@ -141,16 +144,16 @@ __device__ __forceinline__ PrimWork prim_work(const KParams &p, bool edge_first 
 // Compacts the flagged slots of an edge block into s_slots (LDS) and returns how many there are; the threads of the block then take
 // them PRIM_BLOCK at a time: round r, thread t -> edge_round_slot(total, r) (or -1).  Called by every thread of an edge block.
 __shared__ uint32_t s_edge_slots[EDGE_BLOCK_SLOTS];
-__device__ __forceinline__ uint32_t compact_flagged_slots(const KParams &p, const uint8_t *edgeflags, int edge_block)
-{
+__device__ __forceinline__ uint32_t compact_flagged_slots(const KParams &p, const uint8_t *edgeflags, int edge_block, int per_thread = EDGE_SLOTS)
+{ // per_thread <= EDGE_SLOTS: slots per thread of THIS launch's edge blocks (prim_work's edge_slots)
 	__shared__ uint32_t s_count[PRIM_BLOCK / 64];
 	const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-	const int slot0 = (edge_block * PRIM_BLOCK + tid) * EDGE_SLOTS;
+	const int slot0 = (edge_block * PRIM_BLOCK + tid) * per_thread;
 	uint32_t flags = 0; // bit i: slot0 + i is flagged
 	if (p.sigma > 0)
 #pragma unroll
 		for (int i = 0; i < EDGE_SLOTS; i++)
-			if (slot0 + i < 3 * p.T && edgeflags[slot0 + i] != 0)
+			if (i < per_thread && slot0 + i < 3 * p.T && edgeflags[slot0 + i] != 0)
 				flags |= 1u << i;
 	const uint32_t mine = (uint32_t)__popc(flags);
 	// exclusive prefix of `mine` over the lanes of the wavefront, then over the wavefronts
@@ -242,10 +245,17 @@ __global__ __launch_bounds__(PRIM_BLOCK, DR_PRIM_WAVES) void setup_bin_kernel(KP
 		p.C = NC, p.L.P = NC < 3 ? 3 : NC;
 	kernel_stamp(p, 0);
 	DR_WAVE_TRACE_SCOPE(0);
-	const PrimWork pw = prim_work(p);
+	// Small scenes (round 6): a triangle every `sparse` lanes.  A mesh of a thousand large triangles (the hand at 1024^2: 33 tiles per triangle) is 17
+	// wavefronts on 256 CUs, each with 64 triangles' worth of 3 x 3-tile blocks to bin -- two or three rounds of dependent slot requests (bin_rest), a
+	// soup of 200 triangles nine; the lanes in between take part in that dealing and have nothing else to do, so spread over four times the wavefronts
+	// (on a chip that is empty anyway) a wavefront's share fits one round.  The host sets it for launches of at most DR_SPARSE_MAX triangles.
+	// The same for the edge-slot blocks: ONE slot per thread instead of EDGE_SLOTS (a soup flags every edge: 600 slots were one workgroup working
+	// through three rounds of 256 edges, each with its own rounds of slot requests).
+	const int sparse = p.setup_sparse > 1 ? p.setup_sparse : 1, edge_slots = p.setup_sparse > 1 ? 1 : EDGE_SLOTS;
+	const PrimWork pw = prim_work(p, DR_EDGE_FIRST, 0, p.T * sparse, edge_slots);
 	const int view = pw.view;
 	const int item = pw.view_block * PRIM_BLOCK + threadIdx.x; // only an id for the housekeeping below
-	const int n_items = prim_blocks(p.T) * PRIM_BLOCK;
+	const int n_items = (prim_tri_blocks(p.T * sparse) + prim_edge_blocks(p.T, edge_slots)) * PRIM_BLOCK;
 	const bool tri_block = pw.tri;
 	const SceneView s = scene_view(p, view);
 	const ViewPtrs w = view_ptrs(p, view);
@@ -387,8 +397,8 @@ __global__ __launch_bounds__(PRIM_BLOCK, DR_PRIM_WAVES) void setup_bin_kernel(KP
 		int btx0 = 0, bty0 = 0, bntx = 0, bnty = 0, bprim = 0;
 		do
 		{
-			const int k = pw.index * PRIM_BLOCK + threadIdx.x;
-			if (k >= p.T)
+			const int slot = pw.index * PRIM_BLOCK + threadIdx.x, k = slot / sparse;
+			if (k >= p.T || slot != k * sparse)
 				break;
 			TriInputs t;
 			TriRec rec;
@@ -463,7 +473,7 @@ __global__ __launch_bounds__(PRIM_BLOCK, DR_PRIM_WAVES) void setup_bin_kernel(KP
 	}
 	// nothing is written for the ~97 % of slots that are not silhouette edges: records are only reached through the
 	// tile lists, and finalize_kernel works from the same flags
-	const uint32_t n_flagged = compact_flagged_slots(p, s.edgeflags, pw.index);
+	const uint32_t n_flagged = compact_flagged_slots(p, s.edgeflags, pw.index, edge_slots);
 	DR_WAVE_PHASE(1); // flags compacted
 	// A round per PRIM_BLOCK flagged slots: one, unless most edges of the block are flagged (a triangle soup).  The first round is
 	// written out and the others loop over a second copy of the same code: as ONE loop the body kept its loop-invariant values in
