@@ -102,7 +102,10 @@ __device__ __forceinline__ void finalize_body(KParams &p)
 	}
 	const int fill_n = fill_share(p.fill_mode, 1, p.L.nwords), fill_blocks = (p.n_views * fill_n + PRIM_BLOCK / 64 - 1) / (PRIM_BLOCK / 64);
 	const int bx = (int)blockIdx.x - loss_blocks;
-	const int fb = DR_FILL_FIRST ? bx : bx - p.n_views * prim_blocks(p.T); // index among the fill workgroups
+	// (small launches, KParams::setup_sparse: ONE edge slot per thread, as in the set-up kernel -- a soup's 600 flagged edges are three workgroups of one
+	// round each instead of one workgroup of three rounds)
+	const int edge_slots = p.setup_sparse > 1 ? 1 : EDGE_SLOTS, pblocks = prim_tri_blocks(p.T) + prim_edge_blocks(p.T, edge_slots);
+	const int fb = DR_FILL_FIRST ? bx : bx - p.n_views * pblocks; // index among the fill workgroups
 	if (DR_FILL_FIRST ? fb < fill_blocks : fb >= 0)
 	{ // workgroups that stream the background of this kernel's share of the empty tiles (fill_share)
 		const int gw = fb * (PRIM_BLOCK / 64) + (int)(threadIdx.x >> 6);
@@ -113,7 +116,7 @@ __device__ __forceinline__ void finalize_body(KParams &p)
 #ifndef DR_FIN_EDGE_FIRST
 #define DR_FIN_EDGE_FIRST 1 // (triangle blocks first: finalize 37.5 -> 43.5 us)
 #endif
-	const PrimWork pw = prim_work(p, DR_FIN_EDGE_FIRST, (DR_FILL_FIRST ? fill_blocks : 0) + loss_blocks);
+	const PrimWork pw = prim_work(p, DR_FIN_EDGE_FIRST, (DR_FILL_FIRST ? fill_blocks : 0) + loss_blocks, -1, edge_slots);
 	const int view = pw.view;
 	const bool tri_block = pw.tri;
 	const SceneView s = scene_view(p, view);
@@ -148,7 +151,7 @@ __device__ __forceinline__ void finalize_body(KParams &p)
 				acc[i] = 0;
 			return;
 		}
-		const uint32_t n_flagged = compact_flagged_slots(p, s.edgeflags, pw.index);
+		const uint32_t n_flagged = compact_flagged_slots(p, s.edgeflags, pw.index, edge_slots);
 		for (int round = 0; round * PRIM_BLOCK < (int)n_flagged; round++)
 		{
 			const int slot = edge_round_slot(n_flagged, round);
@@ -242,7 +245,7 @@ __device__ __forceinline__ void finalize_body(KParams &p)
 		}
 		return;
 	}
-	const uint32_t n_flagged = compact_flagged_slots(p, s.edgeflags, pw.index);
+	const uint32_t n_flagged = compact_flagged_slots(p, s.edgeflags, pw.index, edge_slots);
 	DR_WAVE_PHASE(1); // flags compacted
 	for (int round = 0; round * PRIM_BLOCK < (int)n_flagged; round++)
 	{ // (a round per PRIM_BLOCK flagged slots: see setup_bin_kernel)

@@ -414,6 +414,11 @@ void forward_launch_constants(KParams &q)
 	q.views_magic = q.n_views == 1 ? 0xffffffffu : (uint32_t)(0x100000000ull / (unsigned long long)q.n_views) + 1u; // (see div_views)
 }
 
+#ifndef DR_SPARSE_MAX
+#define DR_SPARSE_MAX 16384 // triangles (all views) up to which the per-primitive kernels spread their work over more wavefronts (KParams::setup_sparse)
+#endif
+bool small_launch(int T, int n_views) { return (long long)T * n_views <= DR_SPARSE_MAX; }
+
 // Staged forward: counters -> work list + tile bitmap (scan), then the raster on the caller's stream and, forked from it, the
 // background fill on the side stream.  *join receives the event the caller's stream has to wait for before the call returns
 // control to it (the fill overlaps whatever the call launches in between).
@@ -534,10 +539,7 @@ int launch_forward(const DeodrHipScene *sc, KParams &p, hipStream_t stream, hipE
 	const bool fast = (p.C <= CH || many_channels) && !g_force_generic && !det_mode(sc);
 	if (p.T > 0)
 	{
-#ifndef DR_SPARSE_MAX
-#define DR_SPARSE_MAX 16384 // triangles (all views) up to which the set-up kernel spreads them over four times the wavefronts (KParams::setup_sparse)
-#endif
-		p.setup_sparse = (long long)p.T * n_views <= DR_SPARSE_MAX ? 4 : 1;
+		p.setup_sparse = small_launch(p.T, n_views) ? 4 : 1;
 		dim3 grid((unsigned)(prim_tri_blocks(p.T * p.setup_sparse) + prim_edge_blocks(p.T, p.setup_sparse > 1 ? 1 : EDGE_SLOTS)) * (unsigned)n_views);
 		ScopedKernelTimer t(KID_SETUP, stream);
 		// (instances for the vertex dtype and for the channel counts that occur -- RGB, RGB + depth --; other counts: the run-time one)
@@ -608,7 +610,9 @@ int launch_adjoint(const DeodrHipScene *sc, KParams &p, hipStream_t st, bool own
 	if (p.T > 0)
 	{
 		const int fill_words = fast ? sc->n_views * fill_share(p.fill_mode, 1, p.L.nwords) : 0;
-		dim3 g2((unsigned)prim_blocks(p.T) * (unsigned)sc->n_views + (unsigned)((fill_words + PRIM_BLOCK / 64 - 1) / (PRIM_BLOCK / 64)) +
+		p.setup_sparse = small_launch(p.T, sc->n_views) ? 4 : 1; // (finalize_kernel: one edge slot per thread then)
+		dim3 g2((unsigned)(prim_tri_blocks(p.T) + prim_edge_blocks(p.T, p.setup_sparse > 1 ? 1 : EDGE_SLOTS)) * (unsigned)sc->n_views +
+				(unsigned)((fill_words + PRIM_BLOCK / 64 - 1) / (PRIM_BLOCK / 64)) +
 				(p.loss_out ? 1u : 0u)); // (+ the workgroup that adds up the loss)
 		ScopedKernelTimer t(KID_FINALIZE, st);
 		if (p.det && p.vtx_f64)
