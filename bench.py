@@ -210,7 +210,9 @@ def other_configs(dev):
         r.render(ds, 1.0, out=(image, z), check_overflow=True)
         for _ in range(5):
             fit()
-        dt = timed_steps(fit, steps)
+        # (best of three short regions: one host-side stall of tens of milliseconds -- seen once in round 6: configs[4] read 4.57 ms instead of
+        # 0.81 -- otherwise decides the average of ten steps; the headline is not treated that way: its region is the driver's)
+        dt = min(timed_steps(fit, steps) for _ in range(3))
         tex_hw = (ds.texture.shape[0], ds.texture.shape[1]) if ds.texture is not None else None
         alg = survey_8d_bytes(H, W, Cc, ds.nb_triangles, int(ds.depths.shape[1]), n, Vuv=int(ds.uv.shape[0]), tex_hw=tex_hw,
                               bg_image=ds.background_image is not None)  # fmt: skip
