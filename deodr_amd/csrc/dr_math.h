@@ -175,6 +175,25 @@ DR_HD int first_failing(int x_min, int x_max, Pred holds)
 	return lo;
 }
 
+// the reference's slow walks (never taken by a usual frame): ONE out-of-line copy per kernel instead of one inlined at every call site of the
+// raster kernels (DR_SLOW_DIV_OUTLINE = 0 builds the neighbour)
+#ifndef DR_SLOW_DIV_OUTLINE
+#define DR_SLOW_DIV_OUTLINE 1
+#endif
+#if defined(__HIPCC__) && DR_SLOW_DIV_OUTLINE
+#define DR_SLOW __host__ __device__ __attribute__((noinline))
+#else
+#define DR_SLOW DR_HD
+#endif
+DR_SLOW int div_slow_walk(double a, double b, int x_min, int x_max, int ceil_mode)
+{
+	if (x_min >= x_max)
+		return x_min;
+	if (!ceil_mode)
+		return b > 0 ? first_failing(x_min, x_max, [=](int t) { return (t + 1) * b <= a; }) : first_failing(x_min, x_max, [=](int t) { return (t + 1) * b >= a; });
+	return b > 0 ? first_failing(x_min, x_max, [=](int t) { return (t + 1) * b < a; }) : first_failing(x_min, x_max, [=](int t) { return (t + 1) * b > a; });
+}
+
 DR_HD int floor_div(double a, double b, int x_min, int x_max) // H.h:440-479
 {
 	int x;
@@ -186,12 +205,8 @@ DR_HD int floor_div(double a, double b, int x_min, int x_max) // H.h:440-479
 		if (x > x_max)
 			x = x_max;
 	}
-	else if (x_min >= x_max)
-		x = x_min;
-	else if (b > 0)
-		x = first_failing(x_min, x_max, [=](int t) { return (t + 1) * b <= a; });
 	else
-		x = first_failing(x_min, x_max, [=](int t) { return (t + 1) * b >= a; });
+		x = div_slow_walk(a, b, x_min, x_max, 0);
 	return x;
 }
 
@@ -206,12 +221,8 @@ DR_HD int ceil_div(double a, double b, int x_min, int x_max) // H.h:481-519
 		if (x > x_max)
 			x = x_max;
 	}
-	else if (x_min >= x_max)
-		x = x_min;
-	else if (b > 0)
-		x = first_failing(x_min, x_max, [=](int t) { return (t + 1) * b < a; });
 	else
-		x = first_failing(x_min, x_max, [=](int t) { return (t + 1) * b > a; });
+		x = div_slow_walk(a, b, x_min, x_max, 1);
 	return x;
 }
 
