@@ -126,3 +126,33 @@ def test_many_channel_frame_on_the_staged_forward(oracle_api, dt, channels, back
         hr.force_generic(False)
     assert np.abs(out2[0][0] - out[0][0]).max() < (1e-12 if dt == F64 else 1e-6)
     assert (np.isfinite(out2[1][0]) == np.isfinite(out[1][0])).all()
+
+
+@pytest.mark.parametrize("dt", [F32, F64])
+def test_many_channel_frame_64_channels_two_views(oracle_api, dt):
+    """The channel limit (DEODR_HIP_MAX_COLORS = 64): a tile row of 64 float64 channels is 4 KB -- the frame leaves LDS one tile row per pass --, two views."""
+    from hip_util import hip_render, image_report
+
+    views = [scenes.deferred_scene(channels=64, nu=24, n_rings=20, angle=a, width=88, height=64, background_image=True, seed=9) for a in (0.0, 0.4)]
+    ref = checker(oracle_api)
+    ds, r, out = hip_render(views, 0.0, dt)
+    for i, s in enumerate(views):
+        image_ref, z_ref = ref.render(s, 0.0)
+        err, flipped = image_report(out[0][i], image_ref, out[1][i], z_ref, 1e-5)
+        assert flipped == 0 and err < (1e-9 if dt == F64 else 1e-5), (i, err, flipped)
+
+
+def test_antialiase_error_forward_perspective_correct(oracle_api):
+    """perspective_correct has no adjoint in the reference (H.h:810), but its forward exists in every mode: the staged antialiase_error forward too."""
+    from hip_util import hip_render
+
+    s = scenes.sphere_scene(size=112, nu=30, n_rings=24, nb_colors=3, depth_channel=False, angle=0.15)
+    s.perspective_correct = True
+    rs = np.random.RandomState(3)
+    obs = rs.rand(s.height, s.width, 3)
+    ref = checker(oracle_api)
+    image, z, err = ref.render(s, 1.5, True, obs)
+    for dt, tol in ((F64, 1e-9), (F32, 1e-5)):
+        ds, r, out = hip_render(s, 1.5, dt, True, obs)
+        assert np.abs(out[0][0] - image).max() < tol and np.abs(out[2][0] - err).max() < tol * max(1.0, err.max())
+        assert (np.isfinite(out[1][0]) == np.isfinite(z)).all()
