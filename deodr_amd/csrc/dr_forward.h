@@ -478,7 +478,9 @@ __global__ __launch_bounds__(SCAN_BLOCK) void tile_scan_kernel(KParams p)
 	// adds its triangle ids to that entry.
 	bool pair_left = false, pair_right = false;
 	uint32_t ntri_right = 0;
-	if (DR_PAIR_TILES && p.fuse_edges && !p.texture && (p.L.tiles_x & 1) == 0 && p.tile_blocks % (8 * WORK_CHUNK) == 0)
+	// (textured scenes, round 6: below DR_TEX_TWO_KERNELS views per launch only -- KParams::pair_tex, the host's rule: from 8 views on the head walkers
+	// are a kernel of their own and the critical path, pairs among the others bought nothing there and cost 11 %: profiles/r06tp_*)
+	if (DR_PAIR_TILES && p.fuse_edges && (!p.texture || p.pair_tex) && (p.L.tiles_x & 1) == 0 && p.tile_blocks % (8 * WORK_CHUNK) == 0)
 	{
 		const bool plain = work && !heavy && nedge == 0 && ntri > 0;
 		const uint32_t n_next = (uint32_t)__shfl_down((int)(plain ? ntri : 0u), 1, 64), n_prev = (uint32_t)__shfl_up((int)(plain ? ntri : 0u), 1, 64);
@@ -910,7 +912,10 @@ __host__ __device__ inline int fwd_tile_blocks(int ntiles, int n_views, bool dea
 // benchmark scene pair up.  A slot belongs to ONE of the two tiles (slots 0 .. nA - 1 to A, the others to B: binning is exact, a
 // triangle listed only in A covers no pixel of B; a triangle listed in both has two slots), so coverage, depth test -- min (Z,
 // index) per pixel -- and therefore every result are those of the two tiles walked one after the other.
-template <class PixT, bool CLAMP>
+// TEX (round 6): textured scenes pair up too -- configs[4]'s tiles hold 5.9 triangles on average (median 4), and of an edge-free textured tile's 20 k
+// cycles 7.3 k are the prologue and pass 1 that a pair pays once; the winner's texels are fetched per pixel, and the adjoint of pass 1 runs twice
+// (owner_adjoint with the texture-gradient window, tile A then tile B).
+template <class PixT, bool CLAMP, bool TEX = false>
 __device__ __forceinline__ void fwd_pair_tiles(const KParams &p, const ViewPtrs &w, WaveLds &S, int view, int lane, int tile, int nA, int nB, uint32_t my_id,
 											   double *loss_at)
 { // loss_at (or NULL): this walker's partial of the loss, see tile_loss
@@ -1003,18 +1008,36 @@ __device__ __forceinline__ void fwd_pair_tiles(const KParams &p, const ViewPtrs 
 				zB = Z, kB = k, jB = j;
 		}
 	}
-	// colours (no texture in a scene whose tiles are paired; perspective_correct excludes the adjoint, hence a fit step)
+	// colours (perspective_correct excludes the adjoint, hence a fit step)
 	double colA[CH] = {0, 0, 0, 0}, colB[CH] = {0, 0, 0, 0};
 	int kindA = KIND_NONE, kindB = KIND_NONE;
-	if (jA >= 0)
-	{
-		kindA = S.rec[jA].tri().kind;
-		const double *pl = &S.planes[jA * 12];
+	Tap tapA, tapB;
+	double LA = 0, LB = 0;
+	const PixT *texture = (const PixT *)p.texture;
+	// the winner's colour: interpolated, or (TEX) bilinear texture x shade (H.h:1159-1258) from the staged (u, v, shade) planes
+	auto shade_winner = [&](int j, double xx, int &kind, Tap &tap, double &L, double (&col)[CH]) {
+		kind = S.rec[j].tri().kind;
+		const double *pl = &S.planes[j * 12];
+		if (TEX && kind == KIND_TEXTURED)
+		{
+			bilinear_tap(p.tex_w, p.tex_h, plane_at(pl, xx, y), plane_at(pl + 3, xx, y), C, tap);
+			L = plane_at(pl + 6, xx, y);
+			PixT tx[4][4];
+			tap_texels(texture, tap, C, tx);
 #pragma unroll
-		for (int cc = 0; cc < CH; cc++)
-			if (cc < C)
-				colA[cc] = interp_channel(pl, cc, xA, y, false, 0.0);
-	}
+			for (int cc = 0; cc < CH; cc++)
+				col[cc] = cc < C ? bilinear_mix(tap, (double)tx[0][cc], (double)tx[1][cc], (double)tx[2][cc], (double)tx[3][cc]) * L : 0.0;
+		}
+		else
+		{
+#pragma unroll
+			for (int cc = 0; cc < CH; cc++)
+				if (cc < C)
+					col[cc] = interp_channel(pl, cc, xx, y, false, 0.0);
+		}
+	};
+	if (jA >= 0)
+		shade_winner(jA, xA, kindA, tapA, LA, colA);
 	else if (inbA)
 	{
 #pragma unroll
@@ -1023,14 +1046,7 @@ __device__ __forceinline__ void fwd_pair_tiles(const KParams &p, const ViewPtrs 
 				colA[cc] = background_channel<PixT>(p, view, pixA, cc);
 	}
 	if (jB >= 0)
-	{
-		kindB = S.rec[jB].tri().kind;
-		const double *pl = &S.planes[jB * 12];
-#pragma unroll
-		for (int cc = 0; cc < CH; cc++)
-			if (cc < C)
-				colB[cc] = interp_channel(pl, cc, xB, y, false, 0.0);
-	}
+		shade_winner(jB, xB, kindB, tapB, LB, colB);
 	else if (inbB)
 	{
 #pragma unroll
@@ -1080,7 +1096,7 @@ __device__ __forceinline__ void fwd_pair_tiles(const KParams &p, const ViewPtrs 
 			atomic_add_f64(loss_at, r2 - (p.loss_tile_bg[1 + (size_t)view * p.L.ntiles + tile] + p.loss_tile_bg[2 + (size_t)view * p.L.ntiles + tile]));
 	}
 	// adjoint of pass 1 for L = sum (image - obs)^2: the colour is rounded to the pixel type first, like the stored frame
-	if constexpr (sizeof(PixT) == 4)
+	if constexpr (sizeof(PixT) == 4 && !TEX)
 	{ // float32 frame: both tiles through one slot table (owner_adjoint_slots, dr_backward.h)
 		if (__ballot(jA >= 0 || jB >= 0) != 0)
 		{
@@ -1096,7 +1112,8 @@ __device__ __forceinline__ void fwd_pair_tiles(const KParams &p, const ViewPtrs 
 		}
 		return;
 	}
-	Tap no_tap;
+	// (a tile without edges: the whole LDS of the wavefront -- staging area and edge order -- is the texture-gradient window, as in the single-tile path)
+	constexpr int WIN = TEX ? (int)((sizeof(WaveLds) + sizeof(EdgeSort)) / sizeof(double)) : 384;
 	double g[CH];
 	if (__ballot(kA >= 0) != 0)
 	{
@@ -1104,7 +1121,7 @@ __device__ __forceinline__ void fwd_pair_tiles(const KParams &p, const ViewPtrs 
 		for (int cc = 0; cc < CH; cc++)
 			g[cc] = (cc < C && inbA) ? fit_residual<CLAMP>(p, (double)(PixT)colA[cc], (double)obA[cc]) : 0.0;
 		lds_sync();
-		owner_adjoint<PixT, false>(p, w, lane, xA, y, kA, kindA, g, no_tap, 0.0, (double *)&S.rec[0], (uint32_t *)&S.cover[0][0]);
+		owner_adjoint<PixT, TEX>(p, w, lane, xA, y, kA, kA >= 0 ? kindA : (int)KIND_NONE, g, tapA, LA, (double *)&S.rec[0], (uint32_t *)&S.cover[0][0], WIN);
 	}
 	if (__ballot(kB >= 0) != 0)
 	{
@@ -1112,7 +1129,7 @@ __device__ __forceinline__ void fwd_pair_tiles(const KParams &p, const ViewPtrs 
 		for (int cc = 0; cc < CH; cc++)
 			g[cc] = (cc < C && inbB) ? fit_residual<CLAMP>(p, (double)(PixT)colB[cc], (double)obB[cc]) : 0.0;
 		lds_sync();
-		owner_adjoint<PixT, false>(p, w, lane, xB, y, kB, kindB, g, no_tap, 0.0, (double *)&S.rec[0], (uint32_t *)&S.cover[0][0]);
+		owner_adjoint<PixT, TEX>(p, w, lane, xB, y, kB, kB >= 0 ? kindB : (int)KIND_NONE, g, tapB, LB, (double *)&S.rec[0], (uint32_t *)&S.cover[0][0], WIN);
 	}
 }
 
@@ -1268,7 +1285,9 @@ enum FwdMode
 };
 // AA (round 6): antialiase_error -- the image stays un-antialiased, err_buffer = sum_c (image - obs)^2 (H.h:2824-2837) is what the edges blend
 // (rasterize_edge_*_error, H.h:2067-2197, 2371-2478).  Forward-only instances (FUSED = false: the adjoint of this mode is the two-call path's).
-template <class PixT, bool FUSED, bool TEX, int MODE, bool CLAMP, bool AA = false, bool MANYC = false>
+// TEXPAIR: (TEX) the instance also walks PAIRS of textured tiles (fwd_pair_tiles<…, true>): the one-kernel form of a textured fit step only -- compiled into
+// the two kernels of the 8-view form as well (where the scan kernel forms no textured pair) the code alone cost them 13 % (128 registers + spills instead of 101)
+template <class PixT, bool FUSED, bool TEX, int MODE, bool CLAMP, bool AA = false, bool MANYC = false, bool TEXPAIR = false>
 __device__ __forceinline__ void fwd_tiles(const KParams &p, WaveLds *s_lds, EdgeSort *s_es, const uint32_t b)
 { // b: index of this walker among the walkers of the grid (the workgroup index, unless fill workgroups are dealt among them).
   // (32-bit: a grid has fewer than 2^31 workgroups, and every wavefront pays for this arithmetic on the scalar unit before its first load --
@@ -1334,9 +1353,9 @@ __device__ __forceinline__ void fwd_tiles(const KParams &p, WaveLds *s_lds, Edge
 			ids_first = entry_at(rank)->ids[lane < ENTRY_IDS ? lane : 0];
 		}
 		const uint32_t e_tile = (uint32_t)uniform((int)cur.x), e_ntri = (uint32_t)uniform((int)cur.y), e_nedge = (uint32_t)uniform((int)cur.z);
-		if (FUSED && !TEX && MODE == FWD_NO_EDGES && (e_tile & PAIR_FLAG))
+		if (FUSED && (!TEX || TEXPAIR) && MODE == FWD_NO_EDGES && (e_tile & PAIR_FLAG))
 		{ // two adjacent tiles, two pixels per lane (the scan kernel pairs them up: fwd_pair_tiles)
-			fwd_pair_tiles<PixT, CLAMP>(p, w, S, view, lane, (int)(e_tile & ~PAIR_FLAG), (int)(e_ntri & 0xffffu), (int)(e_ntri >> 16), ids12,
+			fwd_pair_tiles<PixT, CLAMP, TEX>(p, w, S, view, lane, (int)(e_tile & ~PAIR_FLAG), (int)(e_ntri & 0xffffu), (int)(e_ntri >> 16), ids12,
 								 p.loss_wave ? p.loss_wave + (size_t)view * LOSS_SLOTS + q % LOSS_SLOTS : nullptr);
 			lds_sync();
 			continue;
@@ -1861,7 +1880,7 @@ __global__ __launch_bounds__(64, DR_FWD_WAVES) void raster_fwd_fast_kernel(KPara
 		const bool chunked = G % (8 * WORK_CHUNK) == 0;
 		const int q = chunked ? (int)div_views(p, b >> 3) * 8 + (int)(b & 7) : 0;
 		if (chunked && q >= (int)p.fwd_heads)
-			fwd_tiles<PixT, FUSED, TEX, FWD_NO_EDGES, CLAMP>(p, s_lds, s_es, b); // the rest of the list: no tile with edges
+			fwd_tiles<PixT, FUSED, TEX, FWD_NO_EDGES, CLAMP, false, false, TEXE == 1>(p, s_lds, s_es, b); // the rest of the list: no tile with edges
 		else
 			fwd_tiles<PixT, FUSED, TEX, FWD_EDGE_ADJ, CLAMP>(p, s_lds, s_es, b); // the head (tiny frames: the whole list)
 	}

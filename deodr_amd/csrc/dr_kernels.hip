@@ -429,6 +429,10 @@ int launch_forward_staged(const KParams &p, bool fused, hipStream_t stream, hipE
 	q.tile_blocks = fwd_tile_blocks(p.L.ntiles, p.n_views, fused && p.fuse_edges);
 	q.heavy_share = heavy_share_for(p.n_views, q.tile_blocks, fused && p.fuse_edges);
 	q.split_part = split_part_for(p.n_views, q.tile_blocks);
+#ifndef DR_PAIR_TEX
+#define DR_PAIR_TEX 1 // (measurement builds: 0 = textured scenes do not pair their tiles, as until round 6)
+#endif
+	q.pair_tex = DR_PAIR_TEX && p.texture != nullptr && (!DR_TEX_TWO_KERNELS || p.n_views < DR_TEX_TWO_KERNELS);
 	forward_launch_constants(q);
 	hipLaunchKernelGGL(tile_scan_kernel, dim3((p.L.ntiles + SCAN_BLOCK - 1) / SCAN_BLOCK, p.n_views), dim3(SCAN_BLOCK), 0, stream, q);
 	if (p.fill_mode == 0)

@@ -220,6 +220,7 @@ struct KParams
 	// Launch constants of the staged forward raster, formed ONCE on the host (round 6): every one of its 27 000 one-wave workgroups used to derive them
 	// on the scalar unit before its first load -- four integer divisions (by the number of views, by the head share, inside fill_share) among the ~420
 	// instructions in front of a walker's first tile, on a scalar unit that twenty wavefronts of a CU share.
+	int pair_tex;		  // tile_scan_kernel: textured scenes pair their edge-free tiles too (launches of fewer than DR_TEX_TWO_KERNELS views)
 	int setup_sparse;	  // set-up kernel: a triangle every `setup_sparse` lanes (1, or 4 for small launches: dr_setup.h)
 	uint32_t fwd_heads;	  // walkers per view on the head of the work list: tile_blocks / heavy_share (0: the list has one class)
 	uint32_t fwd_n_fill;  // workgroups of this launch that stream the background of the forward's share of the empty tiles
