@@ -1137,7 +1137,8 @@ __device__ __forceinline__ void fwd_pair_tiles(const KParams &p, const ViewPtrs 
 // depth, face ids, barycentrics, normals, luminosity, xyz, colours or uv -- 15 channels of a triangle soup in ONE render, sigma = 0 by its own assert).
 // Pass 1 as everywhere (staged records, exact spans, winner = min (Z, index)); the planes of a triangle are 3 C doubles, too many to stage, and only the
 // WINNER's are needed: each lane reads them from memory once the tile is resolved (lanes with the same winner read the same lines).  The un-staged
-// kernel walked the tile's list once per chunk of four channels, a dependent record load per triangle each time: 138 -> ?? us for one 1024^2 view.
+// kernel walked the tile's list once per chunk of four channels, a dependent record load per triangle each time: 133 -> 37 us of forward raster for one 1024^2 view
+// (profiles/r06l_slow_family_after.txt).
 template <class PixT>
 __device__ __forceinline__ void fwd_manyc_tile(const KParams &p, const ViewPtrs &w, WaveLds &S, int view, int lane, int tile, int ntri, uint32_t ids12)
 {
