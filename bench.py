@@ -425,10 +425,12 @@ def timed_steps(step, n):
     return (time.perf_counter() - t0) / n
 
 
-def batch_sweep(scenes_mod, DeviceScene, HipRasterizer, dev, S, sigma, batches=(16, 32)):
-    """The same fit step with more views per launch (the headline is quoted at `--views`, default 8): where the library saturates."""
+def batch_sweep(scenes_mod, DeviceScene, HipRasterizer, dev, S, sigma, batches=(16, 32), cases=None):
+    """The same fit step with more views per launch (the headline is quoted at `--views`, default 8): where the library saturates.
+    `cases` = [(views, frame size)]: the same mesh on larger frames (`frame_sweep`: more pixels per triangle -- the per-triangle work of set-up and
+    finalize and the latency chain of a step are what keeps the 1024^2 / 20 000-triangle step under the frame's bandwidth bound, not the pixel kernels)."""
     out = []
-    for B in batches:
+    for B, S in (cases if cases is not None else [(b, S) for b in batches]):
         views = [scenes_mod.sphere_scene(size=S, angle=float(a)) for a in np.linspace(-0.5, 0.5, B)]
         s0 = views[0]
         stack = lambda n: np.stack([np.asarray(getattr(v, n)) for v in views])
@@ -448,7 +450,7 @@ def batch_sweep(scenes_mod, DeviceScene, HipRasterizer, dev, S, sigma, batches=(
             fit()
         dt = min(timed_steps(fit, 20) for _ in range(3))
         alg = sum(v for k, v in algorithmic_bytes(S, S, Cc, ds.nb_triangles, int(ds.depths.shape[1]), B, True).items() if k != "not_moved")
-        out.append({"views": B, "ms_per_step": dt * 1e3, "Mpixels_s": B * S * S / dt / 1e6, "whole_step_frac": alg / dt / 1e9 / HBM_PEAK_GBS})
+        out.append({"views": B, "size": S, "ms_per_step": dt * 1e3, "Mpixels_s": B * S * S / dt / 1e6, "whole_step_frac": alg / dt / 1e9 / HBM_PEAK_GBS})
         del ds, r, obs, image, z, grads
     return out
 
@@ -682,10 +684,11 @@ def main():
         barrier()
         cold_dt = time.perf_counter() - t0
     probe = hbm_probe(dev) if (rank == 0 and args.test_backend != "gloo") else None
-    single_view = sweep = None
+    single_view = sweep = frames = None
     if not args.no_single_view and not textured and args.test_backend != "gloo":
         single_view = single_view_latency(scenes, DeviceScene, HipRasterizer, dev, S, args.sigma, obs)
         sweep = batch_sweep(scenes, DeviceScene, HipRasterizer, dev, S, args.sigma)
+        frames = batch_sweep(scenes, DeviceScene, HipRasterizer, dev, S, args.sigma, cases=[(1, 2 * S), (8, 2 * S), (1, 4 * S)]) if rank == 0 and S <= 1024 else None
     if dist is not None:
         dist.barrier()
     for _ in range(args.warmup):
@@ -895,6 +898,9 @@ def main():
             out["single_view"], out["batch_sweep"] = single_view, sweep
             # (the north star's 40 % is asked of the forward + backward pass of this scene: where more views per launch take the same code)
             out["roofline"]["whole_step"]["saturated"] = max(out["batch_sweep"], key=lambda e: e["whole_step_frac"])
+            if frames is not None:
+                # the same 20 000-triangle mesh on larger frames (views, size): where the pixel kernels take the step once the per-triangle work is amortised
+                out["frame_sweep"] = frames
         if world == 1 and not args.no_cpu_baseline and not textured:
             out["cpu_baseline"] = cpu_baseline(views[0], 2 * (image[0] - obs).cpu().numpy().astype(np.float64), poses, S)
         result_line = json.dumps(out)
