@@ -383,6 +383,9 @@ __device__ __forceinline__ void fill_background_tile(const KParams &p, int view,
 #define DR_WORK_CHUNK 64
 #endif
 constexpr int SCAN_BLOCK = SCAN_TILES, WORK_CHUNK = DR_WORK_CHUNK;
+#ifndef DR_DYN_WALKERS
+#define DR_DYN_WALKERS 0 // 1: persistent walkers with tickets on the others' list of a many-view fit step (KParams::dyn_groups)
+#endif
 #ifndef DR_PAIR_TILES
 #define DR_PAIR_TILES 1 // (measurement builds: 0 = one tile per wavefront everywhere, as in round 2)
 #endif
@@ -1311,11 +1314,14 @@ __device__ __forceinline__ void fwd_tiles(const KParams &p, WaveLds *s_lds, Edge
 		view = (int)(b - gq * (uint32_t)p.n_views);
 		q = (int)gq;
 	}
-	const ViewPtrs w = view_ptrs(p, view);
 	const int W = p.W, H = p.H, C = p.C, P = p.L.P;
 	const bool persp = p.persp;
 	const PixT *texture = (const PixT *)p.texture;
 	WaveLds &S = s_lds[wave];
+	int grp = 0; // (persistent walkers) the ticket group of `view` this walker draws from: its own XCD's, until that one runs dry
+	for (int hop = 0;; hop++)
+	{ // (one pass, unless the walker is a persistent one that moves on to another group's entries: below)
+	const ViewPtrs w = view_ptrs(p, view);
 	// The first G / p.heavy_share workgroups of a view walk the many-primitive tiles (front of the list), the others the rest (from
 	// the back): the index of a workgroup's entry does not depend on the counts, so the counts, the entry header and the
 	// entry's triangle ids are all requested at once.
@@ -1325,6 +1331,22 @@ __device__ __forceinline__ void fwd_tiles(const KParams &p, WaveLds *s_lds, Edge
 	const int qq = heavy_list ? q : q - Gh, stride = heavy_list ? Gh : G - Gh;
 	const bool chunk_here = chunked && stride % (8 * WORK_CHUNK) == 0;
 	uint32_t rank = chunk_here ? (uint32_t)((((qq >> 3) / WORK_CHUNK) * 8 + (qq & 7)) * WORK_CHUNK + (qq >> 3) % WORK_CHUNK) : (uint32_t)qq;
+	// Persistent walkers (KParams::dyn_groups, the others' list of a many-view fit step): far fewer workgroups than entries, all resident, each taking
+	// its entries by TICKET -- a wave slot then never waits for the dispatcher between two tiles (tools/wave_trace.py --slots: ~1 us from the end of a
+	// one-tile workgroup to the start of the next one on its SIMD, 27 000 times per 8-view step).  One counter per (view, XCD): ticket t of group g is
+	// entry (t / 8) * 64 + g * 8 + t % 8 -- runs of eight neighbouring entries stay on one XCD's L2.  The ticket of the entry after next is requested
+	// (one lane, returning atomic) when a tile starts, the next entry itself a tile ahead as before: no round trip is waited for between tiles.
+	const bool dyn = DR_DYN_WALKERS && MODE == FWD_NO_EDGES && p.dyn_groups > 0;
+	if (hop == 0)
+		grp = qq & (DYN_GROUPS - 1);
+	uint32_t *const tick = &w.edge_tile_cnt[(EDGE_LISTS + 1 + grp) * CNT_STRIDE];
+	auto ticket_rank = [&](uint32_t t) { return (t >> 3) * (8u * DYN_GROUPS) + (uint32_t)grp * 8u + (t & 7u); };
+	uint32_t tk = 0; // (lane 0) the ticket of the entry after the one whose header is in `head`
+	if (dyn)
+	{
+		if (lane0 == 0)
+			tk = atomicAdd(tick, 2u);
+	}
 	// The first entry of a walker (usually its only one) is requested TOGETHER with the count it is checked against -- the position of the
 	// entry does not depend on the count and lies inside the list whatever the count is (rank < stride <= tiles <= work_cap).  As the first
 	// statement of the loop body the load sat behind the branch on the count: a third dependent round trip (count, entry, records) in the
@@ -1332,9 +1354,15 @@ __device__ __forceinline__ void fwd_tiles(const KParams &p, WaveLds *s_lds, Edge
 	auto entry_at = [&](uint32_t r) { return &w.work_list[heavy_list ? r : (uint32_t)p.L.work_cap - 1u - r]; };
 	// (The compiler sinks loads that only the loop body uses below the branch on the count, whatever their place in the source: the empty
 	// asm statement takes the three results as read-write operands, so all three loads are issued, and waited for ONCE, in front of it.)
+	uint32_t n_work_v = w.hdr->work_count[heavy_list ? 0 : 1];
+	if (dyn)
+	{ // (the first two tickets in one request; the count travels with it)
+		const uint32_t t0 = (uint32_t)uniform((int)tk);
+		rank = ticket_rank(t0);
+		tk = t0 + 1u;
+	}
 	uint4 head = *(const uint4 *)entry_at(rank); // {tile, ntri, nedge, sweep_slot}
 	uint32_t ids_first = entry_at(rank)->ids[lane0 < ENTRY_IDS ? lane0 : 0];
-	uint32_t n_work_v = w.hdr->work_count[heavy_list ? 0 : 1];
 	asm volatile("" : "+v"(head.x), "+v"(head.y), "+v"(head.z), "+v"(head.w), "+v"(ids_first), "+v"(n_work_v));
 	const uint32_t n_work = (uint32_t)uniform((int)n_work_v);
 	while (rank < n_work)
@@ -1347,11 +1375,13 @@ __device__ __forceinline__ void fwd_tiles(const KParams &p, WaveLds *s_lds, Edge
 		// now, a whole tile ahead of its use: its position does not depend on anything this tile computes
 		const uint4 cur = head;
 		const uint32_t ids12 = ids_first;
-		rank += (uint32_t)stride;
+		rank = dyn ? ticket_rank((uint32_t)uniform((int)tk)) : rank + (uint32_t)stride;
 		if (rank < n_work)
 		{
 			head = *(const uint4 *)entry_at(rank);
 			ids_first = entry_at(rank)->ids[lane < ENTRY_IDS ? lane : 0];
+			if (dyn && lane == 0)
+				tk = atomicAdd(tick, 1u);
 		}
 		const uint32_t e_tile = (uint32_t)uniform((int)cur.x), e_ntri = (uint32_t)uniform((int)cur.y), e_nedge = (uint32_t)uniform((int)cur.z);
 		if (FUSED && (!TEX || TEXPAIR) && MODE == FWD_NO_EDGES && (e_tile & PAIR_FLAG))
@@ -1794,8 +1824,45 @@ __device__ __forceinline__ void fwd_tiles(const KParams &p, WaveLds *s_lds, Edge
 			tile_body(std::false_type{});
 		lds_sync(); // the next tile of this wavefront reuses the staging area
 	}
-	if (q == 0 && wave_lane() == 0)
+	if (q == 0 && hop == 0 && wave_lane() == 0)
 		close_epoch(p, w, FUSED);
+#ifndef DR_DYN_HOPS
+#define DR_DYN_HOPS 6 // other groups a persistent walker may move on to
+#endif
+	if (!dyn || hop >= DR_DYN_HOPS)
+		break;
+	// This group's entries are all handed out.  Groups finish at different times (views differ in work, XCDs in the long tiles they hold): look at
+	// every group's counter against its number of entries -- lane = 8 * view + group, eight views per pass, ONE round trip -- and move on to one that
+	// has entries left: one of the own XCD's if there is any (its L2 holds that part of the scene), picked by the walker's index so that the
+	// walkers that run dry together do not all queue at one counter.
+	int best = -1;
+	for (int v0 = 0; v0 < p.n_views && best < 0; v0 += 8)
+	{
+		const int v = v0 + (lane0 >> 3), gg = lane0 & 7;
+		int remain = 0;
+		if (v < p.n_views)
+		{
+			const ViewPtrs wv = view_ptrs(p, v);
+			const uint32_t issued = __hip_atomic_load(&wv.edge_tile_cnt[(EDGE_LISTS + 1 + gg) * CNT_STRIDE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			const uint32_t nw = wv.hdr->work_count[1];
+			const int tail = (int)(nw & 63u) - gg * 8;
+			remain = (int)((nw >> 6) * 8u) + (tail < 0 ? 0 : (tail > 8 ? 8 : tail)) - (int)issued;
+		}
+		const unsigned long long any = __ballot(remain > 1), same = any & (0x0101010101010101ull << grp);
+		unsigned long long pick = same ? same : any;
+		if (pick)
+		{
+			uint32_t k = ((b * 2654435761u) >> 16) % (uint32_t)__popcll(pick);
+			for (; k > 0; k--)
+				pick &= pick - 1ull;
+			best = v0 * 8 + (int)__builtin_ctzll(pick);
+		}
+	}
+	if (best < 0)
+		break;
+	view = best >> 3;
+	grp = best & 7;
+	}
 }
 
 #ifndef DR_FUSE_TEX_EDGES
@@ -1844,14 +1911,31 @@ __global__ __launch_bounds__(64, DR_FWD_WAVES) void raster_fwd_fast_kernel(KPara
 	// dispatched behind the last walker they START when the last walker has a slot, and the kernel then ends a fill later (73 MB of
 	// stores per 8-view step: same-box A/B 0.1279 / 0.1274 -> 0.1238 / 0.1232 ms, profiles/r04l).  (Round 3 measured "spread evenly:
 	// nothing" -- with the heavy tiles still deciding when the kernel ends.)
-	const uint32_t n_walk = (uint32_t)p.n_views * (uint32_t)p.tile_blocks, n_fill = p.fwd_n_fill; // (= n_views * fill_share(fill_mode, 2, nwords), from the host)
+	const uint32_t n_walk = (uint32_t)p.n_views * p.fwd_walkers, n_fill = p.fwd_n_fill; // (= n_views * fill_share(fill_mode, 2, nwords), from the host)
 #ifndef DR_FILL_DEAL
 #define DR_FILL_DEAL 1 // (measurement builds: 0 = the fill workgroups behind the walkers, as in round 3)
 #endif
 	const uint32_t dealt = (DR_FILL_DEAL && FUSED && !TEX) ? p.fwd_dealt : 0; // groups of 64 walkers + 8 fill workgroups (the host: fuse_edges && n_walk >= 8 n_fill ? n_fill / 8 : 0)
 	uint32_t b = blockIdx.x + p.block_base; // (32-bit throughout: see fwd_tiles)
 	int fi = -1;
-	if (b < dealt * 72)
+	if (DR_DYN_WALKERS && p.dyn_groups > 0)
+	{ // (persistent walkers: half as many workgroups for the same fill -- sixteen fill workgroups behind every 64 walkers)
+		if (b < dealt * 80)
+		{
+			const uint32_t grp = b / 80, r = b - grp * 80;
+			if (r < 64)
+				b = grp * 64 + r;
+			else
+				fi = (int)(grp * 16 + (r - 64));
+		}
+		else
+		{
+			b -= dealt * 16;
+			if (b >= n_walk)
+				fi = (int)(dealt * 16 + (b - n_walk));
+		}
+	}
+	else if (b < dealt * 72)
 	{
 		const uint32_t grp = b / 72, r = b - grp * 72;
 		if (r < 64)
@@ -1867,6 +1951,8 @@ __global__ __launch_bounds__(64, DR_FWD_WAVES) void raster_fwd_fast_kernel(KPara
 	}
 	if (fi >= 0)
 	{
+		DR_WAVE_TRACE_SCOPE(2);
+		DR_WAVE_TRACE_ROLE(1u);
 		if ((uint32_t)fi < n_fill)
 			fill_share_word(p, 2, (int)((uint32_t)fi % (uint32_t)p.n_views), (int)((uint32_t)fi / (uint32_t)p.n_views), wave_lane());
 		return;

@@ -408,9 +408,29 @@ void forward_launch_constants(KParams &q)
 {
 	const bool chunked = q.tile_blocks % (8 * WORK_CHUNK) == 0;
 	q.fwd_heads = chunked ? (uint32_t)(q.tile_blocks / q.heavy_share) : 0u;
-	const uint32_t n_walk = (uint32_t)q.n_views * (uint32_t)q.tile_blocks;
+	q.fwd_walkers = (uint32_t)q.tile_blocks;
+	q.dyn_groups = 0;
+#ifndef DR_DYN_MIN
+#define DR_DYN_MIN 20000 // walkers (all views) from which the others' list of a fit step is walked by persistent walkers with tickets
+#endif
+#ifndef DR_DYN_TOTAL
+#define DR_DYN_TOTAL 4608 // persistent walkers of all views together (the chip holds 5 120 wavefronts of the forward raster)
+#endif
+	if (DR_DYN_WALKERS && chunked && q.fuse_edges && q.texture == nullptr && (long long)q.n_views * q.tile_blocks >= DR_DYN_MIN)
+	{
+		const uint32_t others = ((uint32_t)DR_DYN_TOTAL / (uint32_t)q.n_views) & ~7u;
+		if (others >= 8 && q.fwd_heads + others < (uint32_t)q.tile_blocks)
+		{
+			q.fwd_walkers = q.fwd_heads + others;
+			q.dyn_groups = DYN_GROUPS;
+		}
+	}
+	const uint32_t n_walk = (uint32_t)q.n_views * q.fwd_walkers;
 	q.fwd_n_fill = (uint32_t)q.n_views * (uint32_t)fill_share(q.fill_mode, 2, q.L.nwords);
-	q.fwd_dealt = (q.fuse_edges && n_walk >= 8 * q.fwd_n_fill) ? q.fwd_n_fill / 8 : 0u;
+	if (q.dyn_groups)
+		q.fwd_dealt = q.fwd_n_fill / 16 < n_walk / 64 ? q.fwd_n_fill / 16 : n_walk / 64; // sixteen fill workgroups behind every 64 walkers
+	else
+		q.fwd_dealt = (q.fuse_edges && n_walk >= 8 * q.fwd_n_fill) ? q.fwd_n_fill / 8 : 0u;
 	q.views_magic = q.n_views == 1 ? 0xffffffffu : (uint32_t)(0x100000000ull / (unsigned long long)q.n_views) + 1u; // (see div_views)
 }
 
@@ -448,7 +468,7 @@ int launch_forward_staged(const KParams &p, bool fused, hipStream_t stream, hipE
 		*join = ss.join;
 	}
 	// (+ the workgroups that stream this kernel's share of the background of the empty tiles, one bitmap word each)
-	const dim3 grid((unsigned)p.n_views * (unsigned)q.tile_blocks + (unsigned)p.n_views * (unsigned)fill_share(p.fill_mode, 2, p.L.nwords));
+	const dim3 grid((unsigned)p.n_views * (unsigned)q.fwd_walkers + (unsigned)p.n_views * (unsigned)fill_share(p.fill_mode, 2, p.L.nwords));
 	const bool tex = p.texture != nullptr; // (see launch_adjoint_raster)
 	const bool common = p.strict && p.W % TILE == 0 && p.H % TILE == 0;
 	hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
@@ -1293,6 +1313,10 @@ int deodr_hip_depth_residual(const void *image, int pixel_dtype, const double *o
 int deodr_hip_debug_wave_phase(void *dst, size_t bytes) // tools/wave_trace.py
 {
 	return check_hip(hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_wave_phase), bytes < sizeof(g_wave_phase) ? bytes : sizeof(g_wave_phase)), "wave phase");
+}
+int deodr_hip_debug_wave_hw(void *dst, size_t bytes) // tools/wave_trace.py --slots
+{
+	return check_hip(hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_wave_hw), bytes < sizeof(g_wave_hw) ? bytes : sizeof(g_wave_hw)), "wave hw ids");
 }
 int deodr_hip_debug_wave_trace(void *dst, size_t bytes) // tools/wave_trace.py
 {

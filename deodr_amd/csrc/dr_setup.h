@@ -193,10 +193,12 @@ __device__ __forceinline__ int edge_round_slot(uint32_t total, int round)
 // timeline of the per-primitive kernels: [wave slot] = (start, end) in 10 ns ticks of the constant 100 MHz counter
 __device__ unsigned long long g_wave_trace[3][1 << 18][2]; // 0 set-up, 1 finalize, 2 forward raster
 __device__ unsigned long long g_wave_phase[4][1 << 16][8];  // 0 set-up, 1 finalize: time stamps inside the wavefronts that work on edges
+__device__ uint32_t g_wave_hw[3][1 << 18][2]; // where the wavefront ran: HW_ID (wave slot, SIMD, CU, SE) | role << 31 (1: a fill workgroup), XCC_ID
 struct WaveTrace
 {
 	int which;
 	unsigned long long t0;
+	uint32_t role = 0;
 	__device__ void phase(int i, int tri = 0) const
 	{
 		if ((threadIdx.x & 63) == 0 && which < 2)
@@ -220,15 +222,22 @@ struct WaveTrace
 			{
 				g_wave_trace[which][id][0] = t0;
 				g_wave_trace[which][id][1] = __builtin_amdgcn_s_memrealtime();
+				uint32_t hw, xcc;
+				asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+				asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+				g_wave_hw[which][id][0] = (hw & 0x7fffffffu) | role << 31;
+				g_wave_hw[which][id][1] = xcc;
 			}
 		}
 	}
 };
 #define DR_WAVE_TRACE_SCOPE(w) WaveTrace wave_trace_scope(w)
+#define DR_WAVE_TRACE_ROLE(r) wave_trace_scope.role = (r)
 #define DR_WAVE_PHASE(i) wave_trace_scope.phase(i)
 #define DR_WAVE_PHASE_T(i) wave_trace_scope.phase(i, 1)
 #else
 #define DR_WAVE_TRACE_SCOPE(w)
+#define DR_WAVE_TRACE_ROLE(r)
 #define DR_WAVE_PHASE(i)
 #define DR_WAVE_PHASE_T(i)
 #endif
@@ -268,7 +277,7 @@ __global__ __launch_bounds__(PRIM_BLOCK, DR_PRIM_WAVES) void setup_bin_kernel(KP
 		w.hdr->snap_count[1 - cur] = 0;
 		w.hdr->work_count[0] = w.hdr->work_count[1] = 0; // filled by tile_scan_kernel, read by the forward raster
 	}
-	if (item <= EDGE_LISTS) // appended to by tile_scan_kernel, the next kernel on the stream
+	if (item <= EDGE_LISTS + DYN_GROUPS) // appended to by tile_scan_kernel, the next kernel on the stream (+ the ticket counters of the forward raster's persistent walkers)
 		w.edge_tile_cnt[item * CNT_STRIDE] = 0;
 	if (p.loss_wave) // (one partial per tile walker of the forward raster, two kernels later)
 		for (int v = item; v < LOSS_SLOTS; v += n_items)

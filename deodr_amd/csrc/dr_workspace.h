@@ -26,6 +26,7 @@ static_assert(K_TRI <= 64 && (K_TRI & (K_TRI - 1)) == 0, "a wavefront loads the 
 constexpr int CH = 4;		// colour channels kept in registers at a time
 constexpr int MAX_SORTED = 64; // edges of a tile whose blending order is cached in LDS
 constexpr int CNT_STRIDE = 32; // uint32 between two append counters (one 128-byte line each)
+constexpr int DYN_GROUPS = 8; // ticket counters per view of the forward raster's persistent walkers (one per XCD; behind the append counters)
 constexpr int PRIO_EDGES = 8; // tiles with more edges than this are listed apart: the adjoint's edge kernel starts with them
 // Tiles that receive more than FIRST_PRIMS triangles (or edges) are the long poles of the forward raster: the scan kernel
 // puts them at the head of the work list, so that the 25-50 us waves start at time 0 instead of ending 30 us after every
@@ -153,7 +154,7 @@ Layout make_layout(int T, int H, int W, int C, size_t pool_pairs)
 	// touches anything else (one coalesced byte per thread instead of a 128-byte record line per triangle, two out of three
 	// of which are culled)
 	L.tri_flag = take((size_t)T);
-	L.edge_tile_cnt = take(sizeof(uint32_t) * (EDGE_LISTS + 1) * CNT_STRIDE); // append counters of the lists + the sweep-slot counter
+	L.edge_tile_cnt = take(sizeof(uint32_t) * (EDGE_LISTS + 1 + DYN_GROUPS) * CNT_STRIDE); // append counters of the lists + the sweep-slot counter + the walkers' ticket counters
 	L.edge_tiles = take(sizeof(uint32_t) * EDGE_LISTS * (size_t)L.ntiles);	   // [list][ntiles]
 	L.edge_slot = take(sizeof(uint32_t) * L.ntiles); // 1 + index of the tile's slot in edge_sweep, 0: none
 	L.sweep_cap = SWEEP_CAP < L.ntiles ? SWEEP_CAP : L.ntiles;
@@ -222,6 +223,8 @@ struct KParams
 	// instructions in front of a walker's first tile, on a scalar unit that twenty wavefronts of a CU share.
 	int pair_tex;		  // tile_scan_kernel: textured scenes pair their edge-free tiles too (launches of fewer than DR_TEX_TWO_KERNELS views)
 	int setup_sparse;	  // set-up kernel: a triangle every `setup_sparse` lanes (1, or 4 for small launches: dr_setup.h)
+	uint32_t fwd_walkers; // walkers per view in the forward raster's grid: tile_blocks, or fwd_heads + the persistent walkers of the others' list (dyn_groups)
+	int dyn_groups;		  // > 0: the walkers of the others' list are persistent and take their entries by ticket (DYN_GROUPS counters per view)
 	uint32_t fwd_heads;	  // walkers per view on the head of the work list: tile_blocks / heavy_share (0: the list has one class)
 	uint32_t fwd_n_fill;  // workgroups of this launch that stream the background of the forward's share of the empty tiles
 	uint32_t fwd_dealt;	  // of those, groups of eight dealt among the walkers (behind every 64), see raster_fwd_fast_kernel

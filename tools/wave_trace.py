@@ -68,3 +68,46 @@ if L.deodr_hip_debug_wave_phase(ph.ctypes.data, ph.nbytes) == 0:
         d = np.diff(t[:, :last + 1], axis=1) * 0.01
         print(f"{name}: {len(t)} wavefronts that went all the way; phase durations (us) mean / p90:",
               [(round(float(d[:, i].mean()), 2), round(float(np.percentile(d[:, i], 90)), 2)) for i in range(last)], " whole mean %.2f" % ((t[:, last] - t[:, 0]).mean() * 0.01))
+
+# --slots: where the wavefronts of the forward raster ran (HW_ID / XCC_ID of each, recorded by the trace build) -- how full the SIMDs are while the
+# grid still has workgroups to hand out, and how long a SIMD waits between the end of one wavefront and the start of the next
+if "--slots" in sys.argv:
+    hw = np.zeros((3, 1 << 18, 2), dtype=np.uint32)
+    L.deodr_hip_debug_wave_hw.argtypes = [C.c_void_p, C.c_size_t]
+    assert L.deodr_hip_debug_wave_hw(hw.ctypes.data, hw.nbytes) == 0
+    for which, name, cap in ((0, "setup_bin_kernel", None), (1, "finalize_kernel", None), (2, "raster_fwd_fast_kernel", None)):
+        t = buf[which].astype(np.int64)
+        ok = t[:, 1] > 0
+        ok &= t[:, 0] > t[ok, 0].max() - 30000
+        t, h = t[ok], hw[which][ok]
+        if len(t) == 0:
+            continue
+        t0 = t[:, 0].min()
+        start, end = (t[:, 0] - t0) * 0.01, (t[:, 1] - t0) * 0.01
+        role = h[:, 0] >> 31
+        simd = (h[:, 1].astype(np.int64) & 0xf) << 16 | (h[:, 0].astype(np.int64) & 0xff30)  # XCC | SE, SH, CU, SIMD (PIPE and WAVE bits masked out)
+        ids = np.unique(simd)
+        last_start = start.max()
+        print(f"{name}: {len(t)} wavefronts ({int(role.sum())} of them fill workgroups: life mean {end[role == 1].mean() - start[role == 1].mean() if role.any() else 0:.2f} us) on {len(ids)} SIMDs;"
+              f" the last one starts at {last_start:.1f} us, the kernel ends at {end.max():.1f}")
+        peak, occ, gaps, idle_at_end = [], [], [], []
+        horizon = np.percentile(start, 99.5)  # the grid has workgroups left to hand out until about here
+        for s in ids:
+            m = simd == s
+            ev = np.concatenate([np.stack([start[m], np.ones(m.sum())], 1), np.stack([end[m], -np.ones(m.sum())], 1)])
+            ev = ev[np.lexsort((ev[:, 1], ev[:, 0]))]
+            n = np.cumsum(ev[:, 1])
+            peak.append(n.max())
+            tt = ev[:, 0]
+            sel = tt[:-1] < horizon
+            occ.append(float((n[:-1][sel] * np.diff(tt)[sel]).sum() / max(horizon - tt[0], 1e-9)))
+            # a wavefront ends while the SIMD is at its peak: how long until the next one starts there
+            e_sorted, s_sorted = np.sort(end[m]), np.sort(start[m])
+            for e in e_sorted[e_sorted < horizon]:
+                j = np.searchsorted(s_sorted, e, side="left")
+                if j < len(s_sorted):
+                    gaps.append(s_sorted[j] - e)
+        gaps = np.array(gaps)
+        print(f"   waves per SIMD at once: peak p50 {np.percentile(peak, 50):.0f} max {max(peak):.0f}; mean occupancy until {horizon:.1f} us (99.5 % of the starts): {np.mean(occ):.2f} waves per SIMD"
+              f" = {np.mean(occ) * len(ids):.0f} in flight")
+        print(f"   from the end of a wavefront to the next start on the same SIMD: mean {gaps.mean():.2f} p50 {np.percentile(gaps, 50):.2f} p90 {np.percentile(gaps, 90):.2f} us ({len(gaps)} ends)")
