@@ -279,7 +279,9 @@ def main_large(n):
             # change owner (float32 note); those are counted, the rest is compared
             flipped = np.isinf(hip_z) != np.isinf(z_ref)
             worst["flips"] += int(flipped.sum())
-            worst["image"] = max(worst["image"], np.abs(hip_image - img_ref).max() / tol_img)
+            # (relative to the value where it is large: a sliver left by the perturbation of a shrunken triangle extrapolates its colours to +- 1 000 over
+            # the pixels it still covers, and a float32 frame holds those to 6e-5 -- scene 91, tests/fuzz_debug_large.py)
+            worst["image"] = max(worst["image"], (np.abs(hip_image - img_ref) / np.maximum(1.0, np.abs(img_ref))).max() / tol_img)
             image_b = 2 * (hip_image - obs[i].cpu().numpy().astype(np.float64))
             g_ref, g_fix = ref.grads(s, sigma, img_ref, z_ref, image_b), fixed.grads(s, sigma, img_ref, z_ref, image_b)
             for k in ("ij_b", "colors_b", "shade_b"):
